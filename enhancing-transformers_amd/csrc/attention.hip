@@ -1,0 +1,418 @@
+// attention.hip — fused (flash-style) multi-head attention forward / backward for gfx950, d_head = 64.
+//
+// Replaces Attention.forward between to_qkv and to_out (reference enhancing/modules/stage1/layers.py:123-130):
+// chunk(3) + 'b n (h d) -> b h n d' + softmax(q k^T * 64^-0.5) v + 'b h n d -> b n (h d)'.  The kernels read the
+// packed [B, N, 3*H*64] bf16 QKV GEMM output directly and write the [B, N, H*64] layout to_out consumes, so
+// neither einops rearrange nor the N x N score matrix (50 MB fp32 per image per layer at base) ever touches HBM;
+// only the row log-sum-exp is saved for backward.
+//
+// MFMA: v_mfma_f32_32x32x16_bf16 with the product computed "swapped" (S^T = K Q^T): each lane then owns ONE
+// query column, so the online-softmax row statistics are lane-local (one cross-half exchange) and the
+// probabilities feed the second MFMA straight from registers (the k-slot permutation of the C layout is applied
+// to the other operand instead).  Operands contracted over their slow storage index (V in P V, K in dS K,
+// dO / Q in the dK / dV products) are read from LDS with ds_read_b64_tr_b16.
+//
+// Forward / dQ: workgroup = 128 queries (4 waves x 32), K/V streamed in 64-key tiles through a 2-stage LDS ring.
+// dK/dV: workgroup = 128 keys (4 waves x 32), Q / dO streamed in 64-query tiles.  dQ and dK/dV are separate
+// kernels (S is recomputed twice) so that no atomics are needed and the result is deterministic.
+#include "common.h"
+
+#define ATT_D 64
+#define ATT_TILE_BYTES 8192  // 64 rows x 64 bf16
+
+// LDS image of a [64 rows][64 d] bf16 tile: 16-B chunk c (0..7) of row r at r*128 + ((c ^ f(r)) << 4) with
+// f(r) = ((r>>1)&1)<<2 | (r>>2)&3 : conflict-free for ds_write_b128 (staging), the 32-row ds_read_b128
+// fragments and the 4-row x 64-B transpose reads (gfx950 bank model; tools/lds_bank_check.py).
+__device__ __forceinline__ int att_off(int r, int c) { return r * 128 + ((c ^ ((((r >> 1) & 1) << 2) | ((r >> 2) & 3))) << 4); }
+
+__device__ __forceinline__ void att_gload(u32x4 (&r)[2], const uint16_t* __restrict__ base, int64_t rs, int row0, int t) {
+  const int c = t & 7, r0 = t >> 3;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) r[i] = *reinterpret_cast<const u32x4*>(base + (int64_t)(row0 + r0 + 32 * i) * rs + c * 8);
+}
+__device__ __forceinline__ void att_sstore(const u32x4 (&r)[2], unsigned char* tile, int t) {
+  const int c = t & 7, r0 = t >> 3;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(tile + att_off(r0 + 32 * i, c)) = r[i];
+}
+// 32x32x16 operand fragment, rows = tile rows rb + (lane&31), k = d: ds*16 + hi*8 + 0..7
+__device__ __forceinline__ s16x8 att_frag_row(const unsigned char* tile, int rb, int ds, int l31, int hi) {
+  return *reinterpret_cast<const s16x8*>(tile + att_off(rb + l31, ds * 2 + hi));
+}
+// 32x32x16 operand fragment contracted over TILE ROWS: index = column cb*32 + (lane&31); k-slot (hi, j) is tile
+// row rbase + 8*(j>>2) + 4*hi + (j&3)  — exactly the rows a lane holds in accumulator registers 8*c2 + j of a
+// 32x32 C tile whose row block starts at rbase - 16*c2 (so P / dS go from registers to the next MFMA unmoved).
+__device__ __forceinline__ s16x8 att_frag_tr(const unsigned char* tile, int rbase, int cb, int lane) {
+  const int G = lane >> 4, s = lane & 15;
+  const int row = rbase + 4 * (G >> 1) + (s >> 2);
+  const int cch = cb * 4 + (G & 1) * 2 + ((s & 3) >> 1);
+  const int sub = (s & 1) * 8;
+  const s16x4 lo = lds_tr_read_b64(tile + att_off(row, cch) + sub);
+  const s16x4 hi = lds_tr_read_b64(tile + att_off(row + 8, cch) + sub);
+  s16x8 o;
+  o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
+  o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
+  return o;
+}
+__device__ __forceinline__ s16x8 pack8_bf16(const float* p) {
+  u32x4 u = {pack_bf16x2(p[0], p[1]), pack_bf16x2(p[2], p[3]), pack_bf16x2(p[4], p[5]), pack_bf16x2(p[6], p[7])};
+  return __builtin_bit_cast(s16x8, u);
+}
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
+
+// =================================================================================================
+// forward
+// =================================================================================================
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, int N, int H, float scale_log2,
+                                                          uint16_t* __restrict__ out, float* __restrict__ lse) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][ATT_TILE_BYTES];  // [stage][K | V]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int64_t RS = (int64_t)3 * H * ATT_D;
+  const uint16_t* Qp = qkv + (int64_t)b * N * RS + h * ATT_D;
+  const uint16_t* Kp = Qp + H * ATT_D;
+  const uint16_t* Vp = Kp + H * ATT_D;
+
+  const bool active = q0 < N;  // N % 64 == 0: a wave's 32 queries are all in or all out
+  const int qrow = active ? q0 + l31 : l31;
+  s16x8 qf[4];
+#pragma unroll
+  for (int ds = 0; ds < 4; ++ds) qf[ds] = *reinterpret_cast<const s16x8*>(Qp + (int64_t)qrow * RS + ds * 16 + hi * 8);
+
+  f32x16 o[2];
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+  float m_run = -__builtin_inff(), l_part = 0.f;
+
+  const int nt = N / 64;
+  u32x4 rk[2], rv[2];
+  att_gload(rk, Kp, RS, 0, t);
+  att_gload(rv, Vp, RS, 0, t);
+  att_sstore(rk, smem[0][0], t);
+  att_sstore(rv, smem[0][1], t);
+  __syncthreads();
+  for (int kt = 0; kt < nt; ++kt) {
+    const int st = kt & 1;
+    if (kt + 1 < nt) {
+      att_gload(rk, Kp, RS, (kt + 1) * 64, t);
+      att_gload(rv, Vp, RS, (kt + 1) * 64, t);
+    }
+    const unsigned char* kt_ = smem[st][0];
+    const unsigned char* vt_ = smem[st][1];
+    // ---- S^T[key][q] = K Q^T ----
+    f32x16 s[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+      for (int ds = 0; ds < 4; ++ds) s[kb] = MFMA32(att_frag_row(kt_, kb * 32, ds, l31, hi), qf[ds], s[kb]);
+    }
+    // ---- online softmax for this lane's query column ----
+    float mx = s[0][0];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx * scale_log2);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float p[2][16];
+    float psum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        p[kb][r] = __builtin_amdgcn_exp2f(s[kb][r] * scale_log2 - m_new);
+        psum += p[kb][r];
+      }
+    l_part = l_part * alpha + psum;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+    // ---- O^T[d][q] += V^T P^T ----
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int c2 = 0; c2 < 2; ++c2) {
+        const s16x8 pb = pack8_bf16(&p[kb][c2 * 8]);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) o[db] = MFMA32(att_frag_tr(vt_, kb * 32 + 16 * c2, db, lane), pb, o[db]);
+      }
+    if (kt + 1 < nt) {
+      att_sstore(rk, smem[st ^ 1][0], t);
+      att_sstore(rv, smem[st ^ 1][1], t);
+    }
+    __syncthreads();
+  }
+  const float l = l_part + __shfl_xor(l_part, 32, 64);
+  const float inv = 1.0f / l;
+  if (!active) return;
+  uint16_t* op = out + ((int64_t)b * N + q0 + l31) * (H * ATT_D) + h * ATT_D;
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int d0 = db * 32 + 8 * g4 + 4 * hi;
+      u32x2 w = {pack_bf16x2(o[db][g4 * 4 + 0] * inv, o[db][g4 * 4 + 1] * inv), pack_bf16x2(o[db][g4 * 4 + 2] * inv, o[db][g4 * 4 + 3] * inv)};
+      *reinterpret_cast<u32x2*>(op + d0) = w;
+    }
+  if (hi == 0) lse[((int64_t)b * H + h) * N + q0 + l31] = (m_run + __builtin_amdgcn_logf(l)) * 0.6931471805599453f;
+}
+
+// =================================================================================================
+// backward: delta[b,h,q] = sum_d dO * O
+// =================================================================================================
+__global__ void attn_delta_kernel(const uint16_t* __restrict__ o, const uint16_t* __restrict__ d_o, int64_t BN, int N, int H,
+                                  float* __restrict__ delta) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (b*N + q) * H + h
+  if (i >= BN * H) return;
+  const int h = (int)(i % H);
+  const int64_t bq = i / H;
+  const int64_t bb = bq / N, q = bq % N;
+  const u32x4* po = reinterpret_cast<const u32x4*>(o + i * ATT_D);
+  const u32x4* pd = reinterpret_cast<const u32x4*>(d_o + i * ATT_D);
+  float acc = 0.f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const u32x4 a = po[c], g = pd[c];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      acc += bf16_bits_to_f32((uint16_t)(a[k] & 0xffffu)) * bf16_bits_to_f32((uint16_t)(g[k] & 0xffffu));
+      acc += bf16_bits_to_f32((uint16_t)(a[k] >> 16)) * bf16_bits_to_f32((uint16_t)(g[k] >> 16));
+    }
+  }
+  delta[(bb * H + h) * N + q] = acc;
+}
+
+// =================================================================================================
+// backward: dQ  (same skeleton as forward; K tile is read both as rows and transposed)
+// =================================================================================================
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ d_o,
+                                                             const float* __restrict__ lse, const float* __restrict__ delta, int N,
+                                                             int H, float scale, float scale_log2, uint16_t* __restrict__ dqkv) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][ATT_TILE_BYTES];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int64_t RS = (int64_t)3 * H * ATT_D;
+  const uint16_t* Qp = qkv + (int64_t)b * N * RS + h * ATT_D;
+  const uint16_t* Kp = Qp + H * ATT_D;
+  const uint16_t* Vp = Kp + H * ATT_D;
+  const uint16_t* dOp = d_o + (int64_t)b * N * (H * ATT_D) + h * ATT_D;
+
+  const bool active = q0 < N;
+  const int qrow = active ? q0 + l31 : l31;
+  s16x8 qf[4], dof[4];
+#pragma unroll
+  for (int ds = 0; ds < 4; ++ds) {
+    qf[ds] = *reinterpret_cast<const s16x8*>(Qp + (int64_t)qrow * RS + ds * 16 + hi * 8);
+    dof[ds] = *reinterpret_cast<const s16x8*>(dOp + (int64_t)qrow * (H * ATT_D) + ds * 16 + hi * 8);
+  }
+  const float lse_q = lse[((int64_t)b * H + h) * N + qrow] * 1.4426950408889634f;
+  const float del_q = delta[((int64_t)b * H + h) * N + qrow];
+
+  f32x16 dq[2];
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[db][r] = 0.f;
+
+  const int nt = N / 64;
+  u32x4 rk[2], rv[2];
+  att_gload(rk, Kp, RS, 0, t);
+  att_gload(rv, Vp, RS, 0, t);
+  att_sstore(rk, smem[0][0], t);
+  att_sstore(rv, smem[0][1], t);
+  __syncthreads();
+  for (int kt = 0; kt < nt; ++kt) {
+    const int st = kt & 1;
+    if (kt + 1 < nt) {
+      att_gload(rk, Kp, RS, (kt + 1) * 64, t);
+      att_gload(rv, Vp, RS, (kt + 1) * 64, t);
+    }
+    const unsigned char* kt_ = smem[st][0];
+    const unsigned char* vt_ = smem[st][1];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int ds = 0; ds < 4; ++ds) {
+        s = MFMA32(att_frag_row(kt_, kb * 32, ds, l31, hi), qf[ds], s);     // S^T[key][q]
+        dp = MFMA32(att_frag_row(vt_, kb * 32, ds, l31, hi), dof[ds], dp);  // dP^T[key][q] = V dO^T
+      }
+      float dsv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pr = __builtin_amdgcn_exp2f(s[r] * scale_log2 - lse_q);
+        dsv[r] = pr * (dp[r] - del_q) * scale;
+      }
+#pragma unroll
+      for (int c2 = 0; c2 < 2; ++c2) {
+        const s16x8 dsb = pack8_bf16(&dsv[c2 * 8]);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) dq[db] = MFMA32(att_frag_tr(kt_, kb * 32 + 16 * c2, db, lane), dsb, dq[db]);  // dQ^T[d][q] += K^T dS^T
+      }
+    }
+    if (kt + 1 < nt) {
+      att_sstore(rk, smem[st ^ 1][0], t);
+      att_sstore(rv, smem[st ^ 1][1], t);
+    }
+    __syncthreads();
+  }
+  if (!active) return;
+  uint16_t* op = dqkv + ((int64_t)b * N + q0 + l31) * RS + h * ATT_D;
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int d0 = db * 32 + 8 * g4 + 4 * hi;
+      u32x2 w = {pack_bf16x2(dq[db][g4 * 4 + 0], dq[db][g4 * 4 + 1]), pack_bf16x2(dq[db][g4 * 4 + 2], dq[db][g4 * 4 + 3])};
+      *reinterpret_cast<u32x2*>(op + d0) = w;
+    }
+}
+
+// =================================================================================================
+// backward: dK, dV  (workgroup owns 128 keys; Q / dO tiles stream through LDS)
+// =================================================================================================
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ d_o,
+                                                              const float* __restrict__ lse, const float* __restrict__ delta, int N,
+                                                              int H, float scale, float scale_log2, uint16_t* __restrict__ dqkv) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][ATT_TILE_BYTES];  // [stage][Q | dO]
+  __shared__ __attribute__((aligned(16))) float s_stat[2][2][64];                   // [stage][lse*log2e | delta]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int key0 = blockIdx.x * 128 + wave * 32;
+  const int64_t RS = (int64_t)3 * H * ATT_D;
+  const int64_t OS = (int64_t)H * ATT_D;
+  const uint16_t* Qp = qkv + (int64_t)b * N * RS + h * ATT_D;
+  const uint16_t* Kp = Qp + H * ATT_D;
+  const uint16_t* Vp = Kp + H * ATT_D;
+  const uint16_t* dOp = d_o + (int64_t)b * N * OS + h * ATT_D;
+  const float* lsep = lse + ((int64_t)b * H + h) * N;
+  const float* delp = delta + ((int64_t)b * H + h) * N;
+
+  const bool active = key0 < N;
+  const int krow = active ? key0 + l31 : l31;
+  s16x8 kf[4], vf[4];
+#pragma unroll
+  for (int ds = 0; ds < 4; ++ds) {
+    kf[ds] = *reinterpret_cast<const s16x8*>(Kp + (int64_t)krow * RS + ds * 16 + hi * 8);
+    vf[ds] = *reinterpret_cast<const s16x8*>(Vp + (int64_t)krow * RS + ds * 16 + hi * 8);
+  }
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
+
+  const int nt = N / 64;
+  u32x4 rq[2], rd[2];
+  float rstat = 0.f;
+  att_gload(rq, Qp, RS, 0, t);
+  att_gload(rd, dOp, OS, 0, t);
+  if (t < 64) rstat = lsep[t] * 1.4426950408889634f; else if (t < 128) rstat = delp[t - 64];
+  att_sstore(rq, smem[0][0], t);
+  att_sstore(rd, smem[0][1], t);
+  if (t < 128) s_stat[0][t >> 6][t & 63] = rstat;
+  __syncthreads();
+  for (int qt = 0; qt < nt; ++qt) {
+    const int st = qt & 1;
+    if (qt + 1 < nt) {
+      att_gload(rq, Qp, RS, (qt + 1) * 64, t);
+      att_gload(rd, dOp, OS, (qt + 1) * 64, t);
+      if (t < 64) rstat = lsep[(qt + 1) * 64 + t] * 1.4426950408889634f; else if (t < 128) rstat = delp[(qt + 1) * 64 + t - 64];
+    }
+    const unsigned char* qt_ = smem[st][0];
+    const unsigned char* dot_ = smem[st][1];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int ds = 0; ds < 4; ++ds) {
+        s = MFMA32(att_frag_row(qt_, qb * 32, ds, l31, hi), kf[ds], s);      // S[q][key]
+        dp = MFMA32(att_frag_row(dot_, qb * 32, ds, l31, hi), vf[ds], dp);   // dP[q][key] = dO V^T
+      }
+      float pv[16], dsv[16];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int row0 = qb * 32 + 8 * g4 + 4 * hi;
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(&s_stat[st][0][row0]);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(&s_stat[st][1][row0]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int r = g4 * 4 + k;
+          pv[r] = __builtin_amdgcn_exp2f(s[r] * scale_log2 - l4[k]);
+          dsv[r] = pv[r] * (dp[r] - d4[k]) * scale;
+        }
+      }
+#pragma unroll
+      for (int c2 = 0; c2 < 2; ++c2) {
+        const s16x8 pa = pack8_bf16(&pv[c2 * 8]);
+        const s16x8 dsa = pack8_bf16(&dsv[c2 * 8]);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          dv[db] = MFMA32(pa, att_frag_tr(dot_, qb * 32 + 16 * c2, db, lane), dv[db]);  // dV[key][d] += P^T dO
+          dk[db] = MFMA32(dsa, att_frag_tr(qt_, qb * 32 + 16 * c2, db, lane), dk[db]);  // dK[key][d] += dS^T Q
+        }
+      }
+    }
+    if (qt + 1 < nt) {
+      att_sstore(rq, smem[st ^ 1][0], t);
+      att_sstore(rd, smem[st ^ 1][1], t);
+      if (t < 128) s_stat[st ^ 1][t >> 6][t & 63] = rstat;
+    }
+    __syncthreads();
+  }
+  if (!active) return;
+  // D[key][d]: lane (d = db*32 + l31, hi) holds key rows (r&3) + 8*(r>>2) + 4*hi
+  uint16_t* dkp = dqkv + (int64_t)b * N * RS + H * ATT_D + h * ATT_D;
+  uint16_t* dvp = dkp + H * ATT_D;
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      dkp[(int64_t)key * RS + db * 32 + l31] = f32_to_bf16_bits(dk[db][r]);
+      dvp[(int64_t)key * RS + db * 32 + l31] = f32_to_bf16_bits(dv[db][r]);
+    }
+}
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" int enh_attention_forward(const enh_bf16* qkv, int B, int N, int H, float scale, enh_bf16* out, float* lse, void* stream) {
+  ENH_REQUIRE(qkv && out && lse, ENH_E_BADARG, "enh_attention_forward: null pointer");
+  ENH_REQUIRE(B > 0 && H > 0 && N > 0 && N % 64 == 0, ENH_E_SHAPE, "enh_attention_forward: need N %% 64 == 0 (B=%d N=%d H=%d)", B, N, H);
+  ENH_REQUIRE(scale > 0.f, ENH_E_BADARG, "enh_attention_forward: scale must be positive");
+  const dim3 grid((N + 127) / 128, H, B);
+  attn_fwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(qkv, N, H, scale * 1.4426950408889634f, out, lse);
+  return enh_check_launch("enh_attention_forward");
+}
+
+extern "C" int enh_attention_backward(const enh_bf16* qkv, const enh_bf16* out, const enh_bf16* dout, const float* lse, int B, int N,
+                                      int H, float scale, enh_bf16* dqkv, float* delta_ws, void* stream) {
+  ENH_REQUIRE(qkv && out && dout && lse && dqkv && delta_ws, ENH_E_BADARG, "enh_attention_backward: null pointer");
+  ENH_REQUIRE(B > 0 && H > 0 && N > 0 && N % 64 == 0, ENH_E_SHAPE, "enh_attention_backward: need N %% 64 == 0 (B=%d N=%d H=%d)", B, N, H);
+  ENH_REQUIRE(scale > 0.f, ENH_E_BADARG, "enh_attention_backward: scale must be positive");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t BN = (int64_t)B * N;
+  attn_delta_kernel<<<(int)((BN * H + 255) / 256), 256, 0, s>>>(out, dout, BN, N, H, delta_ws);
+  const dim3 grid((N + 127) / 128, H, B);
+  const float sl2 = scale * 1.4426950408889634f;
+  attn_bwd_dq_kernel<<<grid, 256, 0, s>>>(qkv, dout, lse, delta_ws, N, H, scale, sl2, dqkv);
+  attn_bwd_dkv_kernel<<<grid, 256, 0, s>>>(qkv, dout, lse, delta_ws, N, H, scale, sl2, dqkv);
+  return enh_check_launch("enh_attention_backward");
+}

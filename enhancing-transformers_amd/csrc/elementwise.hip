@@ -1,0 +1,200 @@
+// elementwise.hip — HBM-bound data movement, reductions and the optimizer step for gfx950.
+//   patchify / unpatchify(+pixel loss): the gather / scatter halves of Conv2d(k=s=p) and
+//   ConvTranspose2d(k=s=p) (reference enhancing/modules/stage1/layers.py:168-171,178,202-205,212) with the
+//   pixel losses of enhancing/losses/vqperceptual.py:113-114 fused into the scatter pass;
+//   colsum: bias gradients; adamw: torch.optim.AdamW as configured at vitvqgan.py:160.
+// All kernels move 8-16 bytes per lane with the contiguous side chosen for the larger tensor.
+#include "common.h"
+
+// img [B,C,H,W] f32 -> patches [M=B*gy*gx, C*p*p] bf16, element order (c, ph, pw)
+__global__ void patchify_kernel(const float* __restrict__ img, int B, int C, int H, int W, int p,
+                                uint16_t* __restrict__ out, int64_t total4) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total4) return;
+  const int p4 = p >> 2, gx_n = W / p, gy_n = H / p;
+  int64_t r = i;
+  const int q = (int)(r % p4); r /= p4;
+  const int ph = (int)(r % p); r /= p;
+  const int c = (int)(r % C); r /= C;       // r = m
+  const int gx = (int)(r % gx_n);
+  const int gy = (int)((r / gx_n) % gy_n);
+  const int b = (int)(r / ((int64_t)gx_n * gy_n));
+  const float4 v = *reinterpret_cast<const float4*>(img + (((size_t)b * C + c) * H + (size_t)gy * p + ph) * W + (size_t)gx * p + q * 4);
+  *reinterpret_cast<uint2*>(out + (size_t)i * 4) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+}
+
+// pix [M, C*p*p] f32 -> xrec [B,C,H,W] f32 ; optional pixel-loss sums (double atomics: order-independent
+// to 1e-16, hence deterministic after rounding to f32) and the patch-layout bf16 loss gradient.
+__global__ __launch_bounds__(256) void unpatchify_loss_kernel(
+    const float* __restrict__ pix, const float* __restrict__ target, int B, int C, int H, int W, int p, float w_l1,
+    float w_l2, float inv_numel, float* __restrict__ xrec, double* __restrict__ sums, uint16_t* __restrict__ dpix,
+    int64_t total4) {
+  __shared__ float s_l1[4], s_l2[4];
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  float l1 = 0.f, l2 = 0.f;
+  if (i < total4) {
+    const int p4 = p >> 2, gx_n = W / p, gy_n = H / p;
+    int64_t r = i;
+    const int q = (int)(r % p4); r /= p4;
+    const int ph = (int)(r % p); r /= p;
+    const int c = (int)(r % C); r /= C;
+    const int gx = (int)(r % gx_n);
+    const int gy = (int)((r / gx_n) % gy_n);
+    const int b = (int)(r / ((int64_t)gx_n * gy_n));
+    const size_t off = (((size_t)b * C + c) * H + (size_t)gy * p + ph) * W + (size_t)gx * p + q * 4;
+    const float4 v = *reinterpret_cast<const float4*>(pix + (size_t)i * 4);
+    if (xrec) *reinterpret_cast<float4*>(xrec + off) = v;
+    if (target) {
+      const float4 x = *reinterpret_cast<const float4*>(target + off);
+      const float d[4] = {v.x - x.x, v.y - x.y, v.z - x.z, v.w - x.w};
+      float g[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        l1 += fabsf(d[k]);
+        l2 += d[k] * d[k];
+        const float sg = d[k] > 0.f ? 1.f : (d[k] < 0.f ? -1.f : 0.f);
+        g[k] = (w_l1 * sg + w_l2 * 2.f * d[k]) * inv_numel;
+      }
+      if (dpix) *reinterpret_cast<uint2*>(dpix + (size_t)i * 4) = make_uint2(pack_bf16x2(g[0], g[1]), pack_bf16x2(g[2], g[3]));
+    }
+  }
+  if (sums) {
+    l1 = wave_sum(l1);
+    l2 = wave_sum(l2);
+    if ((threadIdx.x & 63) == 0) { s_l1[threadIdx.x >> 6] = l1; s_l2[threadIdx.x >> 6] = l2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      atomicAdd(&sums[0], (double)((s_l1[0] + s_l1[1]) + (s_l1[2] + s_l1[3])));
+      atomicAdd(&sums[1], (double)((s_l2[0] + s_l2[1]) + (s_l2[2] + s_l2[3])));
+    }
+  }
+}
+
+// out[n] += sum_m x[m,n] ; x bf16.  Wave = 128 columns (4 B per lane), 4 waves split the rows of a chunk.
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const uint16_t* __restrict__ x, int64_t M, int64_t N,
+                                                          int64_t ldx, int64_t rows_per_block, float* __restrict__ out) {
+  __shared__ float s_part[3][128];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t n0 = (int64_t)blockIdx.x * 128 + lane * 2;
+  const int64_t m_begin = (int64_t)blockIdx.y * rows_per_block;
+  int64_t m_end = m_begin + rows_per_block;
+  if (m_end > M) m_end = M;
+  float a0 = 0.f, a1 = 0.f;
+  if (n0 < N) {  // N is even (N % 8 == 0 enforced by the launcher)
+    for (int64_t m = m_begin + wave; m < m_end; m += 4) {
+      const uint32_t u = *reinterpret_cast<const uint32_t*>(x + (size_t)m * ldx + n0);
+      a0 += bf16_bits_to_f32((uint16_t)(u & 0xffffu));
+      a1 += bf16_bits_to_f32((uint16_t)(u >> 16));
+    }
+  }
+  if (wave > 0) { s_part[wave - 1][lane * 2] = a0; s_part[wave - 1][lane * 2 + 1] = a1; }
+  __syncthreads();
+  if (wave == 0 && n0 < N) {
+    for (int ww = 0; ww < 3; ++ww) { a0 += s_part[ww][lane * 2]; a1 += s_part[ww][lane * 2 + 1]; }
+    atomicAdd(&out[n0], a0);
+    atomicAdd(&out[n0 + 1], a1);
+  }
+}
+
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, int64_t n) {
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    const float4 v = *reinterpret_cast<const float4*>(x + i);
+    *reinterpret_cast<uint2*>(y + i) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+  } else {
+    for (int64_t k = i; k < n; ++k) y[k] = f32_to_bf16_bits(x[k]);
+  }
+}
+
+// AdamW, decoupled weight decay, bias correction (torch.optim.AdamW semantics; vitvqgan.py:160)
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, uint16_t* __restrict__ p16, int64_t n, float lr, float beta1,
+                             float beta2, float eps, float wd, float gscale, float inv_bc1, float inv_sqrt_bc2) {
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n) return;
+  float pv[4], gv[4], mv[4], vv[4];
+  const bool full = i + 3 < n;
+  if (full) {
+    const float4 a = *reinterpret_cast<const float4*>(p + i), b = *reinterpret_cast<const float4*>(g + i);
+    const float4 c = *reinterpret_cast<const float4*>(m + i), d = *reinterpret_cast<const float4*>(v + i);
+    pv[0] = a.x; pv[1] = a.y; pv[2] = a.z; pv[3] = a.w; gv[0] = b.x; gv[1] = b.y; gv[2] = b.z; gv[3] = b.w;
+    mv[0] = c.x; mv[1] = c.y; mv[2] = c.z; mv[3] = c.w; vv[0] = d.x; vv[1] = d.y; vv[2] = d.z; vv[3] = d.w;
+  } else {
+    for (int k = 0; k < 4; ++k) {
+      const bool ok = i + k < n;
+      pv[k] = ok ? p[i + k] : 0.f; gv[k] = ok ? g[i + k] : 0.f; mv[k] = ok ? m[i + k] : 0.f; vv[k] = ok ? v[i + k] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float gg = gv[k] * gscale;
+    pv[k] = pv[k] * (1.0f - lr * wd);
+    mv[k] = mv[k] * beta1 + gg * (1.0f - beta1);
+    vv[k] = vv[k] * beta2 + gg * gg * (1.0f - beta2);
+    const float denom = sqrtf(vv[k]) * inv_sqrt_bc2 + eps;
+    pv[k] = pv[k] - (lr * inv_bc1) * (mv[k] / denom);
+  }
+  if (full) {
+    *reinterpret_cast<float4*>(p + i) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+    *reinterpret_cast<float4*>(m + i) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+    *reinterpret_cast<float4*>(v + i) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    if (p16) *reinterpret_cast<uint2*>(p16 + i) = make_uint2(pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3]));
+  } else {
+    for (int k = 0; k < 4 && i + k < n; ++k) {
+      p[i + k] = pv[k]; m[i + k] = mv[k]; v[i + k] = vv[k];
+      if (p16) p16[i + k] = f32_to_bf16_bits(pv[k]);
+    }
+  }
+}
+
+extern "C" int enh_patchify(const float* img, int B, int C, int H, int W, int p, enh_bf16* patches, void* stream) {
+  ENH_REQUIRE(img && patches, ENH_E_BADARG, "enh_patchify: null pointer");
+  ENH_REQUIRE(B > 0 && C > 0 && p > 0 && p % 4 == 0 && H % p == 0 && W % p == 0, ENH_E_SHAPE, "enh_patchify: need p %% 4 == 0 and H,W divisible by p (B=%d C=%d H=%d W=%d p=%d)", B, C, H, W, p);
+  const int64_t total4 = (int64_t)B * C * H * W / 4;
+  patchify_kernel<<<(int)((total4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(img, B, C, H, W, p, patches, total4);
+  return enh_check_launch("enh_patchify");
+}
+
+extern "C" int enh_unpatchify_loss(const float* pix, const float* target, int B, int C, int H, int W, int p, float w_l1,
+                                   float w_l2, float* xrec, double* sums, enh_bf16* dpix_bf16, void* stream) {
+  ENH_REQUIRE(pix && (xrec || target), ENH_E_BADARG, "enh_unpatchify_loss: null pointer");
+  ENH_REQUIRE(B > 0 && C > 0 && p > 0 && p % 4 == 0 && H % p == 0 && W % p == 0, ENH_E_SHAPE, "enh_unpatchify_loss: need p %% 4 == 0 and H,W divisible by p");
+  const int64_t numel = (int64_t)B * C * H * W, total4 = numel / 4;
+  unpatchify_loss_kernel<<<(int)((total4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+      pix, target, B, C, H, W, p, w_l1, w_l2, 1.0f / (float)numel, xrec, target ? sums : nullptr, dpix_bf16, total4);
+  return enh_check_launch("enh_unpatchify_loss");
+}
+
+extern "C" int enh_colsum_bf16(const enh_bf16* x, int64_t M, int64_t N, int64_t ldx, float* out, int accumulate, void* stream) {
+  ENH_REQUIRE(x && out, ENH_E_BADARG, "enh_colsum_bf16: null pointer");
+  ENH_REQUIRE(M > 0 && N > 0 && N % 2 == 0 && ldx % 2 == 0, ENH_E_SHAPE, "enh_colsum_bf16: N and ldx must be even");
+  hipStream_t s = (hipStream_t)stream;
+  if (!accumulate) {
+    hipError_t e = hipMemsetAsync(out, 0, (size_t)N * sizeof(float), s);
+    if (e != hipSuccess) { enh_set_error("enh_colsum_bf16: memset failed: %s", hipGetErrorString(e)); return ENH_E_HIP_BASE - (int)e; }
+  }
+  int64_t chunks = (M + 511) / 512;
+  if (chunks > 256) chunks = 256;
+  const int64_t rows_per_block = (M + chunks - 1) / chunks;
+  dim3 grid((unsigned)((N + 127) / 128), (unsigned)chunks);
+  colsum_bf16_kernel<<<grid, 256, 0, s>>>(x, M, N, ldx, rows_per_block, out);
+  return enh_check_launch("enh_colsum_bf16");
+}
+
+extern "C" int enh_cast_f32_bf16(const float* x, enh_bf16* y, int64_t n, void* stream) {
+  ENH_REQUIRE(x && y && n > 0, ENH_E_BADARG, "enh_cast_f32_bf16: bad argument");
+  const int64_t n4 = (n + 3) / 4;
+  cast_f32_bf16_kernel<<<(int)((n4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, y, n);
+  return enh_check_launch("enh_cast_f32_bf16");
+}
+
+extern "C" int enh_adamw_step(float* p, const float* g, float* m, float* v, enh_bf16* p_bf16, int64_t n, int step,
+                              float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                              void* stream) {
+  ENH_REQUIRE(p && g && m && v && n > 0 && step >= 1, ENH_E_BADARG, "enh_adamw_step: bad argument");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  const int64_t n4 = (n + 3) / 4;
+  adamw_kernel<<<(int)((n4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(p, g, m, v, p_bf16, n, lr, beta1, beta2, eps, weight_decay,
+                                                                      grad_scale, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)));
+  return enh_check_launch("enh_adamw_step");
+}

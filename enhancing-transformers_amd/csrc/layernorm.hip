@@ -1,0 +1,176 @@
+// layernorm.hip — LayerNorm forward / backward for gfx950 (HBM-bound: one wave per token row, 16-byte
+// coalesced accesses, statistics and all accumulation in f32).
+// Replaces nn.LayerNorm(dim) inside PreNorm and Transformer.norm (reference
+// enhancing/modules/stage1/layers.py:85-92,143): eps 1e-5, biased variance, affine.
+// Forward writes the bf16 operand the following MFMA GEMM consumes (and optionally an f32 copy);
+// backward fuses the residual-stream gradient add and emits the bf16 copy the wgrad/dgrad GEMMs consume.
+#include "common.h"
+
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ b, int64_t M, int D, float eps,
+                                                     uint16_t* __restrict__ y16, float* __restrict__ y32,
+                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nch = D >> 2;
+  const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * D);
+  float4 v[NCH];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + 64 * i;
+    v[i] = c < nch ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+      const float a = v[i].x - mean, bb = v[i].y - mean, cc = v[i].z - mean, dd = v[i].w - mean;
+      q += (a * a + bb * bb) + (cc * cc + dd * dd);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+  if (lane == 0) {
+    if (mean_out) mean_out[row] = mean;
+    if (rstd_out) rstd_out[row] = rstd;
+  }
+  const float4* w4 = reinterpret_cast<const float4*>(w);
+  const float4* b4 = reinterpret_cast<const float4*>(b);
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+      const float4 g = w4[c], be = b4[c];
+      float4 o;
+      o.x = (v[i].x - mean) * rstd * g.x + be.x;
+      o.y = (v[i].y - mean) * rstd * g.y + be.y;
+      o.z = (v[i].z - mean) * rstd * g.z + be.z;
+      o.w = (v[i].w - mean) * rstd * g.w + be.w;
+      if (y32) reinterpret_cast<float4*>(y32 + (size_t)row * D)[c] = o;
+      if (y16) reinterpret_cast<uint2*>(y16 + (size_t)row * D)[c] = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
+    }
+  }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ w, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const float* __restrict__ dres,
+                                                     int64_t M, int D, float* __restrict__ dx32,
+                                                     uint16_t* __restrict__ dx16, float* __restrict__ dw,
+                                                     float* __restrict__ db) {
+  __shared__ float s_dw[3][NCH * 256];  // waves 1..3 park their column partials here
+  __shared__ float s_db[3][NCH * 256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = D >> 2;
+  const float4* w4 = reinterpret_cast<const float4*>(w);
+  float4 gw[NCH], adw[NCH], adb[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + 64 * i;
+    gw[i] = c < nch ? w4[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    adw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    adb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += stride) {
+    const float mu = mean[row], rs = rstd[row];
+    const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * D);
+    const float4* gr = reinterpret_cast<const float4*>(dy + (size_t)row * D);
+    float4 xh[NCH], g[NCH];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        const float4 xv = xr[c], dv = gr[c];
+        xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+        g[i] = make_float4(dv.x * gw[i].x, dv.y * gw[i].y, dv.z * gw[i].z, dv.w * gw[i].w);
+        s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+        s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
+        adw[i].x += dv.x * xh[i].x; adw[i].y += dv.y * xh[i].y; adw[i].z += dv.z * xh[i].z; adw[i].w += dv.w * xh[i].w;
+        adb[i].x += dv.x; adb[i].y += dv.y; adb[i].z += dv.z; adb[i].w += dv.w;
+      } else {
+        xh[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        g[i] = xh[i];
+      }
+    }
+    const float c1 = wave_sum(s1) / (float)D;
+    const float c2 = wave_sum(s2) / (float)D;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        float4 o;
+        o.x = rs * (g[i].x - c1 - xh[i].x * c2);
+        o.y = rs * (g[i].y - c1 - xh[i].y * c2);
+        o.z = rs * (g[i].z - c1 - xh[i].z * c2);
+        o.w = rs * (g[i].w - c1 - xh[i].w * c2);
+        if (dres) {
+          const float4 r = reinterpret_cast<const float4*>(dres + (size_t)row * D)[c];
+          o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        }
+        reinterpret_cast<float4*>(dx32 + (size_t)row * D)[c] = o;
+        if (dx16) reinterpret_cast<uint2*>(dx16 + (size_t)row * D)[c] = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
+      }
+    }
+  }
+  // column partials: 4 waves -> 1 through LDS, then one f32 atomic per column per workgroup
+  if (wave > 0) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      float* pw = &s_dw[wave - 1][(lane + 64 * i) * 4];
+      float* pb = &s_db[wave - 1][(lane + 64 * i) * 4];
+      pw[0] = adw[i].x; pw[1] = adw[i].y; pw[2] = adw[i].z; pw[3] = adw[i].w;
+      pb[0] = adb[i].x; pb[1] = adb[i].y; pb[2] = adb[i].z; pb[3] = adb[i].w;
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        float aw[4] = {adw[i].x, adw[i].y, adw[i].z, adw[i].w};
+        float ab[4] = {adb[i].x, adb[i].y, adb[i].z, adb[i].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          for (int ww = 0; ww < 3; ++ww) { aw[k] += s_dw[ww][c * 4 + k]; ab[k] += s_db[ww][c * 4 + k]; }
+          atomicAdd(&dw[c * 4 + k], aw[k]);
+          atomicAdd(&db[c * 4 + k], ab[k]);
+        }
+      }
+    }
+  }
+}
+
+extern "C" int enh_layernorm_forward(const float* x, const float* w, const float* b, int64_t M, int D, float eps,
+                                     enh_bf16* y_bf16, float* y_f32, float* mean, float* rstd, void* stream) {
+  ENH_REQUIRE(x && w && b && (y_bf16 || y_f32), ENH_E_BADARG, "enh_layernorm_forward: null pointer");
+  ENH_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 2048, ENH_E_SHAPE, "enh_layernorm_forward: need D %% 4 == 0 and D <= 2048, got M=%lld D=%d", (long long)M, D);
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = (int)((M + 3) / 4);
+  if (D <= 512) ln_fwd_kernel<2><<<grid, 256, 0, s>>>(x, w, b, M, D, eps, y_bf16, y_f32, mean, rstd);
+  else if (D <= 1024) ln_fwd_kernel<4><<<grid, 256, 0, s>>>(x, w, b, M, D, eps, y_bf16, y_f32, mean, rstd);
+  else ln_fwd_kernel<8><<<grid, 256, 0, s>>>(x, w, b, M, D, eps, y_bf16, y_f32, mean, rstd);
+  return enh_check_launch("enh_layernorm_forward");
+}
+
+extern "C" int enh_layernorm_backward(const float* dy, const float* x, const float* w, const float* mean,
+                                      const float* rstd, const float* dres, int64_t M, int D, float* dx_f32,
+                                      enh_bf16* dx_bf16, float* dw, float* db, void* stream) {
+  ENH_REQUIRE(dy && x && w && mean && rstd && dx_f32 && dw && db, ENH_E_BADARG, "enh_layernorm_backward: null pointer");
+  ENH_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 2048, ENH_E_SHAPE, "enh_layernorm_backward: need D %% 4 == 0 and D <= 2048, got M=%lld D=%d", (long long)M, D);
+  hipStream_t s = (hipStream_t)stream;
+  int64_t want = (M + 3) / 4;
+  const int grid = (int)(want < 1024 ? want : 1024);
+  if (D <= 512) ln_bwd_kernel<2><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db);
+  else if (D <= 1024) ln_bwd_kernel<4><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db);
+  else ln_bwd_kernel<8><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db);
+  return enh_check_launch("enh_layernorm_backward");
+}

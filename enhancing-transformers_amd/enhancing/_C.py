@@ -1,0 +1,221 @@
+"""ctypes binding of libenh_hip.so (the C ABI declared in include/enh_hip.h).
+
+PyTorch tensors are used only as device-memory containers: every wrapper checks device / dtype /
+contiguity (the reference's native ops do the same with CHECK_CUDA / CHECK_CONTIGUOUS,
+enhancing/losses/op/fused_bias_act.cpp:9-15), passes raw ``data_ptr()`` values plus the current HIP
+stream, and raises ``RuntimeError`` with ``enh_last_error()`` on a non-zero return code.
+
+There is NO fallback: if the shared library is missing or a tensor is not on a ROCm device the call
+fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+import torch
+
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.environ.get("ENH_HIP_LIB", os.path.join(_PKG_ROOT, "lib", "libenh_hip.so"))
+
+ACT_NONE, ACT_TANH, ACT_DTANH = 0, 1, 2
+
+_c = ctypes
+_vp, _i64, _i32, _f32, _sz = _c.c_void_p, _c.c_int64, _c.c_int, _c.c_float, _c.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/enh_hip.h declares (checked by tests)
+SIGNATURES = {
+    "enh_last_error": (_c.c_char_p, []),
+    "enh_abi_version": (_i32, []),
+    "enh_vq_workspace_bytes": (_sz, [_i64, _i32, _i32]),
+    "enh_vq_forward": (_i32, [_vp, _vp, _i64, _i32, _i32, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "enh_vq_backward": (_i32, [_vp, _vp, _vp, _vp, _f32, _vp, _i64, _i32, _i32, _f32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "enh_vq_lookup": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "enh_layernorm_forward": (_i32, [_vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp, _vp]),
+    "enh_layernorm_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "enh_gemm_bf16": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _i64, _i64, _i64, _vp, _i32, _vp, _i64, _vp, _i64, _i64,
+                             _i32, _vp, _vp, _i64, _vp]),
+    "enh_attention_forward": (_i32, [_vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp]),
+    "enh_attention_backward": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp]),
+    "enh_patchify": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "enh_unpatchify_loss": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp]),
+    "enh_colsum_bf16": (_i32, [_vp, _i64, _i64, _i64, _vp, _i32, _vp]),
+    "enh_cast_f32_bf16": (_i32, [_vp, _vp, _i64, _vp]),
+    "enh_adamw_step": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
+}
+
+_LIB = None
+
+
+def lib():
+    """Loads libenh_hip.so (once).  Raises if it has not been built: there is no CPU / eager fallback."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} not found: build it with `python __graft_entry__.py` "
+                               f"(or `make -C enhancing-transformers_amd/csrc`). There is no fallback path.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError here == ABI drift: fail loudly
+            fn.restype, fn.argtypes = res, args
+        _LIB = L
+    return _LIB
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (rc={rc}): {lib().enh_last_error().decode()}")
+
+
+def _p(t: Optional[torch.Tensor], dtype: Optional[torch.dtype] = None, name: str = "tensor"):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be on a ROCm device (got {t.device}); the HIP path has no CPU fallback")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f"{name} must be {dtype}, got {t.dtype}")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+F32, BF16, I64, F64 = torch.float32, torch.bfloat16, torch.int64, torch.float64
+
+# ------------------------------------------------------------------------------------------------
+# quantizer
+# ------------------------------------------------------------------------------------------------
+_WS = {}
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 22), dtype=torch.uint8, device=device)
+        _WS[key] = ws
+    return ws
+
+
+def vq_forward(z: torch.Tensor, codebook: torch.Tensor, beta: float, depth: int, use_norm: bool, want_bf16: bool = True):
+    """z [M,32] f32, codebook [K,32] f32 -> (zq f32 [M,32], zq_bf16|None, idx i64 [M,depth], loss f32 [1])."""
+    M, d = z.shape
+    K = codebook.shape[0]
+    zq = torch.empty_like(z)
+    zq16 = torch.empty(M, d, dtype=BF16, device=z.device) if want_bf16 else None
+    idx = torch.empty(M, depth, dtype=I64, device=z.device)
+    loss = torch.empty(1, dtype=F32, device=z.device)
+    L = lib()
+    nb = L.enh_vq_workspace_bytes(M, K, depth)
+    ws = _workspace(nb, z.device)
+    _check(L.enh_vq_forward(_p(z, F32, "z"), _p(codebook, F32, "codebook"), M, K, d, beta, depth, int(use_norm), _p(zq), _p(zq16),
+                            _p(idx), _p(loss), _p(ws), ws.numel(), _stream()), "enh_vq_forward")
+    return zq, zq16, idx, loss
+
+
+def vq_backward(z, codebook, idx, g_out, g_loss: float, g_loss_dev: Optional[torch.Tensor], beta: float, depth: int,
+                use_residual: bool, use_norm: bool, d_codebook: torch.Tensor, want_bf16: bool = True):
+    """Returns (dz f32, dz_bf16|None); ACCUMULATES into d_codebook [K,32] f32."""
+    M, d = z.shape
+    K = codebook.shape[0]
+    dz = torch.empty_like(z)
+    dz16 = torch.empty(M, d, dtype=BF16, device=z.device) if want_bf16 else None
+    L = lib()
+    nb = L.enh_vq_workspace_bytes(M, K, depth)
+    ws = _workspace(nb, z.device)
+    _check(L.enh_vq_backward(_p(z, F32, "z"), _p(codebook, F32, "codebook"), _p(idx, I64, "idx"), _p(g_out, F32, "g_out"),
+                             float(g_loss), _p(g_loss_dev, F32, "g_loss_dev"), M, K, d, beta, depth, int(use_residual),
+                             int(use_norm), _p(dz), _p(dz16), _p(d_codebook, F32, "d_codebook"), _p(ws), ws.numel(), _stream()),
+           "enh_vq_backward")
+    return dz, dz16
+
+
+def vq_lookup(codebook, idx, use_norm: bool, want_bf16: bool = True):
+    """idx [M,depth] i64 -> (sum_i n(E[idx_i]) f32 [M,32], bf16 copy)."""
+    M, depth = idx.shape
+    K, d = codebook.shape
+    out = torch.empty(M, d, dtype=F32, device=idx.device)
+    out16 = torch.empty(M, d, dtype=BF16, device=idx.device) if want_bf16 else None
+    _check(lib().enh_vq_lookup(_p(codebook, F32, "codebook"), _p(idx, I64, "idx"), M, K, d, depth, int(use_norm), _p(out), _p(out16),
+                               _stream()), "enh_vq_lookup")
+    return out, out16
+
+
+# ------------------------------------------------------------------------------------------------
+# layernorm
+# ------------------------------------------------------------------------------------------------
+def layernorm_forward(x, w, b, eps: float = 1e-5, y_bf16=None, y_f32=None, mean=None, rstd=None):
+    M, D = x.shape
+    _check(lib().enh_layernorm_forward(_p(x, F32, "x"), _p(w, F32, "w"), _p(b, F32, "b"), M, D, eps, _p(y_bf16, BF16, "y_bf16"),
+                                       _p(y_f32, F32, "y_f32"), _p(mean, F32, "mean"), _p(rstd, F32, "rstd"), _stream()),
+           "enh_layernorm_forward")
+
+
+def layernorm_backward(dy, x, w, mean, rstd, dres, dx_f32, dx_bf16, dw, db):
+    M, D = x.shape
+    _check(lib().enh_layernorm_backward(_p(dy, F32, "dy"), _p(x, F32, "x"), _p(w, F32, "w"), _p(mean, F32, "mean"),
+                                        _p(rstd, F32, "rstd"), _p(dres, F32, "dres"), M, D, _p(dx_f32, F32, "dx_f32"),
+                                        _p(dx_bf16, BF16, "dx_bf16"), _p(dw, F32, "dw"), _p(db, F32, "db"), _stream()),
+           "enh_layernorm_backward")
+
+
+# ------------------------------------------------------------------------------------------------
+# GEMM
+# ------------------------------------------------------------------------------------------------
+def gemm(a, b, M: int, N: int, K: int, trans_a: bool = False, trans_b: bool = False, bias=None, act: int = ACT_NONE, aux=None,
+         res=None, res_rows: int = 0, accumulate: bool = False, out_f32=None, out_bf16=None, lda: Optional[int] = None,
+         ldb: Optional[int] = None, ldc: Optional[int] = None):
+    """C[M,N] = epilogue(A(m,k) * B(n,k)); see include/enh_hip.h.  a / b are 2-D bf16 tensors (row-major storage)."""
+    lda = a.stride(0) if lda is None else lda
+    ldb = b.stride(0) if ldb is None else ldb
+    out = out_f32 if out_f32 is not None else out_bf16
+    ldc = out.stride(0) if ldc is None else ldc
+    _check(lib().enh_gemm_bf16(_p(a, BF16, "A"), lda, int(trans_a), _p(b, BF16, "B"), ldb, int(trans_b), M, N, K, _p(bias, F32, "bias"),
+                               act, _p(aux, BF16, "aux"), aux.stride(0) if aux is not None else 0, _p(res, F32, "res"),
+                               res.stride(0) if res is not None else 0, res_rows if res is not None else 0, int(accumulate),
+                               _p(out_f32, F32, "out_f32"), _p(out_bf16, BF16, "out_bf16"), ldc, _stream()), "enh_gemm_bf16")
+
+
+# ------------------------------------------------------------------------------------------------
+# attention
+# ------------------------------------------------------------------------------------------------
+def attention_forward(qkv, B: int, N: int, H: int, scale: float, out, lse):
+    _check(lib().enh_attention_forward(_p(qkv, BF16, "qkv"), B, N, H, scale, _p(out, BF16, "out"), _p(lse, F32, "lse"), _stream()),
+           "enh_attention_forward")
+
+
+def attention_backward(qkv, out, dout, lse, B: int, N: int, H: int, scale: float, dqkv, delta_ws):
+    _check(lib().enh_attention_backward(_p(qkv, BF16, "qkv"), _p(out, BF16, "out"), _p(dout, BF16, "dout"), _p(lse, F32, "lse"), B, N, H,
+                                        scale, _p(dqkv, BF16, "dqkv"), _p(delta_ws, F32, "delta_ws"), _stream()),
+           "enh_attention_backward")
+
+
+# ------------------------------------------------------------------------------------------------
+# data movement / loss / optimizer
+# ------------------------------------------------------------------------------------------------
+def patchify(img, p: int, out):
+    B, C, H, W = img.shape
+    _check(lib().enh_patchify(_p(img, F32, "img"), B, C, H, W, p, _p(out, BF16, "patches"), _stream()), "enh_patchify")
+
+
+def unpatchify_loss(pix, target, B: int, C: int, H: int, W: int, p: int, w_l1: float, w_l2: float, xrec, sums, dpix):
+    _check(lib().enh_unpatchify_loss(_p(pix, F32, "pix"), _p(target, F32, "target"), B, C, H, W, p, w_l1, w_l2, _p(xrec, F32, "xrec"),
+                                     _p(sums, F64, "sums"), _p(dpix, BF16, "dpix"), _stream()), "enh_unpatchify_loss")
+
+
+def colsum(x, M: int, N: int, out, accumulate: bool = False):
+    _check(lib().enh_colsum_bf16(_p(x, BF16, "x"), M, N, x.stride(0), _p(out, F32, "out"), int(accumulate), _stream()), "enh_colsum_bf16")
+
+
+def cast_bf16(x, y):
+    _check(lib().enh_cast_f32_bf16(_p(x, F32, "x"), _p(y, BF16, "y"), x.numel(), _stream()), "enh_cast_f32_bf16")
+
+
+def adamw_step(p, g, m, v, p_bf16, step: int, lr: float, beta1: float = 0.9, beta2: float = 0.99, eps: float = 1e-8,
+               weight_decay: float = 1e-4, grad_scale: float = 1.0):
+    _check(lib().enh_adamw_step(_p(p, F32, "p"), _p(g, F32, "g"), _p(m, F32, "m"), _p(v, F32, "v"), _p(p_bf16, BF16, "p_bf16"),
+                                p.numel(), step, lr, beta1, beta2, eps, weight_decay, grad_scale, _stream()), "enh_adamw_step")

@@ -1,0 +1,156 @@
+/*
+ * enh_hip.h — C ABI of libenh_hip.so: the MI355X (gfx950 / CDNA4) kernels behind the stage-1
+ * ViT-VQGAN / RQ-VAE training path of thuanz123/enhancing-transformers.
+ *
+ * Boundary contract:
+ *   - extern "C", plain pointers and sizes only; no torch / C++ types cross this boundary.
+ *   - Every pointer is a DEVICE pointer owned by the caller (the Python host side allocates them as
+ *     torch tensors and passes data_ptr()).  The library never allocates, frees or retains memory and
+ *     never synchronises: all work is enqueued on `stream` (a hipStream_t passed as void*).
+ *   - Return value: 0 (ENH_OK) or a negative ENH_E_* code; a HIP launch error is returned as
+ *     -(1000 + hipError_t).  enh_last_error() gives a thread-local human-readable message.  This mirrors
+ *     the reference's native-op precedent, where TORCH_CHECK failures surface as a Python RuntimeError
+ *     (enhancing/losses/op/fused_bias_act.cpp:9-15); the Python wrapper raises RuntimeError on rc != 0.
+ *   - All functions are stateless and re-entrant (they are called from autograd worker threads too).
+ *
+ * The reference reaches this path through stock PyTorch ops, not an FFI; each entry
+ * below cites the reference lines whose arithmetic it replaces.  Paths are relative to the reference
+ * repository root.
+ */
+#ifndef ENH_HIP_H
+#define ENH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ENH_OK 0
+#define ENH_E_BADARG (-1)      /* null pointer / non-positive size */
+#define ENH_E_SHAPE (-2)       /* unsupported shape or alignment */
+#define ENH_E_WORKSPACE (-3)   /* workspace too small */
+#define ENH_E_HIP_BASE (-1000) /* rc = ENH_E_HIP_BASE - hipError_t */
+
+typedef uint16_t enh_bf16; /* raw bfloat16 bits */
+
+const char* enh_last_error(void);
+int enh_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Vector / residual quantizer  — enhancing/modules/stage1/quantizers.py:38-92
+ * ------------------------------------------------------------------------------------------------
+ * Arithmetic contract (bit-exactly restated in oracle/vq_oracle.c):
+ *   n(x) = x / max(sqrt(S(x)), 1e-12),  S(x) = chain(x[0..15]) + chain(x[16..31]),
+ *   chain = ascending fmaf chain from 0;  zz = S(zn), ee_k = S(en_k);
+ *   dot_k = fmaf chain over the order k = 0,16,1,17,...,15,31 (f32 MFMA 32x32x2, exact f32);
+ *   d_k = (zz + ee_k) - 2*dot_k ; idx = argmin_k d_k, lowest k on ties  (quantizers.py:78-83).
+ * embed_dim must be 32 (every shipped config: configs/imagenet_vitvq_*.yaml:17-19).
+ */
+
+/* bytes of scratch needed by enh_vq_forward / enh_vq_backward for a codebook of n_embed codes and M tokens */
+size_t enh_vq_workspace_bytes(int64_t M, int n_embed, int depth);
+
+/* Forward of BaseQuantizer.forward + VectorQuantizer.quantize (quantizers.py:38-63,74-92).
+ *   z        [M,32] f32   quantizer input (pre_quant output)
+ *   codebook [K,32] f32   quantizer.embedding.weight
+ *   depth    1 = plain VQ ; >1 = residual quantizer with one shared codebook (use_residual, num_quantizers)
+ *   zq_out   [M,32] f32   straight-through VALUE  z + (sum_i en_i - z)          (quantizers.py:61)
+ *   zq_bf16  [M,32] bf16  optional (may be NULL): same, rounded to bf16 (operand of post_quant GEMM)
+ *   idx_out  [M,depth] i64 code indices (stacked on the last axis as quantizers.py:55)
+ *   loss_out [1] f32      mean_i( beta*mean((en_i-zn_i)^2) + mean((en_i-zn_i)^2) ) (quantizers.py:56,89-90)
+ */
+int enh_vq_forward(const float* z, const float* codebook, int64_t M, int n_embed, int embed_dim,
+                   float beta, int depth, int use_norm, float* zq_out, enh_bf16* zq_bf16,
+                   int64_t* idx_out, float* loss_out, void* workspace, size_t workspace_bytes,
+                   void* stream);
+
+/* Backward (derived from the reference autograd graph):
+ *   g_out   [M,32] f32  grad wrt returned z_q;  g_loss_dev: optional device scalar multiplying g_loss
+ *   use_residual: 1 when the forward ran the residual loop (z is detached at quantizers.py:43, so the
+ *           encoder then receives g_out only, and the codebook grad gets the cross-depth term)
+ *   dz      [M,32] f32  (VQ: g_out + beta-term through the normalise Jacobian; RQ: g_out only)
+ *   dz_bf16 optional bf16 copy ; d_codebook [K,32] f32 is ACCUMULATED into (caller zeroes it).
+ */
+int enh_vq_backward(const float* z, const float* codebook, const int64_t* idx, const float* g_out,
+                    float g_loss, const float* g_loss_dev, int64_t M, int n_embed, int embed_dim,
+                    float beta, int depth, int use_residual, int use_norm, float* dz, enh_bf16* dz_bf16,
+                    float* d_codebook, void* workspace, size_t workspace_bytes, void* stream);
+
+/* decode_codes front half (vitvqgan.py:81-87): out[m] = sum_i n(codebook[idx[m,i]]) as f32 and bf16 */
+int enh_vq_lookup(const float* codebook, const int64_t* idx, int64_t M, int n_embed, int embed_dim,
+                  int depth, int use_norm, float* out, enh_bf16* out_bf16, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * LayerNorm — nn.LayerNorm(dim), eps 1e-5, biased variance (enhancing/modules/stage1/layers.py:85-92,143)
+ * ------------------------------------------------------------------------------------------------ */
+/* y = (x-mean)*rstd*w + b.  x [M,D] f32; y_bf16 [M,D] (GEMM operand) and/or y_f32 (either may be NULL);
+ * mean,rstd [M] f32 saved for backward (may be NULL for inference).  D % 4 == 0, D <= 2048. */
+int enh_layernorm_forward(const float* x, const float* w, const float* b, int64_t M, int D, float eps,
+                          enh_bf16* y_bf16, float* y_f32, float* mean, float* rstd, void* stream);
+/* dx = LN-backward(dy) [+ dres];  dy [M,D] f32, dres optional f32 residual-stream gradient that is added;
+ * dx_f32 [M,D] f32 and optional dx_bf16 copy; dw,db [D] f32 are ACCUMULATED (atomics; caller zeroes). */
+int enh_layernorm_backward(const float* dy, const float* x, const float* w, const float* mean,
+                           const float* rstd, const float* dres, int64_t M, int D, float* dx_f32,
+                           enh_bf16* dx_bf16, float* dw, float* db, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * bf16 MFMA GEMM with fused epilogue — every nn.Linear / patch conv on the path
+ * (layers.py:99-101,118,120,169,204; vitvqgan.py:38-39) and their dgrad / wgrad.
+ * ------------------------------------------------------------------------------------------------
+ * C[M,N] = epilogue( sum_k A(m,k) * B(n,k) ),  f32 accumulation on v_mfma_f32_16x16x32_bf16.
+ *   trans_a = 0: A stored [M][K] (lda elements between rows) ; 1: A stored [K][M]
+ *   trans_b = 0: B stored [N][K] (nn.Linear.weight layout)   ; 1: B stored [K][N]
+ *   epilogue, in this order:  v = acc ; v += bias[n] (f32, optional) ; v = tanh(v) if act == 1 ;
+ *     v *= (1 - aux[m,n]^2) if act == 2 (aux bf16 = saved tanh output: tanh backward) ;
+ *     v += res[(m % res_rows), n] (f32, optional; res_rows = M for a residual, n_tokens for a pos-embed) ;
+ *     v += C_old if accumulate ;  store to c_f32 and/or c_bf16 (ldc).
+ *   Requirements: K % 8 == 0, lda/ldb % 8 == 0, 16-byte aligned bases; for trans_a M % 8 == 0; trans_b N % 8 == 0.
+ */
+#define ENH_ACT_NONE 0
+#define ENH_ACT_TANH 1
+#define ENH_ACT_DTANH 2
+int enh_gemm_bf16(const enh_bf16* A, int64_t lda, int trans_a, const enh_bf16* B, int64_t ldb, int trans_b,
+                  int64_t M, int64_t N, int64_t K, const float* bias, int act, const enh_bf16* aux,
+                  int64_t ldaux, const float* res, int64_t ldres, int64_t res_rows, int accumulate,
+                  float* c_f32, enh_bf16* c_bf16, int64_t ldc, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused attention — Attention.forward layers.py:122-132 without materialising the N x N matrix
+ * ------------------------------------------------------------------------------------------------
+ * qkv [B,N,3*H*64] bf16 packed exactly as to_qkv emits it (q | k | v thirds, head-major, layers.py:123-124);
+ * out [B,N,H*64] bf16 in the 'b n (h d)' layout to_out consumes (layers.py:130); lse [B,H,N] f32 =
+ * row log-sum-exp of the scaled scores (saved for backward).  dim_head = 64, N % 64 == 0.
+ */
+int enh_attention_forward(const enh_bf16* qkv, int B, int N, int H, float scale, enh_bf16* out, float* lse,
+                          void* stream);
+/* dqkv [B,N,3*H*64] bf16 ; delta_ws [B,H,N] f32 scratch */
+int enh_attention_backward(const enh_bf16* qkv, const enh_bf16* out, const enh_bf16* dout, const float* lse,
+                           int B, int N, int H, float scale, enh_bf16* dqkv, float* delta_ws, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Patch (un)embedding data movement, pixel loss, reductions, optimizer
+ * ------------------------------------------------------------------------------------------------ */
+/* 'b c h w -> (b gy gx) (c ph pw)' gather of Conv2d(k=s=p) as a GEMM operand (layers.py:168-171,178);
+ * also maps an image-layout gradient to the patch layout (same permutation). */
+int enh_patchify(const float* img, int B, int C, int H, int W, int p, enh_bf16* patches, void* stream);
+/* Inverse scatter of ConvTranspose2d(k=s=p) (layers.py:202-205,212) fused with the pixel losses
+ * (vqperceptual.py:113-114): pix [M, C*p*p] f32 (to_pixel GEMM output incl. bias) -> xrec [B,C,H,W] f32;
+ * if target != NULL: sums[0] += sum|xrec-x|, sums[1] += sum (xrec-x)^2 (f64 atomics; caller zeroes) and
+ * dpix_bf16 [M, C*p*p] = (w_l1*sign(diff) + w_l2*2*diff) / numel  (grad of w_l1*L1 + w_l2*L2), optional. */
+int enh_unpatchify_loss(const float* pix, const float* target, int B, int C, int H, int W, int p, float w_l1,
+                        float w_l2, float* xrec, double* sums, enh_bf16* dpix_bf16, void* stream);
+/* out[n] (+)= sum_m x[m,n] (bias gradients); x bf16 [M,N] */
+int enh_colsum_bf16(const enh_bf16* x, int64_t M, int64_t N, int64_t ldx, float* out, int accumulate, void* stream);
+/* f32 -> bf16 cast (weight shadows) */
+int enh_cast_f32_bf16(const float* x, enh_bf16* y, int64_t n, void* stream);
+/* torch.optim.AdamW(lr, betas=(0.9,0.99), weight_decay=1e-4) step over one flat buffer (vitvqgan.py:160),
+ * also refreshes the bf16 shadow used by the GEMMs.  grad_scale multiplies g first (DDP mean / accumulation). */
+int enh_adamw_step(float* p, const float* g, float* m, float* v, enh_bf16* p_bf16, int64_t n, int step, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ENH_HIP_H */

@@ -1,0 +1,311 @@
+"""Op-level parity tests of the HIP kernels (through the C ABI via ctypes) against the CPU oracle.
+
+Tolerances (relative Frobenius error vs the fp32 oracle fed the SAME bf16-representable operands):
+  * integer outputs (code indices): bit-exact;
+  * fp32-output kernels: <= 1e-4 (observed ~1e-6: only the fp32 summation order differs);
+  * bf16-output kernels: <= 2.5e-3 — the storage dtype's own quantisation floor is 2^-9/sqrt(3) = 1.13e-3;
+  * fused attention (probabilities rounded to bf16 before P.V, bf16 output): <= 5e-3.
+"""
+import numpy as np
+import pytest
+import torch
+
+from util import bf16r, rel
+
+pytestmark = pytest.mark.gpu
+
+F32_TOL, BF16_TOL, ATT_TOL = 1e-4, 2.5e-3, 5e-3
+
+
+@pytest.fixture(scope="module")
+def C():
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    from enhancing import _C
+    _C.lib()  # fail loudly if the HIP extension is missing
+    return _C
+
+
+# ---------------------------------------------------------------------------------------------
+# quantizer
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,K,depth", [(1000, 8192, 1), (777, 500, 1), (640, 8192, 4), (96, 1024, 2)])
+def test_vq_forward_bit_exact_vs_c_oracle(C, M, K, depth):
+    import vitvq_oracle as O
+    import vq_oracle as VC
+    z, E, _ = O.make_vq_inputs(100 + M, M, K)
+    zq_c, idx_c, loss_c = VC.forward(z.numpy(), E.numpy(), 0.25, depth)
+    zq, zq16, idx, loss = C.vq_forward(z.cuda(), E.cuda(), 0.25, depth, True)
+    assert torch.equal(idx.cpu(), torch.from_numpy(idx_c)), "code indices must be bit-exact"
+    assert np.array_equal(zq.cpu().numpy().view(np.uint32), zq_c.view(np.uint32)), "z_q must be bit-exact"
+    assert abs(loss.item() - float(loss_c)) <= 1e-6 * abs(float(loss_c))
+    assert torch.equal(zq16.cpu(), zq.cpu().to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("name", ["vq_k8192_m4096", "vq_k512_m1024", "rq4_k8192_m2048"])
+def test_vq_forward_golden_reference(C, golden_dir, name):
+    """indices / loss / z_q against vectors produced by the REFERENCE's VectorQuantizer (oracle/make_golden.py)."""
+    import vitvq_oracle as O
+    g = np.load(f"{golden_dir}/{name}.npz")
+    M, K, depth = int(g["M"]), int(g["K"]), max(int(g["num_quantizers"]), 1)
+    z, E, _ = O.make_vq_inputs(int(g["seed"]), M, K)
+    zq, _, idx, loss = C.vq_forward(z.cuda(), E.cuda(), float(g["beta"]), depth, True)
+    assert np.array_equal(idx.cpu().numpy(), g["idx"].astype(np.int64).reshape(M, depth)), "indices differ from the reference"
+    assert abs(loss.item() - float(g["loss"])) <= 2e-6 * abs(float(g["loss"]))
+    assert np.abs(zq.cpu().numpy()[:64] - g["zq_first"].reshape(64, 32)).max() <= 5e-7
+    assert abs(zq.double().sum().item() - float(g["zq_sum"])) <= 1e-3
+
+
+@pytest.mark.parametrize("M,K,depth,resid", [(1024, 1024, 1, False), (512, 2048, 4, True), (256, 512, 1, True)])
+def test_vq_backward_vs_autograd(C, M, K, depth, resid):
+    import vitvq_oracle as O
+    z, E, g = O.make_vq_inputs(7 + depth, M, K)
+    zt = z.clone().requires_grad_(True)
+    Et = E.clone().requires_grad_(True)
+    zq, loss, idx = O.quantizer_forward(zt, Et, 0.25, True, resid, depth if resid else None)
+    gl = 0.7
+    ((zq * g).sum() + gl * loss).backward()
+    dE = torch.zeros(K, 32, device="cuda")
+    idx_d = idx.view(M, -1).cuda()
+    dz, dz16 = C.vq_backward(z.cuda(), E.cuda(), idx_d, g.cuda(), gl, None, 0.25, depth, resid, True, dE)
+    assert rel(dz, zt.grad) <= F32_TOL
+    assert rel(dE, Et.grad) <= F32_TOL
+    assert rel(dz16.float(), zt.grad) <= BF16_TOL
+
+
+def test_vq_full_size_match_rate(C):
+    """BASELINE config-2 op vectors: M = 131072 tokens, K = 8192.  HIP == C oracle bit-exact; vs the plain
+    PyTorch oracle every mismatch (if any) must be an fp32 near-tie (top-2 gap < 1e-6)."""
+    import vitvq_oracle as O
+    import vq_oracle as VC
+    M, K = 131072, 8192
+    z, E, _ = O.make_vq_inputs(1234, M, K)
+    zq, _, idx, loss = C.vq_forward(z.cuda(), E.cuda(), 0.25, 1, True)
+    idx = idx.cpu().view(-1)
+    _, idx_c, _ = VC.forward(z.numpy(), E.numpy(), 0.25, 1)
+    assert torch.equal(idx, torch.from_numpy(idx_c).view(-1))
+    # plain-PyTorch oracle (the reference's formula) in chunks
+    mism = 0
+    torch.set_num_threads(max(torch.get_num_threads(), 8))
+    for s in range(0, M, 16384):
+        zz = z[s:s + 16384]
+        _, _, it = O.vq_quantize(zz, E)
+        bad = (it != idx[s:s + 16384]).nonzero().view(-1)
+        for j in bad.tolist():
+            zn = torch.nn.functional.normalize(zz[j:j + 1].double(), dim=-1)
+            en = torch.nn.functional.normalize(E.double(), dim=-1)
+            d = ((zn ** 2).sum(1, keepdim=True) + (en ** 2).sum(1) - 2 * zn @ en.t()).view(-1)
+            gap = (d[it[j]] - d[idx[s + j]]).abs().item()
+            assert gap < 1e-6, f"token {s + j}: indices {it[j].item()} vs {idx[s + j].item()} differ with gap {gap}"
+        mism += len(bad)
+    rate = 1.0 - mism / M
+    print(f"VQ argmin match-rate vs PyTorch oracle: {rate:.8f} ({mism} near-tie mismatches of {M})")
+    assert rate >= 0.9999
+
+
+def test_vq_lookup(C):
+    import vitvq_oracle as O
+    _, E, _ = O.make_vq_inputs(3, 64, 1024)
+    idx = torch.randint(0, 1024, (300, 4), generator=torch.Generator().manual_seed(0))
+    ref = O.l2norm(torch.nn.functional.embedding(idx, E)).sum(-2)
+    out, out16 = C.vq_lookup(E.cuda(), idx.cuda(), True)
+    assert rel(out, ref) <= 1e-6
+
+
+# ---------------------------------------------------------------------------------------------
+# layernorm
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,D", [(1027, 768), (64, 128), (300, 512), (130, 1280), (33, 2048)])
+def test_layernorm_fwd_bwd(C, M, D):
+    g = torch.Generator().manual_seed(M + D)
+    x = torch.randn(M, D, generator=g) * 2 + 0.5
+    w = 1 + 0.1 * torch.randn(D, generator=g)
+    b = 0.1 * torch.randn(D, generator=g)
+    dy = torch.randn(M, D, generator=g)
+    dres = torch.randn(M, D, generator=g)
+    xt, wt, bt = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = torch.nn.functional.layer_norm(xt, (D,), wt, bt, 1e-5)
+    y.backward(dy)
+    xd = x.cuda()
+    y16 = torch.empty(M, D, dtype=torch.bfloat16, device="cuda")
+    y32 = torch.empty(M, D, device="cuda")
+    mean = torch.empty(M, device="cuda"); rstd = torch.empty(M, device="cuda")
+    C.layernorm_forward(xd, w.cuda(), b.cuda(), 1e-5, y16, y32, mean, rstd)
+    assert rel(y32, y) <= F32_TOL
+    assert rel(y16.float(), y) <= BF16_TOL
+    dx = torch.empty(M, D, device="cuda"); dx16 = torch.empty(M, D, dtype=torch.bfloat16, device="cuda")
+    dw = torch.zeros(D, device="cuda"); db = torch.zeros(D, device="cuda")
+    C.layernorm_backward(dy.cuda(), xd, w.cuda(), mean, rstd, dres.cuda(), dx, dx16, dw, db)
+    assert rel(dx, xt.grad + dres) <= F32_TOL
+    assert rel(dw, wt.grad) <= F32_TOL and rel(db, bt.grad) <= F32_TOL
+    assert rel(dx16.float(), xt.grad + dres) <= BF16_TOL
+
+
+# ---------------------------------------------------------------------------------------------
+# GEMM
+# ---------------------------------------------------------------------------------------------
+def _mk(shape, g, scale=1.0):
+    return bf16r(torch.randn(*shape, generator=g) * scale)
+
+
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (1000, 192, 768), (136, 32, 64), (384, 768, 3072), (128, 2304, 32)])
+def test_gemm_layouts(C, ta, tb, M, N, K):
+    if ta and M % 8:
+        pytest.skip("trans_a needs M % 8 == 0")
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = _mk((M, K), g)
+    B = _mk((N, K), g)
+    ref = A.double() @ B.double().t()
+    a = (A.t().contiguous() if ta else A).to(torch.bfloat16).cuda()
+    b = (B.t().contiguous() if tb else B).to(torch.bfloat16).cuda()
+    out = torch.full((M, N), float("nan"), device="cuda")
+    out16 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    C.gemm(a, b, M, N, K, trans_a=ta, trans_b=tb, out_f32=out, out_bf16=out16)
+    assert rel(out, ref) <= F32_TOL, f"ta={ta} tb={tb}"
+    assert rel(out16.float(), ref) <= BF16_TOL
+
+
+def test_gemm_epilogues(C):
+    g = torch.Generator().manual_seed(5)
+    M, N, K, T = 512, 384, 256, 128
+    A, B = _mk((M, K), g, 0.5), _mk((N, K), g, 0.1)
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    pos = torch.randn(T, N, generator=g)
+    a, b = A.to(torch.bfloat16).cuda(), B.to(torch.bfloat16).cuda()
+    base = A.double() @ B.double().t()
+    # bias + tanh -> bf16
+    o16 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    C.gemm(a, b, M, N, K, bias=bias.cuda(), act=C.ACT_TANH, out_bf16=o16)
+    assert rel(o16.float(), torch.tanh(base + bias.double())) <= BF16_TOL
+    # bias + residual (in place on the residual stream)
+    x = res.clone().cuda()
+    C.gemm(a, b, M, N, K, bias=bias.cuda(), res=x, res_rows=M, out_f32=x)
+    assert rel(x, base + bias.double() + res.double()) <= F32_TOL
+    # bias + position table (row index modulo T)
+    o = torch.empty(M, N, device="cuda")
+    C.gemm(a, b, M, N, K, bias=bias.cuda(), res=pos.cuda(), res_rows=T, out_f32=o)
+    assert rel(o, base + bias.double() + pos.double().repeat(M // T, 1)) <= F32_TOL
+    # tanh backward: v * (1 - h^2)
+    h = bf16r(torch.tanh(torch.randn(M, N, generator=g)))
+    C.gemm(a, b, M, N, K, act=C.ACT_DTANH, aux=h.to(torch.bfloat16).cuda(), out_bf16=o16)
+    assert rel(o16.float(), base * (1 - h.double() ** 2)) <= BF16_TOL
+    # accumulate
+    o = res.clone().cuda()
+    C.gemm(a, b, M, N, K, accumulate=True, out_f32=o)
+    assert rel(o, base + res.double()) <= F32_TOL
+
+
+def test_gemm_wgrad_splitk(C):
+    """dW[N_out, K_in] += dY^T X over many tokens: the split-K (f32 atomics) path."""
+    g = torch.Generator().manual_seed(9)
+    tokens, n_out, k_in = 8192, 256, 192
+    dY, X = _mk((tokens, n_out), g, 0.1), _mk((tokens, k_in), g)
+    ref = dY.double().t() @ X.double()
+    dW = torch.zeros(n_out, k_in, device="cuda")
+    C.gemm(dY.to(torch.bfloat16).cuda(), X.to(torch.bfloat16).cuda(), n_out, k_in, tokens, trans_a=True, trans_b=True, accumulate=True, out_f32=dW)
+    assert rel(dW, ref) <= F32_TOL
+    C.gemm(dY.to(torch.bfloat16).cuda(), X.to(torch.bfloat16).cuda(), n_out, k_in, tokens, trans_a=True, trans_b=True, accumulate=True, out_f32=dW)
+    assert rel(dW, 2 * ref) <= F32_TOL
+
+
+def test_gemm_rejects_bad_shapes(C):
+    a = torch.zeros(8, 12, dtype=torch.bfloat16, device="cuda")
+    o = torch.zeros(8, 8, device="cuda")
+    with pytest.raises(RuntimeError):
+        C.gemm(a, a, 8, 8, 12, out_f32=o)  # K % 8 != 0
+    with pytest.raises(RuntimeError):
+        C.gemm(a.cpu(), a, 8, 8, 8, out_f32=o)  # host tensor: no CPU fallback
+
+
+# ---------------------------------------------------------------------------------------------
+# attention
+# ---------------------------------------------------------------------------------------------
+def _attn_ref(qkv, B, N, H, scale):
+    q, k, v = qkv.double().view(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    s = (q @ k.transpose(-1, -2)) * scale
+    p = torch.softmax(s, dim=-1)
+    return (p @ v).permute(0, 2, 1, 3).reshape(B, N, H * 64), torch.logsumexp(s, dim=-1)
+
+
+@pytest.mark.parametrize("B,N,H", [(2, 1024, 3), (3, 64, 2), (1, 256, 12), (2, 192, 1)])
+def test_attention_forward_backward(C, B, N, H):
+    g = torch.Generator().manual_seed(B * 100 + N + H)
+    qkv = bf16r(torch.randn(B, N, 3 * H * 64, generator=g) * 1.5)
+    do = bf16r(torch.randn(B, N, H * 64, generator=g))
+    scale = 64 ** -0.5
+    qt = qkv.clone().requires_grad_(True)
+    ref, lse_ref = _attn_ref(qt, B, N, H, scale)
+    ref.backward(do.double())
+    qd = qkv.to(torch.bfloat16).cuda()
+    out = torch.empty(B, N, H * 64, dtype=torch.bfloat16, device="cuda")
+    lse = torch.empty(B, H, N, device="cuda")
+    C.attention_forward(qd, B, N, H, scale, out, lse)
+    assert rel(out.float(), ref) <= ATT_TOL
+    assert rel(lse, lse_ref) <= 1e-5
+    dqkv = torch.full((B, N, 3 * H * 64), float("nan"), dtype=torch.bfloat16, device="cuda")
+    delta = torch.empty(B, H, N, device="cuda")
+    C.attention_backward(qd, out, do.to(torch.bfloat16).cuda(), lse, B, N, H, scale, dqkv, delta)
+    gq, gk, gv = qt.grad.view(B, N, 3, H * 64).unbind(2)
+    dq, dk, dv = dqkv.float().view(B, N, 3, H * 64).unbind(2)
+    assert rel(dq, gq) <= 2 * ATT_TOL and rel(dk, gk) <= 2 * ATT_TOL and rel(dv, gv) <= 2 * ATT_TOL, (rel(dq, gq), rel(dk, gk), rel(dv, gv))
+
+
+def test_attention_spiked_scores(C):
+    """one key dominating a row (forces the running max to jump mid-sweep): online-softmax rescale path."""
+    B, N, H = 1, 512, 2
+    g = torch.Generator().manual_seed(0)
+    qkv = torch.randn(B, N, 3 * H * 64, generator=g)
+    qkv[0, 5, :64] *= 6.0
+    qkv[0, 300, H * 64:H * 64 + 64] = qkv[0, 5, :64] * 1.5   # key 300 of head 0 aligned with query 5
+    qkv = bf16r(qkv)
+    ref, _ = _attn_ref(qkv, B, N, H, 0.125)
+    out = torch.empty(B, N, H * 64, dtype=torch.bfloat16, device="cuda")
+    lse = torch.empty(B, H, N, device="cuda")
+    C.attention_forward(qkv.to(torch.bfloat16).cuda(), B, N, H, 0.125, out, lse)
+    assert torch.isfinite(out.float()).all()
+    assert rel(out.float(), ref) <= ATT_TOL
+
+
+# ---------------------------------------------------------------------------------------------
+# data movement, loss, reductions, optimizer
+# ---------------------------------------------------------------------------------------------
+def test_patchify_unpatchify_loss(C):
+    import vitvq_oracle as O
+    B, Cc, S, p = 3, 3, 64, 8
+    g = torch.Generator().manual_seed(1)
+    img = torch.rand(B, Cc, S, S, generator=g)
+    out = torch.empty(B * (S // p) ** 2, Cc * p * p, dtype=torch.bfloat16, device="cuda")
+    C.patchify(img.cuda(), p, out)
+    assert torch.equal(out.cpu(), O.patchify(img, p).reshape(-1, Cc * p * p).to(torch.bfloat16))
+    pix = torch.randn(B * (S // p) ** 2, Cc * p * p, generator=g)
+    xrec = torch.empty(B, Cc, S, S, device="cuda")
+    sums = torch.zeros(2, dtype=torch.float64, device="cuda")
+    dpix = torch.empty_like(out)
+    C.unpatchify_loss(pix.cuda(), img.cuda(), B, Cc, S, S, p, 0.3, 1.0, xrec, sums, dpix)
+    ref = O.unpatchify(pix.view(B, -1, Cc * p * p), p, Cc, S, S)
+    assert torch.equal(xrec.cpu(), ref)
+    d = (ref - img).double()
+    assert abs(sums[0].item() - d.abs().sum().item()) <= 1e-6 * d.abs().sum().item()
+    assert abs(sums[1].item() - (d ** 2).sum().item()) <= 1e-6 * (d ** 2).sum().item()
+    gref = O.patchify(((0.3 * torch.sign(d) + 2.0 * d) / d.numel()).float(), p).reshape(-1, Cc * p * p)
+    assert rel(dpix.float(), gref) <= BF16_TOL
+
+
+def test_colsum_cast_adamw(C):
+    import vitvq_oracle as O
+    g = torch.Generator().manual_seed(2)
+    x = bf16r(torch.randn(5000, 192, generator=g))
+    out = torch.empty(192, device="cuda")
+    C.colsum(x.to(torch.bfloat16).cuda(), 5000, 192, out)
+    assert rel(out, x.double().sum(0)) <= F32_TOL
+    n = 100003
+    p, gr = torch.randn(n, generator=g), torch.randn(n, generator=g) * 0.01
+    m, v = torch.zeros(n), torch.zeros(n)
+    pd, gd, md, vd = p.cuda(), gr.cuda(), m.cuda(), v.cuda()
+    p16 = torch.empty(n, dtype=torch.bfloat16, device="cuda")
+    for step in (1, 2, 3):
+        O.adamw_step(p, gr, m, v, step, 4.5e-6)
+        C.adamw_step(pd, gd, md, vd, p16, step, 4.5e-6)
+    assert rel(pd, p) <= 1e-6 and rel(md, m) <= 1e-5 and rel(vd, v) <= 1e-5
+    assert torch.equal(p16.cpu(), pd.cpu().to(torch.bfloat16))

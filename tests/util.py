@@ -1,0 +1,14 @@
+import torch
+
+
+def rel(a: torch.Tensor, b: torch.Tensor) -> float:
+    """relative Frobenius error ||a-b|| / ||b|| in float64 (the parity metric of SURVEY.md §8d)."""
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-300)).item()
+
+
+def bf16r(x: torch.Tensor) -> torch.Tensor:
+    """round to bf16 and back: test inputs are made bf16-representable so that the fp32 oracle and the bf16
+    MFMA path consume IDENTICAL operand values."""
+    return x.to(torch.bfloat16).to(torch.float32)
