@@ -1,0 +1,53 @@
+"""Data module with the reference's contract (reference enhancing/dataloader/__init__.py:14-53):
+``DataModuleFromConfig(batch_size, train=None, validation=None, test=None, num_workers=None)`` whose loaders
+yield ``{'image': FloatTensor[B,3,H,W] in [0,1], 'class': LongTensor[B,1]}`` (imagenet.py:23,31-36)."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch.utils.data import DataLoader, Dataset
+
+from ..utils.general import initialize_from_config
+
+
+class DataModuleFromConfig:
+    def __init__(self, batch_size: int, train=None, validation=None, test=None, num_workers: Optional[int] = None):
+        self.batch_size = batch_size
+        self.dataset_configs = dict()
+        self.num_workers = num_workers if num_workers is not None else batch_size * 2
+        if train is not None:
+            self.dataset_configs["train"] = train
+        if validation is not None:
+            self.dataset_configs["validation"] = validation
+        if test is not None:
+            self.dataset_configs["test"] = test
+        self.datasets = None
+        self.rank, self.world = 0, 1
+
+    def prepare_data(self):
+        for cfg in self.dataset_configs.values():
+            initialize_from_config(cfg)
+
+    def setup(self, stage=None, rank: int = 0, world: int = 1):
+        self.rank, self.world = rank, world
+        self.datasets = {k: initialize_from_config(c) for k, c in self.dataset_configs.items()}
+        for d in self.datasets.values():
+            if hasattr(d, "set_shard"):
+                d.set_shard(rank, world)
+
+    def _loader(self, key: str, shuffle: bool) -> DataLoader:
+        if self.datasets is None:
+            self.setup()
+        ds = self.datasets[key]
+        workers = 0 if getattr(ds, "in_process", False) else self.num_workers
+        return DataLoader(ds, batch_size=self.batch_size, num_workers=workers, shuffle=shuffle and not getattr(ds, "in_process", False))
+
+    def train_dataloader(self):
+        return self._loader("train", True)
+
+    def val_dataloader(self):
+        return self._loader("validation", False)
+
+    def test_dataloader(self):
+        return self._loader("test", False)

@@ -1,0 +1,27 @@
+"""Optimizer facade over the engine's flat buffers (what ``ViTVQ.configure_optimizers`` returns in place of
+``torch.optim.AdamW``, reference vitvqgan.py:160)."""
+from __future__ import annotations
+
+
+class FusedAdamW:
+    def __init__(self, engine, lr: float, betas=(0.9, 0.99), eps: float = 1e-8, weight_decay: float = 1e-4) -> None:
+        self.engine = engine
+        self.param_groups = [dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)]
+        self.grad_scale = 1.0  # 1 / accumulate_grad_batches
+
+    def zero_grad(self, set_to_none: bool = False) -> None:
+        self.engine.store.zero_grad()
+
+    def step(self) -> None:
+        g = self.param_groups[0]
+        self.engine.optimizer_step(g["lr"], g["betas"], g["eps"], g["weight_decay"], self.grad_scale)
+
+    def state_dict(self) -> dict:
+        s = self.engine.store
+        return dict(step=s.step_count, m=s.m.detach().cpu(), v=s.v.detach().cpu(), param_groups=self.param_groups)
+
+    def load_state_dict(self, sd: dict) -> None:
+        s = self.engine.store
+        s.step_count = int(sd["step"])
+        s.m.copy_(sd["m"]); s.v.copy_(sd["v"])
+        self.param_groups = sd["param_groups"]

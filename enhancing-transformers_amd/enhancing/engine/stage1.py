@@ -1,0 +1,371 @@
+"""Static HIP schedule of the stage-1 tokenizer: ViT encoder -> pre_quant -> VQ/RQ -> post_quant -> ViT decoder ->
+pixel + codebook loss -> backward -> AdamW, for one process = one MI355X.
+
+This replaces what the reference gets from ``pl.Trainer.fit`` + autograd over stock PyTorch ops
+(reference main.py:51-61, vitvqgan.py:44-72,101-115,152-160): the forward and the hand-derived backward are
+explicit sequences of C-ABI kernel launches (``enhancing._C``) on the current HIP stream, over
+
+  * ONE flat fp32 parameter buffer (+ flat grad, Adam m / v, bf16 shadow) that the ``nn.Parameter``s of the
+    module tree are views of — so ``state_dict`` / ``load_state_dict`` / checkpoints keep the reference's keys,
+    AdamW is a single launch and DDP all-reduces contiguous slices;
+  * a per-batch-size activation arena allocated once (the residual stream and LayerNorm statistics stay fp32,
+    GEMM operands are bf16, attention saves only the row log-sum-exp).
+
+PyTorch is used for device memory, streams and ``torch.distributed`` only.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from .. import _C
+
+F32, BF16 = torch.float32, torch.bfloat16
+_ALIGN = 64  # elements; keeps every parameter view 16-byte aligned in both the fp32 and the bf16 buffer
+
+
+class ParamStore:
+    """Flattens the trainable parameters of a module tree into contiguous device buffers."""
+
+    def __init__(self, module: nn.Module, device: torch.device) -> None:
+        self.device = device
+        self.names: List[str] = []
+        self.offsets: Dict[str, Tuple[int, int, torch.Size]] = {}
+        params = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
+        total = 0
+        for n, p in params:
+            self.names.append(n)
+            self.offsets[n] = (total, p.numel(), p.shape)
+            total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.numel = total
+        self.p = torch.zeros(total, dtype=F32, device=device)
+        self.g = torch.zeros(total, dtype=F32, device=device)
+        self.m = torch.zeros(total, dtype=F32, device=device)
+        self.v = torch.zeros(total, dtype=F32, device=device)
+        self.p16 = torch.zeros(total, dtype=BF16, device=device)
+        self.w: Dict[str, torch.Tensor] = {}
+        self.w16: Dict[str, torch.Tensor] = {}
+        self.grad: Dict[str, torch.Tensor] = {}
+        for n, p in params:
+            off, cnt, shp = self.offsets[n]
+            view = self.p[off:off + cnt].view(shp)
+            view.copy_(p.data.to(device=device, dtype=F32))
+            p.data = view                      # the nn.Parameter now aliases the flat buffer
+            p.grad = self.g[off:off + cnt].view(shp)
+            self.w[n], self.w16[n], self.grad[n] = view, self.p16[off:off + cnt].view(shp), p.grad
+        # frozen tensors (position tables) just move to the device
+        for n, p in module.named_parameters():
+            if not p.requires_grad:
+                p.data = p.data.to(device=device, dtype=F32).contiguous()
+                self.w[n] = p.data
+        self.step_count = 0
+        self.refresh_shadows()
+
+    def refresh_shadows(self) -> None:
+        _C.cast_bf16(self.p, self.p16)
+
+    def zero_grad(self) -> None:
+        self.g.zero_()
+
+    def slice_of(self, prefix: str) -> Tuple[int, int]:
+        """[begin, end) range of the flat buffers covered by parameters whose name starts with prefix."""
+        offs = [self.offsets[n] for n in self.names if n.startswith(prefix)]
+        begin = min(o for o, _, _ in offs)
+        end = max((o + c + _ALIGN - 1) // _ALIGN * _ALIGN for o, c, _ in offs)
+        return begin, end
+
+
+class _Tower:
+    """One pre-norm transformer stack (reference layers.py:135-150) as a static kernel schedule."""
+
+    def __init__(self, store: ParamStore, prefix: str, dim: int, depth: int, heads: int, mlp: int, n_tok: int) -> None:
+        self.s, self.prefix = store, prefix
+        self.dim, self.depth, self.heads, self.mlp, self.n_tok = dim, depth, heads, mlp, n_tok
+        self.inner = heads * 64
+        self.scale = 64 ** -0.5
+        self._bufs: Dict[Tuple[int, bool], dict] = {}
+        t = prefix + "transformer."
+        self.L = []
+        for i in range(depth):
+            q = f"{t}layers.{i}."
+            self.L.append(dict(
+                ln1_w=q + "0.norm.weight", ln1_b=q + "0.norm.bias", wqkv=q + "0.fn.to_qkv.weight",
+                wout=q + "0.fn.to_out.weight", bout=q + "0.fn.to_out.bias",
+                ln2_w=q + "1.norm.weight", ln2_b=q + "1.norm.bias", w1=q + "1.fn.net.0.weight", b1=q + "1.fn.net.0.bias",
+                w2=q + "1.fn.net.2.weight", b2=q + "1.fn.net.2.bias"))
+        self.lnf_w, self.lnf_b = t + "norm.weight", t + "norm.bias"
+
+    # ---- activation arena --------------------------------------------------------------------
+    def bufs(self, B: int, save: bool) -> dict:
+        key = (B, save)
+        if key in self._bufs:
+            return self._bufs[key]
+        dev, M, H, N = self.s.device, B * self.n_tok, self.heads, self.n_tok
+        e = lambda *shape, dt=F32: torch.empty(*shape, dtype=dt, device=dev)
+        n_layer_sets = self.depth if save else 1
+        layers = []
+        for _ in range(n_layer_sets):
+            layers.append(dict(a1=e(M, self.dim, dt=BF16), qkv=e(M, 3 * self.inner, dt=BF16), o=e(M, self.inner, dt=BF16),
+                               lse=e(B, H, N), x_mid=e(M, self.dim), a2=e(M, self.dim, dt=BF16), hid=e(M, self.mlp, dt=BF16),
+                               mean1=e(M), rstd1=e(M), mean2=e(M), rstd2=e(M)))
+        b = dict(layers=layers, x=[e(M, self.dim) for _ in range(self.depth + 1 if save else 2)],
+                 xf16=e(M, self.dim, dt=BF16), xf32=e(M, self.dim), meanf=e(M), rstdf=e(M))
+        if save:  # backward scratch, shared by all layers
+            b.update(gA=e(M, self.dim), gA16=e(M, self.dim, dt=BF16), gB=e(M, self.dim), gB16=e(M, self.dim, dt=BF16),
+                     dA=e(M, self.dim), dhid16=e(M, self.mlp, dt=BF16), do16=e(M, self.inner, dt=BF16),
+                     dqkv16=e(M, 3 * self.inner, dt=BF16), delta=e(B, H, N))
+        self._bufs[key] = b
+        return b
+
+    def input_buffer(self, B: int, save: bool) -> torch.Tensor:
+        return self.bufs(B, save)["x"][0]
+
+    # ---- forward -----------------------------------------------------------------------------
+    def forward(self, B: int, save: bool, want_f32: bool = False) -> dict:
+        """x[0] must already hold the tower input.  Returns the buffer dict; output = b['xf16'] (+ b['xf32'])."""
+        s, b = self.s, self.bufs(B, save)
+        M, dim, inner, mlp = B * self.n_tok, self.dim, self.inner, self.mlp
+        x = b["x"][0]
+        for i, P in enumerate(self.L):
+            A = b["layers"][i if save else 0]
+            _C.layernorm_forward(x, s.w[P["ln1_w"]], s.w[P["ln1_b"]], 1e-5, A["a1"], None, A["mean1"], A["rstd1"])
+            _C.gemm(A["a1"], s.w16[P["wqkv"]], M, 3 * inner, dim, out_bf16=A["qkv"])
+            _C.attention_forward(A["qkv"], B, self.n_tok, self.heads, self.scale, A["o"], A["lse"])
+            _C.gemm(A["o"], s.w16[P["wout"]], M, dim, inner, bias=s.w[P["bout"]], res=x, res_rows=M, out_f32=A["x_mid"])
+            _C.layernorm_forward(A["x_mid"], s.w[P["ln2_w"]], s.w[P["ln2_b"]], 1e-5, A["a2"], None, A["mean2"], A["rstd2"])
+            _C.gemm(A["a2"], s.w16[P["w1"]], M, mlp, dim, bias=s.w[P["b1"]], act=_C.ACT_TANH, out_bf16=A["hid"])
+            x_next = b["x"][i + 1] if save else b["x"][(i + 1) & 1]
+            _C.gemm(A["hid"], s.w16[P["w2"]], M, dim, mlp, bias=s.w[P["b2"]], res=A["x_mid"], res_rows=M, out_f32=x_next)
+            x = x_next
+        b["x_last"] = x
+        _C.layernorm_forward(x, s.w[self.lnf_w], s.w[self.lnf_b], 1e-5, b["xf16"], b["xf32"] if want_f32 else None,
+                             b["meanf"], b["rstdf"])
+        return b
+
+    # ---- backward ----------------------------------------------------------------------------
+    def backward(self, B: int, d_xf: torch.Tensor, on_layer_done=None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """d_xf: grad wrt the final-LayerNorm output, f32 [M, dim].  Accumulates parameter grads; returns the grad
+        wrt the tower input as (f32, bf16)."""
+        s, b = self.s, self.bufs(B, True)
+        M, dim, inner, mlp = B * self.n_tok, self.dim, self.inner, self.mlp
+        g = s.grad
+        gA, gA16, gB, gB16, dA = b["gA"], b["gA16"], b["gB"], b["gB16"], b["dA"]
+        _C.layernorm_backward(d_xf, b["x"][self.depth], s.w[self.lnf_w], b["meanf"], b["rstdf"], None, gA, gA16,
+                              g[self.lnf_w], g[self.lnf_b])
+        for i in range(self.depth - 1, -1, -1):
+            P, A = self.L[i], b["layers"][i]
+            # ---- MLP: x_out = fc2(tanh(fc1(a2))) + x_mid ----
+            _C.gemm(gA16, A["hid"], dim, mlp, M, trans_a=True, trans_b=True, accumulate=True, out_f32=g[P["w2"]])
+            _C.colsum(gA16, M, dim, g[P["b2"]], accumulate=True)
+            _C.gemm(gA16, s.w16[P["w2"]], M, mlp, dim, trans_b=True, act=_C.ACT_DTANH, aux=A["hid"], out_bf16=b["dhid16"])
+            _C.gemm(b["dhid16"], A["a2"], mlp, dim, M, trans_a=True, trans_b=True, accumulate=True, out_f32=g[P["w1"]])
+            _C.colsum(b["dhid16"], M, mlp, g[P["b1"]], accumulate=True)
+            _C.gemm(b["dhid16"], s.w16[P["w1"]], M, dim, mlp, trans_b=True, out_f32=dA)
+            _C.layernorm_backward(dA, A["x_mid"], s.w[P["ln2_w"]], A["mean2"], A["rstd2"], gA, gB, gB16, g[P["ln2_w"]], g[P["ln2_b"]])
+            # ---- attention: x_mid = to_out(attn(to_qkv(a1))) + x_in ----
+            _C.gemm(gB16, A["o"], dim, inner, M, trans_a=True, trans_b=True, accumulate=True, out_f32=g[P["wout"]])
+            _C.colsum(gB16, M, dim, g[P["bout"]], accumulate=True)
+            _C.gemm(gB16, s.w16[P["wout"]], M, inner, dim, trans_b=True, out_bf16=b["do16"])
+            _C.attention_backward(A["qkv"], A["o"], b["do16"], A["lse"], B, self.n_tok, self.heads, self.scale, b["dqkv16"], b["delta"])
+            _C.gemm(b["dqkv16"], A["a1"], 3 * inner, dim, M, trans_a=True, trans_b=True, accumulate=True, out_f32=g[P["wqkv"]])
+            _C.gemm(b["dqkv16"], s.w16[P["wqkv"]], M, dim, 3 * inner, trans_b=True, out_f32=dA)
+            _C.layernorm_backward(dA, b["x"][i], s.w[P["ln1_w"]], A["mean1"], A["rstd1"], gB, gA, gA16, g[P["ln1_w"]], g[P["ln1_b"]])
+            if on_layer_done is not None:
+                on_layer_done(f"{self.prefix}transformer.layers.{i}.")
+        return gA, gA16
+
+
+class Stage1Engine:
+    """Binds a ``ViTVQ`` module tree to the HIP schedule on one device."""
+
+    def __init__(self, model: nn.Module, device: Optional[torch.device] = None) -> None:
+        if not torch.cuda.is_available():
+            raise RuntimeError("Stage1Engine needs a ROCm device (MI355X); the HIP path has no CPU fallback")
+        _C.lib()
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.model = model
+        enc, dec, q = model.encoder, model.decoder, model.quantizer
+        self.store = ParamStore(model, self.device)
+        self.patch, self.size, self.C = enc.patch_size[0], enc.image_size[0], enc.channels
+        self.n_tok = enc.num_patches
+        self.pd = enc.patch_dim
+        self.enc = _Tower(self.store, "encoder.", enc.dim, enc.transformer.depth, enc.transformer.heads, enc.transformer.mlp_dim, self.n_tok)
+        self.dec = _Tower(self.store, "decoder.", dec.dim, dec.transformer.depth, dec.transformer.heads, dec.transformer.mlp_dim, self.n_tok)
+        self.q = q
+        self.ed = q.embed_dim
+        self._io: Dict[int, dict] = {}
+        enc._engine = dec._engine = self
+        self.world = 1
+        self.comm = None  # enhancing.engine.ddp.GradSync when running data-parallel
+
+    # ---- helpers -----------------------------------------------------------------------------
+    def _io_bufs(self, B: int) -> dict:
+        if B not in self._io:
+            dev, M = self.device, B * self.n_tok
+            e = lambda *shape, dt=F32: torch.empty(*shape, dtype=dt, device=dev)
+            self._io[B] = dict(patches=e(M, self.pd, dt=BF16), h=e(M, self.ed), pix=e(M, self.pd), xrec=e(B, self.C, self.size, self.size),
+                               dpix16=e(M, self.pd, dt=BF16), sums=torch.zeros(2, dtype=torch.float64, device=dev),
+                               d_xf_dec=e(M, self.dec.dim), d_xf_enc=e(M, self.enc.dim), dzq=e(M, self.ed), bias_pix=e(self.pd),
+                               g_bias_pix=e(self.pd))
+        return self._io[B]
+
+    def _check_img(self, img: torch.Tensor) -> torch.Tensor:
+        if img.dim() != 4 or img.shape[1] != self.C or img.shape[2] != self.size or img.shape[3] != self.size:
+            raise RuntimeError(f"expected images [B,{self.C},{self.size},{self.size}], got {tuple(img.shape)}")
+        return img.to(device=self.device, dtype=F32).contiguous()
+
+    # ---- forward pieces ----------------------------------------------------------------------
+    def _encode_tokens(self, img: torch.Tensor, save: bool, want_f32: bool = False) -> dict:
+        """patch-embed GEMM (+bias +pos table) -> encoder tower.  reference layers.py:177-182"""
+        B, s, io = img.shape[0], self.store, self._io_bufs(img.shape[0])
+        M = B * self.n_tok
+        _C.patchify(img, self.patch, io["patches"])
+        w16 = s.w16["encoder.to_patch_embedding.0.weight"].view(self.enc.dim, self.pd)
+        _C.gemm(io["patches"], w16, M, self.enc.dim, self.pd, bias=s.w["encoder.to_patch_embedding.0.bias"],
+                res=s.w["encoder.en_pos_embedding"].view(self.n_tok, self.enc.dim), res_rows=self.n_tok,
+                out_f32=self.enc.input_buffer(B, save))
+        return self.enc.forward(B, save, want_f32)
+
+    def _pre_quant(self, xf16: torch.Tensor, B: int) -> torch.Tensor:
+        s, io = self.store, self._io_bufs(B)
+        _C.gemm(xf16, s.w16["pre_quant.weight"], B * self.n_tok, self.ed, self.enc.dim, bias=s.w["pre_quant.bias"], out_f32=io["h"])
+        return io["h"]
+
+    def _decode_tokens(self, zq16: torch.Tensor, B: int, save: bool) -> torch.Tensor:
+        """post_quant (+bias +pos table) -> decoder tower -> to_pixel GEMM.  reference vitvqgan.py:68-72, layers.py:209-214"""
+        s, io, M = self.store, self._io_bufs(B), B * self.n_tok
+        _C.gemm(zq16, s.w16["post_quant.weight"], M, self.dec.dim, self.ed, bias=s.w["post_quant.bias"],
+                res=s.w["decoder.de_pos_embedding"].view(self.n_tok, self.dec.dim), res_rows=self.n_tok,
+                out_f32=self.dec.input_buffer(B, save))
+        b = self.dec.forward(B, save)
+        pp = self.patch * self.patch
+        io["bias_pix"].view(self.C, pp).copy_(s.w["decoder.to_pixel.1.bias"].view(self.C, 1).expand(self.C, pp))
+        wpix16 = s.w16["decoder.to_pixel.1.weight"].view(self.dec.dim, self.pd)  # stored [K][N]
+        _C.gemm(b["xf16"], wpix16, M, self.pd, self.dec.dim, trans_b=True, bias=io["bias_pix"], out_f32=io["pix"])
+        return io["pix"]
+
+    # ---- inference API (reference vitvqgan.py:44-90) -------------------------------------------
+    @torch.no_grad()
+    def encode_codes(self, img: torch.Tensor) -> torch.Tensor:
+        img = self._check_img(img)
+        B = img.shape[0]
+        b = self._encode_tokens(img, save=False)
+        h = self._pre_quant(b["xf16"], B)
+        _, _, idx, _ = _C.vq_forward(h, self.store.w["quantizer.embedding.weight"], float(self.q.beta), self.q.depth, self.q.use_norm, False)
+        return idx.view(B, self.n_tok, self.q.depth) if self.q.use_residual else idx.view(B, self.n_tok)
+
+    @torch.no_grad()
+    def reconstruct(self, img: torch.Tensor):
+        """forward without saving activations -> (xrec [B,C,H,W] f32, qloss scalar, indices)."""
+        img = self._check_img(img)
+        B, io = img.shape[0], self._io_bufs(img.shape[0])
+        b = self._encode_tokens(img, save=False)
+        h = self._pre_quant(b["xf16"], B)
+        zq, zq16, idx, qloss = _C.vq_forward(h, self.store.w["quantizer.embedding.weight"], float(self.q.beta), self.q.depth, self.q.use_norm)
+        pix = self._decode_tokens(zq16, B, save=False)
+        _C.unpatchify_loss(pix, None, B, self.C, self.size, self.size, self.patch, 0.0, 0.0, io["xrec"], None, None)
+        idx = idx.view(B, self.n_tok, self.q.depth) if self.q.use_residual else idx.view(B, self.n_tok)
+        return io["xrec"].clone(), qloss.view(()).clone(), idx
+
+    @torch.no_grad()
+    def decode_from_quant(self, quant: torch.Tensor) -> torch.Tensor:
+        """decode(quant) for quant [B, N, embed_dim] f32 (reference vitvqgan.py:68-72)."""
+        B = quant.shape[0]
+        io = self._io_bufs(B)
+        zq16 = quant.reshape(B * self.n_tok, self.ed).to(device=self.device, dtype=BF16).contiguous()
+        pix = self._decode_tokens(zq16, B, save=False)
+        _C.unpatchify_loss(pix, None, B, self.C, self.size, self.size, self.patch, 0.0, 0.0, io["xrec"], None, None)
+        return io["xrec"].clone()
+
+    @torch.no_grad()
+    def encoder_forward(self, img: torch.Tensor) -> torch.Tensor:
+        img = self._check_img(img)
+        b = self._encode_tokens(img, save=False, want_f32=True)
+        return b["xf32"].view(img.shape[0], self.n_tok, self.enc.dim).clone()
+
+    @torch.no_grad()
+    def decoder_forward(self, tok: torch.Tensor) -> torch.Tensor:
+        """ViTDecoder.forward(token) for token [B, N, dim] f32 (post_quant output) — reference layers.py:209-214."""
+        B, s, io, M = tok.shape[0], self.store, self._io_bufs(tok.shape[0]), tok.shape[0] * self.n_tok
+        x0 = self.dec.input_buffer(B, False)
+        torch.add(tok.reshape(M, self.dec.dim).to(device=self.device, dtype=F32), s.w["decoder.de_pos_embedding"].view(self.n_tok, self.dec.dim).repeat(B, 1), out=x0)
+        b = self.dec.forward(B, False)
+        pp = self.patch * self.patch
+        io["bias_pix"].view(self.C, pp).copy_(s.w["decoder.to_pixel.1.bias"].view(self.C, 1).expand(self.C, pp))
+        _C.gemm(b["xf16"], s.w16["decoder.to_pixel.1.weight"].view(self.dec.dim, self.pd), M, self.pd, self.dec.dim, trans_b=True,
+                bias=io["bias_pix"], out_f32=io["pix"])
+        _C.unpatchify_loss(io["pix"], None, B, self.C, self.size, self.size, self.patch, 0.0, 0.0, io["xrec"], None, None)
+        return io["xrec"].clone()
+
+    # ---- fused training step: ViTVQ.training_step(optimizer_idx=0) + backward (vitvqgan.py:101-115) -----
+    def forward_backward(self, img: torch.Tensor, w_l1: float = 0.0, w_l2: float = 1.0, codebook_weight: float = 1.0,
+                         zero_grad: bool = True) -> dict:
+        """One AE forward + backward with loss = w_l1*L1 + w_l2*L2 + codebook_weight*qloss
+        (vqperceptual.py:113-117,131-132 with perceptual / adversarial weights 0).  Gradients are ACCUMULATED into
+        the flat grad buffer (zeroed first unless zero_grad=False: gradient accumulation, main.py:22,57)."""
+        img = self._check_img(img)
+        B, s, io, M = img.shape[0], self.store, self._io_bufs(img.shape[0]), img.shape[0] * self.n_tok
+        g = s.grad
+        if zero_grad:
+            s.zero_grad()
+        # ---------------- forward ----------------
+        eb = self._encode_tokens(img, save=True)
+        h = self._pre_quant(eb["xf16"], B)
+        E = s.w["quantizer.embedding.weight"]
+        zq, zq16, idx, qloss = _C.vq_forward(h, E, float(self.q.beta), self.q.depth, self.q.use_norm)
+        pix = self._decode_tokens(zq16, B, save=True)
+        db = self.dec.bufs(B, True)
+        io["sums"].zero_()
+        _C.unpatchify_loss(pix, img, B, self.C, self.size, self.size, self.patch, w_l1, w_l2, io["xrec"], io["sums"], io["dpix16"])
+        # ---------------- backward ----------------
+        notify = self.comm.layer_done if self.comm is not None else None
+        d_xf = io["d_xf_dec"]
+        wpix = "decoder.to_pixel.1.weight"
+        _C.gemm(db["xf16"], io["dpix16"], self.dec.dim, self.pd, M, trans_a=True, trans_b=True, accumulate=True, out_f32=g[wpix].view(self.dec.dim, self.pd))
+        _C.colsum(io["dpix16"], M, self.pd, io["g_bias_pix"], accumulate=False)
+        g["decoder.to_pixel.1.bias"].add_(io["g_bias_pix"].view(self.C, -1).sum(1))
+        _C.gemm(io["dpix16"], s.w16[wpix].view(self.dec.dim, self.pd), M, self.dec.dim, self.pd, out_f32=d_xf)
+        if notify:
+            notify("decoder.to_pixel.")
+        g0, g016 = self.dec.backward(B, d_xf, notify)
+        _C.gemm(g016, zq16, self.dec.dim, self.ed, M, trans_a=True, trans_b=True, accumulate=True, out_f32=g["post_quant.weight"])
+        _C.colsum(g016, M, self.dec.dim, g["post_quant.bias"], accumulate=True)
+        _C.gemm(g016, s.w16["post_quant.weight"], M, self.ed, self.dec.dim, trans_b=True, out_f32=io["dzq"])
+        dh, dh16 = _C.vq_backward(h, E, idx, io["dzq"], codebook_weight, None, float(self.q.beta), self.q.depth, bool(self.q.use_residual),
+                                  self.q.use_norm, g["quantizer.embedding.weight"])
+        _C.gemm(dh16, eb["xf16"], self.ed, self.enc.dim, M, trans_a=True, trans_b=True, accumulate=True, out_f32=g["pre_quant.weight"])
+        _C.colsum(dh16, M, self.ed, g["pre_quant.bias"], accumulate=True)
+        d_xe = io["d_xf_enc"]
+        _C.gemm(dh16, s.w16["pre_quant.weight"], M, self.enc.dim, self.ed, trans_b=True, out_f32=d_xe)
+        if notify:
+            notify("post_quant."); notify("pre_quant."); notify("quantizer.")
+        e0, e016 = self.enc.backward(B, d_xe, notify)
+        wpe = "encoder.to_patch_embedding.0.weight"
+        _C.gemm(e016, io["patches"], self.enc.dim, self.pd, M, trans_a=True, trans_b=True, accumulate=True, out_f32=g[wpe].view(self.enc.dim, self.pd))
+        _C.colsum(e016, M, self.enc.dim, g["encoder.to_patch_embedding.0.bias"], accumulate=True)
+        if notify:
+            notify("encoder.to_patch_embedding.")
+        numel = float(img.numel())
+        l1 = (io["sums"][0] / numel).float()
+        l2 = (io["sums"][1] / numel).float()
+        ql = qloss.view(())
+        nll = w_l1 * l1 + w_l2 * l2
+        return dict(loss=nll + codebook_weight * ql, quant_loss=ql, rec_loss=nll, loglaplace_loss=l1, loggaussian_loss=l2,
+                    xrec=io["xrec"], indices=idx, h=h)
+
+    def optimizer_step(self, lr: float, betas=(0.9, 0.99), eps: float = 1e-8, weight_decay: float = 1e-4, grad_scale: float = 1.0) -> None:
+        """torch.optim.AdamW over the single parameter group of vitvqgan.py:153-160 (one fused launch)."""
+        s = self.store
+        if self.comm is not None:
+            self.comm.finish()
+            grad_scale = grad_scale / self.comm.world
+        s.step_count += 1
+        _C.adamw_step(s.p, s.g, s.m, s.v, s.p16, s.step_count, lr, betas[0], betas[1], eps, weight_decay, grad_scale)
+
+    def train_step(self, img: torch.Tensor, lr: float, **loss_kw) -> dict:
+        out = self.forward_backward(img, **loss_kw)
+        self.optimizer_step(lr)
+        return out

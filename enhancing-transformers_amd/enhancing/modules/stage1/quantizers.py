@@ -1,0 +1,92 @@
+"""Vector / residual quantizer of the stage-1 tokenizer with the reference's constructor and
+``forward(z) -> (z_q, loss, indices)`` contract (reference enhancing/modules/stage1/quantizers.py:19-92).
+
+The arithmetic — l2-normalise, pairwise distance against the whole codebook, argmin, gather, commit/codebook
+loss, the shared-codebook residual loop and the straight-through estimator — is ONE fused gfx950 kernel
+(``enh_vq_forward``) plus its hand-derived backward (``enh_vq_backward``), wrapped in a
+``torch.autograd.Function`` so the module composes with ordinary autograd.  "RQ-VAE" is
+``use_residual=True, num_quantizers=D`` on this same class, exactly as in the reference."""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from ... import _C
+
+
+class _QuantizeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, codebook, beta, depth, use_residual, use_norm):
+        shp = z.shape
+        z2 = z.detach().reshape(-1, shp[-1]).contiguous()
+        cb = codebook.detach().contiguous()
+        zq, _, idx, loss = _C.vq_forward(z2, cb, beta, depth, use_norm, want_bf16=False)
+        ctx.save_for_backward(z2, cb, idx)
+        ctx.cfg = (beta, depth, use_residual, use_norm, shp)
+        idx_out = idx.view(*shp[:-1], depth) if use_residual else idx.view(*shp[:-1])
+        ctx.mark_non_differentiable(idx_out)
+        return zq.view(shp), loss.view(()), idx_out
+
+    @staticmethod
+    def backward(ctx, g_zq, g_loss, _g_idx):
+        z2, cb, idx = ctx.saved_tensors
+        beta, depth, use_residual, use_norm, shp = ctx.cfg
+        if g_zq is None:
+            g_zq = torch.zeros(shp, dtype=torch.float32, device=z2.device)
+        g_out = g_zq.reshape(-1, shp[-1]).contiguous().float()
+        d_cb = torch.zeros_like(cb)
+        g_loss_dev = None if g_loss is None else g_loss.reshape(1).float().contiguous()
+        dz, _ = _C.vq_backward(z2, cb, idx, g_out, 1.0 if g_loss is not None else 0.0, g_loss_dev, beta, depth, use_residual,
+                               use_norm, d_cb, want_bf16=False)
+        return dz.view(shp), d_cb, None, None, None, None
+
+
+class BaseQuantizer(nn.Module):
+    def __init__(self, embed_dim: int, n_embed: int, straight_through: bool = True, use_norm: bool = True,
+                 use_residual: bool = False, num_quantizers: Optional[int] = None) -> None:
+        super().__init__()
+        self.straight_through = straight_through
+        self.use_norm = use_norm
+        self.norm = (lambda x: torch.nn.functional.normalize(x, dim=-1)) if use_norm else (lambda x: x)
+        self.use_residual = use_residual
+        self.num_quantizers = num_quantizers
+        self.embed_dim = embed_dim
+        self.n_embed = n_embed
+        self.embedding = nn.Embedding(self.n_embed, self.embed_dim)
+        self.embedding.weight.data.normal_()  # quantizers.py:33
+
+
+class VectorQuantizer(BaseQuantizer):
+    """reference quantizers.py:66-92.  embed_dim must be 32 (the fused kernel's MFMA tiling; every reference
+    config uses 32)."""
+
+    def __init__(self, embed_dim: int, n_embed: int, beta: float = 0.25, use_norm: bool = True,
+                 use_residual: bool = False, num_quantizers: Optional[int] = None, **kwargs) -> None:
+        super().__init__(embed_dim, n_embed, True, use_norm, use_residual, num_quantizers)
+        if embed_dim != 32:
+            raise ValueError("the fused gfx950 quantizer kernel requires embed_dim == 32")
+        if use_residual and not num_quantizers:
+            raise ValueError("use_residual=True needs num_quantizers")
+        self.beta = beta
+
+    @property
+    def depth(self) -> int:
+        return int(self.num_quantizers) if self.use_residual else 1
+
+    def forward(self, z: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        return _QuantizeFn.apply(z, self.embedding.weight, float(self.beta), self.depth, bool(self.use_residual), bool(self.use_norm))
+
+    def quantize(self, z: torch.Tensor):
+        """single-level quantize (reference quantizers.py:74-92): (normalised code, loss, indices)."""
+        zq, loss, idx = _QuantizeFn.apply(z, self.embedding.weight, float(self.beta), 1, False, bool(self.use_norm))
+        return zq, loss, idx
+
+    def lookup(self, code: torch.Tensor) -> torch.Tensor:
+        """decode_codes front half (reference vitvqgan.py:82-87): n(E[code]) summed over the depth axis."""
+        depth = self.depth
+        shp = code.shape[:-1] if self.use_residual else code.shape
+        out, _ = _C.vq_lookup(self.embedding.weight.detach().contiguous(), code.reshape(-1, depth).contiguous(), self.use_norm,
+                              want_bf16=False)
+        return out.view(*shp, self.embed_dim)

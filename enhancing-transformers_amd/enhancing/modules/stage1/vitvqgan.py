@@ -1,0 +1,187 @@
+"""ViT-VQGAN / RQ-VAE stage-1 tokenizer with the reference's constructor, method set and state-dict layout
+(reference enhancing/modules/stage1/vitvqgan.py:25-188), running on the MI355X HIP engine.
+
+Differences from the reference, all forced by the environment or by the tier's scope:
+  * pytorch-lightning is not installable here, so this is a plain ``nn.Module`` that implements the Lightning
+    *protocol* the reference relies on (``training_step(batch, batch_idx, optimizer_idx)``,
+    ``validation_step``, ``configure_optimizers``, ``log`` / ``log_dict``, ``global_step``, ``learning_rate``);
+    the in-repo trainer (``enhancing.engine.trainer``) drives it the way ``pl.Trainer.fit`` does.
+  * ``training_step(optimizer_idx=0)`` runs the fused forward+backward schedule and leaves the gradients in
+    ``param.grad`` (views of one flat buffer); it returns the detached loss.  Loss modules that need LPIPS or
+    the StyleGAN discriminator are outside this round's scope and raise on construction
+    unless their weights are zero.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from ...utils.general import initialize_from_config
+from .layers import ViTDecoder as Decoder
+from .layers import ViTEncoder as Encoder
+from .quantizers import VectorQuantizer
+
+
+def _get(cfg, key, default=None):
+    return cfg[key] if key in cfg else default
+
+
+class ViTVQ(nn.Module):
+    def __init__(self, image_key: str, image_size: int, patch_size: int, encoder, decoder, quantizer, loss,
+                 path: Optional[str] = None, ignore_keys: List[str] = list(), scheduler=None) -> None:
+        super().__init__()
+        self.path = path
+        self.ignore_keys = ignore_keys
+        self.image_key = image_key
+        self.scheduler = scheduler
+        self.learning_rate = 4.5e-6  # main.py:24,41 overwrite this with --base_lr
+        self.global_step = 0
+        self.logged: Dict[str, Any] = {}
+
+        self.loss = initialize_from_config(loss)
+        self.encoder = Encoder(image_size=image_size, patch_size=patch_size, **encoder)
+        self.decoder = Decoder(image_size=image_size, patch_size=patch_size, **decoder)
+        self.quantizer = VectorQuantizer(**quantizer)
+        # nn.Linear keeps torch's default init, as the reference does (vitvqgan.py:38-39); used as containers
+        self.pre_quant = nn.Linear(_get(encoder, "dim"), _get(quantizer, "embed_dim"))
+        self.post_quant = nn.Linear(_get(quantizer, "embed_dim"), _get(decoder, "dim"))
+        self._engine = None
+
+        if path is not None:
+            self.init_from_ckpt(path, ignore_keys)
+
+    # ---- engine binding ----------------------------------------------------------------------
+    @property
+    def engine(self):
+        if self._engine is None:
+            from ...engine.stage1 import Stage1Engine
+            self._engine = Stage1Engine(self)
+        return self._engine
+
+    @property
+    def device(self) -> torch.device:
+        return self._engine.device if self._engine is not None else torch.device("cpu")
+
+    def init_from_ckpt(self, path: str, ignore_keys: List[str] = list()):
+        """reference vitvqgan.py:50-59: torch.load(path)['state_dict'], prefix filter, strict=False."""
+        sd = torch.load(path, map_location="cpu")["state_dict"]
+        for k in list(sd.keys()):
+            for ik in ignore_keys:
+                if k.startswith(ik):
+                    print("Deleting key {} from state_dict.".format(k))
+                    del sd[k]
+        self.load_state_dict(sd, strict=False)
+        print(f"Restored from {path}")
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        out = super().load_state_dict(state_dict, strict=strict, **kw)
+        if self._engine is not None:
+            self._engine.store.refresh_shadows()  # bf16 operand copies follow the fp32 masters
+        return out
+
+    # ---- reference API -----------------------------------------------------------------------
+    def forward(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(dec, diff) — reference vitvqgan.py:44-48 (inference path: nothing is saved for backward; training goes
+        through training_step)."""
+        xrec, qloss, _ = self.engine.reconstruct(x)
+        return xrec, qloss
+
+    def encode(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(quant, emb_loss) — reference vitvqgan.py:61-66"""
+        eng = self.engine
+        h = self.pre_quant_tokens(x)
+        quant, emb_loss, _ = self.quantizer(h)
+        return quant, emb_loss
+
+    def pre_quant_tokens(self, x: torch.Tensor) -> torch.Tensor:
+        """h = pre_quant(encoder(x)) as f32 [B, N, embed_dim] (the quantizer's input: op-boundary parity point)."""
+        eng = self.engine
+        x = eng._check_img(x)
+        with torch.no_grad():
+            b = eng._encode_tokens(x, save=False)
+            h = eng._pre_quant(b["xf16"], x.shape[0])
+        return h.view(x.shape[0], eng.n_tok, eng.ed).clone()
+
+    def decode(self, quant: torch.Tensor) -> torch.Tensor:
+        """reference vitvqgan.py:68-72"""
+        return self.engine.decode_from_quant(quant)
+
+    def encode_codes(self, x: torch.Tensor) -> torch.Tensor:
+        """reference vitvqgan.py:74-79 -> int64 [B, N] or [B, N, D]"""
+        return self.engine.encode_codes(x)
+
+    def decode_codes(self, code: torch.Tensor) -> torch.Tensor:
+        """reference vitvqgan.py:81-90"""
+        self.engine  # make sure parameters live on the device
+        quant = self.quantizer.lookup(code.to(self.device))
+        return self.decode(quant)
+
+    def get_input(self, batch, key: str = 'image') -> Any:
+        """reference vitvqgan.py:92-99"""
+        x = batch[key]
+        if len(x.shape) == 3:
+            x = x[..., None]
+        if x.dtype == torch.double:
+            x = x.float()
+        return x.contiguous()
+
+    # ---- Lightning protocol ------------------------------------------------------------------
+    def log(self, name: str, value, **_) -> None:
+        self.logged[name] = value
+
+    def log_dict(self, d: Dict[str, Any], **_) -> None:
+        self.logged.update(d)
+
+    def _loss_weights(self) -> Tuple[float, float, float]:
+        L = self.loss
+        return float(getattr(L, "loglaplace_weight", 0.0)), float(getattr(L, "loggaussian_weight", 1.0)), float(getattr(L, "codebook_weight", 1.0))
+
+    def training_step(self, batch, batch_idx: int, optimizer_idx: int = 0, zero_grad: bool = True):
+        """reference vitvqgan.py:101-127.  optimizer_idx 0 = autoencoder: forward + backward run fused on the engine
+        and the returned loss is detached (the gradients are already in param.grad)."""
+        x = self.get_input(batch, self.image_key)
+        if optimizer_idx == 0:
+            w1, w2, cw = self._loss_weights()
+            out = self.engine.forward_backward(x, w_l1=w1, w_l2=w2, codebook_weight=cw, zero_grad=zero_grad)
+            log = {"train/total_loss": out["loss"], "train/quant_loss": out["quant_loss"], "train/rec_loss": out["rec_loss"],
+                   "train/loglaplace_loss": out["loglaplace_loss"], "train/loggaussian_loss": out["loggaussian_loss"],
+                   "train/perceptual_loss": torch.zeros((), device=out["loss"].device)}
+            self.log("train/total_loss", out["loss"])
+            self.log_dict({k: v for k, v in log.items() if k != "train/total_loss"})
+            return out["loss"]
+        if optimizer_idx == 1:
+            if not hasattr(self.loss, "discriminator"):
+                return None
+            raise NotImplementedError("the StyleGAN discriminator step is outside this round's scope (SURVEY.md §8f rank 1)")
+
+    @torch.no_grad()
+    def validation_step(self, batch, batch_idx: int) -> Dict:
+        """reference vitvqgan.py:129-150 (AE branch)"""
+        x = self.get_input(batch, self.image_key)
+        xrec, qloss = self(x)
+        aeloss, log = self.loss(qloss, x.to(xrec.device), xrec, 0, self.global_step, batch_idx, last_layer=self.decoder.get_last_layer(), split="val")
+        self.log("val/rec_loss", log["val/rec_loss"])
+        self.log("val/total_loss", aeloss)
+        self.log_dict({k: v for k, v in log.items() if k not in ("val/rec_loss", "val/total_loss")})
+        return self.logged
+
+    def configure_optimizers(self):
+        """reference vitvqgan.py:152-178: one AdamW(lr, betas=(0.9, 0.99), weight_decay=1e-4) over encoder + decoder +
+        pre/post_quant + quantizer as a single group -> here ONE fused launch over the flat buffer."""
+        from ...engine.optim import FusedAdamW
+        optimizers = [FusedAdamW(self.engine, lr=self.learning_rate, betas=(0.9, 0.99), weight_decay=1e-4)]
+        schedulers = []
+        if self.scheduler is not None:
+            self.scheduler.params.start = self.learning_rate
+            sched = initialize_from_config(self.scheduler)
+            schedulers = [{"scheduler": sched, "interval": "step", "frequency": 1}]
+        return optimizers, schedulers
+
+    @torch.no_grad()
+    def log_images(self, batch, *args, **kwargs) -> Dict:
+        """reference vitvqgan.py:180-188"""
+        x = self.get_input(batch, self.image_key)
+        xrec, _ = self(x)
+        return {"originals": x, "reconstructions": xrec}

@@ -1,0 +1,101 @@
+"""Per-kernel timing at the BASELINE shapes (ViT-VQGAN base, per-GPU batch B) — dev tool, run on the GPU box."""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "enhancing-transformers_amd"))
+from enhancing import _C  # noqa: E402
+
+B = int(os.environ.get("MB_BATCH", "64"))
+N, H, DIM, MLP = 1024, 12, 768, 3072
+M = B * N
+dev = "cuda"
+
+
+def timeit(fn, iters=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e-3
+
+
+def bf(*shape):
+    return (torch.randn(*shape, device=dev) * 0.5).to(torch.bfloat16)
+
+
+def gemm_case(name, m, n, k, ta=False, tb=False, out="bf16", acc=False):
+    a = bf(k, m) if ta else bf(m, k)
+    b = bf(k, n) if tb else bf(n, k)
+    o32 = torch.zeros(m, n, device=dev) if out == "f32" else None
+    o16 = torch.empty(m, n, dtype=torch.bfloat16, device=dev) if out == "bf16" else None
+    t = timeit(lambda: _C.gemm(a, b, m, n, k, trans_a=ta, trans_b=tb, accumulate=acc, out_f32=o32, out_bf16=o16))
+    print(f"{name:34s} M={m:7d} N={n:5d} K={k:7d}  {t*1e3:8.3f} ms  {2*m*n*k/t/1e12:7.1f} TFLOP/s", flush=True)
+
+
+print(f"batch {B}  tokens {M}")
+gemm_case("fwd qkv   (NT)", M, 3 * DIM, DIM)
+gemm_case("fwd fc1   (NT)", M, MLP, DIM)
+gemm_case("fwd fc2   (NT)", M, DIM, MLP, out="f32")
+gemm_case("fwd out   (NT)", M, DIM, DIM, out="f32")
+gemm_case("dgrad qkv (NN)", M, DIM, 3 * DIM, tb=True, out="f32")
+gemm_case("dgrad fc2 (NN)", M, MLP, DIM, tb=True)
+gemm_case("dgrad fc1 (NN)", M, DIM, MLP, tb=True, out="f32")
+gemm_case("wgrad qkv (TN, split-K)", 3 * DIM, DIM, M, ta=True, tb=True, out="f32", acc=True)
+gemm_case("wgrad fc1 (TN, split-K)", MLP, DIM, M, ta=True, tb=True, out="f32", acc=True)
+gemm_case("wgrad fc2 (TN, split-K)", DIM, MLP, M, ta=True, tb=True, out="f32", acc=True)
+gemm_case("pre_quant (N=32)", M, 32, DIM, out="f32")
+gemm_case("to_pixel  (N=192, NN)", M, 192, DIM, tb=True, out="f32")
+
+qkv = bf(B, N, 3 * H * 64)
+out = torch.empty(B, N, H * 64, dtype=torch.bfloat16, device=dev)
+lse = torch.empty(B, H, N, device=dev)
+t = timeit(lambda: _C.attention_forward(qkv, B, N, H, 0.125, out, lse))
+fl = 4 * B * H * N * N * 64
+print(f"{'attention fwd':34s} {t*1e3:8.3f} ms  {fl/t/1e12:7.1f} TFLOP/s")
+do = bf(B, N, H * 64)
+dqkv = torch.empty_like(qkv)
+delta = torch.empty(B, H, N, device=dev)
+t = timeit(lambda: _C.attention_backward(qkv, out, do, lse, B, N, H, 0.125, dqkv, delta))
+print(f"{'attention bwd (dq + dkv)':34s} {t*1e3:8.3f} ms  {2.5*fl/t/1e12:7.1f} TFLOP/s (5-matmul algorithmic; 7 executed)")
+
+z = torch.randn(M, 32, device=dev)
+E = torch.randn(8192, 32, device=dev)
+t = timeit(lambda: _C.vq_forward(z, E, 0.25, 1, True))
+print(f"{'vq forward K=8192':34s} {t*1e3:8.3f} ms  {2*M*8192*32/t/1e12:7.1f} TFLOP/s f32  ({M/t/1e6:.1f} Mtok/s)")
+t = timeit(lambda: _C.vq_forward(z, E, 0.25, 4, True))
+print(f"{'rq forward depth 4':34s} {t*1e3:8.3f} ms  {4*2*M*8192*32/t/1e12:7.1f} TFLOP/s f32")
+idx = torch.randint(0, 8192, (M, 1), device=dev)
+dE = torch.zeros(8192, 32, device=dev)
+t = timeit(lambda: _C.vq_backward(z, E, idx, z, 1.0, None, 0.25, 1, False, True, dE))
+print(f"{'vq backward (random idx)':34s} {t*1e3:8.3f} ms")
+idx0 = torch.randint(0, 30, (M, 1), device=dev)
+t = timeit(lambda: _C.vq_backward(z, E, idx0, z, 1.0, None, 0.25, 1, False, True, dE))
+print(f"{'vq backward (30 hot codes)':34s} {t*1e3:8.3f} ms")
+
+x = torch.randn(M, DIM, device=dev)
+w = torch.ones(DIM, device=dev); bb = torch.zeros(DIM, device=dev)
+y16 = torch.empty(M, DIM, dtype=torch.bfloat16, device=dev)
+mean = torch.empty(M, device=dev); rstd = torch.empty(M, device=dev)
+t = timeit(lambda: _C.layernorm_forward(x, w, bb, 1e-5, y16, None, mean, rstd))
+print(f"{'layernorm fwd':34s} {t*1e3:8.3f} ms  {M*DIM*6/t/1e12:6.2f} TB/s")
+dx = torch.empty_like(x); dx16 = torch.empty_like(y16); dw = torch.zeros(DIM, device=dev); db = torch.zeros(DIM, device=dev)
+t = timeit(lambda: _C.layernorm_backward(x, x, w, mean, rstd, x, dx, dx16, dw, db))
+print(f"{'layernorm bwd (+res)':34s} {t*1e3:8.3f} ms  {M*DIM*18/t/1e12:6.2f} TB/s")
+n = 170_664_000
+p = torch.randn(n, device=dev); g = torch.randn(n, device=dev); m_ = torch.zeros(n, device=dev); v_ = torch.zeros(n, device=dev)
+p16 = torch.empty(n, dtype=torch.bfloat16, device=dev)
+t = timeit(lambda: _C.adamw_step(p, g, m_, v_, p16, 1, 4.5e-6))
+print(f"{'adamw 170.7M params':34s} {t*1e3:8.3f} ms  {n*30/t/1e12:6.2f} TB/s")
+hb = bf(M, MLP)
+o = torch.empty(MLP, device=dev)
+t = timeit(lambda: _C.colsum(hb, M, MLP, o))
+print(f"{'colsum [M,3072] bf16':34s} {t*1e3:8.3f} ms  {M*MLP*2/t/1e12:6.2f} TB/s")
