@@ -1,0 +1,163 @@
+"""bench.py — images/sec of the ViT-VQGAN-base 256x256 stage-1 AE training step on N MI355X (one process per GPU).
+
+Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches it under
+torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env, RCCL over xGMI).  A "step" = one full AE
+training step of configs/imagenet_vitvq_base.yaml on one synthetic ImageNet-shaped batch per GPU: forward + backward +
+gradient all-reduce + fused AdamW, loss = 1.0*L2 + 1.0*codebook (LPIPS / GAN weights 0 — stated in config.workload).
+Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+Extra objects: "roofline" (dominant kernel = the bf16 MFMA GEMM instantiation with the largest share of the step, timed
+live with HIP events on the launch stream inside the timed region) and "cpu_baseline" (the CPU oracle — a port of the
+reference's PyTorch path, oracle/vitvq_oracle.py — timed on the host cores on a bounded sample, rank 0 / N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "enhancing-transformers_amd"))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+FWD_GFLOP_PER_IMG_BASE = 426.44      # SURVEY.md §8(d) / BASELINE.md
+STEP_TFLOP_PER_IMG_BASE = 1.279      # 1 fwd + 1 bwd = 3x forward
+MFMA_BF16_PEAK_TFLOPS = 2500.0       # dense, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(max_seconds: float = 25.0):
+    """CPU oracle (port of the reference's PyTorch path) timed on the host cores: base config, batch 4."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import vitvq_oracle as O
+    # 256 torch threads on the 2-socket GPU host are pathologically slow for this op mix (measured: 355 s per batch-4
+    # step), so the baseline uses 32 threads — the count is reported in "cores"
+    cores = min(os.cpu_count() or 1, int(os.environ.get("ENH_CPU_BASELINE_THREADS", "32")))
+    torch.set_num_threads(cores)
+    cfg = dict(image_size=256, patch_size=8, encoder=dict(dim=768, depth=12, heads=12, mlp_dim=3072),
+               decoder=dict(dim=768, depth=12, heads=12, mlp_dim=3072), quantizer=dict(embed_dim=32, n_embed=8192))
+    B = 2
+    P = O.make_params(cfg, 0)
+    m = {k: torch.zeros_like(v) for k, v in P.items()}
+    v = {k: torch.zeros_like(v_) for k, v_ in P.items()}
+    x = O.make_images(0, B, 256)
+    times, t_begin, step = [], time.time(), 0
+    while True:
+        step += 1
+        t0 = time.time()
+        _, _, grads, _ = O.train_step_grads(x, P, cfg)
+        for k, g in grads.items():
+            O.adamw_step(P[k], g, m[k], v[k], step, 4.5e-6)
+        times.append(time.time() - t0)
+        if step >= 2 or time.time() - t_begin > max_seconds:
+            break
+    best = min(times[1:]) if len(times) > 1 else times[0]
+    return {"value": B / best, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{len(times)} AE train steps (fwd+bwd+AdamW, fp32) of ViT-VQGAN-base at batch {B}; best of the post-warm-up steps"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("ENH_BENCH_BATCH", "128")), help="images per GPU per step")
+    ap.add_argument("--config", type=str, default="imagenet_vitvq_base")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from enhancing import _C
+    from enhancing.engine.ddp import GradSync, init_process_group_from_env
+    from enhancing.utils.general import get_config_from_file, initialize_from_config, set_seed
+
+    rank, local_rank, world = init_process_group_from_env("nccl" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+    set_seed(0)  # identical init on every rank (then broadcast anyway, as DDP does)
+    cfg = get_config_from_file(os.path.join(ROOT, "configs", args.config + ".yaml"))
+    model = initialize_from_config(cfg.model)
+    eng = model.engine
+    if world > 1:
+        eng.comm = GradSync(eng.store)
+        eng.comm.broadcast_parameters(0)
+        eng.store.refresh_shadows()
+    B, size = args.batch, cfg.model.params.image_size
+    # synthetic ImageNet-shaped batches, distinct per rank (seed + rank), resident in HBM before timing
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    nbatch = 2
+    low = torch.rand(nbatch, B, 3, size // 16, size // 16, device=dev, generator=g)
+    batches = [(torch.nn.functional.interpolate(low[i], size=(size, size), mode="bilinear") +
+                0.05 * torch.randn(B, 3, size, size, device=dev, generator=g)).clamp_(0, 1).contiguous() for i in range(nbatch)]
+    lr = 4.5e-6
+
+    def step(i):
+        out = eng.forward_backward(batches[i % nbatch], w_l1=0.0, w_l2=1.0, codebook_weight=1.0)
+        eng.optimizer_step(lr)
+        return out
+
+    for i in range(args.warmup):
+        out = step(i)
+    timer = _C.KernelTimer()
+    _C.TIMER = timer
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    _C.TIMER = None
+    loss = float(out["loss"])
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+        return
+    img_per_s = args.steps * B * world / elapsed
+    ks = timer.summary()
+    gemms = {k: v for k, v in ks.items() if k.startswith("gemm_bf16_kernel")}
+    dom = max(gemms, key=lambda k: gemms[k]["total_ms"])
+    d = gemms[dom]
+    achieved = d["work"] / d["launches"] / (d["avg_ms"] * 1e-3) / 1e12
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_gemm.json")
+    traffic = None
+    if os.path.exists(pmc_path):
+        try:
+            traffic = json.load(open(pmc_path)).get(dom, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    is_base = args.config == "imagenet_vitvq_base"
+    res = {
+        "metric": "images/sec ViT-VQGAN-base 256px stage-1 train", "value": round(img_per_s, 2), "unit": "images/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"{args.config}.yaml AE training step (1 fwd + 1 bwd + grad all-reduce + AdamW), loss = 1.0*L2 + 1.0*codebook "
+                               f"(LPIPS/GAN weights 0), K=8192 x 32 l2-normalised codes, fp32 master weights, bf16 MFMA operands / fp32 accumulate",
+                   "per_gpu_batch": B, "global_batch": B * world, "image": f"{size}x{size}", "parallelism": f"dp{world}"},
+        "final_loss": loss,
+        "step_mfma_frac": round(img_per_s / world * STEP_TFLOP_PER_IMG_BASE / MFMA_BF16_PEAK_TFLOPS, 4) if is_base else None,
+        "roofline": {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
+                     "launches_timed": d["launches"], "avg_launch_ms": round(d["avg_ms"], 4),
+                     "share_of_step": round(d["total_ms"] / (elapsed * 1e3), 3)},
+        "kernels": {k: {"launches": v["launches"], "total_ms": round(v["total_ms"], 2), "tflops": round(v["work"] / (v["total_ms"] * 1e-3) / 1e12, 1)}
+                    for k, v in sorted(ks.items())},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline()
+    print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+
+
+if __name__ == "__main__":
+    main()

@@ -86,6 +86,39 @@ def _stream():
 
 F32, BF16, I64, F64 = torch.float32, torch.bfloat16, torch.int64, torch.float64
 
+
+class KernelTimer:
+    """Optional per-launch timing with HIP events on the launch stream (torch's current stream is the stream every
+    kernel of this library is enqueued on).  bench.py installs one to compute the roofline figures live."""
+
+    def __init__(self) -> None:
+        self.records = {}
+
+    def run(self, name: str, work: float, fn) -> None:
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn()
+        e.record()
+        self.records.setdefault(name, []).append((s, e, work))
+
+    def summary(self) -> dict:
+        torch.cuda.synchronize()
+        out = {}
+        for name, recs in self.records.items():
+            ms = [s.elapsed_time(e) for s, e, _ in recs]
+            out[name] = dict(launches=len(recs), total_ms=sum(ms), avg_ms=sum(ms) / len(ms), work=sum(w for _, _, w in recs))
+        return out
+
+
+TIMER: Optional[KernelTimer] = None
+
+
+def _timed(name: str, work: float, fn) -> None:
+    if TIMER is None:
+        fn()
+    else:
+        TIMER.run(name, work, fn)
+
 # ------------------------------------------------------------------------------------------------
 # quantizer
 # ------------------------------------------------------------------------------------------------
@@ -103,6 +136,7 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
 
 def vq_forward(z: torch.Tensor, codebook: torch.Tensor, beta: float, depth: int, use_norm: bool, want_bf16: bool = True):
     """z [M,32] f32, codebook [K,32] f32 -> (zq f32 [M,32], zq_bf16|None, idx i64 [M,depth], loss f32 [1])."""
+    _p(z, F32, "z"); _p(codebook, F32, "codebook")  # device / dtype / contiguity first: fail before allocating
     M, d = z.shape
     K = codebook.shape[0]
     zq = torch.empty_like(z)
@@ -120,6 +154,7 @@ def vq_forward(z: torch.Tensor, codebook: torch.Tensor, beta: float, depth: int,
 def vq_backward(z, codebook, idx, g_out, g_loss: float, g_loss_dev: Optional[torch.Tensor], beta: float, depth: int,
                 use_residual: bool, use_norm: bool, d_codebook: torch.Tensor, want_bf16: bool = True):
     """Returns (dz f32, dz_bf16|None); ACCUMULATES into d_codebook [K,32] f32."""
+    _p(z, F32, "z"); _p(codebook, F32, "codebook")
     M, d = z.shape
     K = codebook.shape[0]
     dz = torch.empty_like(z)
@@ -136,6 +171,7 @@ def vq_backward(z, codebook, idx, g_out, g_loss: float, g_loss_dev: Optional[tor
 
 def vq_lookup(codebook, idx, use_norm: bool, want_bf16: bool = True):
     """idx [M,depth] i64 -> (sum_i n(E[idx_i]) f32 [M,32], bf16 copy)."""
+    _p(idx, I64, "idx"); _p(codebook, F32, "codebook")
     M, depth = idx.shape
     K, d = codebook.shape
     out = torch.empty(M, d, dtype=F32, device=idx.device)
@@ -174,24 +210,28 @@ def gemm(a, b, M: int, N: int, K: int, trans_a: bool = False, trans_b: bool = Fa
     ldb = b.stride(0) if ldb is None else ldb
     out = out_f32 if out_f32 is not None else out_bf16
     ldc = out.stride(0) if ldc is None else ldc
-    _check(lib().enh_gemm_bf16(_p(a, BF16, "A"), lda, int(trans_a), _p(b, BF16, "B"), ldb, int(trans_b), M, N, K, _p(bias, F32, "bias"),
-                               act, _p(aux, BF16, "aux"), aux.stride(0) if aux is not None else 0, _p(res, F32, "res"),
-                               res.stride(0) if res is not None else 0, res_rows if res is not None else 0, int(accumulate),
-                               _p(out_f32, F32, "out_f32"), _p(out_bf16, BF16, "out_bf16"), ldc, _stream()), "enh_gemm_bf16")
+    args = (_p(a, BF16, "A"), lda, int(trans_a), _p(b, BF16, "B"), ldb, int(trans_b), M, N, K, _p(bias, F32, "bias"),
+            act, _p(aux, BF16, "aux"), aux.stride(0) if aux is not None else 0, _p(res, F32, "res"),
+            res.stride(0) if res is not None else 0, res_rows if res is not None else 0, int(accumulate),
+            _p(out_f32, F32, "out_f32"), _p(out_bf16, BF16, "out_bf16"), ldc, _stream())
+    _timed(f"gemm_bf16_kernel<{'T' if trans_a else 'N'}{'T' if trans_b else 'N'}>", 2.0 * M * N * K,
+           lambda: _check(lib().enh_gemm_bf16(*args), "enh_gemm_bf16"))
 
 
 # ------------------------------------------------------------------------------------------------
 # attention
 # ------------------------------------------------------------------------------------------------
 def attention_forward(qkv, B: int, N: int, H: int, scale: float, out, lse):
-    _check(lib().enh_attention_forward(_p(qkv, BF16, "qkv"), B, N, H, scale, _p(out, BF16, "out"), _p(lse, F32, "lse"), _stream()),
-           "enh_attention_forward")
+    _timed("attn_fwd_kernel", 4.0 * B * H * N * N * 64,
+           lambda: _check(lib().enh_attention_forward(_p(qkv, BF16, "qkv"), B, N, H, scale, _p(out, BF16, "out"), _p(lse, F32, "lse"), _stream()),
+                          "enh_attention_forward"))
 
 
 def attention_backward(qkv, out, dout, lse, B: int, N: int, H: int, scale: float, dqkv, delta_ws):
-    _check(lib().enh_attention_backward(_p(qkv, BF16, "qkv"), _p(out, BF16, "out"), _p(dout, BF16, "dout"), _p(lse, F32, "lse"), B, N, H,
-                                        scale, _p(dqkv, BF16, "dqkv"), _p(delta_ws, F32, "delta_ws"), _stream()),
-           "enh_attention_backward")
+    _timed("attn_bwd (delta+dq+dkv kernels)", 10.0 * B * H * N * N * 64,
+           lambda: _check(lib().enh_attention_backward(_p(qkv, BF16, "qkv"), _p(out, BF16, "out"), _p(dout, BF16, "dout"), _p(lse, F32, "lse"), B, N, H,
+                                                       scale, _p(dqkv, BF16, "dqkv"), _p(delta_ws, F32, "delta_ws"), _stream()),
+                          "enh_attention_backward"))
 
 
 # ------------------------------------------------------------------------------------------------

@@ -1,0 +1,84 @@
+"""In-repo training loop standing in for ``pl.Trainer.fit`` (reference main.py:51-61; pytorch-lightning is not
+installable in this environment).  It drives the Lightning protocol of ``ViTVQ`` the way Lightning 1.5 does for
+the stage-1 configs: per batch, ``training_step(batch, batch_idx, optimizer_idx)`` for each optimizer, gradient
+accumulation over ``accumulate_grad_batches`` batches, ``strategy="ddp"`` = one process per GPU with gradient
+all-reduce (RCCL), a ``{"state_dict": ...}`` checkpoint per epoch (general.py:49-55), scalar logs to a JSONL sink."""
+from __future__ import annotations
+
+import json
+import os
+import time
+from typing import Optional
+
+import torch
+
+from .ddp import GradSync, init_process_group_from_env
+
+
+class Trainer:
+    def __init__(self, max_epochs: int = 100, precision: int = 32, gpus: int = 1, num_nodes: int = 1, strategy: Optional[str] = None,
+                 accumulate_grad_batches: int = 1, callbacks=None, logger=None, max_steps: Optional[int] = None,
+                 default_root_dir: str = "experiments", log_every_n_steps: int = 10, val_batches: int = 4) -> None:
+        self.max_epochs, self.max_steps = max_epochs, max_steps
+        self.precision = precision  # accepted for CLI compatibility: compute is always bf16-operand MFMA / fp32 accumulate
+        self.accum = max(int(accumulate_grad_batches), 1)
+        self.strategy = strategy
+        self.root = default_root_dir
+        self.log_every = log_every_n_steps
+        self.val_batches = val_batches
+        self.rank, self.local_rank, self.world = 0, 0, 1
+        self.global_step = 0
+
+    def _log(self, rec: dict) -> None:
+        if self.rank != 0:
+            return
+        os.makedirs(self.root, exist_ok=True)
+        with open(os.path.join(self.root, "metrics.jsonl"), "a") as f:
+            f.write(json.dumps(rec) + "\n")
+
+    def fit(self, model, data) -> None:
+        self.rank, self.local_rank, self.world = init_process_group_from_env()
+        torch.cuda.set_device(self.local_rank)
+        eng = model.engine
+        if self.world > 1:
+            eng.comm = GradSync(eng.store)
+            eng.comm.broadcast_parameters(0)
+            eng.store.refresh_shadows()
+        data.setup(rank=self.rank, world=self.world)
+        (opt, *_), _scheds = model.configure_optimizers()
+        opt.grad_scale = 1.0 / self.accum
+        sched = _scheds[0]["scheduler"] if _scheds else None
+        base_lr = opt.param_groups[0]["lr"]
+        t0, seen = time.time(), 0
+        for epoch in range(self.max_epochs):
+            for batch_idx, batch in enumerate(data.train_dataloader()):
+                first = batch_idx % self.accum == 0
+                loss = model.training_step(batch, batch_idx, 0, zero_grad=first)
+                seen += batch["image"].shape[0] * self.world
+                if (batch_idx + 1) % self.accum == 0:
+                    if sched is not None:
+                        opt.param_groups[0]["lr"] = base_lr * sched(self.global_step)
+                    opt.step()
+                    self.global_step += 1
+                    model.global_step = self.global_step
+                    if self.global_step % self.log_every == 0:
+                        rec = {k: float(v) for k, v in model.logged.items() if k.startswith("train/")}
+                        rec.update(step=self.global_step, epoch=epoch, images_per_s=seen / (time.time() - t0))
+                        self._log(rec)
+                        if self.rank == 0:
+                            print(json.dumps(rec), flush=True)
+                    if self.max_steps is not None and self.global_step >= self.max_steps:
+                        break
+            if "validation" in data.dataset_configs:
+                for vi, vb in enumerate(data.val_dataloader()):
+                    if vi >= self.val_batches:
+                        break
+                    model.validation_step(vb, vi)
+                self._log({k: float(v) for k, v in model.logged.items() if k.startswith("val/")} | {"epoch": epoch})
+            if self.rank == 0:
+                ck = os.path.join(self.root, "ckpt")
+                os.makedirs(ck, exist_ok=True)
+                torch.save({"state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()}, "epoch": epoch,
+                            "global_step": self.global_step, "optimizer": opt.state_dict()}, os.path.join(ck, f"epoch={epoch:02d}.ckpt"))
+            if self.max_steps is not None and self.global_step >= self.max_steps:
+                break

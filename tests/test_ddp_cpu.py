@@ -1,0 +1,78 @@
+"""world_size-2 gloo test of the bucketed gradient all-reduce (the N > 1 path of bench.py / main.py) on CPU."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+class FakeStore:
+    """what GradSync needs from enhancing.engine.stage1.ParamStore: flat p / g and slice_of(prefix)."""
+
+    def __init__(self, rank):
+        self.sizes = {"encoder.a.": 1000, "encoder.b.": 3000, "decoder.a.": 500, "decoder.b.": 2500, "quantizer.": 64}
+        self.off, o = {}, 0
+        for k, n in self.sizes.items():
+            self.off[k] = (o, o + n); o += n
+        g = torch.Generator().manual_seed(100 + rank)
+        self.g = torch.randn(o, generator=g)
+        self.p = torch.full((o,), float(rank))
+
+    def slice_of(self, prefix):
+        return self.off[prefix]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "enhancing-transformers_amd"))
+    from enhancing.engine.ddp import GradSync
+    store = FakeStore(rank)
+    local = store.g.clone()
+    sync = GradSync(store, min_bucket_elems=2000)
+    sync.broadcast_parameters(0)
+    assert torch.all(store.p == 0.0)
+    for step in range(2):  # two steps: state must reset between them
+        store.g.copy_(local)
+        for prefix in ["decoder.b.", "decoder.a.", "quantizer.", "encoder.b.", "encoder.a."]:  # backward order
+            sync.layer_done(prefix)
+        sync.finish()
+    q.put((rank, store.g.clone(), local))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradsync_gloo_world2():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    got.sort(key=lambda t: t[0])
+    total = got[0][2] + got[1][2]
+    for _, reduced, _ in got:
+        assert torch.allclose(reduced, total, atol=1e-6)   # SUM; the 1/world mean is folded into AdamW's grad_scale
+
+
+def test_gradsync_detects_unannounced_slices():
+    """single-process group: if the schedule forgets a unit, finish() must not silently skip its gradients."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        import pytest
+        from enhancing.engine.ddp import GradSync
+        store = FakeStore(0)
+        sync = GradSync(store)
+        sync.layer_done("decoder.b.")
+        with pytest.raises(RuntimeError, match="announced"):
+            sync.finish()
+    finally:
+        dist.destroy_process_group()
