@@ -18,6 +18,7 @@
 // output columns of one row: the epilogue reads bias / residual / aux and writes C with 16-byte (f32) or
 // 8-byte (bf16) accesses.  Workgroup ids are remapped so each XCD (private L2) walks a contiguous run of
 // tiles, n-fastest, sharing the A row-panel and the weight matrix in that L2.
+#include <stdlib.h>
 #include "common.h"
 
 #define G_BM 128
@@ -43,6 +44,7 @@ struct GemmArgs {
   int accumulate;       // 1: += C_old ; 2: split-K partial -> f32 atomicAdd into c_f32
   float* c_f32; uint16_t* c_bf16; int64_t ldc;
   int nbm, nbn;
+  int ablate;  // debug only (ENH_GEMM_ABLATE): 1 = no global->LDS loads, 2 = no MFMA, 3 = no LDS fragment reads
 };
 
 // global -> registers: one 128 x 64 (row layout) or 64 x 128 (kmaj layout) bf16 operand tile, 4 x 16 B per thread
@@ -97,6 +99,70 @@ __device__ __forceinline__ s16x8 tile_frag(const unsigned char* tile, int base, 
   }
 }
 
+// ---- epilogue: lane (lg, l16) holds C[m = .. + l16][n = .. + lg*4 + 0..3] (MFMA issued with swapped operands) ----
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& args, f32x4 (&acc)[4][4], int64_t m0, int64_t n0, int wm, int wn,
+                                              int lg, int l16) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t m = m0 + wm * 64 + i * 16 + l16;
+    if (m >= args.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t n = n0 + wn * 64 + j * 16 + lg * 4;
+      if (n >= args.N) continue;  // N % 4 == 0: the 4 columns are in or out together
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      float* cp = args.c_f32 ? args.c_f32 + m * args.ldc + n : nullptr;
+      if (args.accumulate == 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(cp + r, v[r]);
+        continue;
+      }
+      if (args.bias) {
+        const float4 b4 = *reinterpret_cast<const float4*>(args.bias + n);
+        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+      }
+      if (args.act == ENH_ACT_TANH) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
+      } else if (args.act == ENH_ACT_DTANH) {
+        const uint2 a2 = *reinterpret_cast<const uint2*>(args.aux + m * args.ldaux + n);
+        const float h0 = bf16_bits_to_f32((uint16_t)(a2.x & 0xffffu)), h1 = bf16_bits_to_f32((uint16_t)(a2.x >> 16));
+        const float h2 = bf16_bits_to_f32((uint16_t)(a2.y & 0xffffu)), h3 = bf16_bits_to_f32((uint16_t)(a2.y >> 16));
+        v[0] *= 1.f - h0 * h0; v[1] *= 1.f - h1 * h1; v[2] *= 1.f - h2 * h2; v[3] *= 1.f - h3 * h3;
+      }
+      if (args.res) {
+        const float4 r4 = *reinterpret_cast<const float4*>(args.res + (m % args.res_rows) * args.ldres + n);
+        v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+      }
+      if (args.accumulate == 1 && cp) {
+        const float4 o4 = *reinterpret_cast<const float4*>(cp);
+        v[0] += o4.x; v[1] += o4.y; v[2] += o4.z; v[3] += o4.w;
+      }
+      if (cp) *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+      if (args.c_bf16) *reinterpret_cast<uint2*>(args.c_bf16 + m * args.ldc + n) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+    }
+  }
+}
+
+// tile scheduling shared by both kernels
+__device__ __forceinline__ void gemm_tile_coords(const GemmArgs& args, int& split, int& tile_m, int& tile_n) {
+  // (1) XCD-aware: workgroup b runs on XCD b % 8 -> give each XCD a contiguous run of tile slots;
+  // (2) grouped order inside the run: 8 row-panels x all column tiles, row-fastest, so the ~64 tiles an XCD has in
+  //     flight form an ~8 x 8 patch whose A and B panels (8 x 196 KB each at K = 768) both stay in its 4 MiB L2.
+  const int nwg = args.nbm * args.nbn;  // tiles per K-split
+  split = blockIdx.x / nwg;
+  int bid = blockIdx.x - split * nwg;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, pos = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+  }
+  const int per_group = 8 * args.nbn;
+  const int grp = bid / per_group, within = bid - grp * per_group;
+  const int rows = (args.nbm - grp * 8) < 8 ? (args.nbm - grp * 8) : 8;
+  tile_m = grp * 8 + within % rows;
+  tile_n = within / rows;
+}
+
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2 stages][A tile | B tile]
@@ -105,15 +171,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs args) 
   const int wm = wave >> 1, wn = wave & 1;
   const int l16 = lane & 15, lg = lane >> 4;
 
-  // ---- XCD-aware tile order: workgroup b runs on XCD b % 8; give each XCD a contiguous run of tiles ----
-  const int nwg = args.nbm * args.nbn;  // tiles per K-split
-  const int split = blockIdx.x / nwg;
-  int bid = blockIdx.x - split * nwg;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, pos = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
-  }
-  const int tile_m = bid / args.nbn, tile_n = bid - tile_m * args.nbn;
+  int split, tile_m, tile_n;
+  gemm_tile_coords(args, split, tile_m, tile_n);
   const int64_t m0 = (int64_t)tile_m * G_BM, n0 = (int64_t)tile_n * G_BN;
   const int64_t k_begin = (int64_t)split * args.k_per_split;
   int64_t k_end = k_begin + args.k_per_split;
@@ -165,47 +224,533 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs args) 
     __syncthreads();
   }
 
-  // ---- epilogue: lane (lg, l16) holds C[m = .. + l16][n = .. + lg*4 + 0..3] ----
+  gemm_epilogue(args, acc, m0, n0, wm, wn, lg, l16);
+}
+
+
+// =================================================================================================
+// direct-to-LDS variant: global_load_lds (16 B / lane) writes the swizzled LDS image itself — the LDS destination
+// of a wave instruction is lane-linear (base + lane*16 B, verified in profiles/hw_probe_r01.txt), so the XOR swizzle
+// is applied to each lane's SOURCE address instead.  No staging VGPRs, no ds_write pass.  Requires every K-slice to
+// be a multiple of 64 (no zero-fill is possible); out-of-range rows / columns are clamped to the last valid one —
+// their products land in outputs that are never stored.
+// =================================================================================================
+template <bool TR>
+__device__ __forceinline__ void tile_glds_setup(const uint16_t* (&src)[4], const uint16_t* __restrict__ P, int64_t ld, int64_t x0,
+                                                int64_t X, int64_t k_begin, int wave, int lane) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int64_t m = m0 + wm * 64 + i * 16 + l16;
-    if (m >= args.M) continue;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int64_t n = n0 + wn * 64 + j * 16 + lg * 4;
-      if (n >= args.N) continue;  // N % 4 == 0: the 4 columns are in or out together
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      float* cp = args.c_f32 ? args.c_f32 + m * args.ldc + n : nullptr;
-      if (args.accumulate == 2) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) atomicAdd(cp + r, v[r]);
-        continue;
-      }
-      if (args.bias) {
-        const float4 b4 = *reinterpret_cast<const float4*>(args.bias + n);
-        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-      }
-      if (args.act == ENH_ACT_TANH) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
-      } else if (args.act == ENH_ACT_DTANH) {
-        const uint2 a2 = *reinterpret_cast<const uint2*>(args.aux + m * args.ldaux + n);
-        const float h0 = bf16_bits_to_f32((uint16_t)(a2.x & 0xffffu)), h1 = bf16_bits_to_f32((uint16_t)(a2.x >> 16));
-        const float h2 = bf16_bits_to_f32((uint16_t)(a2.y & 0xffffu)), h3 = bf16_bits_to_f32((uint16_t)(a2.y >> 16));
-        v[0] *= 1.f - h0 * h0; v[1] *= 1.f - h1 * h1; v[2] *= 1.f - h2 * h2; v[3] *= 1.f - h3 * h3;
-      }
-      if (args.res) {
-        const float4 r4 = *reinterpret_cast<const float4*>(args.res + (m % args.res_rows) * args.ldres + n);
-        v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
-      }
-      if (args.accumulate == 1 && cp) {
-        const float4 o4 = *reinterpret_cast<const float4*>(cp);
-        v[0] += o4.x; v[1] += o4.y; v[2] += o4.z; v[3] += o4.w;
-      }
-      if (cp) *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
-      if (args.c_bf16) *reinterpret_cast<uint2*>(args.c_bf16 + m * args.ldc + n) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+    const int inst = wave * 4 + i;  // which 1-KiB slab of the 16-KiB tile this wave instruction fills
+    if (!TR) {
+      const int r = inst * 8 + (lane >> 3), pc = lane & 7;  // LDS row, physical 16-B chunk
+      const int c = pc ^ ((r >> 1) & 7);                    // logical chunk that must land there (lds_row_off)
+      int64_t row = x0 + r;
+      if (row > X - 1) row = X - 1;
+      src[i] = P + row * ld + k_begin + c * 8;
+    } else {
+      const int k = inst * 4 + (lane >> 4), pp = lane & 15;  // LDS k-row, physical 16-B piece
+      const int q = (pp >> 1) ^ ((k & 3) | (((k >> 3) & 1) << 2));  // logical 32-B chunk (lds_kmaj_off)
+      int64_t col = x0 + q * 16 + (pp & 1) * 8;
+      if (col > X - 8) col = X - 8;
+      src[i] = P + (k_begin + k) * ld + col;
     }
   }
+}
+template <bool TR>
+__device__ __forceinline__ void tile_glds_issue(const uint16_t* (&src)[4], unsigned char* tile, int64_t ld, int wave) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    __builtin_amdgcn_global_load_lds((const GLB_AS void*)src[i], (LDS_AS void*)(tile + (wave * 4 + i) * 1024), 16, 0, 0);
+    src[i] += TR ? (int64_t)G_BK * ld : (int64_t)G_BK;
+  }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_glds_kernel(const GemmArgs args) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2 stages][A tile | B tile]
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l16 = lane & 15, lg = lane >> 4;
+  int split, tile_m, tile_n;
+  gemm_tile_coords(args, split, tile_m, tile_n);
+  const int64_t m0 = (int64_t)tile_m * G_BM, n0 = (int64_t)tile_n * G_BN;
+  const int64_t k_begin = (int64_t)split * args.k_per_split;
+  int64_t k_end = k_begin + args.k_per_split;
+  if (k_end > args.K) k_end = args.K;
+  const int nk = (int)((k_end - k_begin) / G_BK);
+
+  const uint16_t* sa_src[4];
+  const uint16_t* sb_src[4];
+  tile_glds_setup<TA>(sa_src, args.A, args.lda, m0, args.M, k_begin, wave, lane);
+  tile_glds_setup<TB>(sb_src, args.B, args.ldb, n0, args.N, k_begin, wave, lane);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (nk > 0) {
+    tile_glds_issue<TA>(sa_src, smem, args.lda, wave);
+    tile_glds_issue<TB>(sb_src, smem + G_TILE_BYTES, args.ldb, wave);
+  }
+  __syncthreads();  // hipcc drains vmcnt(0) before the barrier while an LDS-DMA is in flight
+  for (int kt = 0; kt < nk; ++kt) {
+    const int stage = kt & 1;
+    if (kt + 1 < nk) {
+      unsigned char* na = smem + (stage ^ 1) * (2 * G_TILE_BYTES);
+      tile_glds_issue<TA>(sa_src, na, args.lda, wave);
+      tile_glds_issue<TB>(sb_src, na + G_TILE_BYTES, args.ldb, wave);
+    }
+    const unsigned char* sa = smem + stage * (2 * G_TILE_BYTES);
+    const unsigned char* sb = sa + G_TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      s16x8 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = tile_frag<TA>(sa, wm * 64 + i * 16, ks, lg, l16);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = tile_frag<TB>(sb, wn * 64 + j * 16, ks, lg, l16);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[j]), __builtin_bit_cast(bf16x8, fa[i]), acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  gemm_epilogue(args, acc, m0, n0, wm, wn, lg, l16);
+}
+
+
+// =================================================================================================
+// 3-stage pipelined variant ("p3"): 256 x 128 x 64 workgroup tile, 8 waves (4 x 2), one workgroup per CU.
+// A stage = three 16-KiB sub-tiles [A rows 0-127 | A rows 128-255 | B] in exactly the swizzled formats above,
+// filled by global_load_lds (6 x 1 KiB wave-instructions per wave).  The ring holds 3 stages (144 KiB LDS): while
+// stage kt is multiplied, stages kt+1 and kt+2 are in flight.  Waves wait with a COUNTED s_waitcnt vmcnt(6)
+// (their own 6 loads of the newest stage may stay outstanding) and meet at a raw s_barrier — the loads stay in flight
+// across barriers instead of being drained to vmcnt(0) at each one (cdna_hip_programming.md §5 "Pipelining across
+// barriers").  WAR safety: stage kt+2 reuses the buffer read during step kt-1, and every wave has passed this step's
+// barrier only after finishing its kt-1 reads.
+// =================================================================================================
+#define G3_BM 256
+#define G3_STAGE_BYTES (3 * G_TILE_BYTES)
+#define G3_STAGES 3
+
+template <bool TR>
+__device__ __forceinline__ const uint16_t* glds_src_ptr(const uint16_t* __restrict__ P, int64_t ld, int64_t x0, int64_t X,
+                                                        int64_t k_begin, int slab, int lane) {
+  if (!TR) {
+    const int r = slab * 8 + (lane >> 3), pc = lane & 7;
+    const int c = pc ^ ((r >> 1) & 7);
+    int64_t row = x0 + r;
+    if (row > X - 1) row = X - 1;
+    return P + row * ld + k_begin + c * 8;
+  } else {
+    const int k = slab * 4 + (lane >> 4), pp = lane & 15;
+    const int q = (pp >> 1) ^ ((k & 3) | (((k >> 3) & 1) << 2));
+    int64_t col = x0 + q * 16 + (pp & 1) * 8;
+    if (col > X - 8) col = X - 8;
+    return P + (k_begin + k) * ld + col;
+  }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_p3_kernel(const GemmArgs args) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [3 stages][A0 | A1 | B]
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wn = wave & 1;  // 4 x 2 waves, each 64 x 64
+  const int l16 = lane & 15, lg = lane >> 4;
+  int split, tile_m, tile_n;
+  gemm_tile_coords(args, split, tile_m, tile_n);
+  const int64_t m0 = (int64_t)tile_m * G3_BM, n0 = (int64_t)tile_n * G_BN;
+  const int64_t k_begin = (int64_t)split * args.k_per_split;
+  int64_t k_end = k_begin + args.k_per_split;
+  if (k_end > args.K) k_end = args.K;
+  const int nk = (int)((k_end - k_begin) / G_BK);
+
+  // this wave's 6 of the 48 one-KiB slabs of a stage: slab id g = wave*6 + i -> sub-tile g>>4, slab g&15
+  const uint16_t* src[6];
+  int lds_off[6];
+  int64_t step[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int g = wave * 6 + i, sub = g >> 4, slab = g & 15;
+    lds_off[i] = sub * G_TILE_BYTES + slab * 1024;
+    if (sub < 2) {
+      src[i] = glds_src_ptr<TA>(args.A, args.lda, m0 + sub * 128, args.M, k_begin, slab, lane);
+      step[i] = TA ? (int64_t)G_BK * args.lda : (int64_t)G_BK;
+    } else {
+      src[i] = glds_src_ptr<TB>(args.B, args.ldb, n0, args.N, k_begin, slab, lane);
+      step[i] = TB ? (int64_t)G_BK * args.ldb : (int64_t)G_BK;
+    }
+  }
+#define G3_ISSUE(BUF)                                                                                                    \
+  do {                                                                                                                   \
+    unsigned char* base_ = smem + (BUF) * G3_STAGE_BYTES;                                                                \
+    _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) {                                                                   \
+      __builtin_amdgcn_global_load_lds((const GLB_AS void*)src[i_], (LDS_AS void*)(base_ + lds_off[i_]), 16, 0, 0);      \
+      src[i_] += step[i_];                                                                                               \
+    }                                                                                                                    \
+  } while (0)
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (nk > 0) G3_ISSUE(0);
+  if (nk > 1) G3_ISSUE(1);
+  int buf = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < nk) G3_ISSUE(buf >= 1 ? buf - 1 : 2);  // (kt + 2) % 3
+    const unsigned char* sa = smem + buf * G3_STAGE_BYTES + (wm >> 1) * G_TILE_BYTES;
+    const unsigned char* sb = smem + buf * G3_STAGE_BYTES + 2 * G_TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      s16x8 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = tile_frag<TA>(sa, (wm & 1) * 64 + i * 16, ks, lg, l16);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = tile_frag<TB>(sb, wn * 64 + j * 16, ks, lg, l16);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[j]), __builtin_bit_cast(bf16x8, fa[i]), acc[i][j], 0, 0, 0);
+    }
+    buf = buf == 2 ? 0 : buf + 1;
+  }
+  gemm_epilogue(args, acc, m0, n0, wm, wn, lg, l16);
+}
+
+
+// =================================================================================================
+// "pipe2": 128 x 128 x 64 tile, 4 waves, two LDS stages, direct-to-LDS loads — with the K-loop software-pipelined
+// around ONE mid-iteration barrier:
+//     read F1 = fragments (kt, k 32..63)            | LDS latency of F1 hides under ...
+//     16 MFMAs on F0 = fragments (kt, k 0..31)      | ... these MFMAs
+//     lgkmcnt(0) ; vmcnt(0) ; s_barrier             <- every wave now holds ALL of stage kt in registers, and its
+//                                                      share of stage kt+1 (issued one full iteration ago) has landed
+//     global_load_lds stage kt+2 -> the buffer of stage kt   (free: nobody reads it any more)
+//     read F0 = fragments (kt+1, k 0..31)           | latency hides under ...
+//     16 MFMAs on F1                                | ... these MFMAs
+// so loads get a whole iteration to arrive with only two 32-KiB buffers (two workgroups per CU), and no ds_read
+// latency is exposed in steady state.  Raw s_barrier + explicit waits: __syncthreads() would drain differently.
+// =================================================================================================
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_pipe2_kernel(const GemmArgs args) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2 stages][A tile | B tile]
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l16 = lane & 15, lg = lane >> 4;
+  int split, tile_m, tile_n;
+  gemm_tile_coords(args, split, tile_m, tile_n);
+  const int64_t m0 = (int64_t)tile_m * G_BM, n0 = (int64_t)tile_n * G_BN;
+  const int64_t k_begin = (int64_t)split * args.k_per_split;
+  int64_t k_end = k_begin + args.k_per_split;
+  if (k_end > args.K) k_end = args.K;
+  const int nk = (int)((k_end - k_begin) / G_BK);
+
+  const uint16_t* src[8];
+  int64_t step[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    src[i] = glds_src_ptr<TA>(args.A, args.lda, m0, args.M, k_begin, wave * 4 + i, lane);
+    src[4 + i] = glds_src_ptr<TB>(args.B, args.ldb, n0, args.N, k_begin, wave * 4 + i, lane);
+    step[i] = TA ? (int64_t)G_BK * args.lda : (int64_t)G_BK;
+    step[4 + i] = TB ? (int64_t)G_BK * args.ldb : (int64_t)G_BK;
+  }
+#define P2_ISSUE(BUF)                                                                                                    \
+  do {                                                                                                                   \
+    unsigned char* base_ = smem + (BUF) * (2 * G_TILE_BYTES);                                                            \
+    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                                                   \
+      __builtin_amdgcn_global_load_lds((const GLB_AS void*)src[i_],                                                      \
+                                       (LDS_AS void*)(base_ + (i_ >> 2) * G_TILE_BYTES + (wave * 4 + (i_ & 3)) * 1024), 16, 0, 0); \
+      src[i_] += step[i_];                                                                                               \
+    }                                                                                                                    \
+  } while (0)
+#define P2_READ(FA, FB, BUF, KS)                                                                                         \
+  do {                                                                                                                   \
+    const unsigned char* sa_ = smem + (BUF) * (2 * G_TILE_BYTES);                                                        \
+    const unsigned char* sb_ = sa_ + G_TILE_BYTES;                                                                       \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) FA[i_] = tile_frag<TA>(sa_, wm * 64 + i_ * 16, KS, lg, l16);        \
+    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) FB[j_] = tile_frag<TB>(sb_, wn * 64 + j_ * 16, KS, lg, l16);        \
+  } while (0)
+#define P2_MMA(FA, FB)                                                                                                   \
+  do {                                                                                                                   \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                                     \
+      _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                                   \
+        acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, FB[j_]), __builtin_bit_cast(bf16x8, FA[i_]), acc[i_][j_], 0, 0, 0); \
+  } while (0)
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  s16x8 fa0[4], fb0[4], fa1[4], fb1[4];
+
+  if (nk > 0) {
+    P2_ISSUE(0);
+    if (nk > 1) {
+      P2_ISSUE(1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // stage 0 landed (stage 1's 8 loads may be outstanding)
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    P2_READ(fa0, fb0, 0, 0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): same state on both edges into the loop header
+  }
+  int buf = 0;
+  const int abl = args.ablate;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (abl != 3) P2_READ(fa1, fb1, buf, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (abl != 2) P2_MMA(fa0, fb0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0): F1 in registers, my share of stage kt+1 landed
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 2 < nk && abl != 1) P2_ISSUE(buf);
+    if (kt + 1 < nk && abl != 3) P2_READ(fa0, fb0, buf ^ 1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (abl != 2) P2_MMA(fa1, fb1);
+    else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { asm volatile("" ::"v"(fa0[i]), "v"(fb0[i]), "v"(fa1[i]), "v"(fb1[i])); }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only: next F0 has arrived under the MFMAs above (builtin, so the
+                                         // compiler's wait-count pass sees it and adds no conservative wait at the loop top)
+    buf ^= 1;
+  }
+#undef P2_ISSUE
+#undef P2_READ
+#undef P2_MMA
+  gemm_epilogue(args, acc, m0, n0, wm, wn, lg, l16);
+}
+
+
+// =================================================================================================
+// "t256": 256 x 256 x 64 workgroup tile, 8 waves (2 x 4), each 128 x 64 = 4 x 2 tiles of v_mfma_f32_32x32x16_bf16.
+// Motivation (measured, profiles/r01_gemm_ablation.txt): the 128 x 128 tile is bound by global->LDS ingest
+// (~30 B/clk/CU sustained; 64 FLOP per staged byte needs 64 B/clk/CU at MFMA peak).  256 x 256 doubles the
+// intensity to 128 FLOP/B.  A stage = four 16-KiB sub-tiles [A rows 0-127 | A rows 128-255 | B 0-127 | B 128-255];
+// two stages = 128 KiB LDS, one workgroup per CU.  Schedule = pipe2 with the K-step split into four k16 sub-steps and
+// two alternating fragment sets (6 fragments each): the reads of sub-step s+1 are issued before the 8 MFMAs of
+// sub-step s; after sub-step 2 every wave holds the rest of stage kt in registers -> lgkmcnt(0) + vmcnt(0) + barrier,
+// global_load_lds of stage kt+2 into the freed buffer, first fragments of stage kt+1, then sub-step 3's MFMAs.
+// The contraction-major ("kmaj") sub-tiles use a second swizzle (q ^ (2*(k&3) | (k>>2)&1)) that keeps the 32-column
+// transpose reads of this fragment shape conflict-free.
+// =================================================================================================
+#define G4_BM 256
+#define G4_BN 256
+#define G4_STAGE_BYTES (4 * G_TILE_BYTES)
+__device__ __forceinline__ int lds_kmaj2_off(int k, int q) { return k * 256 + ((q ^ (((k & 3) << 1) | ((k >> 2) & 1))) << 5); }
+
+template <bool TR>
+__device__ __forceinline__ const uint16_t* glds_src_ptr2(const uint16_t* __restrict__ P, int64_t ld, int64_t x0, int64_t X,
+                                                         int64_t k_begin, int slab, int lane) {
+  if (!TR) return glds_src_ptr<false>(P, ld, x0, X, k_begin, slab, lane);
+  const int k = slab * 4 + (lane >> 4), pp = lane & 15;
+  const int q = (pp >> 1) ^ (((k & 3) << 1) | ((k >> 2) & 1));
+  int64_t col = x0 + q * 16 + (pp & 1) * 8;
+  if (col > X - 8) col = X - 8;
+  return P + (k_begin + k) * ld + col;
+}
+// 32x32x16 operand fragment: index = base + (lane & 31), k = s*16 + (lane>>5)*8 + 0..7
+template <bool TR>
+__device__ __forceinline__ s16x8 frag32(const unsigned char* tile, int base, int s, int lane) {
+  const int l31 = lane & 31, hi = lane >> 5;
+  if (!TR) {
+    return *reinterpret_cast<const s16x8*>(tile + lds_row_off(base + l31, s * 2 + hi));
+  } else {
+    const int G = lane >> 4, s16 = lane & 15;
+    const int kr = s * 16 + hi * 8 + (s16 >> 2);
+    const int q = (base >> 4) + (G & 1);
+    const s16x4 lo = lds_tr_read_b64(tile + lds_kmaj2_off(kr, q) + (s16 & 3) * 8);
+    const s16x4 up = lds_tr_read_b64(tile + lds_kmaj2_off(kr + 4, q) + (s16 & 3) * 8);
+    s16x8 o;
+    o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
+    o[4] = up[0]; o[5] = up[1]; o[6] = up[2]; o[7] = up[3];
+    return o;
+  }
+}
+
+// epilogue for the swapped 32x32 accumulator layout: acc[i][j][r] = C[m0 + i*32 + (lane&31)][n0 + j*32 + 8*(r>>2) + 4*(lane>>5) + (r&3)]
+__device__ __forceinline__ void gemm_epilogue32(const GemmArgs& args, f32x16 (&acc)[4][2], int64_t mw, int64_t nw, int lane) {
+  const int l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t m = mw + i * 32 + l31;
+    if (m >= args.M) continue;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int64_t n = nw + j * 32 + 8 * g4 + 4 * hi;
+        if (n >= args.N) continue;
+        float v[4] = {acc[i][j][g4 * 4 + 0], acc[i][j][g4 * 4 + 1], acc[i][j][g4 * 4 + 2], acc[i][j][g4 * 4 + 3]};
+        float* cp = args.c_f32 ? args.c_f32 + m * args.ldc + n : nullptr;
+        if (args.accumulate == 2) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) atomicAdd(cp + r, v[r]);
+          continue;
+        }
+        if (args.bias) {
+          const float4 b4 = *reinterpret_cast<const float4*>(args.bias + n);
+          v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+        }
+        if (args.act == ENH_ACT_TANH) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
+        } else if (args.act == ENH_ACT_DTANH) {
+          const uint2 a2 = *reinterpret_cast<const uint2*>(args.aux + m * args.ldaux + n);
+          const float h0 = bf16_bits_to_f32((uint16_t)(a2.x & 0xffffu)), h1 = bf16_bits_to_f32((uint16_t)(a2.x >> 16));
+          const float h2 = bf16_bits_to_f32((uint16_t)(a2.y & 0xffffu)), h3 = bf16_bits_to_f32((uint16_t)(a2.y >> 16));
+          v[0] *= 1.f - h0 * h0; v[1] *= 1.f - h1 * h1; v[2] *= 1.f - h2 * h2; v[3] *= 1.f - h3 * h3;
+        }
+        if (args.res) {
+          const float4 r4 = *reinterpret_cast<const float4*>(args.res + (m % args.res_rows) * args.ldres + n);
+          v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+        }
+        if (args.accumulate == 1 && cp) {
+          const float4 o4 = *reinterpret_cast<const float4*>(cp);
+          v[0] += o4.x; v[1] += o4.y; v[2] += o4.z; v[3] += o4.w;
+        }
+        if (cp) *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+        if (args.c_bf16) *reinterpret_cast<uint2*>(args.c_bf16 + m * args.ldc + n) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+      }
+    }
+  }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_t256_kernel(const GemmArgs args) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2 stages][A0 | A1 | B0 | B1]
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 2, wn = wave & 3;  // 2 x 4 waves, each 128 (M) x 64 (N)
+  int split, tile_m, tile_n;
+  gemm_tile_coords(args, split, tile_m, tile_n);
+  const int64_t m0 = (int64_t)tile_m * G4_BM, n0 = (int64_t)tile_n * G4_BN;
+  const int64_t k_begin = (int64_t)split * args.k_per_split;
+  int64_t k_end = k_begin + args.k_per_split;
+  if (k_end > args.K) k_end = args.K;
+  const int nk = (int)((k_end - k_begin) / G_BK);
+
+  const uint16_t* src[8];
+  int lds_off[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int g = wave * 8 + i, sub = g >> 4, slab = g & 15;
+    lds_off[i] = sub * G_TILE_BYTES + slab * 1024;
+    src[i] = sub < 2 ? glds_src_ptr2<TA>(args.A, args.lda, m0 + sub * 128, args.M, k_begin, slab, lane)
+                     : glds_src_ptr2<TB>(args.B, args.ldb, n0 + (sub - 2) * 128, args.N, k_begin, slab, lane);
+  }
+  const int64_t step_a = TA ? (int64_t)G_BK * args.lda : (int64_t)G_BK;
+  const int64_t step_b = TB ? (int64_t)G_BK * args.ldb : (int64_t)G_BK;
+  // waves 0-3 stage A slabs (sub-tiles 0,1), waves 4-7 stage B slabs (sub-tiles 2,3): g>>4 = wave>>1 ... per-wave uniform
+  const int64_t my_step = wave < 4 ? step_a : step_b;
+#define T4_ISSUE(BUF)                                                                                                    \
+  do {                                                                                                                   \
+    unsigned char* base_ = smem + (BUF) * G4_STAGE_BYTES;                                                                \
+    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                                                   \
+      __builtin_amdgcn_global_load_lds((const GLB_AS void*)src[i_], (LDS_AS void*)(base_ + lds_off[i_]), 16, 0, 0);      \
+      src[i_] += my_step;                                                                                                \
+    }                                                                                                                    \
+  } while (0)
+#define T4_READ(FA, FB, BUF, S)                                                                                          \
+  do {                                                                                                                   \
+    const unsigned char* sa_ = smem + (BUF) * G4_STAGE_BYTES + wm * G_TILE_BYTES;                                        \
+    const unsigned char* sb_ = smem + (BUF) * G4_STAGE_BYTES + (2 + (wn >> 1)) * G_TILE_BYTES;                           \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) FA[i_] = frag32<TA>(sa_, i_ * 32, S, lane);                         \
+    _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) FB[j_] = frag32<TB>(sb_, (wn & 1) * 64 + j_ * 32, S, lane);         \
+  } while (0)
+#define T4_MMA(FA, FB)                                                                                                   \
+  do {                                                                                                                   \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                                     \
+      _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                                   \
+        acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, FB[j_]), __builtin_bit_cast(bf16x8, FA[i_]), acc[i_][j_], 0, 0, 0); \
+  } while (0)
+#define T4_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define T4_WAIT_LDS() __builtin_amdgcn_s_waitcnt(0xC07F) /* lgkmcnt(0) */
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  s16x8 fae[4], fbe[2], fao[4], fbo[2];
+
+  if (nk > 0) {
+    T4_ISSUE(0);
+    if (nk > 1) {
+      T4_ISSUE(1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    T4_READ(fae, fbe, 0, 0);
+    T4_WAIT_LDS();
+  }
+  int buf = 0;
+  const int abl = args.ablate;
+  if (abl == 0) {
+    for (int kt = 0; kt < nk; ++kt) {
+      T4_READ(fao, fbo, buf, 1); T4_FENCE(); T4_MMA(fae, fbe); T4_FENCE(); T4_WAIT_LDS();
+      T4_READ(fae, fbe, buf, 2); T4_FENCE(); T4_MMA(fao, fbo); T4_FENCE(); T4_WAIT_LDS();
+      T4_READ(fao, fbo, buf, 3); T4_FENCE(); T4_MMA(fae, fbe); T4_FENCE();
+      __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0): stage kt is entirely in registers, stage kt+1 has landed
+      __builtin_amdgcn_s_barrier();
+      T4_FENCE();
+      if (kt + 2 < nk) T4_ISSUE(buf);
+      if (kt + 1 < nk) T4_READ(fae, fbe, buf ^ 1, 0);
+      T4_FENCE(); T4_MMA(fao, fbo); T4_FENCE(); T4_WAIT_LDS();
+      buf ^= 1;
+    }
+  } else {  // debug ablations (ENH_GEMM_ABLATE): 1 = no loads, 2 = no MFMA, 3 = no LDS reads, 4 = 1+3, 5 = 4 + no barrier
+    const bool ld = abl != 1 && abl < 4, rd = abl != 3 && abl < 4, mm = abl != 2, bar = abl != 5;
+    for (int kt = 0; kt < nk; ++kt) {
+      if (rd) T4_READ(fao, fbo, buf, 1); T4_FENCE(); if (mm) T4_MMA(fae, fbe); T4_FENCE(); T4_WAIT_LDS();
+      if (rd) T4_READ(fae, fbe, buf, 2); T4_FENCE(); if (mm) T4_MMA(fao, fbo); T4_FENCE(); T4_WAIT_LDS();
+      if (rd) T4_READ(fao, fbo, buf, 3); T4_FENCE(); if (mm) T4_MMA(fae, fbe); T4_FENCE();
+      __builtin_amdgcn_s_waitcnt(0x0070);
+      if (bar) __builtin_amdgcn_s_barrier();
+      T4_FENCE();
+      if (kt + 2 < nk && ld) T4_ISSUE(buf);
+      if (kt + 1 < nk && rd) T4_READ(fae, fbe, buf ^ 1, 0);
+      T4_FENCE(); if (mm) T4_MMA(fao, fbo); T4_FENCE(); T4_WAIT_LDS();
+      if (!mm) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(fae[i]), "v"(fao[i]));
+        asm volatile("" ::"v"(fbe[0]), "v"(fbe[1]), "v"(fbo[0]), "v"(fbo[1]));
+      }
+      buf ^= 1;
+    }
+  }
+#undef T4_ISSUE
+#undef T4_READ
+#undef T4_MMA
+#undef T4_FENCE
+#undef T4_WAIT_LDS
+  gemm_epilogue32(args, acc, m0 + wm * 128, n0 + wn * 64, lane);
 }
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -226,42 +771,75 @@ extern "C" int enh_gemm_bf16(const enh_bf16* A, int64_t lda, int trans_a, const 
   ENH_REQUIRE(accumulate == 0 || (accumulate == 1 && c_f32), ENH_E_BADARG, "enh_gemm_bf16: accumulate needs an f32 output");
   ENH_REQUIRE((!c_f32 || aligned16(c_f32)) && (!c_bf16 || (reinterpret_cast<uintptr_t>(c_bf16) & 7u) == 0), ENH_E_SHAPE, "enh_gemm_bf16: output alignment");
 
+  static const int kernel_sel = [] {  // ENH_GEMM_KERNEL = reg | glds | p3 | pipe2 (default)
+    const char* e = getenv("ENH_GEMM_KERNEL");
+    if (e && e[0] == 'r') return 0;
+    if (e && e[0] == 'g') return 1;
+    if (e && e[0] == 'p' && e[1] == '3') return 2;
+    if (e && e[0] == 'p') return 3;
+    return 4;  // t256
+  }();  // ... | t256 (default)
+  const bool k64 = K % G_BK == 0 && (!trans_a || M >= 8) && (!trans_b || N >= 8);
+  int family = k64 ? kernel_sel : 0;
+  if (family == 2 && M < 256) family = 1;  // the 256-row tile would mostly multiply clamped rows
+  if (family == 4 && (M < 256 || N < 256)) family = 3;
+  const int bm = family == 2 ? G3_BM : (family == 4 ? G4_BM : G_BM);
+  const int bn = family == 4 ? G4_BN : G_BN;
+
   GemmArgs g;
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.M = M; g.N = N; g.K = K;
   g.bias = bias; g.act = act; g.aux = aux; g.ldaux = ldaux; g.res = res; g.ldres = ldres; g.res_rows = res_rows;
   g.accumulate = accumulate; g.c_f32 = c_f32; g.c_bf16 = c_bf16; g.ldc = ldc;
-  g.nbm = (int)((M + G_BM - 1) / G_BM);
-  g.nbn = (int)((N + G_BN - 1) / G_BN);
+  { const char* e = getenv("ENH_GEMM_ABLATE"); g.ablate = e ? atoi(e) : 0; }
+  g.nbm = (int)((M + bm - 1) / bm);
+  g.nbn = (int)((N + bn - 1) / bn);
   const int64_t tiles = (int64_t)g.nbm * g.nbn;
   ENH_REQUIRE(tiles < (1ll << 30), ENH_E_SHAPE, "enh_gemm_bf16: grid too large");
   // split-K (f32 atomics into a pre-initialised C) when a weight-gradient-shaped problem cannot fill 256 CUs
+  const int64_t ksteps = (K + G_BK - 1) / G_BK;
+  const int64_t fill = family == 4 ? 256 : (family == 2 ? 512 : 768);  // workgroups wanted (p3: one 8-wave workgroup per CU)
   int splits = 1;
-  if (accumulate == 1 && c_f32 && !c_bf16 && !bias && act == ENH_ACT_NONE && !res && tiles < 384 && K >= 2048) {
-    const int64_t ksteps = (K + G_BK - 1) / G_BK;
-    int64_t want = (768 + tiles - 1) / tiles;
+  if (accumulate == 1 && c_f32 && !c_bf16 && !bias && act == ENH_ACT_NONE && !res && tiles < fill / 2 && K >= 2048) {
+    int64_t want = (fill + tiles - 1) / tiles;
     if (want > ksteps / 8) want = ksteps / 8;
     if (want > 64) want = 64;
     if (want >= 2) splits = (int)want;
   }
-  const int64_t ksteps = (K + G_BK - 1) / G_BK;
   g.k_per_split = ((ksteps + splits - 1) / splits) * G_BK;
   splits = (int)((K + g.k_per_split - 1) / g.k_per_split);
   if (splits > 1) g.accumulate = 2;
   const dim3 grid((unsigned)(tiles * splits));
-  const size_t lds = 4 * G_TILE_BYTES;
   hipStream_t s = (hipStream_t)stream;
   static const bool attr_set = [] {
-    const int bytes = 4 * G_TILE_BYTES;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    const int b2 = 4 * G_TILE_BYTES, b3 = G3_STAGES * G3_STAGE_BYTES;
+#define SET_ATTR(K_, B_) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&K_), hipFuncAttributeMaxDynamicSharedMemorySize, B_)
+    SET_ATTR((gemm_bf16_kernel<false, false>), b2); SET_ATTR((gemm_bf16_kernel<false, true>), b2);
+    SET_ATTR((gemm_bf16_kernel<true, false>), b2); SET_ATTR((gemm_bf16_kernel<true, true>), b2);
+    SET_ATTR((gemm_bf16_glds_kernel<false, false>), b2); SET_ATTR((gemm_bf16_glds_kernel<false, true>), b2);
+    SET_ATTR((gemm_bf16_glds_kernel<true, false>), b2); SET_ATTR((gemm_bf16_glds_kernel<true, true>), b2);
+    SET_ATTR((gemm_bf16_p3_kernel<false, false>), b3); SET_ATTR((gemm_bf16_p3_kernel<false, true>), b3);
+    SET_ATTR((gemm_bf16_p3_kernel<true, false>), b3); SET_ATTR((gemm_bf16_p3_kernel<true, true>), b3);
+    SET_ATTR((gemm_bf16_pipe2_kernel<false, false>), b2); SET_ATTR((gemm_bf16_pipe2_kernel<false, true>), b2);
+    SET_ATTR((gemm_bf16_pipe2_kernel<true, false>), b2); SET_ATTR((gemm_bf16_pipe2_kernel<true, true>), b2);
+    SET_ATTR((gemm_bf16_t256_kernel<false, false>), 2 * G4_STAGE_BYTES); SET_ATTR((gemm_bf16_t256_kernel<false, true>), 2 * G4_STAGE_BYTES);
+    SET_ATTR((gemm_bf16_t256_kernel<true, false>), 2 * G4_STAGE_BYTES); SET_ATTR((gemm_bf16_t256_kernel<true, true>), 2 * G4_STAGE_BYTES);
+#undef SET_ATTR
     return true;
   }();
   (void)attr_set;
-  if (!trans_a && !trans_b) gemm_bf16_kernel<false, false><<<grid, 256, lds, s>>>(g);
-  else if (!trans_a && trans_b) gemm_bf16_kernel<false, true><<<grid, 256, lds, s>>>(g);
-  else if (trans_a && !trans_b) gemm_bf16_kernel<true, false><<<grid, 256, lds, s>>>(g);
-  else gemm_bf16_kernel<true, true><<<grid, 256, lds, s>>>(g);
+  const size_t lds2 = 4 * G_TILE_BYTES, lds3 = G3_STAGES * G3_STAGE_BYTES;
+#define LAUNCH(KERN, THREADS, LDS)                                                          \
+  do {                                                                                      \
+    if (!trans_a && !trans_b) KERN<false, false><<<grid, THREADS, LDS, s>>>(g);            \
+    else if (!trans_a && trans_b) KERN<false, true><<<grid, THREADS, LDS, s>>>(g);         \
+    else if (trans_a && !trans_b) KERN<true, false><<<grid, THREADS, LDS, s>>>(g);         \
+    else KERN<true, true><<<grid, THREADS, LDS, s>>>(g);                                   \
+  } while (0)
+  if (family == 4) LAUNCH(gemm_bf16_t256_kernel, 512, (size_t)(2 * G4_STAGE_BYTES));
+  else if (family == 3) LAUNCH(gemm_bf16_pipe2_kernel, 256, lds2);
+  else if (family == 2) LAUNCH(gemm_bf16_p3_kernel, 512, lds3);
+  else if (family == 1) LAUNCH(gemm_bf16_glds_kernel, 256, lds2);
+  else LAUNCH(gemm_bf16_kernel, 256, lds2);
+#undef LAUNCH
   return enh_check_launch("enh_gemm_bf16");
 }

@@ -241,6 +241,45 @@ __global__ void vq_loss_finalize_kernel(const float* __restrict__ partials, int 
 }
 
 // ---------------------------------------------------------------------------------------------
+// codebook-gradient scatter: at initialisation a few dozen codes receive every token (27-34 distinct
+// codes), so per-token global atomics serialise on ~1000 addresses.  Each workgroup therefore first aggregates its 128
+// tokens in an LDS hash table keyed by code (linear probing, LDS float atomics), then issues ONE global atomic per
+// distinct code per column.
+// ---------------------------------------------------------------------------------------------
+#define VQ_HT 256       // slots (>= 2x the 128 tokens of a workgroup)
+#define VQ_HT_PITCH 33  // floats per slot row (33: rows land on different LDS banks)
+__device__ __forceinline__ void vq_scatter_block(int* s_keys, float* s_acc, int code, bool live, int hi, const float (&v)[16],
+                                                 float* __restrict__ dE) {
+  const int t = threadIdx.x;
+  s_keys[t] = -1;
+#pragma unroll
+  for (int k = 0; k < (VQ_HT * VQ_HT_PITCH + 255) / 256; ++k) {
+    const int e = t + 256 * k;
+    if (e < VQ_HT * VQ_HT_PITCH) s_acc[e] = 0.f;
+  }
+  __syncthreads();
+  if (live) {
+    unsigned h = ((unsigned)code * 2654435761u) >> 24;
+    for (int probe = 0; probe < VQ_HT; ++probe) {
+      const int prev = atomicCAS(&s_keys[h], -1, code);
+      if (prev == -1 || prev == code) break;
+      h = (h + 1) & (VQ_HT - 1);
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) atomicAdd(&s_acc[h * VQ_HT_PITCH + hi * 16 + j], v[j]);
+  }
+  __syncthreads();
+#pragma unroll 4
+  for (int k = 0; k < VQ_HT * VQ_D / 256; ++k) {
+    const int e = t + 256 * k;
+    const int row = e >> 5, j = e & 31;
+    const int key = s_keys[row];
+    if (key >= 0) atomicAdd(&dE[(size_t)key * VQ_D + j], s_acc[row * VQ_HT_PITCH + j]);
+  }
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
 // backward: replay r_i, then reverse recursion for the cross-depth term
 // ---------------------------------------------------------------------------------------------
 template <int MAXD>
@@ -249,6 +288,8 @@ __global__ __launch_bounds__(256) void vq_bwd_kernel(
     const float* __restrict__ enrm, const int64_t* __restrict__ idx, const float* __restrict__ g_out, float g_loss,
     const float* __restrict__ g_loss_dev, int64_t M, int depth, int use_norm, int use_residual, float beta,
     float* __restrict__ dz, uint16_t* __restrict__ dz_bf16, float* __restrict__ dE) {
+  __shared__ int s_keys[VQ_HT];
+  __shared__ float s_acc[VQ_HT * VQ_HT_PITCH];
   const int lane = threadIdx.x & 63;
   const int col = lane & 31, hi = lane >> 5;
   const int64_t tok = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 32 + col;
@@ -301,10 +342,7 @@ __global__ __launch_bounds__(256) void vq_bwd_kernel(
 #pragma unroll
         for (int j = 0; j < 16; ++j) v[j] = (v[j] - e[i][j] * dot) / nr;
       }
-      if (live) {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) atomicAdd(&dE[(size_t)code[i] * VQ_D + hi * 16 + j], v[j]);
-      }
+      vq_scatter_block(s_keys, s_acc, code[i], live, hi, v, dE);
       // encoder side: own_i = J^T(r_i)[ gL*beta*c*(zn - en) ]
       float w[16], dp2 = 0.f;
 #pragma unroll

@@ -148,7 +148,8 @@ def _mk(shape, g, scale=1.0):
 
 
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
-@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (1000, 192, 768), (136, 32, 64), (384, 768, 3072), (128, 2304, 32)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (1000, 192, 768), (136, 32, 64), (384, 768, 3072), (128, 2304, 32),
+                                   (520, 768, 192), (768, 512, 2048), (1288, 264, 64)])
 def test_gemm_layouts(C, ta, tb, M, N, K):
     if ta and M % 8:
         pytest.skip("trans_a needs M % 8 == 0")
@@ -165,9 +166,10 @@ def test_gemm_layouts(C, ta, tb, M, N, K):
     assert rel(out16.float(), ref) <= BF16_TOL
 
 
-def test_gemm_epilogues(C):
+@pytest.mark.parametrize("kernel_shape", [(512, 384, 256, 128), (1024, 768, 192, 256)])
+def test_gemm_epilogues(C, kernel_shape):
     g = torch.Generator().manual_seed(5)
-    M, N, K, T = 512, 384, 256, 128
+    M, N, K, T = kernel_shape
     A, B = _mk((M, K), g, 0.5), _mk((N, K), g, 0.1)
     bias = torch.randn(N, generator=g)
     res = torch.randn(M, N, generator=g)

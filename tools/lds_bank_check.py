@@ -67,6 +67,22 @@ if __name__ == "__main__":
             for half in (0, 4):
                 ad = [lds_kmaj_off(ks * 32 + (l >> 4) * 8 + ((l & 15) >> 2) + half, base >> 4) + ((l & 15) & 3) * 8 for l in range(64)]
                 report(f"gemm kmaj-tile tr-read base {base} ks {ks} +{half}", read_b64(ad))
+    # t256 kernel: 32-index fragments on the row layout and on the second contraction-major swizzle
+    def kmaj2(k, q):
+        return k * 256 + ((q ^ (((k & 3) << 1) | ((k >> 2) & 1))) << 5)
+    for base in (0, 32, 96):
+        for sstep in range(4):
+            report(f"t256 row frag32 ds_read_b128 base {base} s {sstep}", read_b128([lds_row_off(base + (l & 31), sstep * 2 + (l >> 5)) for l in range(64)]))
+            for plus in (0, 4):
+                ad = []
+                for l in range(64):
+                    G, s16, hi = l >> 4, l & 15, l >> 5
+                    ad.append(kmaj2(sstep * 16 + hi * 8 + (s16 >> 2) + plus, (base >> 4) + (G & 1)) + (s16 & 3) * 8)
+                report(f"t256 kmaj2 tr-read base {base} s {sstep} +{plus}", read_b64(ad))
+    for w in range(4):
+        t = [w * 64 + l for l in range(64)]
+        # LDS-DMA writes are lane-linear by construction; check the register-staged equivalent anyway
+        report(f"t256 kmaj2 ds_write_b128-equivalent wave {w}", write_b128([kmaj2(x >> 4, (x & 15) >> 1) + (((x & 15) & 1) << 4) for x in t]))
     # attention
     for w in range(4):
         t = [w * 64 + l for l in range(64)]
