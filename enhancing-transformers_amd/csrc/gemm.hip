@@ -698,53 +698,72 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_t256_kernel(const GemmArgs a
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   s16x8 fae[4], fbe[2], fao[4], fbo[2];
 
+  // ---- staggered two-group schedule ----------------------------------------------------------------------------
+  // Each k16 sub-step is split into a READ segment (fragment ds_reads of the NEXT sub-step + a share of the
+  // global_load_lds traffic) and an MMA segment (8 MFMAs), every segment closed by s_barrier.  Waves 4-7 (the second
+  // wave of every SIMD) run ONE barrier behind waves 0-3, so on each SIMD one wave is always inside an MMA segment
+  // while its partner issues LDS / VMEM work: the matrix pipe is fed continuously and read / load issue is hidden.
+  //   stage kt lives in buffer kt & 1; its sub-step-0 fragments are read in R3 of step kt-1, sub-steps 1..3 in R0..R2;
+  //   stage kt+2 is loaded into the same buffer: first half issued in R3(kt) — by then both groups have completed
+  //   their last reads of stage kt (lgkmcnt(0) before the barrier closing R2) — second half in R0(kt+1); every wave
+  //   waits vmcnt(0) at the end of R2(kt+1), i.e. before the barriers that precede any R3(kt+1) read of that stage.
+  const bool late = wave >= 4;  // wave-uniform (readfirstlane above)
+#define T4_BAR() __builtin_amdgcn_s_barrier()
+#define T4_HALF(BUF, H)                                                                                                  \
+  do {                                                                                                                   \
+    unsigned char* base_ = smem + (BUF) * G4_STAGE_BYTES;                                                                \
+    _Pragma("unroll") for (int i_ = (H) * 4; i_ < (H) * 4 + 4; ++i_) {                                                   \
+      __builtin_amdgcn_global_load_lds((const GLB_AS void*)src[i_], (LDS_AS void*)(base_ + lds_off[i_]), 16, 0, 0);      \
+      src[i_] += my_step;                                                                                                \
+    }                                                                                                                    \
+  } while (0)
+#define T4_MMA_SEG(FA, FB)                                                                                               \
+  do {                                                                                                                   \
+    T4_WAIT_LDS();                                                                                                       \
+    T4_FENCE();                                                                                                          \
+    __builtin_amdgcn_s_setprio(1);                                                                                       \
+    T4_MMA(FA, FB);                                                                                                      \
+    __builtin_amdgcn_s_setprio(0);                                                                                       \
+    T4_FENCE();                                                                                                          \
+    T4_BAR();                                                                                                            \
+  } while (0)
+
   if (nk > 0) {
     T4_ISSUE(0);
-    if (nk > 1) {
-      T4_ISSUE(1);
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
+    if (nk > 1) T4_ISSUE(1);
+    __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
+    T4_BAR();
     T4_READ(fae, fbe, 0, 0);
-    T4_WAIT_LDS();
-  }
-  int buf = 0;
-  const int abl = args.ablate;
-  if (abl == 0) {
+    if (late) T4_BAR();  // stagger: the second wave of every SIMD runs one barrier behind
+    int buf = 0;
     for (int kt = 0; kt < nk; ++kt) {
-      T4_READ(fao, fbo, buf, 1); T4_FENCE(); T4_MMA(fae, fbe); T4_FENCE(); T4_WAIT_LDS();
-      T4_READ(fae, fbe, buf, 2); T4_FENCE(); T4_MMA(fao, fbo); T4_FENCE(); T4_WAIT_LDS();
-      T4_READ(fao, fbo, buf, 3); T4_FENCE(); T4_MMA(fae, fbe); T4_FENCE();
-      __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0): stage kt is entirely in registers, stage kt+1 has landed
-      __builtin_amdgcn_s_barrier();
+      // ---- sub-step 0 ----
+      T4_READ(fao, fbo, buf, 1);
+      if (kt >= 1 && kt + 1 < nk) T4_HALF(buf ^ 1, 1);   // second half of stage kt+1 (first half went out in R3(kt-1))
+      T4_FENCE(); T4_BAR();
+      T4_MMA_SEG(fae, fbe);
+      // ---- sub-step 1 ----
+      T4_READ(fae, fbe, buf, 2);
+      T4_FENCE(); T4_BAR();
+      T4_MMA_SEG(fao, fbo);
+      // ---- sub-step 2 ----
+      T4_READ(fao, fbo, buf, 3);
       T4_FENCE();
-      if (kt + 2 < nk) T4_ISSUE(buf);
+      __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0): my share of stage kt+1 has landed ; lgkmcnt(0): my reads of stage kt are done
+      T4_BAR();
+      T4_MMA_SEG(fae, fbe);
+      // ---- sub-step 3 ----
       if (kt + 1 < nk) T4_READ(fae, fbe, buf ^ 1, 0);
-      T4_FENCE(); T4_MMA(fao, fbo); T4_FENCE(); T4_WAIT_LDS();
+      if (kt + 2 < nk) T4_HALF(buf, 0);                   // first half of stage kt+2 into the buffer stage kt just vacated
+      T4_FENCE(); T4_BAR();
+      T4_MMA_SEG(fao, fbo);
       buf ^= 1;
     }
-  } else {  // debug ablations (ENH_GEMM_ABLATE): 1 = no loads, 2 = no MFMA, 3 = no LDS reads, 4 = 1+3, 5 = 4 + no barrier
-    const bool ld = abl != 1 && abl < 4, rd = abl != 3 && abl < 4, mm = abl != 2, bar = abl != 5;
-    for (int kt = 0; kt < nk; ++kt) {
-      if (rd) T4_READ(fao, fbo, buf, 1); T4_FENCE(); if (mm) T4_MMA(fae, fbe); T4_FENCE(); T4_WAIT_LDS();
-      if (rd) T4_READ(fae, fbe, buf, 2); T4_FENCE(); if (mm) T4_MMA(fao, fbo); T4_FENCE(); T4_WAIT_LDS();
-      if (rd) T4_READ(fao, fbo, buf, 3); T4_FENCE(); if (mm) T4_MMA(fae, fbe); T4_FENCE();
-      __builtin_amdgcn_s_waitcnt(0x0070);
-      if (bar) __builtin_amdgcn_s_barrier();
-      T4_FENCE();
-      if (kt + 2 < nk && ld) T4_ISSUE(buf);
-      if (kt + 1 < nk && rd) T4_READ(fae, fbe, buf ^ 1, 0);
-      T4_FENCE(); if (mm) T4_MMA(fao, fbo); T4_FENCE(); T4_WAIT_LDS();
-      if (!mm) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(fae[i]), "v"(fao[i]));
-        asm volatile("" ::"v"(fbe[0]), "v"(fbe[1]), "v"(fbo[0]), "v"(fbo[1]));
-      }
-      buf ^= 1;
-    }
+    if (!late) T4_BAR();  // barrier counts must match across the workgroup
   }
+#undef T4_BAR
+#undef T4_HALF
+#undef T4_MMA_SEG
 #undef T4_ISSUE
 #undef T4_READ
 #undef T4_MMA
@@ -777,10 +796,13 @@ extern "C" int enh_gemm_bf16(const enh_bf16* A, int64_t lda, int trans_a, const 
     if (e && e[0] == 'g') return 1;
     if (e && e[0] == 'p' && e[1] == '3') return 2;
     if (e && e[0] == 'p') return 3;
-    return 4;  // t256
+    if (e && e[0] == 't') return 4;
+    return -1;  // auto: per-shape choice below
   }();  // ... | t256 (default)
   const bool k64 = K % G_BK == 0 && (!trans_a || M >= 8) && (!trans_b || N >= 8);
-  int family = k64 ? kernel_sel : 0;
+  // auto (measured on MI355X, profiles/r01_gemm_ablation.txt): the 256x256 tile wins when the K loop is long and the
+  // A operand is row-major (fc2 forward, dgrad of qkv / fc1); everything else runs the 128x128 pipe2 kernel.
+  int family = !k64 ? 0 : (kernel_sel >= 0 ? kernel_sel : ((K >= 2048 && !trans_a) ? 4 : 3));
   if (family == 2 && M < 256) family = 1;  // the 256-row tile would mostly multiply clamped rows
   if (family == 4 && (M < 256 || N < 256)) family = 3;
   const int bm = family == 2 ? G3_BM : (family == 4 ? G4_BM : G_BM);
