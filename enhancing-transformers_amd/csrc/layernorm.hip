@@ -63,19 +63,20 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ rstd, const float* __restrict__ dres,
                                                      int64_t M, int D, float* __restrict__ dx32,
                                                      uint16_t* __restrict__ dx16, float* __restrict__ dw,
-                                                     float* __restrict__ db) {
+                                                     float* __restrict__ db, float* __restrict__ dxsum) {
   __shared__ float s_dw[3][NCH * 256];  // waves 1..3 park their column partials here
   __shared__ float s_db[3][NCH * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = D >> 2;
   const float4* w4 = reinterpret_cast<const float4*>(w);
-  float4 gw[NCH], adw[NCH], adb[NCH];
+  float4 gw[NCH], adw[NCH], adb[NCH], adx[NCH];
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int c = lane + 64 * i;
     gw[i] = c < nch ? w4[c] : make_float4(0.f, 0.f, 0.f, 0.f);
     adw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     adb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    adx[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   const int64_t stride = (int64_t)gridDim.x * 4;
   for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += stride) {
@@ -117,6 +118,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         }
         reinterpret_cast<float4*>(dx32 + (size_t)row * D)[c] = o;
         if (dx16) reinterpret_cast<uint2*>(dx16 + (size_t)row * D)[c] = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
+        adx[i].x += o.x; adx[i].y += o.y; adx[i].z += o.z; adx[i].w += o.w;
       }
     }
   }
@@ -147,6 +149,32 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
       }
     }
   }
+  // optional: column sums of dx (= the bias gradient of the Linear that produced this LayerNorm's input stream)
+  if (dxsum) {
+    __syncthreads();
+    if (wave > 0) {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        float* pw = &s_dw[wave - 1][(lane + 64 * i) * 4];
+        pw[0] = adx[i].x; pw[1] = adx[i].y; pw[2] = adx[i].z; pw[3] = adx[i].w;
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+          float ax[4] = {adx[i].x, adx[i].y, adx[i].z, adx[i].w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            for (int ww = 0; ww < 3; ++ww) ax[k] += s_dw[ww][c * 4 + k];
+            atomicAdd(&dxsum[c * 4 + k], ax[k]);
+          }
+        }
+      }
+    }
+  }
 }
 
 extern "C" int enh_layernorm_forward(const float* x, const float* w, const float* b, int64_t M, int D, float eps,
@@ -163,14 +191,14 @@ extern "C" int enh_layernorm_forward(const float* x, const float* w, const float
 
 extern "C" int enh_layernorm_backward(const float* dy, const float* x, const float* w, const float* mean,
                                       const float* rstd, const float* dres, int64_t M, int D, float* dx_f32,
-                                      enh_bf16* dx_bf16, float* dw, float* db, void* stream) {
+                                      enh_bf16* dx_bf16, float* dw, float* db, float* dx_colsum, void* stream) {
   ENH_REQUIRE(dy && x && w && mean && rstd && dx_f32 && dw && db, ENH_E_BADARG, "enh_layernorm_backward: null pointer");
   ENH_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 2048, ENH_E_SHAPE, "enh_layernorm_backward: need D %% 4 == 0 and D <= 2048, got M=%lld D=%d", (long long)M, D);
   hipStream_t s = (hipStream_t)stream;
   int64_t want = (M + 3) / 4;
   const int grid = (int)(want < 1024 ? want : 1024);
-  if (D <= 512) ln_bwd_kernel<2><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db);
-  else if (D <= 1024) ln_bwd_kernel<4><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db);
-  else ln_bwd_kernel<8><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db);
+  if (D <= 512) ln_bwd_kernel<2><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum);
+  else if (D <= 1024) ln_bwd_kernel<4><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum);
+  else ln_bwd_kernel<8><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum);
   return enh_check_launch("enh_layernorm_backward");
 }

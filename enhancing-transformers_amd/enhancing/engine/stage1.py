@@ -97,6 +97,7 @@ class _Tower:
                 ln2_w=q + "1.norm.weight", ln2_b=q + "1.norm.bias", w1=q + "1.fn.net.0.weight", b1=q + "1.fn.net.0.bias",
                 w2=q + "1.fn.net.2.weight", b2=q + "1.fn.net.2.bias"))
         self.lnf_w, self.lnf_b = t + "norm.weight", t + "norm.bias"
+        self.first_bias_grad = None  # set by the engine: grad buffer of the bias that feeds layer 0's input (patch-embed / post_quant)
 
     # ---- activation arena --------------------------------------------------------------------
     def bufs(self, B: int, save: bool) -> dict:
@@ -153,26 +154,28 @@ class _Tower:
         M, dim, inner, mlp = B * self.n_tok, self.dim, self.inner, self.mlp
         g = s.grad
         gA, gA16, gB, gB16, dA = b["gA"], b["gA16"], b["gB"], b["gB16"], b["dA"]
+        # every LN backward also emits the column sums of the residual-stream gradient it produces = the bias gradient of
+        # the Linear (fc2 / to_out) that wrote that stream
         _C.layernorm_backward(d_xf, b["x"][self.depth], s.w[self.lnf_w], b["meanf"], b["rstdf"], None, gA, gA16,
-                              g[self.lnf_w], g[self.lnf_b])
+                              g[self.lnf_w], g[self.lnf_b], g[self.L[-1]["b2"]] if self.depth else None)
         for i in range(self.depth - 1, -1, -1):
             P, A = self.L[i], b["layers"][i]
             # ---- MLP: x_out = fc2(tanh(fc1(a2))) + x_mid ----
             _C.gemm(gA16, A["hid"], dim, mlp, M, trans_a=True, trans_b=True, accumulate=True, out_f32=g[P["w2"]])
-            _C.colsum(gA16, M, dim, g[P["b2"]], accumulate=True)
             _C.gemm(gA16, s.w16[P["w2"]], M, mlp, dim, trans_b=True, act=_C.ACT_DTANH, aux=A["hid"], out_bf16=b["dhid16"])
             _C.gemm(b["dhid16"], A["a2"], mlp, dim, M, trans_a=True, trans_b=True, accumulate=True, out_f32=g[P["w1"]])
             _C.colsum(b["dhid16"], M, mlp, g[P["b1"]], accumulate=True)
             _C.gemm(b["dhid16"], s.w16[P["w1"]], M, dim, mlp, trans_b=True, out_f32=dA)
-            _C.layernorm_backward(dA, A["x_mid"], s.w[P["ln2_w"]], A["mean2"], A["rstd2"], gA, gB, gB16, g[P["ln2_w"]], g[P["ln2_b"]])
+            _C.layernorm_backward(dA, A["x_mid"], s.w[P["ln2_w"]], A["mean2"], A["rstd2"], gA, gB, gB16, g[P["ln2_w"]], g[P["ln2_b"]],
+                                  g[P["bout"]])
             # ---- attention: x_mid = to_out(attn(to_qkv(a1))) + x_in ----
             _C.gemm(gB16, A["o"], dim, inner, M, trans_a=True, trans_b=True, accumulate=True, out_f32=g[P["wout"]])
-            _C.colsum(gB16, M, dim, g[P["bout"]], accumulate=True)
             _C.gemm(gB16, s.w16[P["wout"]], M, inner, dim, trans_b=True, out_bf16=b["do16"])
             _C.attention_backward(A["qkv"], A["o"], b["do16"], A["lse"], B, self.n_tok, self.heads, self.scale, b["dqkv16"], b["delta"])
             _C.gemm(b["dqkv16"], A["a1"], 3 * inner, dim, M, trans_a=True, trans_b=True, accumulate=True, out_f32=g[P["wqkv"]])
             _C.gemm(b["dqkv16"], s.w16[P["wqkv"]], M, dim, 3 * inner, trans_b=True, out_f32=dA)
-            _C.layernorm_backward(dA, b["x"][i], s.w[P["ln1_w"]], A["mean1"], A["rstd1"], gB, gA, gA16, g[P["ln1_w"]], g[P["ln1_b"]])
+            _C.layernorm_backward(dA, b["x"][i], s.w[P["ln1_w"]], A["mean1"], A["rstd1"], gB, gA, gA16, g[P["ln1_w"]], g[P["ln1_b"]],
+                                  g[self.L[i - 1]["b2"]] if i > 0 else self.first_bias_grad)
             if on_layer_done is not None:
                 on_layer_done(f"{self.prefix}transformer.layers.{i}.")
         return gA, gA16
@@ -194,6 +197,8 @@ class Stage1Engine:
         self.pd = enc.patch_dim
         self.enc = _Tower(self.store, "encoder.", enc.dim, enc.transformer.depth, enc.transformer.heads, enc.transformer.mlp_dim, self.n_tok)
         self.dec = _Tower(self.store, "decoder.", dec.dim, dec.transformer.depth, dec.transformer.heads, dec.transformer.mlp_dim, self.n_tok)
+        self.enc.first_bias_grad = self.store.grad["encoder.to_patch_embedding.0.bias"]
+        self.dec.first_bias_grad = self.store.grad["post_quant.bias"]
         self.q = q
         self.ed = q.embed_dim
         self._io: Dict[int, dict] = {}
@@ -332,7 +337,6 @@ class Stage1Engine:
             notify("decoder.to_pixel.")
         g0, g016 = self.dec.backward(B, d_xf, notify)
         _C.gemm(g016, zq16, self.dec.dim, self.ed, M, trans_a=True, trans_b=True, accumulate=True, out_f32=g["post_quant.weight"])
-        _C.colsum(g016, M, self.dec.dim, g["post_quant.bias"], accumulate=True)
         _C.gemm(g016, s.w16["post_quant.weight"], M, self.ed, self.dec.dim, trans_b=True, out_f32=io["dzq"])
         dh, dh16 = _C.vq_backward(h, E, idx, io["dzq"], codebook_weight, None, float(self.q.beta), self.q.depth, bool(self.q.use_residual),
                                   self.q.use_norm, g["quantizer.embedding.weight"])
@@ -345,7 +349,6 @@ class Stage1Engine:
         e0, e016 = self.enc.backward(B, d_xe, notify)
         wpe = "encoder.to_patch_embedding.0.weight"
         _C.gemm(e016, io["patches"], self.enc.dim, self.pd, M, trans_a=True, trans_b=True, accumulate=True, out_f32=g[wpe].view(self.enc.dim, self.pd))
-        _C.colsum(e016, M, self.enc.dim, g["encoder.to_patch_embedding.0.bias"], accumulate=True)
         if notify:
             notify("encoder.to_patch_embedding.")
         numel = float(img.numel())

@@ -90,10 +90,12 @@ int enh_vq_lookup(const float* codebook, const int64_t* idx, int64_t M, int n_em
 int enh_layernorm_forward(const float* x, const float* w, const float* b, int64_t M, int D, float eps,
                           enh_bf16* y_bf16, float* y_f32, float* mean, float* rstd, void* stream);
 /* dx = LN-backward(dy) [+ dres];  dy [M,D] f32, dres optional f32 residual-stream gradient that is added;
- * dx_f32 [M,D] f32 and optional dx_bf16 copy; dw,db [D] f32 are ACCUMULATED (atomics; caller zeroes). */
+ * dx_f32 [M,D] f32 and optional dx_bf16 copy; dw,db [D] f32 are ACCUMULATED (atomics; caller zeroes);
+ * dx_colsum [D] f32, optional: += column sums of dx — the bias gradient of the Linear whose output feeds this
+ * residual stream (to_out / fc2), fused here so no separate reduction pass over dx is needed. */
 int enh_layernorm_backward(const float* dy, const float* x, const float* w, const float* mean,
                            const float* rstd, const float* dres, int64_t M, int D, float* dx_f32,
-                           enh_bf16* dx_bf16, float* dw, float* db, void* stream);
+                           enh_bf16* dx_bf16, float* dw, float* db, float* dx_colsum, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * bf16 MFMA GEMM with fused epilogue — every nn.Linear / patch conv on the path

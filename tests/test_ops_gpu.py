@@ -134,7 +134,9 @@ def test_layernorm_fwd_bwd(C, M, D):
     assert rel(y16.float(), y) <= BF16_TOL
     dx = torch.empty(M, D, device="cuda"); dx16 = torch.empty(M, D, dtype=torch.bfloat16, device="cuda")
     dw = torch.zeros(D, device="cuda"); db = torch.zeros(D, device="cuda")
-    C.layernorm_backward(dy.cuda(), xd, w.cuda(), mean, rstd, dres.cuda(), dx, dx16, dw, db)
+    dxs = torch.zeros(D, device="cuda")
+    C.layernorm_backward(dy.cuda(), xd, w.cuda(), mean, rstd, dres.cuda(), dx, dx16, dw, db, dxs)
+    assert rel(dxs, (xt.grad + dres).double().sum(0)) <= F32_TOL
     assert rel(dx, xt.grad + dres) <= F32_TOL
     assert rel(dw, wt.grad) <= F32_TOL and rel(db, bt.grad) <= F32_TOL
     assert rel(dx16.float(), xt.grad + dres) <= BF16_TOL
