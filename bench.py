@@ -74,6 +74,8 @@ def main():
 
     rank, local_rank, world = init_process_group_from_env("nccl" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if os.environ.get("ENH_FORCE_DEVICE") is not None:  # test hook: several ranks on one GPU (with ENH_DIST_BACKEND=gloo)
+        local_rank = int(os.environ["ENH_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
     set_seed(0)  # identical init on every rank (then broadcast anyway, as DDP does)

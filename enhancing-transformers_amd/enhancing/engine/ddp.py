@@ -34,8 +34,9 @@ class GradSync:
         self.min_bucket = min_bucket_elems
         self._pending: List[Tuple[int, int]] = []   # finished slices not yet flushed (coalesced when adjacent)
         self._handles = []
-        self._covered = 0
+        self._done: List[Tuple[int, int]] = []       # every slice announced in this step
         self.bytes_reduced = 0
+        self.gap_elems = 0                           # elements finish() had to reduce because nobody announced them
 
     def broadcast_parameters(self, src: int = 0) -> None:
         """DDP's initial parameter broadcast: every rank starts from rank `src`'s weights."""
@@ -45,7 +46,7 @@ class GradSync:
     def layer_done(self, prefix: str) -> None:
         b, e = self.store.slice_of(prefix)
         self._pending.append((b, e))
-        self._covered += e - b
+        self._done.append((b, e))
         if sum(y - x for x, y in self._pending) >= self.min_bucket:
             self._flush()
 
@@ -66,20 +67,24 @@ class GradSync:
         self._pending = []
 
     def finish(self) -> None:
-        """Flush what is left, reduce anything the schedule did not announce, and wait."""
+        """Flush what is left, all-reduce any range of the flat gradient nobody announced (safety net: a missed unit must
+        never leave un-synchronised gradients; `gap_elems` records it so tests can insist on zero), and wait."""
         self._flush()
-        if self._covered < self.store.g.numel():
-            # safety net: a unit was never announced -> reduce the whole buffer's remainder in one go
-            if self._covered == 0:
-                self._handles.append(dist.all_reduce(self.store.g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
-            else:
-                for h in self._handles:
-                    h.wait()
-                raise RuntimeError(f"GradSync: only {self._covered} of {self.store.g.numel()} gradient elements were announced")
+        n = self.store.g.numel()
+        cur, gaps = 0, []
+        for b, e in sorted(self._done):
+            if b > cur:
+                gaps.append((cur, b))
+            cur = max(cur, e)
+        if cur < n:
+            gaps.append((cur, n))
+        for b, e in gaps:
+            self.gap_elems += e - b
+            self._handles.append(dist.all_reduce(self.store.g[b:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
         for h in self._handles:
             h.wait()
         self._handles = []
-        self._covered = 0
+        self._done = []
 
 
 def init_process_group_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
@@ -92,6 +97,7 @@ def init_process_group_from_env(backend: Optional[str] = None) -> Tuple[int, int
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = os.environ.get("ENH_DIST_BACKEND", backend)  # test hook: gloo lets 2 ranks share one GPU (RCCL refuses)
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":

@@ -158,6 +158,8 @@ class _Tower:
         # the Linear (fc2 / to_out) that wrote that stream
         _C.layernorm_backward(d_xf, b["x"][self.depth], s.w[self.lnf_w], b["meanf"], b["rstdf"], None, gA, gA16,
                               g[self.lnf_w], g[self.lnf_b], g[self.L[-1]["b2"]] if self.depth else None)
+        if on_layer_done is not None:
+            on_layer_done(f"{self.prefix}transformer.norm.")
         for i in range(self.depth - 1, -1, -1):
             P, A = self.L[i], b["layers"][i]
             # ---- MLP: x_out = fc2(tanh(fc1(a2))) + x_mid ----

@@ -165,3 +165,60 @@ def test_loss_decreases_and_matches_oracle_trajectory(tiny):
     print("loss trajectory ours", ours, "oracle", ref)
     assert ours[-1] < ours[0]
     assert all(abs(a - b) <= 2e-2 * abs(b) for a, b in zip(ours, ref))
+
+
+def _ddp_worker(rank, world, port, q):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      ENH_DIST_BACKEND="gloo")
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (os.path.join(root, "enhancing-transformers_amd"), os.path.join(root, "oracle"), os.path.join(root, "tests")):
+        sys.path.insert(0, p)
+    import torch
+    import vitvq_oracle as O
+    from enhancing.engine.ddp import GradSync, init_process_group_from_env
+    init_process_group_from_env()
+    torch.cuda.set_device(0)
+    cfg = O.TINY_CFG
+    P = O.make_params(cfg, seed=11)
+    if rank == 1:  # a different init on rank 1 must be overwritten by the broadcast from rank 0
+        P = {k: (v + 0.1 if v.dtype.is_floating_point and "pos_embedding" not in k else v) for k, v in P.items()}
+    m = _build(cfg, P)
+    eng = m.engine
+    eng.comm = GradSync(eng.store, min_bucket_elems=1 << 14)
+    eng.comm.broadcast_parameters(0)
+    eng.store.refresh_shadows()
+    x = O.make_images(5, 4, cfg["image_size"])[rank * 2:(rank + 1) * 2]  # each rank gets its half of the global batch
+    m.training_step({"image": x}, 0, 0)
+    eng.comm.finish()
+    assert eng.comm.gap_elems == 0, "the backward schedule must announce every parameter slice"
+    q.put((rank, (eng.store.g.detach().cpu() / world).numpy(), eng.store.p.detach().cpu().numpy()))  # numpy: pickled by value
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_data_parallel_equals_full_batch():
+    """2 processes (gloo, sharing this GPU), each with half of a 4-image batch: the all-reduced mean gradient must equal
+    the single-process gradient of the full batch (what DDP guarantees the reference, main.py:56)."""
+    import socket
+    import torch.multiprocessing as mp
+    import vitvq_oracle as O
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=90) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.array_equal(got[0][1], got[1][1]) and np.array_equal(got[0][2], got[1][2])  # identical reduced grads / params on both ranks
+    cfg = O.TINY_CFG
+    m = _build(cfg, O.make_params(cfg, seed=11))
+    m.training_step({"image": O.make_images(5, 4, cfg["image_size"])}, 0, 0)
+    full = m.engine.store.g.detach().cpu()
+    # per-rank losses are means over the local half-batch -> mean of the two rank gradients == full-batch gradient (up to bf16 noise;
+    # the codebook loss is a per-rank mean too, exactly as under the reference's DDP)
+    assert rel(torch.from_numpy(got[0][1]), full) <= 2e-2, rel(torch.from_numpy(got[0][1]), full)
