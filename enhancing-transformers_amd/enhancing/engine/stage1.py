@@ -183,6 +183,31 @@ class _Tower:
         return gA, gA16
 
 
+class _AEFunction(torch.autograd.Function):
+    """Autograd bridge over the static schedule: parameters are NOT inputs (their gradients are accumulated into the flat
+    buffer that `param.grad` aliases, the way the fused training step does); the image receives no gradient."""
+
+    @staticmethod
+    def forward(ctx, engine, img, anchor):
+        st = engine.forward_train(img)
+        B, io = st["B"], engine._io_bufs(st["B"])
+        _C.unpatchify_loss(st["pix"], None, B, engine.C, engine.size, engine.size, engine.patch, 0.0, 0.0, io["xrec"], None, None)
+        ctx.engine, ctx.st = engine, st
+        return io["xrec"].clone(), st["qloss"].view(()).clone()
+
+    @staticmethod
+    def backward(ctx, g_xrec, g_qloss):
+        engine, st = ctx.engine, ctx.st
+        B, io = st["B"], engine._io_bufs(st["B"])
+        if g_xrec is None:
+            io["dpix16"].zero_()
+        else:
+            _C.patchify(g_xrec.to(dtype=F32).contiguous(), engine.patch, io["dpix16"])
+        g_dev = None if g_qloss is None else g_qloss.reshape(1).to(dtype=F32).contiguous()
+        engine.backward_from(st, io["dpix16"], 1.0 if g_qloss is not None else 0.0, g_dev)
+        return None, None, None
+
+
 class Stage1Engine:
     """Binds a ``ViTVQ`` module tree to the HIP schedule on one device."""
 
@@ -307,40 +332,43 @@ class Stage1Engine:
         _C.unpatchify_loss(io["pix"], None, B, self.C, self.size, self.size, self.patch, 0.0, 0.0, io["xrec"], None, None)
         return io["xrec"].clone()
 
-    # ---- fused training step: ViTVQ.training_step(optimizer_idx=0) + backward (vitvqgan.py:101-115) -----
-    def forward_backward(self, img: torch.Tensor, w_l1: float = 0.0, w_l2: float = 1.0, codebook_weight: float = 1.0,
-                         zero_grad: bool = True) -> dict:
-        """One AE forward + backward with loss = w_l1*L1 + w_l2*L2 + codebook_weight*qloss
-        (vqperceptual.py:113-117,131-132 with perceptual / adversarial weights 0).  Gradients are ACCUMULATED into
-        the flat grad buffer (zeroed first unless zero_grad=False: gradient accumulation, main.py:22,57)."""
+    # ---- training: forward (activations saved) / backward, used fused by training_step and split by autograd -----
+    def forward_train(self, img: torch.Tensor) -> dict:
+        """Forward with every activation the backward needs kept in the arena of this batch size.  ONE forward may be
+        outstanding per batch size: a later forward_train overwrites the arena (checked through `_fwd_serial`)."""
         img = self._check_img(img)
-        B, s, io, M = img.shape[0], self.store, self._io_bufs(img.shape[0]), img.shape[0] * self.n_tok
-        g = s.grad
-        if zero_grad:
-            s.zero_grad()
-        # ---------------- forward ----------------
+        B, s = img.shape[0], self.store
         eb = self._encode_tokens(img, save=True)
         h = self._pre_quant(eb["xf16"], B)
         E = s.w["quantizer.embedding.weight"]
         zq, zq16, idx, qloss = _C.vq_forward(h, E, float(self.q.beta), self.q.depth, self.q.use_norm)
         pix = self._decode_tokens(zq16, B, save=True)
+        self._fwd_serial = getattr(self, "_fwd_serial", 0) + 1
+        return dict(img=img, B=B, eb=eb, h=h, zq16=zq16, idx=idx, qloss=qloss, pix=pix, serial=self._fwd_serial)
+
+    def backward_from(self, st: dict, dpix16: torch.Tensor, g_loss: float, g_loss_dev: Optional[torch.Tensor] = None) -> None:
+        """Backward of forward_train given dpix16 = d loss / d pix in the patch layout [M, C*p*p] (bf16) and the gradient
+        flowing into the codebook loss (host scalar g_loss times optional device scalar).  ACCUMULATES into the flat grads."""
+        if st["serial"] != self._fwd_serial:
+            raise RuntimeError("backward called for a forward whose saved activations were overwritten by a later forward_train")
+        B, s, io = st["B"], self.store, self._io_bufs(st["B"])
+        M, g = B * self.n_tok, s.grad
+        eb, h, zq16, idx = st["eb"], st["h"], st["zq16"], st["idx"]
+        E = s.w["quantizer.embedding.weight"]
         db = self.dec.bufs(B, True)
-        io["sums"].zero_()
-        _C.unpatchify_loss(pix, img, B, self.C, self.size, self.size, self.patch, w_l1, w_l2, io["xrec"], io["sums"], io["dpix16"])
-        # ---------------- backward ----------------
         notify = self.comm.layer_done if self.comm is not None else None
         d_xf = io["d_xf_dec"]
         wpix = "decoder.to_pixel.1.weight"
-        _C.gemm(db["xf16"], io["dpix16"], self.dec.dim, self.pd, M, trans_a=True, trans_b=True, accumulate=True, out_f32=g[wpix].view(self.dec.dim, self.pd))
-        _C.colsum(io["dpix16"], M, self.pd, io["g_bias_pix"], accumulate=False)
+        _C.gemm(db["xf16"], dpix16, self.dec.dim, self.pd, M, trans_a=True, trans_b=True, accumulate=True, out_f32=g[wpix].view(self.dec.dim, self.pd))
+        _C.colsum(dpix16, M, self.pd, io["g_bias_pix"], accumulate=False)
         g["decoder.to_pixel.1.bias"].add_(io["g_bias_pix"].view(self.C, -1).sum(1))
-        _C.gemm(io["dpix16"], s.w16[wpix].view(self.dec.dim, self.pd), M, self.dec.dim, self.pd, out_f32=d_xf)
+        _C.gemm(dpix16, s.w16[wpix].view(self.dec.dim, self.pd), M, self.dec.dim, self.pd, out_f32=d_xf)
         if notify:
             notify("decoder.to_pixel.")
         g0, g016 = self.dec.backward(B, d_xf, notify)
         _C.gemm(g016, zq16, self.dec.dim, self.ed, M, trans_a=True, trans_b=True, accumulate=True, out_f32=g["post_quant.weight"])
         _C.gemm(g016, s.w16["post_quant.weight"], M, self.ed, self.dec.dim, trans_b=True, out_f32=io["dzq"])
-        dh, dh16 = _C.vq_backward(h, E, idx, io["dzq"], codebook_weight, None, float(self.q.beta), self.q.depth, bool(self.q.use_residual),
+        dh, dh16 = _C.vq_backward(h, E, idx, io["dzq"], g_loss, g_loss_dev, float(self.q.beta), self.q.depth, bool(self.q.use_residual),
                                   self.q.use_norm, g["quantizer.embedding.weight"])
         _C.gemm(dh16, eb["xf16"], self.ed, self.enc.dim, M, trans_a=True, trans_b=True, accumulate=True, out_f32=g["pre_quant.weight"])
         _C.colsum(dh16, M, self.ed, g["pre_quant.bias"], accumulate=True)
@@ -353,13 +381,38 @@ class Stage1Engine:
         _C.gemm(e016, io["patches"], self.enc.dim, self.pd, M, trans_a=True, trans_b=True, accumulate=True, out_f32=g[wpe].view(self.enc.dim, self.pd))
         if notify:
             notify("encoder.to_patch_embedding.")
+
+    def forward_backward(self, img: torch.Tensor, w_l1: float = 0.0, w_l2: float = 1.0, codebook_weight: float = 1.0,
+                         zero_grad: bool = True) -> dict:
+        """Fused ViTVQ.training_step(optimizer_idx=0) + backward (vitvqgan.py:101-115) with
+        loss = w_l1*L1 + w_l2*L2 + codebook_weight*qloss (vqperceptual.py:113-117,131-132, perceptual / adversarial weights 0).
+        Gradients are ACCUMULATED into the flat grad buffer (zeroed first unless zero_grad=False: gradient accumulation,
+        main.py:22,57)."""
+        if zero_grad:
+            self.store.zero_grad()
+        st = self.forward_train(img)
+        img, B, io = st["img"], st["B"], self._io_bufs(st["B"])
+        io["sums"].zero_()
+        _C.unpatchify_loss(st["pix"], img, B, self.C, self.size, self.size, self.patch, w_l1, w_l2, io["xrec"], io["sums"], io["dpix16"])
+        self.backward_from(st, io["dpix16"], codebook_weight)
         numel = float(img.numel())
         l1 = (io["sums"][0] / numel).float()
         l2 = (io["sums"][1] / numel).float()
-        ql = qloss.view(())
+        ql = st["qloss"].view(())
         nll = w_l1 * l1 + w_l2 * l2
         return dict(loss=nll + codebook_weight * ql, quant_loss=ql, rec_loss=nll, loglaplace_loss=l1, loggaussian_loss=l2,
-                    xrec=io["xrec"], indices=idx, h=h)
+                    xrec=io["xrec"], indices=st["idx"], h=st["h"])
+
+    def differentiable_forward(self, img: torch.Tensor):
+        """(xrec, qloss) connected to autograd: `.backward()` on any function of them runs backward_from and leaves the
+        parameter gradients in `param.grad` (views of the flat buffer).  The reference's ViTVQ.forward contract
+        (vitvqgan.py:44-48) for callers that bring their own loss module."""
+        return _AEFunction.apply(self, img, self._anchor())
+
+    def _anchor(self) -> torch.Tensor:
+        if getattr(self, "_anchor_t", None) is None:
+            self._anchor_t = torch.zeros(1, device=self.device, requires_grad=True)  # makes autograd call our backward
+        return self._anchor_t
 
     def optimizer_step(self, lr: float, betas=(0.9, 0.99), eps: float = 1e-8, weight_decay: float = 1e-4, grad_scale: float = 1.0) -> None:
         """torch.optim.AdamW over the single parameter group of vitvqgan.py:153-160 (one fused launch)."""

@@ -83,8 +83,10 @@ class ViTVQ(nn.Module):
 
     # ---- reference API -----------------------------------------------------------------------
     def forward(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-        """(dec, diff) — reference vitvqgan.py:44-48 (inference path: nothing is saved for backward; training goes
-        through training_step)."""
+        """(dec, diff) — reference vitvqgan.py:44-48.  Under torch.no_grad() nothing is saved; with grad enabled the outputs
+        are connected to autograd (one outstanding forward per batch size) so any loss module on top can call .backward()."""
+        if torch.is_grad_enabled():
+            return self.engine.differentiable_forward(x)
         xrec, qloss, _ = self.engine.reconstruct(x)
         return xrec, qloss
 
@@ -134,6 +136,12 @@ class ViTVQ(nn.Module):
     def log_dict(self, d: Dict[str, Any], **_) -> None:
         self.logged.update(d)
 
+    def _fusable_loss(self) -> bool:
+        """the pixel + codebook losses of this package are fused into the unpatchify kernel; anything else goes through autograd"""
+        from ...losses.vqperceptual import VQLPIPS
+        return isinstance(self.loss, VQLPIPS) and float(getattr(self.loss, "perceptual_weight", 0.0)) == 0.0 and \
+            float(getattr(self.loss, "adversarial_weight", 0.0)) == 0.0
+
     def _loss_weights(self) -> Tuple[float, float, float]:
         L = self.loss
         return float(getattr(L, "loglaplace_weight", 0.0)), float(getattr(L, "loggaussian_weight", 1.0)), float(getattr(L, "codebook_weight", 1.0))
@@ -142,6 +150,17 @@ class ViTVQ(nn.Module):
         """reference vitvqgan.py:101-127.  optimizer_idx 0 = autoencoder: forward + backward run fused on the engine
         and the returned loss is detached (the gradients are already in param.grad)."""
         x = self.get_input(batch, self.image_key)
+        if optimizer_idx == 0 and not self._fusable_loss():
+            # generic path, exactly the reference's: forward -> loss module -> autograd backward (vitvqgan.py:103-115)
+            if zero_grad:
+                self.engine.store.zero_grad()
+            xrec, qloss = self(x)
+            aeloss, log_dict_ae = self.loss(qloss, x.to(xrec.device), xrec, optimizer_idx, self.global_step, batch_idx,
+                                            last_layer=self.decoder.get_last_layer(), split="train")
+            aeloss.backward()
+            self.log("train/total_loss", aeloss.detach())
+            self.log_dict({k: v for k, v in log_dict_ae.items() if k != "train/total_loss"})
+            return aeloss.detach()
         if optimizer_idx == 0:
             w1, w2, cw = self._loss_weights()
             out = self.engine.forward_backward(x, w_l1=w1, w_l2=w2, codebook_weight=cw, zero_grad=zero_grad)

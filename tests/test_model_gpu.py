@@ -222,3 +222,35 @@ def test_data_parallel_equals_full_batch():
     # per-rank losses are means over the local half-batch -> mean of the two rank gradients == full-batch gradient (up to bf16 noise;
     # the codebook loss is a per-rank mean too, exactly as under the reference's DDP)
     assert rel(torch.from_numpy(got[0][1]), full) <= 2e-2, rel(torch.from_numpy(got[0][1]), full)
+
+
+def test_forward_is_differentiable_with_a_custom_loss(tiny):
+    """reference contract: `xrec, qloss = model(x)` feeds ANY torch loss and `.backward()` fills the parameter grads
+    (vitvqgan.py:44-48,103-115).  A loss the fused kernel does not know (L1 + 0.3*qloss + Charbonnier) vs oracle autograd."""
+    import vitvq_oracle as O
+    cfg, P, x, _ = tiny
+    m = _build(cfg, P)
+
+    def custom(xrec, qloss, target):
+        d = xrec - target
+        return d.abs().mean() + 0.3 * qloss + torch.sqrt(d * d + 1e-3).mean()
+
+    m.engine.store.zero_grad()
+    xrec, qloss = m(x)
+    assert xrec.requires_grad and qloss.requires_grad
+    loss = custom(xrec, qloss, x.to(xrec.device))
+    loss.backward()
+    leaves = {k: v.detach().clone().requires_grad_(not k.endswith("pos_embedding")) for k, v in P.items()}
+    o_xrec, o_q = O.forward(x, leaves, cfg)
+    o_loss = custom(o_xrec, o_q, x)
+    o_loss.backward()
+    assert abs(loss.item() - o_loss.item()) <= 1e-2 * abs(o_loss.item())
+    errs = {k: rel(p.grad, leaves[k].grad) for k, p in m.named_parameters() if leaves[k].grad is not None}
+    worst = max(errs, key=errs.get)
+    print(f"custom-loss autograd path: worst grad {worst} {errs[worst]:.2e}")
+    assert errs[worst] <= GRAD_TOL, errs
+    # a second forward invalidates the first one's saved activations: its backward must refuse, not corrupt
+    a, _ = m(x)
+    b, _ = m(x)
+    with pytest.raises(RuntimeError, match="overwritten"):
+        a.sum().backward()
