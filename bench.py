@@ -126,7 +126,7 @@ def main():
         return
     img_per_s = args.steps * B * world / elapsed
     ks = timer.summary()
-    gemms = {k: v for k, v in ks.items() if k.startswith("gemm_bf16_kernel")}
+    gemms = {k: v for k, v in ks.items() if k.startswith("gemm_bf16_")}
     dom = max(gemms, key=lambda k: gemms[k]["total_ms"])
     d = gemms[dom]
     achieved = d["work"] / d["launches"] / (d["avg_ms"] * 1e-3) / 1e12

@@ -44,6 +44,7 @@ struct GemmArgs {
   int accumulate;       // 1: += C_old ; 2: split-K partial -> f32 atomicAdd into c_f32
   float* c_f32; uint16_t* c_bf16; int64_t ldc;
   int nbm, nbn;
+  int splits;  // number of K-slices (1 = no split-K; otherwise a multiple of 8)
   int ablate;  // debug only (ENH_GEMM_ABLATE): 1 = no global->LDS loads, 2 = no MFMA, 3 = no LDS fragment reads
 };
 
@@ -150,6 +151,8 @@ __device__ __forceinline__ void gemm_tile_coords(const GemmArgs& args, int& spli
   // (2) grouped order inside the run: 8 row-panels x all column tiles, row-fastest, so the ~64 tiles an XCD has in
   //     flight form an ~8 x 8 patch whose A and B panels (8 x 196 KB each at K = 768) both stay in its 4 MiB L2.
   const int nwg = args.nbm * args.nbn;  // tiles per K-split
+  // (tried: pinning each K-slice of a split-K launch to one XCD halves the fabric traffic PMC reports, but runs 10-15 % slower —
+  //  the duplicated fetches were Infinity-Cache hits, and spreading a slice over all XCDs gives more channel parallelism)
   split = blockIdx.x / nwg;
   int bid = blockIdx.x - split * nwg;
   {
@@ -514,24 +517,34 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_pipe2_kernel(const GemmArgs 
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): same state on both edges into the loop header
   }
   int buf = 0;
-  const int abl = args.ablate;
   for (int kt = 0; kt < nk; ++kt) {
-    if (abl != 3) P2_READ(fa1, fb1, buf, 1);
+    P2_READ(fa1, fb1, buf, 1);
     __builtin_amdgcn_sched_barrier(0);
-    if (abl != 2) P2_MMA(fa0, fb0);
+    P2_MMA(fa0, fb0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0): F1 in registers, my share of stage kt+1 landed
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (kt + 2 < nk && abl != 1) P2_ISSUE(buf);
-    if (kt + 1 < nk && abl != 3) P2_READ(fa0, fb0, buf ^ 1, 0);
+    if (kt + 1 < nk) P2_READ(fa0, fb0, buf ^ 1, 0);
     __builtin_amdgcn_sched_barrier(0);
-    if (abl != 2) P2_MMA(fa1, fb1);
-    else {
+    // second half: the 8 global_load_lds of stage kt+2 are spread one per two MFMAs instead of issued as a burst — a
+    // burst is back-pressured by the texture addresser (~64 B/clk/CU) and the in-order wave cannot issue MFMAs meanwhile
+    const bool more = kt + 2 < nk;
+    unsigned char* nbase = smem + buf * (2 * G_TILE_BYTES);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { asm volatile("" ::"v"(fa0[i]), "v"(fb0[i]), "v"(fa1[i]), "v"(fb1[i])); }
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int ld = i * 2 + jj;  // load slot 0..7
+        acc[i][jj * 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb1[jj * 2]), __builtin_bit_cast(bf16x8, fa1[i]), acc[i][jj * 2], 0, 0, 0);
+        acc[i][jj * 2 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb1[jj * 2 + 1]), __builtin_bit_cast(bf16x8, fa1[i]), acc[i][jj * 2 + 1], 0, 0, 0);
+        if (more) {
+          __builtin_amdgcn_global_load_lds((const GLB_AS void*)src[ld], (LDS_AS void*)(nbase + (ld >> 2) * G_TILE_BYTES + (wave * 4 + (ld & 3)) * 1024), 16, 0, 0);
+          src[ld] += step[ld];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
-    __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only: next F0 has arrived under the MFMAs above (builtin, so the
                                          // compiler's wait-count pass sees it and adds no conservative wait at the loop top)
     buf ^= 1;
@@ -774,6 +787,33 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_t256_kernel(const GemmArgs a
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// kernel family: 0 = register-staged (any K % 8), 1 = glds 2-buffer, 2 = p3, 3 = pipe2, 4 = t256
+static int gemm_family(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K) {
+  static const int kernel_sel = [] {  // ENH_GEMM_KERNEL = reg | glds | p3 | pipe2 | t256 ; unset = per-shape choice
+    const char* e = getenv("ENH_GEMM_KERNEL");
+    if (!e) return -1;
+    if (e[0] == 'r') return 0;
+    if (e[0] == 'g') return 1;
+    if (e[0] == 'p' && e[1] == '3') return 2;
+    if (e[0] == 'p') return 3;
+    if (e[0] == 't') return 4;
+    return -1;
+  }();
+  const bool k64 = K % G_BK == 0 && (!trans_a || M >= 8) && (!trans_b || N >= 8);
+  // per-shape choice (measured on MI355X, profiles/r01_gemm_ablation.txt): the 256x256 tile wins when the K loop is long
+  // and the A operand is row-major (fc2 forward, dgrad of qkv / fc1); everything else runs the 128x128 pipe2 kernel.
+  int family = !k64 ? 0 : (kernel_sel >= 0 ? kernel_sel : ((K >= 2048 && !trans_a) ? 4 : 3));
+  if (family == 2 && M < 256) family = 1;  // the 256-row tile would mostly multiply clamped rows
+  if (family == 4 && (M < 256 || N < 256)) family = 3;
+  return family;
+}
+
+extern "C" const char* enh_gemm_bf16_variant(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K) {
+  static const char* names[5] = {"gemm_bf16_kernel", "gemm_bf16_glds_kernel", "gemm_bf16_p3_kernel", "gemm_bf16_pipe2_kernel",
+                                 "gemm_bf16_t256_kernel"};
+  return names[gemm_family(trans_a, trans_b, M, N, K)];
+}
+
 extern "C" int enh_gemm_bf16(const enh_bf16* A, int64_t lda, int trans_a, const enh_bf16* B, int64_t ldb, int trans_b,
                              int64_t M, int64_t N, int64_t K, const float* bias, int act, const enh_bf16* aux,
                              int64_t ldaux, const float* res, int64_t ldres, int64_t res_rows, int accumulate,
@@ -790,21 +830,7 @@ extern "C" int enh_gemm_bf16(const enh_bf16* A, int64_t lda, int trans_a, const 
   ENH_REQUIRE(accumulate == 0 || (accumulate == 1 && c_f32), ENH_E_BADARG, "enh_gemm_bf16: accumulate needs an f32 output");
   ENH_REQUIRE((!c_f32 || aligned16(c_f32)) && (!c_bf16 || (reinterpret_cast<uintptr_t>(c_bf16) & 7u) == 0), ENH_E_SHAPE, "enh_gemm_bf16: output alignment");
 
-  static const int kernel_sel = [] {  // ENH_GEMM_KERNEL = reg | glds | p3 | pipe2 (default)
-    const char* e = getenv("ENH_GEMM_KERNEL");
-    if (e && e[0] == 'r') return 0;
-    if (e && e[0] == 'g') return 1;
-    if (e && e[0] == 'p' && e[1] == '3') return 2;
-    if (e && e[0] == 'p') return 3;
-    if (e && e[0] == 't') return 4;
-    return -1;  // auto: per-shape choice below
-  }();  // ... | t256 (default)
-  const bool k64 = K % G_BK == 0 && (!trans_a || M >= 8) && (!trans_b || N >= 8);
-  // auto (measured on MI355X, profiles/r01_gemm_ablation.txt): the 256x256 tile wins when the K loop is long and the
-  // A operand is row-major (fc2 forward, dgrad of qkv / fc1); everything else runs the 128x128 pipe2 kernel.
-  int family = !k64 ? 0 : (kernel_sel >= 0 ? kernel_sel : ((K >= 2048 && !trans_a) ? 4 : 3));
-  if (family == 2 && M < 256) family = 1;  // the 256-row tile would mostly multiply clamped rows
-  if (family == 4 && (M < 256 || N < 256)) family = 3;
+  const int family = gemm_family(trans_a, trans_b, M, N, K);
   const int bm = family == 2 ? G3_BM : (family == 4 ? G4_BM : G_BM);
   const int bn = family == 4 ? G4_BN : G_BN;
 
@@ -829,6 +855,7 @@ extern "C" int enh_gemm_bf16(const enh_bf16* A, int64_t lda, int trans_a, const 
   }
   g.k_per_split = ((ksteps + splits - 1) / splits) * G_BK;
   splits = (int)((K + g.k_per_split - 1) / g.k_per_split);
+  g.splits = splits;
   if (splits > 1) g.accumulate = 2;
   const dim3 grid((unsigned)(tiles * splits));
   hipStream_t s = (hipStream_t)stream;

@@ -183,9 +183,14 @@ extern "C" int enh_layernorm_forward(const float* x, const float* w, const float
   ENH_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 2048, ENH_E_SHAPE, "enh_layernorm_forward: need D %% 4 == 0 and D <= 2048, got M=%lld D=%d", (long long)M, D);
   hipStream_t s = (hipStream_t)stream;
   const int grid = (int)((M + 3) / 4);
-  if (D <= 512) ln_fwd_kernel<2><<<grid, 256, 0, s>>>(x, w, b, M, D, eps, y_bf16, y_f32, mean, rstd);
-  else if (D <= 1024) ln_fwd_kernel<4><<<grid, 256, 0, s>>>(x, w, b, M, D, eps, y_bf16, y_f32, mean, rstd);
-  else ln_fwd_kernel<8><<<grid, 256, 0, s>>>(x, w, b, M, D, eps, y_bf16, y_f32, mean, rstd);
+  switch ((D + 255) / 256) {  // float4 chunks per lane: registers (hence occupancy) scale with it
+    case 1: ln_fwd_kernel<1><<<grid, 256, 0, s>>>(x, w, b, M, D, eps, y_bf16, y_f32, mean, rstd); break;
+    case 2: ln_fwd_kernel<2><<<grid, 256, 0, s>>>(x, w, b, M, D, eps, y_bf16, y_f32, mean, rstd); break;
+    case 3: ln_fwd_kernel<3><<<grid, 256, 0, s>>>(x, w, b, M, D, eps, y_bf16, y_f32, mean, rstd); break;
+    case 4: ln_fwd_kernel<4><<<grid, 256, 0, s>>>(x, w, b, M, D, eps, y_bf16, y_f32, mean, rstd); break;
+    case 5: ln_fwd_kernel<5><<<grid, 256, 0, s>>>(x, w, b, M, D, eps, y_bf16, y_f32, mean, rstd); break;
+    default: ln_fwd_kernel<8><<<grid, 256, 0, s>>>(x, w, b, M, D, eps, y_bf16, y_f32, mean, rstd); break;
+  }
   return enh_check_launch("enh_layernorm_forward");
 }
 
@@ -196,9 +201,14 @@ extern "C" int enh_layernorm_backward(const float* dy, const float* x, const flo
   ENH_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 2048, ENH_E_SHAPE, "enh_layernorm_backward: need D %% 4 == 0 and D <= 2048, got M=%lld D=%d", (long long)M, D);
   hipStream_t s = (hipStream_t)stream;
   int64_t want = (M + 3) / 4;
-  const int grid = (int)(want < 1024 ? want : 1024);
-  if (D <= 512) ln_bwd_kernel<2><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum);
-  else if (D <= 1024) ln_bwd_kernel<4><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum);
-  else ln_bwd_kernel<8><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum);
+  const int grid = (int)(want < 2048 ? want : 2048);
+  switch ((D + 255) / 256) {
+    case 1: ln_bwd_kernel<1><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum); break;
+    case 2: ln_bwd_kernel<2><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum); break;
+    case 3: ln_bwd_kernel<3><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum); break;
+    case 4: ln_bwd_kernel<4><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum); break;
+    case 5: ln_bwd_kernel<5><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum); break;
+    default: ln_bwd_kernel<8><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum); break;
+  }
   return enh_check_launch("enh_layernorm_backward");
 }

@@ -36,6 +36,7 @@ SIGNATURES = {
     "enh_layernorm_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "enh_gemm_bf16": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _i64, _i64, _i64, _vp, _i32, _vp, _i64, _vp, _i64, _i64,
                              _i32, _vp, _vp, _i64, _vp]),
+    "enh_gemm_bf16_variant": (_c.c_char_p, [_i32, _i32, _i64, _i64, _i64]),
     "enh_attention_forward": (_i32, [_vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp]),
     "enh_attention_backward": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp]),
     "enh_patchify": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
@@ -214,8 +215,12 @@ def gemm(a, b, M: int, N: int, K: int, trans_a: bool = False, trans_b: bool = Fa
             act, _p(aux, BF16, "aux"), aux.stride(0) if aux is not None else 0, _p(res, F32, "res"),
             res.stride(0) if res is not None else 0, res_rows if res is not None else 0, int(accumulate),
             _p(out_f32, F32, "out_f32"), _p(out_bf16, BF16, "out_bf16"), ldc, _stream())
-    _timed(f"gemm_bf16_kernel<{'T' if trans_a else 'N'}{'T' if trans_b else 'N'}>", 2.0 * M * N * K,
-           lambda: _check(lib().enh_gemm_bf16(*args), "enh_gemm_bf16"))
+    if TIMER is None:
+        _check(lib().enh_gemm_bf16(*args), "enh_gemm_bf16")
+    else:  # label with the symbol rocprofv3 will report, e.g. "gemm_bf16_pipe2_kernel<false, true>"
+        fam = lib().enh_gemm_bf16_variant(int(trans_a), int(trans_b), M, N, K).decode()
+        TIMER.run(f"{fam}<{'true' if trans_a else 'false'}, {'true' if trans_b else 'false'}>", 2.0 * M * N * K,
+                  lambda: _check(lib().enh_gemm_bf16(*args), "enh_gemm_bf16"))
 
 
 # ------------------------------------------------------------------------------------------------

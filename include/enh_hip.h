@@ -118,6 +118,10 @@ int enh_gemm_bf16(const enh_bf16* A, int64_t lda, int trans_a, const enh_bf16* B
                   int64_t ldaux, const float* res, int64_t ldres, int64_t res_rows, int accumulate,
                   float* c_f32, enh_bf16* c_bf16, int64_t ldc, void* stream);
 
+/* name of the kernel family enh_gemm_bf16 launches for this shape (measurement aid: lets callers label timings with
+ * the symbol a profiler will report); the choice is per shape, overridable with ENH_GEMM_KERNEL */
+const char* enh_gemm_bf16_variant(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K);
+
 /* ------------------------------------------------------------------------------------------------
  * Fused attention — Attention.forward layers.py:122-132 without materialising the N x N matrix
  * ------------------------------------------------------------------------------------------------
