@@ -54,6 +54,16 @@ __device__ inline s16x4 lds_tr_read_b64(const void* lds_ptr) {
   return __builtin_bit_cast(s16x4, v);
 }
 
+// Same instruction issued through inline asm: the compiler's wait-count pass treats the tr-read INTRINSIC as a potential
+// reader of in-flight LDS-DMA data and inserts s_waitcnt vmcnt(0) in front of it, which destroys the load pipeline of
+// kernels that keep global_load_lds in flight across their fragment reads.  With the asm form nothing is inserted: the
+// caller must (a) have waited (vmcnt + barrier) for the data this read needs and (b) wait lgkmcnt before using the result
+// (cdna_hip_programming.md §5.7 item 1) — the t256 GEMM schedule does both explicitly.
+__device__ inline void lds_tr_read_b64_asm(unsigned long long& out, const void* lds_ptr) {
+  const unsigned addr = (unsigned)(uintptr_t)(LDS_AS const void*)lds_ptr;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(out) : "v"(addr) : "memory");
+}
+
 __device__ inline float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

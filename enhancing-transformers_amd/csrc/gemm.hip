@@ -593,12 +593,13 @@ __device__ __forceinline__ s16x8 frag32(const unsigned char* tile, int base, int
     const int G = lane >> 4, s16 = lane & 15;
     const int kr = s * 16 + hi * 8 + (s16 >> 2);
     const int q = (base >> 4) + (G & 1);
-    const s16x4 lo = lds_tr_read_b64(tile + lds_kmaj2_off(kr, q) + (s16 & 3) * 8);
-    const s16x4 up = lds_tr_read_b64(tile + lds_kmaj2_off(kr + 4, q) + (s16 & 3) * 8);
-    s16x8 o;
-    o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
-    o[4] = up[0]; o[5] = up[1]; o[6] = up[2]; o[7] = up[3];
-    return o;
+    typedef __attribute__((ext_vector_type(2))) unsigned long long u64x2;
+    u64x2 o;
+    unsigned long long lo, up;
+    lds_tr_read_b64_asm(lo, tile + lds_kmaj2_off(kr, q) + (s16 & 3) * 8);
+    lds_tr_read_b64_asm(up, tile + lds_kmaj2_off(kr + 4, q) + (s16 & 3) * 8);
+    o[0] = lo; o[1] = up;
+    return __builtin_bit_cast(s16x8, o);
   }
 }
 
@@ -848,7 +849,9 @@ extern "C" int enh_gemm_bf16(const enh_bf16* A, int64_t lda, int trans_a, const 
   const int64_t fill = family == 4 ? 256 : (family == 2 ? 512 : 768);  // workgroups wanted (p3: one 8-wave workgroup per CU)
   int splits = 1;
   if (accumulate == 1 && c_f32 && !c_bf16 && !bias && act == ENH_ACT_NONE && !res && tiles < fill / 2 && K >= 2048) {
-    int64_t want = (fill + tiles - 1) / tiles;
+    int64_t want;
+    if (family == 4) want = 256 / tiles;  // one 8-wave workgroup per CU: exactly ONE round of <= 256 workgroups (no ragged 2nd round)
+    else want = (fill + tiles - 1) / tiles;
     if (want > ksteps / 8) want = ksteps / 8;
     if (want > 64) want = 64;
     if (want >= 2) splits = (int)want;

@@ -1,20 +1,24 @@
 """Op-level parity tests of the HIP kernels (through the C ABI via ctypes) against the CPU oracle.
 
-Tolerances (relative Frobenius error vs the fp32 oracle fed the SAME bf16-representable operands):
+Tolerances (relative Frobenius error vs the fp64/fp32 oracle fed the SAME bf16-representable operands):
   * integer outputs (code indices): bit-exact;
-  * fp32-output kernels: <= 1e-4 (observed ~1e-6: only the fp32 summation order differs);
-  * bf16-output kernels: <= 2.5e-3 — the storage dtype's own quantisation floor is 2^-9/sqrt(3) = 1.13e-3;
-  * fused attention (probabilities rounded to bf16 before P.V, bf16 output): <= 5e-3.
+  * fp32-output kernels: <= 1e-5 (measured 6e-8 .. 2e-7 on MI355X: only the fp32 summation order differs) — well inside the
+    1e-3 the north-star asks for;
+  * bf16-output kernels: <= 1.15 x the bf16 ROUNDING FLOOR of the exact result, computed in the test (util.bf16_floor; 1.66e-3
+    for Gaussian data: no bf16-stored tensor can be closer to an fp32 reference than that, so 1e-3 is unattainable for them by
+    construction; measured: GEMM / LayerNorm exactly at the floor);
+  * fused attention (probabilities rounded to bf16 before P.V, bf16 output): <= 1.5 x floor (measured 1.10 x); its
+    gradients (two chained bf16 roundings) <= 1e-2.
 """
 import numpy as np
 import pytest
 import torch
 
-from util import bf16r, rel
+from util import bf16_floor, bf16r, rel
 
 pytestmark = pytest.mark.gpu
 
-F32_TOL, BF16_TOL, ATT_TOL = 1e-4, 2.5e-3, 5e-3
+F32_TOL, BF16_TOL, ATT_TOL = 1e-5, 2.5e-3, 5e-3   # BF16_TOL / ATT_TOL are absolute caps; the floor-relative asserts are the tight ones
 
 
 @pytest.fixture(scope="module")
@@ -131,7 +135,7 @@ def test_layernorm_fwd_bwd(C, M, D):
     mean = torch.empty(M, device="cuda"); rstd = torch.empty(M, device="cuda")
     C.layernorm_forward(xd, w.cuda(), b.cuda(), 1e-5, y16, y32, mean, rstd)
     assert rel(y32, y) <= F32_TOL
-    assert rel(y16.float(), y) <= BF16_TOL
+    assert rel(y16.float(), y) <= 1.15 * bf16_floor(y) + 1e-6
     dx = torch.empty(M, D, device="cuda"); dx16 = torch.empty(M, D, dtype=torch.bfloat16, device="cuda")
     dw = torch.zeros(D, device="cuda"); db = torch.zeros(D, device="cuda")
     dxs = torch.zeros(D, device="cuda")
@@ -165,7 +169,7 @@ def test_gemm_layouts(C, ta, tb, M, N, K):
     out16 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
     C.gemm(a, b, M, N, K, trans_a=ta, trans_b=tb, out_f32=out, out_bf16=out16)
     assert rel(out, ref) <= F32_TOL, f"ta={ta} tb={tb}"
-    assert rel(out16.float(), ref) <= BF16_TOL
+    assert rel(out16.float(), ref) <= 1.15 * bf16_floor(ref) + 1e-6
 
 
 @pytest.mark.parametrize("kernel_shape", [(512, 384, 256, 128), (1024, 768, 192, 256)])
@@ -208,9 +212,9 @@ def test_gemm_wgrad_splitk(C):
     ref = dY.double().t() @ X.double()
     dW = torch.zeros(n_out, k_in, device="cuda")
     C.gemm(dY.to(torch.bfloat16).cuda(), X.to(torch.bfloat16).cuda(), n_out, k_in, tokens, trans_a=True, trans_b=True, accumulate=True, out_f32=dW)
-    assert rel(dW, ref) <= F32_TOL
+    assert rel(dW, ref) <= 1e-4  # split-K: f32 atomics in arbitrary order over 8192-long sums
     C.gemm(dY.to(torch.bfloat16).cuda(), X.to(torch.bfloat16).cuda(), n_out, k_in, tokens, trans_a=True, trans_b=True, accumulate=True, out_f32=dW)
-    assert rel(dW, 2 * ref) <= F32_TOL
+    assert rel(dW, 2 * ref) <= 1e-4
 
 
 def test_gemm_rejects_bad_shapes(C):
@@ -245,7 +249,7 @@ def test_attention_forward_backward(C, B, N, H):
     out = torch.empty(B, N, H * 64, dtype=torch.bfloat16, device="cuda")
     lse = torch.empty(B, H, N, device="cuda")
     C.attention_forward(qd, B, N, H, scale, out, lse)
-    assert rel(out.float(), ref) <= ATT_TOL
+    assert rel(out.float(), ref) <= 1.5 * bf16_floor(ref)
     assert rel(lse, lse_ref) <= 1e-5
     dqkv = torch.full((B, N, 3 * H * 64), float("nan"), dtype=torch.bfloat16, device="cuda")
     delta = torch.empty(B, H, N, device="cuda")
