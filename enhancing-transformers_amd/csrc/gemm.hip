@@ -846,15 +846,19 @@ extern "C" int enh_gemm_bf16(const enh_bf16* A, int64_t lda, int trans_a, const 
   ENH_REQUIRE(tiles < (1ll << 30), ENH_E_SHAPE, "enh_gemm_bf16: grid too large");
   // split-K (f32 atomics into a pre-initialised C) when a weight-gradient-shaped problem cannot fill 256 CUs
   const int64_t ksteps = (K + G_BK - 1) / G_BK;
-  const int64_t fill = family == 4 ? 256 : (family == 2 ? 512 : 768);  // workgroups wanted (p3: one 8-wave workgroup per CU)
+  const int64_t fill = family == 4 ? 256 : 512;  // resident workgroup slots
   int splits = 1;
   if (accumulate == 1 && c_f32 && !c_bf16 && !bias && act == ENH_ACT_NONE && !res && tiles < fill / 2 && K >= 2048) {
-    int64_t want;
-    if (family == 4) want = 256 / tiles;  // one 8-wave workgroup per CU: exactly ONE round of <= 256 workgroups (no ragged 2nd round)
-    else want = (fill + tiles - 1) / tiles;
+    // measured (profiles/r01_gemm_ablation.txt): the f32-atomic epilogue makes every extra K-slice expensive and a ragged
+    // last round is worse still -> the largest split count whose workgroups fit ONE round of resident slots
+    // (2 workgroups per CU for the 128x128 kernels, 1 for t256)
+    const int64_t slots = family == 4 ? 256 : 512;
+    int64_t want = slots / tiles;
     if (want > ksteps / 8) want = ksteps / 8;
     if (want > 64) want = 64;
     if (want >= 2) splits = (int)want;
+    static const int force = [] { const char* e = getenv("ENH_GEMM_SPLITS"); return e ? atoi(e) : 0; }();  // tuning hook
+    if (force > 0 && force <= ksteps) splits = force;
   }
   g.k_per_split = ((ksteps + splits - 1) / splits) * G_BK;
   splits = (int)((K + g.k_per_split - 1) / g.k_per_split);
