@@ -139,7 +139,8 @@ def main():
             traffic = None
     is_base = args.config == "imagenet_vitvq_base"
     res = {
-        "metric": "images/sec ViT-VQGAN-base 256px stage-1 train", "value": round(img_per_s, 2), "unit": "images/s",
+        "metric": "images/sec ViT-VQGAN-base 256px stage-1 train" if is_base else f"images/sec {args.config} 256px stage-1 train",
+        "value": round(img_per_s, 2), "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"{args.config}.yaml AE training step (1 fwd + 1 bwd + grad all-reduce + AdamW), loss = 1.0*L2 + 1.0*codebook "
