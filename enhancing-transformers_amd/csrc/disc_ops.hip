@@ -1,0 +1,122 @@
+// disc_ops.hip — gfx950 versions of the reference's ONLY native code: the two StyleGAN2-discriminator ops
+//   fused_bias_act  (reference enhancing/losses/op/fused_bias_act_kernel.cu:18-65, bound at fused_bias_act.cpp:17-31)
+//   upfirdn2d       (reference enhancing/losses/op/upfirdn2d_kernel.cu:49-207, bound at upfirdn2d.cpp:17-30)
+// Both are HBM-bound streaming kernels: 16-byte accesses along the contiguous (W) axis, one pass over the data.
+// SURVEY.md §8f rank 1 ("next" row): the discriminator itself (equalised-lr convolutions on MFMA, minibatch-stddev, R1)
+// is not built yet; these two ops are what its activation / blur layers call.
+#include "common.h"
+
+// y = act(x + b[(i / step_b) % size_b]) * scale      (act = leaky-relu, reference "act*10+grad" cases 30 / 31)
+//   grad == 0: act(v) = v > 0 ? v : alpha * v
+//   grad == 1: y = (x + b) * (ref > 0 ? 1 : alpha) * scale   — first and second derivative paths, gated by the saved OUTPUT ref
+__global__ void fused_bias_act_kernel(const float* __restrict__ x, const float* __restrict__ b, const float* __restrict__ ref,
+                                      float* __restrict__ y, int64_t n, int64_t step_b, int size_b, int grad, float alpha,
+                                      float scale) {
+  const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i0 >= n) return;
+  float v[4], r[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool full = i0 + 3 < n;
+  if (full) {
+    const float4 t = *reinterpret_cast<const float4*>(x + i0);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    if (grad) { const float4 q = *reinterpret_cast<const float4*>(ref + i0); r[0] = q.x; r[1] = q.y; r[2] = q.z; r[3] = q.w; }
+  } else {
+    for (int k = 0; k < 4; ++k) { v[k] = i0 + k < n ? x[i0 + k] : 0.f; if (grad) r[k] = i0 + k < n ? ref[i0 + k] : 0.f; }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float t = v[k];
+    if (b) t += b[((i0 + k) / step_b) % size_b];
+    if (grad == 0) t = (t > 0.f ? t : alpha * t) * scale;
+    else t = t * (r[k] > 0.f ? 1.f : alpha) * scale;
+    v[k] = t;
+  }
+  if (full) *reinterpret_cast<float4*>(y + i0) = make_float4(v[0], v[1], v[2], v[3]);
+  else for (int k = 0; k < 4 && i0 + k < n; ++k) y[i0 + k] = v[k];
+}
+
+// out[c] (+)= sum over batch and the inner axis of x [B, C, inner]  (bias gradient of the op above)
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x, int B, int C, int64_t inner, float* __restrict__ out) {
+  __shared__ float s_part[4];
+  const int c = blockIdx.x;
+  float acc = 0.f;
+  for (int bb = blockIdx.y; bb < B; bb += gridDim.y) {
+    const float* p = x + ((int64_t)bb * C + c) * inner;
+    for (int64_t i = threadIdx.x; i < inner; i += 256) acc += p[i];
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(&out[c], (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]));
+}
+
+// upfirdn2d on [major, in_h, in_w] planes (minor = 1, as the reference reshapes NCHW at upfirdn2d.py:100):
+//   out[m][oy][ox] = sum_{ky,kx} kernel[kh-1-ky][kw-1-kx] * P[oy*down_y + ky][ox*down_x + kx],
+//   P = zero-upsampled (up_x, up_y) input shifted by (pad_x0, pad_y0), zero outside   (upfirdn2d.py:168-209)
+__global__ void upfirdn2d_kernel(const float* __restrict__ in, const float* __restrict__ kernel, float* __restrict__ out,
+                                 int64_t major, int in_h, int in_w, int out_h, int out_w, int kh, int kw, int up_x, int up_y,
+                                 int down_x, int down_y, int pad_x0, int pad_y0) {
+  __shared__ float s_k[64];
+  if (threadIdx.x < kh * kw) s_k[threadIdx.x] = kernel[(kh - 1 - threadIdx.x / kw) * kw + (kw - 1 - threadIdx.x % kw)];
+  __syncthreads();
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = major * out_h * out_w;
+  if (idx >= total) return;
+  const int ox = (int)(idx % out_w);
+  const int oy = (int)((idx / out_w) % out_h);
+  const int64_t m = idx / ((int64_t)out_w * out_h);
+  const float* plane = in + m * (int64_t)in_h * in_w;
+  float acc = 0.f;
+  for (int ky = 0; ky < kh; ++ky) {
+    const int py = oy * down_y + ky - pad_y0;   // coordinate in the upsampled image
+    if (py < 0 || py % up_y) continue;
+    const int iy = py / up_y;
+    if (iy >= in_h) continue;
+    for (int kx = 0; kx < kw; ++kx) {
+      const int px = ox * down_x + kx - pad_x0;
+      if (px < 0 || px % up_x) continue;
+      const int ix = px / up_x;
+      if (ix >= in_w) continue;
+      acc = fmaf(s_k[ky * kw + kx], plane[(int64_t)iy * in_w + ix], acc);
+    }
+  }
+  out[idx] = acc;
+}
+
+extern "C" int enh_fused_bias_act(const float* x, const float* bias, const float* ref, float* y, int64_t n, int64_t step_b, int size_b,
+                                  int act, int grad, float alpha, float scale, void* stream) {
+  ENH_REQUIRE(x && y && n > 0, ENH_E_BADARG, "enh_fused_bias_act: bad argument");
+  ENH_REQUIRE(act == 3 && (grad == 0 || grad == 1), ENH_E_SHAPE, "enh_fused_bias_act: only leaky-relu (act = 3), grad 0 or 1, is used by the reference");
+  ENH_REQUIRE(grad == 0 || ref, ENH_E_BADARG, "enh_fused_bias_act: grad = 1 needs the saved output `ref`");
+  ENH_REQUIRE(!bias || (step_b > 0 && size_b > 0), ENH_E_BADARG, "enh_fused_bias_act: bias needs step_b / size_b");
+  const int64_t n4 = (n + 3) / 4;
+  fused_bias_act_kernel<<<(int)((n4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, bias, ref, y, n, step_b > 0 ? step_b : 1, size_b > 0 ? size_b : 1,
+                                                                               grad, alpha, scale);
+  return enh_check_launch("enh_fused_bias_act");
+}
+
+extern "C" int enh_channel_sum_f32(const float* x, int B, int C, int64_t inner, float* out, int accumulate, void* stream) {
+  ENH_REQUIRE(x && out && B > 0 && C > 0 && inner > 0, ENH_E_BADARG, "enh_channel_sum_f32: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  if (!accumulate) {
+    hipError_t e = hipMemsetAsync(out, 0, (size_t)C * sizeof(float), s);
+    if (e != hipSuccess) { enh_set_error("enh_channel_sum_f32: memset failed"); return ENH_E_HIP_BASE - (int)e; }
+  }
+  const int by = B < 32 ? B : 32;
+  channel_sum_kernel<<<dim3(C, by), 256, 0, s>>>(x, B, C, inner, out);
+  return enh_check_launch("enh_channel_sum_f32");
+}
+
+extern "C" int enh_upfirdn2d(const float* in, const float* kernel, float* out, int64_t major, int in_h, int in_w, int kh, int kw, int up_x,
+                             int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream) {
+  ENH_REQUIRE(in && kernel && out && major > 0 && in_h > 0 && in_w > 0, ENH_E_BADARG, "enh_upfirdn2d: bad argument");
+  ENH_REQUIRE(kh > 0 && kw > 0 && kh * kw <= 64 && up_x > 0 && up_y > 0 && down_x > 0 && down_y > 0, ENH_E_SHAPE, "enh_upfirdn2d: kernel up to 64 taps, positive up / down factors");
+  ENH_REQUIRE(pad_x0 >= 0 && pad_x1 >= 0 && pad_y0 >= 0 && pad_y1 >= 0, ENH_E_SHAPE, "enh_upfirdn2d: negative pads (cropping) are not used by the reference's Blur and are not supported");
+  const int out_h = (in_h * up_y + pad_y0 + pad_y1 - kh + down_y) / down_y;
+  const int out_w = (in_w * up_x + pad_x0 + pad_x1 - kw + down_x) / down_x;
+  ENH_REQUIRE(out_h > 0 && out_w > 0, ENH_E_SHAPE, "enh_upfirdn2d: empty output");
+  const int64_t total = major * out_h * out_w;
+  upfirdn2d_kernel<<<(int)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(in, kernel, out, major, in_h, in_w, out_h, out_w, kh, kw, up_x, up_y,
+                                                                             down_x, down_y, pad_x0, pad_y0);
+  return enh_check_launch("enh_upfirdn2d");
+}

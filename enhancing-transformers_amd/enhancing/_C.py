@@ -43,6 +43,9 @@ SIGNATURES = {
     "enh_unpatchify_loss": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp]),
     "enh_colsum_bf16": (_i32, [_vp, _i64, _i64, _i64, _vp, _i32, _vp]),
     "enh_cast_f32_bf16": (_i32, [_vp, _vp, _i64, _vp]),
+    "enh_fused_bias_act": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _f32, _f32, _vp]),
+    "enh_channel_sum_f32": (_i32, [_vp, _i32, _i32, _i64, _vp, _i32, _vp]),
+    "enh_upfirdn2d": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "enh_adamw_step": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
 }
 
@@ -264,3 +267,43 @@ def adamw_step(p, g, m, v, p_bf16, step: int, lr: float, beta1: float = 0.9, bet
                weight_decay: float = 1e-4, grad_scale: float = 1.0):
     _check(lib().enh_adamw_step(_p(p, F32, "p"), _p(g, F32, "g"), _p(m, F32, "m"), _p(v, F32, "v"), _p(p_bf16, BF16, "p_bf16"),
                                 p.numel(), step, lr, beta1, beta2, eps, weight_decay, grad_scale, _stream()), "enh_adamw_step")
+
+
+# ------------------------------------------------------------------------------------------------
+# discriminator native ops (reference enhancing/losses/op/*)
+# ------------------------------------------------------------------------------------------------
+def fused_bias_act(x, bias, ref, grad: int, alpha: float, scale: float):
+    """fused.fused_bias_act(input, bias, refer, 3, grad, alpha, scale) -> new tensor (the op allocates its output, as the reference's does)."""
+    _p(x, F32, "input")
+    y = torch.empty_like(x)
+    step_b = 1
+    for d in x.shape[2:]:
+        step_b *= d
+    size_b = bias.numel() if bias is not None and bias.numel() else 0
+    b = bias if size_b else None
+    _check(lib().enh_fused_bias_act(_p(x, F32, "input"), _p(b, F32, "bias"), _p(ref if ref is not None and ref.numel() else None, F32, "refer"),
+                                    _p(y), x.numel(), step_b, size_b, 3, grad, alpha, scale, _stream()), "enh_fused_bias_act")
+    return y
+
+
+def channel_sum(x):
+    """sum over every axis except 1 of an f32 [B, C, ...] tensor -> [C]"""
+    _p(x, F32, "x")
+    B, C = x.shape[0], x.shape[1]
+    inner = x.numel() // (B * C)
+    out = torch.empty(C, dtype=F32, device=x.device)
+    _check(lib().enh_channel_sum_f32(_p(x), B, C, inner, _p(out), 0, _stream()), "enh_channel_sum_f32")
+    return out
+
+
+def upfirdn2d(x, kernel, up_x: int, up_y: int, down_x: int, down_y: int, pad_x0: int, pad_x1: int, pad_y0: int, pad_y1: int):
+    """upfirdn2d_op.upfirdn2d on x viewed [major, in_h, in_w]; returns [major, out_h, out_w]."""
+    _p(x, F32, "input"); _p(kernel, F32, "kernel")
+    major, in_h, in_w = x.shape
+    kh, kw = kernel.shape
+    out_h = (in_h * up_y + pad_y0 + pad_y1 - kh + down_y) // down_y
+    out_w = (in_w * up_x + pad_x0 + pad_x1 - kw + down_x) // down_x
+    out = torch.empty(major, out_h, out_w, dtype=F32, device=x.device)
+    _check(lib().enh_upfirdn2d(_p(x), _p(kernel), _p(out), major, in_h, in_w, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1,
+                               _stream()), "enh_upfirdn2d")
+    return out

@@ -156,6 +156,21 @@ int enh_cast_f32_bf16(const float* x, enh_bf16* y, int64_t n, void* stream);
 int enh_adamw_step(float* p, const float* g, float* m, float* v, enh_bf16* p_bf16, int64_t n, int step, float lr,
                    float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * StyleGAN2-discriminator native ops ("next" row) — drop-ins for the reference's two pybind ops
+ * ------------------------------------------------------------------------------------------------ */
+/* fused.fused_bias_act(input, bias, refer, act, grad, alpha, scale) — enhancing/losses/op/fused_bias_act.cpp:17-31.
+ * y = lrelu(x + bias[(i / step_b) % size_b]) * scale (grad = 0) or (x + bias) * (ref > 0 ? 1 : alpha) * scale (grad = 1: first and
+ * second derivative, gated by the saved output).  f32, contiguous; bias / ref may be NULL; only act = 3 (leaky-relu) is used. */
+int enh_fused_bias_act(const float* x, const float* bias, const float* ref, float* y, int64_t n, int64_t step_b, int size_b,
+                       int act, int grad, float alpha, float scale, void* stream);
+/* out[c] (+)= sum_{b,i} x[b,c,i] : the bias gradient `grad_input.sum(dim)` of fused_act.py:37-41 */
+int enh_channel_sum_f32(const float* x, int B, int C, int64_t inner, float* out, int accumulate, void* stream);
+/* upfirdn2d_op.upfirdn2d(input [major,in_h,in_w,1], kernel [kh,kw], up, down, pads) — enhancing/losses/op/upfirdn2d.cpp:17-30;
+ * out [major, out_h, out_w], out_h = (in_h*up_y + pad_y0 + pad_y1 - kh + down_y) / down_y (same for w).  f32; pads >= 0. */
+int enh_upfirdn2d(const float* in, const float* kernel, float* out, int64_t major, int in_h, int in_w, int kh, int kw, int up_x,
+                  int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

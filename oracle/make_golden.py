@@ -138,3 +138,8 @@ if __name__ == "__main__":
     gold_quantizer("rq4_k8192_m2048", 4321, 2048, 8192, {"use_residual": True, "num_quantizers": 4})
     gold_vit_tiny()
     print("golden vectors written to", GOLD)
+
+
+# NOTE: tests/golden/disc_ops.npz (discriminator native ops) is produced by the AST-extraction snippet documented in
+# oracle/disc_ops_oracle.py: the reference's op/*.py cannot be imported (they JIT-compile CUDA sources at import), so its pure-Python
+# fallbacks `upfirdn2d_native` and the CPU branch of `fused_leaky_relu` are extracted with `ast` and executed as they are.
