@@ -21,6 +21,9 @@
 #include <stdlib.h>
 #include "common.h"
 
+#ifndef ENH_NT_EPILOGUE
+#define ENH_NT_EPILOGUE 1  // C is written once and not re-read by this kernel: keep it out of the L2 the operand slices live in
+#endif
 #define G_BM 128
 #define G_BN 128
 #define G_BK 64
@@ -139,8 +142,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& args, f32x4 (&acc)
         const float4 o4 = *reinterpret_cast<const float4*>(cp);
         v[0] += o4.x; v[1] += o4.y; v[2] += o4.z; v[3] += o4.w;
       }
-      if (cp) *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
-      if (args.c_bf16) *reinterpret_cast<uint2*>(args.c_bf16 + m * args.ldc + n) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+      if (cp) { const f32x4 o_ = {v[0], v[1], v[2], v[3]}; if (ENH_NT_EPILOGUE) __builtin_nontemporal_store(o_, reinterpret_cast<f32x4*>(cp)); else *reinterpret_cast<f32x4*>(cp) = o_; }
+      if (args.c_bf16) { const u32x2 o_ = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])}; if (ENH_NT_EPILOGUE) __builtin_nontemporal_store(o_, reinterpret_cast<u32x2*>(args.c_bf16 + m * args.ldc + n)); else *reinterpret_cast<u32x2*>(args.c_bf16 + m * args.ldc + n) = o_; }
     }
   }
 }
@@ -644,8 +647,8 @@ __device__ __forceinline__ void gemm_epilogue32(const GemmArgs& args, f32x16 (&a
           const float4 o4 = *reinterpret_cast<const float4*>(cp);
           v[0] += o4.x; v[1] += o4.y; v[2] += o4.z; v[3] += o4.w;
         }
-        if (cp) *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
-        if (args.c_bf16) *reinterpret_cast<uint2*>(args.c_bf16 + m * args.ldc + n) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+        if (cp) { const f32x4 o_ = {v[0], v[1], v[2], v[3]}; if (ENH_NT_EPILOGUE) __builtin_nontemporal_store(o_, reinterpret_cast<f32x4*>(cp)); else *reinterpret_cast<f32x4*>(cp) = o_; }
+        if (args.c_bf16) { const u32x2 o_ = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])}; if (ENH_NT_EPILOGUE) __builtin_nontemporal_store(o_, reinterpret_cast<u32x2*>(args.c_bf16 + m * args.ldc + n)); else *reinterpret_cast<u32x2*>(args.c_bf16 + m * args.ldc + n) = o_; }
       }
     }
   }
