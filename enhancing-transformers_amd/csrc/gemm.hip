@@ -22,7 +22,8 @@
 #include "common.h"
 
 #ifndef ENH_NT_EPILOGUE
-#define ENH_NT_EPILOGUE 1  // C is written once and not re-read by this kernel: keep it out of the L2 the operand slices live in
+#define ENH_NT_EPILOGUE 0  // tried 1 (non-temporal C stores, to keep L2 for the operand slices): 442 -> 407 img/s, because the NEXT kernel
+                           // (LayerNorm, attention, the following GEMM) finds C in L2 / Infinity Cache when it is stored normally
 #endif
 #define G_BM 128
 #define G_BN 128
