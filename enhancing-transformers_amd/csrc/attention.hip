@@ -60,16 +60,29 @@ __device__ __forceinline__ s16x8 pack8_bf16(const float* p) {
 }
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
 
+// Workgroup -> (block-within-head, head) mapping.  Hardware places workgroup L on XCD L % 8 (each XCD has a private L2), and the nblk
+// workgroups of one (batch, head) all stream the SAME K/V (or Q/dO) — so they are given ids that are congruent mod 8 and adjacent in
+// dispatch order: the head's 256 KiB of K/V is then fetched into ONE L2 and re-used there, instead of once per XCD (8x the fabric traffic).
+__device__ __forceinline__ bool att_block_coords(int nblk, int n_heads_total, int& blk, int& head) {
+  const int L = blockIdx.x;
+  const int xcd = L & 7, r = L >> 3;
+  head = (r / nblk) * 8 + xcd;
+  blk = r % nblk;
+  return head < n_heads_total;
+}
+
 // =================================================================================================
 // forward
 // =================================================================================================
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, int N, int H, float scale_log2,
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, int B, int N, int H, float scale_log2,
                                                           uint16_t* __restrict__ out, float* __restrict__ lse) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][ATT_TILE_BYTES];  // [stage][K | V]
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  int blk, head;
+  if (!att_block_coords((N + 127) / 128, B * H, blk, head)) return;
+  const int b = head / H, h = head - b * H;
+  const int q0 = blk * 128 + wave * 32;
   const int64_t RS = (int64_t)3 * H * ATT_D;
   const uint16_t* Qp = qkv + (int64_t)b * N * RS + h * ATT_D;
   const uint16_t* Kp = Qp + H * ATT_D;
@@ -195,13 +208,15 @@ __global__ void attn_delta_kernel(const uint16_t* __restrict__ o, const uint16_t
 // backward: dQ  (same skeleton as forward; K tile is read both as rows and transposed)
 // =================================================================================================
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ d_o,
-                                                             const float* __restrict__ lse, const float* __restrict__ delta, int N,
+                                                             const float* __restrict__ lse, const float* __restrict__ delta, int B, int N,
                                                              int H, float scale, float scale_log2, uint16_t* __restrict__ dqkv) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][ATT_TILE_BYTES];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  int blk, head;
+  if (!att_block_coords((N + 127) / 128, B * H, blk, head)) return;
+  const int b = head / H, h = head - b * H;
+  const int q0 = blk * 128 + wave * 32;
   const int64_t RS = (int64_t)3 * H * ATT_D;
   const uint16_t* Qp = qkv + (int64_t)b * N * RS + h * ATT_D;
   const uint16_t* Kp = Qp + H * ATT_D;
@@ -285,14 +300,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
 // backward: dK, dV  (workgroup owns 128 keys; Q / dO tiles stream through LDS)
 // =================================================================================================
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ d_o,
-                                                              const float* __restrict__ lse, const float* __restrict__ delta, int N,
+                                                              const float* __restrict__ lse, const float* __restrict__ delta, int B, int N,
                                                               int H, float scale, float scale_log2, uint16_t* __restrict__ dqkv) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][ATT_TILE_BYTES];  // [stage][Q | dO]
   __shared__ __attribute__((aligned(16))) float s_stat[2][2][64];                   // [stage][lse*log2e | delta]
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int key0 = blockIdx.x * 128 + wave * 32;
+  int blk, head;
+  if (!att_block_coords((N + 127) / 128, B * H, blk, head)) return;
+  const int b = head / H, h = head - b * H;
+  const int key0 = blk * 128 + wave * 32;
   const int64_t RS = (int64_t)3 * H * ATT_D;
   const int64_t OS = (int64_t)H * ATT_D;
   const uint16_t* Qp = qkv + (int64_t)b * N * RS + h * ATT_D;
@@ -397,8 +414,9 @@ extern "C" int enh_attention_forward(const enh_bf16* qkv, int B, int N, int H, f
   ENH_REQUIRE(qkv && out && lse, ENH_E_BADARG, "enh_attention_forward: null pointer");
   ENH_REQUIRE(B > 0 && H > 0 && N > 0 && N % 64 == 0, ENH_E_SHAPE, "enh_attention_forward: need N %% 64 == 0 (B=%d N=%d H=%d)", B, N, H);
   ENH_REQUIRE(scale > 0.f, ENH_E_BADARG, "enh_attention_forward: scale must be positive");
-  const dim3 grid((N + 127) / 128, H, B);
-  attn_fwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(qkv, N, H, scale * 1.4426950408889634f, out, lse);
+  const int64_t nblk = (N + 127) / 128, heads = (int64_t)B * H;
+  const dim3 grid((unsigned)(((heads + 7) / 8) * 8 * nblk));  // 1-D: see att_block_coords
+  attn_fwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(qkv, B, N, H, scale * 1.4426950408889634f, out, lse);
   return enh_check_launch("enh_attention_forward");
 }
 
@@ -410,9 +428,10 @@ extern "C" int enh_attention_backward(const enh_bf16* qkv, const enh_bf16* out, 
   hipStream_t s = (hipStream_t)stream;
   const int64_t BN = (int64_t)B * N;
   attn_delta_kernel<<<(int)((BN * H + 255) / 256), 256, 0, s>>>(out, dout, BN, N, H, delta_ws);
-  const dim3 grid((N + 127) / 128, H, B);
+  const int64_t nblk = (N + 127) / 128, heads = (int64_t)B * H;
+  const dim3 grid((unsigned)(((heads + 7) / 8) * 8 * nblk));
   const float sl2 = scale * 1.4426950408889634f;
-  attn_bwd_dq_kernel<<<grid, 256, 0, s>>>(qkv, dout, lse, delta_ws, N, H, scale, sl2, dqkv);
-  attn_bwd_dkv_kernel<<<grid, 256, 0, s>>>(qkv, dout, lse, delta_ws, N, H, scale, sl2, dqkv);
+  attn_bwd_dq_kernel<<<grid, 256, 0, s>>>(qkv, dout, lse, delta_ws, B, N, H, scale, sl2, dqkv);
+  attn_bwd_dkv_kernel<<<grid, 256, 0, s>>>(qkv, dout, lse, delta_ws, B, N, H, scale, sl2, dqkv);
   return enh_check_launch("enh_attention_backward");
 }
