@@ -46,6 +46,12 @@ SIGNATURES = {
     "enh_fused_bias_act": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _f32, _f32, _vp]),
     "enh_channel_sum_f32": (_i32, [_vp, _i32, _i32, _i64, _vp, _i32, _vp]),
     "enh_upfirdn2d": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "enh_gemm_f32": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _i64, _i64, _i64, _vp, _i32, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _i64, _vp]),
+    "enh_attention_forward_f32": (_i32, [_vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp]),
+    "enh_attention_backward_f32": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp]),
+    "enh_colsum_f32": (_i32, [_vp, _i64, _i64, _i64, _vp, _i32, _vp]),
+    "enh_patch_perm_f32": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "enh_unpatchify_loss_f32": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp]),
     "enh_adamw_step": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
 }
 
@@ -307,3 +313,70 @@ def upfirdn2d(x, kernel, up_x: int, up_y: int, down_x: int, down_y: int, pad_x0:
     _check(lib().enh_upfirdn2d(_p(x), _p(kernel), _p(out), major, in_h, in_w, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1,
                                _stream()), "enh_upfirdn2d")
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# dtype-dispatching front-ends (bf16 product path / fp32 exact mode) used by the engine
+# ------------------------------------------------------------------------------------------------
+def mm(a, b, M: int, N: int, K: int, out, trans_a: bool = False, trans_b: bool = False, bias=None, act: int = ACT_NONE, aux=None, res=None,
+       res_rows: int = 0, accumulate: bool = False):
+    """C = epilogue(A B^T) into `out`; bf16 operands -> MFMA kernel (out may be bf16 or f32), f32 operands -> exact f32 kernel."""
+    if a.dtype == BF16:
+        if out.dtype == BF16:
+            gemm(a, b, M, N, K, trans_a, trans_b, bias, act, aux, res, res_rows, accumulate, out_bf16=out)
+        else:
+            gemm(a, b, M, N, K, trans_a, trans_b, bias, act, aux, res, res_rows, accumulate, out_f32=out)
+        return
+    _check(lib().enh_gemm_f32(_p(a, F32, "A"), a.stride(0), int(trans_a), _p(b, F32, "B"), b.stride(0), int(trans_b), M, N, K, _p(bias, F32, "bias"), act,
+                              _p(aux, F32, "aux"), aux.stride(0) if aux is not None else 0, _p(res, F32, "res"), res.stride(0) if res is not None else 0,
+                              res_rows if res is not None else 0, int(accumulate), _p(out, F32, "out"), out.stride(0), _stream()), "enh_gemm_f32")
+
+
+def ln_fwd(x, w, b, y, mean, rstd, y_extra_f32=None):
+    if y.dtype == BF16:
+        layernorm_forward(x, w, b, 1e-5, y, y_extra_f32, mean, rstd)
+    else:
+        layernorm_forward(x, w, b, 1e-5, None, y, mean, rstd)
+
+
+def ln_bwd(dy, x, w, mean, rstd, dres, dx, dx_operand, dw, db, dx_colsum=None):
+    """dx_operand: the tensor the following GEMMs read (a bf16 copy in the product path, dx itself in exact mode)."""
+    layernorm_backward(dy, x, w, mean, rstd, dres, dx, dx_operand if dx_operand.dtype == BF16 else None, dw, db, dx_colsum)
+
+
+def attn_fwd(qkv, B, N, H, scale, out, lse):
+    if qkv.dtype == BF16:
+        attention_forward(qkv, B, N, H, scale, out, lse)
+    else:
+        _check(lib().enh_attention_forward_f32(_p(qkv, F32, "qkv"), B, N, H, scale, _p(out, F32, "out"), _p(lse, F32, "lse"), _stream()), "enh_attention_forward_f32")
+
+
+def attn_bwd(qkv, out, dout, lse, B, N, H, scale, dqkv, delta_ws):
+    if qkv.dtype == BF16:
+        attention_backward(qkv, out, dout, lse, B, N, H, scale, dqkv, delta_ws)
+    else:
+        _check(lib().enh_attention_backward_f32(_p(qkv, F32, "qkv"), _p(out, F32, "out"), _p(dout, F32, "dout"), _p(lse, F32, "lse"), B, N, H, scale,
+                                                _p(dqkv, F32, "dqkv"), _p(delta_ws, F32, "delta_ws"), _stream()), "enh_attention_backward_f32")
+
+
+def colsum_any(x, M, N, out, accumulate=False):
+    if x.dtype == BF16:
+        colsum(x, M, N, out, accumulate)
+    else:
+        _check(lib().enh_colsum_f32(_p(x, F32, "x"), M, N, x.stride(0), _p(out, F32, "out"), int(accumulate), _stream()), "enh_colsum_f32")
+
+
+def patchify_any(img, p, out):
+    if out.dtype == BF16:
+        patchify(img, p, out)
+    else:
+        B, C, H, W = img.shape
+        _check(lib().enh_patch_perm_f32(_p(img, F32, "img"), _p(out, F32, "patches"), B, C, H, W, p, 1, _stream()), "enh_patch_perm_f32")
+
+
+def unpatchify_loss_any(pix, target, B, C, H, W, p, w_l1, w_l2, xrec, sums, dpix):
+    if dpix is None or dpix.dtype == BF16 or target is None:
+        unpatchify_loss(pix, target, B, C, H, W, p, w_l1, w_l2, xrec, sums, dpix)
+    else:
+        _check(lib().enh_unpatchify_loss_f32(_p(pix, F32, "pix"), _p(target, F32, "target"), B, C, H, W, p, w_l1, w_l2, _p(xrec, F32, "xrec"),
+                                             _p(sums, F64, "sums"), _p(dpix, F32, "dpix"), _stream()), "enh_unpatchify_loss_f32")

@@ -30,8 +30,9 @@ _ALIGN = 64  # elements; keeps every parameter view 16-byte aligned in both the 
 class ParamStore:
     """Flattens the trainable parameters of a module tree into contiguous device buffers."""
 
-    def __init__(self, module: nn.Module, device: torch.device) -> None:
+    def __init__(self, module: nn.Module, device: torch.device, precision: str = "bf16") -> None:
         self.device = device
+        self.precision = precision
         self.names: List[str] = []
         self.offsets: Dict[str, Tuple[int, int, torch.Size]] = {}
         params = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
@@ -61,11 +62,14 @@ class ParamStore:
             if not p.requires_grad:
                 p.data = p.data.to(device=device, dtype=F32).contiguous()
                 self.w[n] = p.data
+        # GEMM operand view of every weight: the bf16 shadow (product path) or the fp32 master itself (exact mode)
+        self.wa = self.w16 if precision == "bf16" else self.w
         self.step_count = 0
         self.refresh_shadows()
 
     def refresh_shadows(self) -> None:
-        _C.cast_bf16(self.p, self.p16)
+        if self.precision == "bf16":
+            _C.cast_bf16(self.p, self.p16)
 
     def zero_grad(self) -> None:
         self.g.zero_()
@@ -105,6 +109,7 @@ class _Tower:
         if key in self._bufs:
             return self._bufs[key]
         dev, M, H, N = self.s.device, B * self.n_tok, self.heads, self.n_tok
+        BF16 = torch.bfloat16 if self.s.precision == "bf16" else torch.float32  # activation-operand dtype of this precision mode
         e = lambda *shape, dt=F32: torch.empty(*shape, dtype=dt, device=dev)
         n_layer_sets = self.depth if save else 1
         layers = []
@@ -114,8 +119,10 @@ class _Tower:
                                mean1=e(M), rstd1=e(M), mean2=e(M), rstd2=e(M)))
         b = dict(layers=layers, x=[e(M, self.dim) for _ in range(self.depth + 1 if save else 2)],
                  xf16=e(M, self.dim, dt=BF16), xf32=e(M, self.dim), meanf=e(M), rstdf=e(M))
-        if save:  # backward scratch, shared by all layers
-            b.update(gA=e(M, self.dim), gA16=e(M, self.dim, dt=BF16), gB=e(M, self.dim), gB16=e(M, self.dim, dt=BF16),
+        if save:  # backward scratch, shared by all layers (in exact mode the "16" operand copies ARE the f32 tensors)
+            exact = self.s.precision != "bf16"
+            gA, gB = e(M, self.dim), e(M, self.dim)
+            b.update(gA=gA, gA16=gA if exact else e(M, self.dim, dt=BF16), gB=gB, gB16=gB if exact else e(M, self.dim, dt=BF16),
                      dA=e(M, self.dim), dhid16=e(M, self.mlp, dt=BF16), do16=e(M, self.inner, dt=BF16),
                      dqkv16=e(M, 3 * self.inner, dt=BF16), delta=e(B, H, N))
         self._bufs[key] = b
@@ -132,18 +139,19 @@ class _Tower:
         x = b["x"][0]
         for i, P in enumerate(self.L):
             A = b["layers"][i if save else 0]
-            _C.layernorm_forward(x, s.w[P["ln1_w"]], s.w[P["ln1_b"]], 1e-5, A["a1"], None, A["mean1"], A["rstd1"])
-            _C.gemm(A["a1"], s.w16[P["wqkv"]], M, 3 * inner, dim, out_bf16=A["qkv"])
-            _C.attention_forward(A["qkv"], B, self.n_tok, self.heads, self.scale, A["o"], A["lse"])
-            _C.gemm(A["o"], s.w16[P["wout"]], M, dim, inner, bias=s.w[P["bout"]], res=x, res_rows=M, out_f32=A["x_mid"])
-            _C.layernorm_forward(A["x_mid"], s.w[P["ln2_w"]], s.w[P["ln2_b"]], 1e-5, A["a2"], None, A["mean2"], A["rstd2"])
-            _C.gemm(A["a2"], s.w16[P["w1"]], M, mlp, dim, bias=s.w[P["b1"]], act=_C.ACT_TANH, out_bf16=A["hid"])
+            _C.ln_fwd(x, s.w[P["ln1_w"]], s.w[P["ln1_b"]], A["a1"], A["mean1"], A["rstd1"])
+            _C.mm(A["a1"], s.wa[P["wqkv"]], M, 3 * inner, dim, A["qkv"])
+            _C.attn_fwd(A["qkv"], B, self.n_tok, self.heads, self.scale, A["o"], A["lse"])
+            _C.mm(A["o"], s.wa[P["wout"]], M, dim, inner, A["x_mid"], bias=s.w[P["bout"]], res=x, res_rows=M)
+            _C.ln_fwd(A["x_mid"], s.w[P["ln2_w"]], s.w[P["ln2_b"]], A["a2"], A["mean2"], A["rstd2"])
+            _C.mm(A["a2"], s.wa[P["w1"]], M, mlp, dim, A["hid"], bias=s.w[P["b1"]], act=_C.ACT_TANH)
             x_next = b["x"][i + 1] if save else b["x"][(i + 1) & 1]
-            _C.gemm(A["hid"], s.w16[P["w2"]], M, dim, mlp, bias=s.w[P["b2"]], res=A["x_mid"], res_rows=M, out_f32=x_next)
+            _C.mm(A["hid"], s.wa[P["w2"]], M, dim, mlp, x_next, bias=s.w[P["b2"]], res=A["x_mid"], res_rows=M)
             x = x_next
         b["x_last"] = x
-        _C.layernorm_forward(x, s.w[self.lnf_w], s.w[self.lnf_b], 1e-5, b["xf16"], b["xf32"] if want_f32 else None,
-                             b["meanf"], b["rstdf"])
+        _C.ln_fwd(x, s.w[self.lnf_w], s.w[self.lnf_b], b["xf16"], b["meanf"], b["rstdf"], b["xf32"] if want_f32 else None)
+        if want_f32 and b["xf16"].dtype == F32:
+            b["xf32"] = b["xf16"]
         return b
 
     # ---- backward ----------------------------------------------------------------------------
@@ -156,28 +164,27 @@ class _Tower:
         gA, gA16, gB, gB16, dA = b["gA"], b["gA16"], b["gB"], b["gB16"], b["dA"]
         # every LN backward also emits the column sums of the residual-stream gradient it produces = the bias gradient of
         # the Linear (fc2 / to_out) that wrote that stream
-        _C.layernorm_backward(d_xf, b["x"][self.depth], s.w[self.lnf_w], b["meanf"], b["rstdf"], None, gA, gA16,
-                              g[self.lnf_w], g[self.lnf_b], g[self.L[-1]["b2"]] if self.depth else None)
+        _C.ln_bwd(d_xf, b["x"][self.depth], s.w[self.lnf_w], b["meanf"], b["rstdf"], None, gA, gA16,
+                  g[self.lnf_w], g[self.lnf_b], g[self.L[-1]["b2"]] if self.depth else None)
         if on_layer_done is not None:
             on_layer_done(f"{self.prefix}transformer.norm.")
         for i in range(self.depth - 1, -1, -1):
             P, A = self.L[i], b["layers"][i]
             # ---- MLP: x_out = fc2(tanh(fc1(a2))) + x_mid ----
-            _C.gemm(gA16, A["hid"], dim, mlp, M, trans_a=True, trans_b=True, accumulate=True, out_f32=g[P["w2"]])
-            _C.gemm(gA16, s.w16[P["w2"]], M, mlp, dim, trans_b=True, act=_C.ACT_DTANH, aux=A["hid"], out_bf16=b["dhid16"])
-            _C.gemm(b["dhid16"], A["a2"], mlp, dim, M, trans_a=True, trans_b=True, accumulate=True, out_f32=g[P["w1"]])
-            _C.colsum(b["dhid16"], M, mlp, g[P["b1"]], accumulate=True)
-            _C.gemm(b["dhid16"], s.w16[P["w1"]], M, dim, mlp, trans_b=True, out_f32=dA)
-            _C.layernorm_backward(dA, A["x_mid"], s.w[P["ln2_w"]], A["mean2"], A["rstd2"], gA, gB, gB16, g[P["ln2_w"]], g[P["ln2_b"]],
-                                  g[P["bout"]])
+            _C.mm(gA16, A["hid"], dim, mlp, M, g[P["w2"]], trans_a=True, trans_b=True, accumulate=True)
+            _C.mm(gA16, s.wa[P["w2"]], M, mlp, dim, b["dhid16"], trans_b=True, act=_C.ACT_DTANH, aux=A["hid"])
+            _C.mm(b["dhid16"], A["a2"], mlp, dim, M, g[P["w1"]], trans_a=True, trans_b=True, accumulate=True)
+            _C.colsum_any(b["dhid16"], M, mlp, g[P["b1"]], accumulate=True)
+            _C.mm(b["dhid16"], s.wa[P["w1"]], M, dim, mlp, dA, trans_b=True)
+            _C.ln_bwd(dA, A["x_mid"], s.w[P["ln2_w"]], A["mean2"], A["rstd2"], gA, gB, gB16, g[P["ln2_w"]], g[P["ln2_b"]], g[P["bout"]])
             # ---- attention: x_mid = to_out(attn(to_qkv(a1))) + x_in ----
-            _C.gemm(gB16, A["o"], dim, inner, M, trans_a=True, trans_b=True, accumulate=True, out_f32=g[P["wout"]])
-            _C.gemm(gB16, s.w16[P["wout"]], M, inner, dim, trans_b=True, out_bf16=b["do16"])
-            _C.attention_backward(A["qkv"], A["o"], b["do16"], A["lse"], B, self.n_tok, self.heads, self.scale, b["dqkv16"], b["delta"])
-            _C.gemm(b["dqkv16"], A["a1"], 3 * inner, dim, M, trans_a=True, trans_b=True, accumulate=True, out_f32=g[P["wqkv"]])
-            _C.gemm(b["dqkv16"], s.w16[P["wqkv"]], M, dim, 3 * inner, trans_b=True, out_f32=dA)
-            _C.layernorm_backward(dA, b["x"][i], s.w[P["ln1_w"]], A["mean1"], A["rstd1"], gB, gA, gA16, g[P["ln1_w"]], g[P["ln1_b"]],
-                                  g[self.L[i - 1]["b2"]] if i > 0 else self.first_bias_grad)
+            _C.mm(gB16, A["o"], dim, inner, M, g[P["wout"]], trans_a=True, trans_b=True, accumulate=True)
+            _C.mm(gB16, s.wa[P["wout"]], M, inner, dim, b["do16"], trans_b=True)
+            _C.attn_bwd(A["qkv"], A["o"], b["do16"], A["lse"], B, self.n_tok, self.heads, self.scale, b["dqkv16"], b["delta"])
+            _C.mm(b["dqkv16"], A["a1"], 3 * inner, dim, M, g[P["wqkv"]], trans_a=True, trans_b=True, accumulate=True)
+            _C.mm(b["dqkv16"], s.wa[P["wqkv"]], M, dim, 3 * inner, dA, trans_b=True)
+            _C.ln_bwd(dA, b["x"][i], s.w[P["ln1_w"]], A["mean1"], A["rstd1"], gB, gA, gA16, g[P["ln1_w"]], g[P["ln1_b"]],
+                      g[self.L[i - 1]["b2"]] if i > 0 else self.first_bias_grad)
             if on_layer_done is not None:
                 on_layer_done(f"{self.prefix}transformer.layers.{i}.")
         return gA, gA16
@@ -202,7 +209,7 @@ class _AEFunction(torch.autograd.Function):
         if g_xrec is None:
             io["dpix16"].zero_()
         else:
-            _C.patchify(g_xrec.to(dtype=F32).contiguous(), engine.patch, io["dpix16"])
+            _C.patchify_any(g_xrec.to(dtype=F32).contiguous(), engine.patch, io["dpix16"])
         g_dev = None if g_qloss is None else g_qloss.reshape(1).to(dtype=F32).contiguous()
         engine.backward_from(st, io["dpix16"], 1.0 if g_qloss is not None else 0.0, g_dev)
         return None, None, None
@@ -211,14 +218,22 @@ class _AEFunction(torch.autograd.Function):
 class Stage1Engine:
     """Binds a ``ViTVQ`` module tree to the HIP schedule on one device."""
 
-    def __init__(self, model: nn.Module, device: Optional[torch.device] = None) -> None:
+    def __init__(self, model: nn.Module, device: Optional[torch.device] = None, precision: Optional[str] = None) -> None:
+        """precision: "bf16" (product path: bf16 MFMA operands, fp32 accumulation / residual stream / master weights) or "fp32" (exact
+        mode for parity runs: every operand fp32); default from ENH_PRECISION, else "bf16"."""
+        import os
+        precision = precision or os.environ.get("ENH_PRECISION", "bf16")
+        if precision not in ("bf16", "fp32"):
+            raise ValueError(f"precision must be 'bf16' or 'fp32', got {precision!r}")
+        self.precision = precision
+        self.adt = BF16 if precision == "bf16" else F32
         if not torch.cuda.is_available():
             raise RuntimeError("Stage1Engine needs a ROCm device (MI355X); the HIP path has no CPU fallback")
         _C.lib()
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self.model = model
         enc, dec, q = model.encoder, model.decoder, model.quantizer
-        self.store = ParamStore(model, self.device)
+        self.store = ParamStore(model, self.device, precision)
         self.patch, self.size, self.C = enc.patch_size[0], enc.image_size[0], enc.channels
         self.n_tok = enc.num_patches
         self.pd = enc.patch_dim
@@ -238,8 +253,8 @@ class Stage1Engine:
         if B not in self._io:
             dev, M = self.device, B * self.n_tok
             e = lambda *shape, dt=F32: torch.empty(*shape, dtype=dt, device=dev)
-            self._io[B] = dict(patches=e(M, self.pd, dt=BF16), h=e(M, self.ed), pix=e(M, self.pd), xrec=e(B, self.C, self.size, self.size),
-                               dpix16=e(M, self.pd, dt=BF16), sums=torch.zeros(2, dtype=torch.float64, device=dev),
+            self._io[B] = dict(patches=e(M, self.pd, dt=self.adt), h=e(M, self.ed), pix=e(M, self.pd), xrec=e(B, self.C, self.size, self.size),
+                               dpix16=e(M, self.pd, dt=self.adt), sums=torch.zeros(2, dtype=torch.float64, device=dev),
                                d_xf_dec=e(M, self.dec.dim), d_xf_enc=e(M, self.enc.dim), dzq=e(M, self.ed), bias_pix=e(self.pd),
                                g_bias_pix=e(self.pd))
         return self._io[B]
@@ -254,29 +269,27 @@ class Stage1Engine:
         """patch-embed GEMM (+bias +pos table) -> encoder tower.  reference layers.py:177-182"""
         B, s, io = img.shape[0], self.store, self._io_bufs(img.shape[0])
         M = B * self.n_tok
-        _C.patchify(img, self.patch, io["patches"])
-        w16 = s.w16["encoder.to_patch_embedding.0.weight"].view(self.enc.dim, self.pd)
-        _C.gemm(io["patches"], w16, M, self.enc.dim, self.pd, bias=s.w["encoder.to_patch_embedding.0.bias"],
-                res=s.w["encoder.en_pos_embedding"].view(self.n_tok, self.enc.dim), res_rows=self.n_tok,
-                out_f32=self.enc.input_buffer(B, save))
+        _C.patchify_any(img, self.patch, io["patches"])
+        w16 = s.wa["encoder.to_patch_embedding.0.weight"].view(self.enc.dim, self.pd)
+        _C.mm(io["patches"], w16, M, self.enc.dim, self.pd, self.enc.input_buffer(B, save), bias=s.w["encoder.to_patch_embedding.0.bias"],
+              res=s.w["encoder.en_pos_embedding"].view(self.n_tok, self.enc.dim), res_rows=self.n_tok)
         return self.enc.forward(B, save, want_f32)
 
     def _pre_quant(self, xf16: torch.Tensor, B: int) -> torch.Tensor:
         s, io = self.store, self._io_bufs(B)
-        _C.gemm(xf16, s.w16["pre_quant.weight"], B * self.n_tok, self.ed, self.enc.dim, bias=s.w["pre_quant.bias"], out_f32=io["h"])
+        _C.mm(xf16, s.wa["pre_quant.weight"], B * self.n_tok, self.ed, self.enc.dim, io["h"], bias=s.w["pre_quant.bias"])
         return io["h"]
 
     def _decode_tokens(self, zq16: torch.Tensor, B: int, save: bool) -> torch.Tensor:
         """post_quant (+bias +pos table) -> decoder tower -> to_pixel GEMM.  reference vitvqgan.py:68-72, layers.py:209-214"""
         s, io, M = self.store, self._io_bufs(B), B * self.n_tok
-        _C.gemm(zq16, s.w16["post_quant.weight"], M, self.dec.dim, self.ed, bias=s.w["post_quant.bias"],
-                res=s.w["decoder.de_pos_embedding"].view(self.n_tok, self.dec.dim), res_rows=self.n_tok,
-                out_f32=self.dec.input_buffer(B, save))
+        _C.mm(zq16, s.wa["post_quant.weight"], M, self.dec.dim, self.ed, self.dec.input_buffer(B, save), bias=s.w["post_quant.bias"],
+              res=s.w["decoder.de_pos_embedding"].view(self.n_tok, self.dec.dim), res_rows=self.n_tok)
         b = self.dec.forward(B, save)
         pp = self.patch * self.patch
         io["bias_pix"].view(self.C, pp).copy_(s.w["decoder.to_pixel.1.bias"].view(self.C, 1).expand(self.C, pp))
-        wpix16 = s.w16["decoder.to_pixel.1.weight"].view(self.dec.dim, self.pd)  # stored [K][N]
-        _C.gemm(b["xf16"], wpix16, M, self.pd, self.dec.dim, trans_b=True, bias=io["bias_pix"], out_f32=io["pix"])
+        wpix16 = s.wa["decoder.to_pixel.1.weight"].view(self.dec.dim, self.pd)  # stored [K][N]
+        _C.mm(b["xf16"], wpix16, M, self.pd, self.dec.dim, io["pix"], trans_b=True, bias=io["bias_pix"])
         return io["pix"]
 
     # ---- inference API (reference vitvqgan.py:44-90) -------------------------------------------
@@ -296,8 +309,10 @@ class Stage1Engine:
         B, io = img.shape[0], self._io_bufs(img.shape[0])
         b = self._encode_tokens(img, save=False)
         h = self._pre_quant(b["xf16"], B)
-        zq, zq16, idx, qloss = _C.vq_forward(h, self.store.w["quantizer.embedding.weight"], float(self.q.beta), self.q.depth, self.q.use_norm)
-        pix = self._decode_tokens(zq16, B, save=False)
+        exact = self.precision != "bf16"
+        zq, zq16, idx, qloss = _C.vq_forward(h, self.store.w["quantizer.embedding.weight"], float(self.q.beta), self.q.depth, self.q.use_norm,
+                                             want_bf16=not exact)
+        pix = self._decode_tokens(zq if exact else zq16, B, save=False)
         _C.unpatchify_loss(pix, None, B, self.C, self.size, self.size, self.patch, 0.0, 0.0, io["xrec"], None, None)
         idx = idx.view(B, self.n_tok, self.q.depth) if self.q.use_residual else idx.view(B, self.n_tok)
         return io["xrec"].clone(), qloss.view(()).clone(), idx
@@ -307,7 +322,7 @@ class Stage1Engine:
         """decode(quant) for quant [B, N, embed_dim] f32 (reference vitvqgan.py:68-72)."""
         B = quant.shape[0]
         io = self._io_bufs(B)
-        zq16 = quant.reshape(B * self.n_tok, self.ed).to(device=self.device, dtype=BF16).contiguous()
+        zq16 = quant.reshape(B * self.n_tok, self.ed).to(device=self.device, dtype=self.adt).contiguous()
         pix = self._decode_tokens(zq16, B, save=False)
         _C.unpatchify_loss(pix, None, B, self.C, self.size, self.size, self.patch, 0.0, 0.0, io["xrec"], None, None)
         return io["xrec"].clone()
@@ -327,8 +342,8 @@ class Stage1Engine:
         b = self.dec.forward(B, False)
         pp = self.patch * self.patch
         io["bias_pix"].view(self.C, pp).copy_(s.w["decoder.to_pixel.1.bias"].view(self.C, 1).expand(self.C, pp))
-        _C.gemm(b["xf16"], s.w16["decoder.to_pixel.1.weight"].view(self.dec.dim, self.pd), M, self.pd, self.dec.dim, trans_b=True,
-                bias=io["bias_pix"], out_f32=io["pix"])
+        _C.mm(b["xf16"], s.wa["decoder.to_pixel.1.weight"].view(self.dec.dim, self.pd), M, self.pd, self.dec.dim, io["pix"], trans_b=True,
+              bias=io["bias_pix"])
         _C.unpatchify_loss(io["pix"], None, B, self.C, self.size, self.size, self.patch, 0.0, 0.0, io["xrec"], None, None)
         return io["xrec"].clone()
 
@@ -341,7 +356,10 @@ class Stage1Engine:
         eb = self._encode_tokens(img, save=True)
         h = self._pre_quant(eb["xf16"], B)
         E = s.w["quantizer.embedding.weight"]
-        zq, zq16, idx, qloss = _C.vq_forward(h, E, float(self.q.beta), self.q.depth, self.q.use_norm)
+        exact = self.precision != "bf16"
+        zq, zq16, idx, qloss = _C.vq_forward(h, E, float(self.q.beta), self.q.depth, self.q.use_norm, want_bf16=not exact)
+        if exact:
+            zq16 = zq
         pix = self._decode_tokens(zq16, B, save=True)
         self._fwd_serial = getattr(self, "_fwd_serial", 0) + 1
         return dict(img=img, B=B, eb=eb, h=h, zq16=zq16, idx=idx, qloss=qloss, pix=pix, serial=self._fwd_serial)
@@ -359,26 +377,29 @@ class Stage1Engine:
         notify = self.comm.layer_done if self.comm is not None else None
         d_xf = io["d_xf_dec"]
         wpix = "decoder.to_pixel.1.weight"
-        _C.gemm(db["xf16"], dpix16, self.dec.dim, self.pd, M, trans_a=True, trans_b=True, accumulate=True, out_f32=g[wpix].view(self.dec.dim, self.pd))
-        _C.colsum(dpix16, M, self.pd, io["g_bias_pix"], accumulate=False)
+        _C.mm(db["xf16"], dpix16, self.dec.dim, self.pd, M, g[wpix].view(self.dec.dim, self.pd), trans_a=True, trans_b=True, accumulate=True)
+        _C.colsum_any(dpix16, M, self.pd, io["g_bias_pix"], accumulate=False)
         g["decoder.to_pixel.1.bias"].add_(io["g_bias_pix"].view(self.C, -1).sum(1))
-        _C.gemm(dpix16, s.w16[wpix].view(self.dec.dim, self.pd), M, self.dec.dim, self.pd, out_f32=d_xf)
+        _C.mm(dpix16, s.wa[wpix].view(self.dec.dim, self.pd), M, self.dec.dim, self.pd, d_xf)
         if notify:
             notify("decoder.to_pixel.")
         g0, g016 = self.dec.backward(B, d_xf, notify)
-        _C.gemm(g016, zq16, self.dec.dim, self.ed, M, trans_a=True, trans_b=True, accumulate=True, out_f32=g["post_quant.weight"])
-        _C.gemm(g016, s.w16["post_quant.weight"], M, self.ed, self.dec.dim, trans_b=True, out_f32=io["dzq"])
+        _C.mm(g016, zq16, self.dec.dim, self.ed, M, g["post_quant.weight"], trans_a=True, trans_b=True, accumulate=True)
+        _C.mm(g016, s.wa["post_quant.weight"], M, self.ed, self.dec.dim, io["dzq"], trans_b=True)
+        exact = self.precision != "bf16"
         dh, dh16 = _C.vq_backward(h, E, idx, io["dzq"], g_loss, g_loss_dev, float(self.q.beta), self.q.depth, bool(self.q.use_residual),
-                                  self.q.use_norm, g["quantizer.embedding.weight"])
-        _C.gemm(dh16, eb["xf16"], self.ed, self.enc.dim, M, trans_a=True, trans_b=True, accumulate=True, out_f32=g["pre_quant.weight"])
-        _C.colsum(dh16, M, self.ed, g["pre_quant.bias"], accumulate=True)
+                                  self.q.use_norm, g["quantizer.embedding.weight"], want_bf16=not exact)
+        if exact:
+            dh16 = dh
+        _C.mm(dh16, eb["xf16"], self.ed, self.enc.dim, M, g["pre_quant.weight"], trans_a=True, trans_b=True, accumulate=True)
+        _C.colsum_any(dh16, M, self.ed, g["pre_quant.bias"], accumulate=True)
         d_xe = io["d_xf_enc"]
-        _C.gemm(dh16, s.w16["pre_quant.weight"], M, self.enc.dim, self.ed, trans_b=True, out_f32=d_xe)
+        _C.mm(dh16, s.wa["pre_quant.weight"], M, self.enc.dim, self.ed, d_xe, trans_b=True)
         if notify:
             notify("post_quant."); notify("pre_quant."); notify("quantizer.")
         e0, e016 = self.enc.backward(B, d_xe, notify)
         wpe = "encoder.to_patch_embedding.0.weight"
-        _C.gemm(e016, io["patches"], self.enc.dim, self.pd, M, trans_a=True, trans_b=True, accumulate=True, out_f32=g[wpe].view(self.enc.dim, self.pd))
+        _C.mm(e016, io["patches"], self.enc.dim, self.pd, M, g[wpe].view(self.enc.dim, self.pd), trans_a=True, trans_b=True, accumulate=True)
         if notify:
             notify("encoder.to_patch_embedding.")
 
@@ -393,7 +414,7 @@ class Stage1Engine:
         st = self.forward_train(img)
         img, B, io = st["img"], st["B"], self._io_bufs(st["B"])
         io["sums"].zero_()
-        _C.unpatchify_loss(st["pix"], img, B, self.C, self.size, self.size, self.patch, w_l1, w_l2, io["xrec"], io["sums"], io["dpix16"])
+        _C.unpatchify_loss_any(st["pix"], img, B, self.C, self.size, self.size, self.patch, w_l1, w_l2, io["xrec"], io["sums"], io["dpix16"])
         self.backward_from(st, io["dpix16"], codebook_weight)
         numel = float(img.numel())
         l1 = (io["sums"][0] / numel).float()
@@ -421,7 +442,8 @@ class Stage1Engine:
             self.comm.finish()
             grad_scale = grad_scale / self.comm.world
         s.step_count += 1
-        _C.adamw_step(s.p, s.g, s.m, s.v, s.p16, s.step_count, lr, betas[0], betas[1], eps, weight_decay, grad_scale)
+        _C.adamw_step(s.p, s.g, s.m, s.v, s.p16 if self.precision == "bf16" else None, s.step_count, lr, betas[0], betas[1], eps, weight_decay,
+                      grad_scale)
 
     def train_step(self, img: torch.Tensor, lr: float, **loss_kw) -> dict:
         out = self.forward_backward(img, **loss_kw)

@@ -48,6 +48,7 @@ class ViTVQ(nn.Module):
         self.pre_quant = nn.Linear(_get(encoder, "dim"), _get(quantizer, "embed_dim"))
         self.post_quant = nn.Linear(_get(quantizer, "embed_dim"), _get(decoder, "dim"))
         self._engine = None
+        self.precision = None  # None -> ENH_PRECISION or "bf16"; set to "fp32" BEFORE first use for the exact (parity) mode
 
         if path is not None:
             self.init_from_ckpt(path, ignore_keys)
@@ -57,7 +58,7 @@ class ViTVQ(nn.Module):
     def engine(self):
         if self._engine is None:
             from ...engine.stage1 import Stage1Engine
-            self._engine = Stage1Engine(self)
+            self._engine = Stage1Engine(self, precision=self.precision)
         return self._engine
 
     @property

@@ -171,6 +171,22 @@ int enh_channel_sum_f32(const float* x, int B, int C, int64_t inner, float* out,
 int enh_upfirdn2d(const float* in, const float* kernel, float* out, int64_t major, int in_h, int in_w, int kh, int kw, int up_x,
                   int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * fp32 "exact mode": the same contractions with fp32 operands and fixed ascending-k fp32 accumulation (no bf16 anywhere), for end-to-end
+ * parity runs against the fp32 CPU oracle (SURVEY.md §8d metric 3).  Same argument meaning as the bf16 entries above; all tensors f32.
+ * ------------------------------------------------------------------------------------------------ */
+int enh_gemm_f32(const float* A, int64_t lda, int trans_a, const float* B, int64_t ldb, int trans_b, int64_t M, int64_t N, int64_t K,
+                 const float* bias, int act, const float* aux, int64_t ldaux, const float* res, int64_t ldres, int64_t res_rows,
+                 int accumulate, float* C, int64_t ldc, void* stream);
+int enh_attention_forward_f32(const float* qkv, int B, int N, int H, float scale, float* out, float* lse, void* stream);
+int enh_attention_backward_f32(const float* qkv, const float* out, const float* dout, const float* lse, int B, int N, int H, float scale,
+                               float* dqkv, float* delta_ws, void* stream);
+int enh_colsum_f32(const float* x, int64_t M, int64_t N, int64_t ldx, float* out, int accumulate, void* stream);
+/* to_patches = 1: img [B,C,H,W] -> patches [M, C*p*p] ; 0: the inverse scatter */
+int enh_patch_perm_f32(const float* src, float* dst, int B, int C, int H, int W, int p, int to_patches, void* stream);
+int enh_unpatchify_loss_f32(const float* pix, const float* target, int B, int C, int H, int W, int p, float w_l1, float w_l2, float* xrec,
+                            double* sums, float* dpix, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
