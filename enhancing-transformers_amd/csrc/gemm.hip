@@ -9,15 +9,17 @@
 // index is the slow storage index are staged as-is and read from LDS with the hardware transpose read
 // ds_read_b64_tr_b16 (semantics verified on MI355X, profiles/hw_probe_r01.txt).
 //
-// Tiling: 128x128x64 workgroup tile, 256 threads = 4 waves in 2x2, each wave 64x64 = 4x4 tiles of
-// v_mfma_f32_16x16x32_bf16 (f32 accumulate).  Global -> register -> LDS staging, double-buffered, one
-// barrier per K-step (the next tile's global loads are in flight during the MFMAs).  LDS images are
-// XOR-swizzled so that ds_write_b128, ds_read_b128 and the transpose reads are bank-conflict free under the
-// gfx950 bank model (MI355X_MICROARCH.md §LDS; checked by tools/lds_bank_check.py).
-// The MFMA is issued with swapped operands (D = B_frag x A_frag) so each lane ends up with 4 CONSECUTIVE
-// output columns of one row: the epilogue reads bias / residual / aux and writes C with 16-byte (f32) or
-// 8-byte (bf16) accesses.  Workgroup ids are remapped so each XCD (private L2) walks a contiguous run of
-// tiles, n-fastest, sharing the A row-panel and the weight matrix in that L2.
+// Kernel families (enh_gemm_bf16_variant() reports the per-shape choice; ENH_GEMM_KERNEL = reg | pipe2 | t256 overrides):
+//   gemm_bf16_pipe2_kernel  128x128x64 tile, 4 waves (2x2, each 4x4 v_mfma_f32_16x16x32_bf16), two 32-KiB LDS stages filled by
+//                           global_load_lds, K-loop software-pipelined around one mid-iteration barrier; 2 workgroups per CU.  Default.
+//   gemm_bf16_t256_kernel   256x256x64 tile, 8 waves (2x4, each 4x2 v_mfma_f32_32x32x16_bf16), two 64-KiB stages, staggered two-group
+//                           schedule; chosen for long-K forward / dgrad shapes (half the staged bytes per flop).
+//   gemm_bf16_kernel        register-staged 128x128x64 fallback for K not a multiple of 64 (zero-fills partial tiles).
+// All LDS images are XOR-swizzled so that staging writes, ds_read_b128 fragments and the transpose reads are bank-conflict free under
+// the gfx950 bank model (MI355X_MICROARCH.md §LDS; checked by tools/lds_bank_check.py; SQ_LDS_BANK_CONFLICT = 0 measured).
+// The MFMA is issued with swapped operands (D = B_frag x A_frag) so each lane ends up with 4 CONSECUTIVE output columns of one row: the
+// epilogue reads bias / residual / aux and writes C with 16-byte (f32) or 8-byte (bf16) accesses.  Workgroup ids are remapped so each XCD
+// (private L2) walks a contiguous, grouped run of tiles.  What bounds these kernels (L2 misses, not structure): DESIGN.md §3.1.
 #include <stdlib.h>
 #include "common.h"
 
@@ -49,7 +51,6 @@ struct GemmArgs {
   float* c_f32; uint16_t* c_bf16; int64_t ldc;
   int nbm, nbn;
   int splits;  // number of K-slices (1 = no split-K; otherwise a multiple of 8)
-  int ablate;  // debug only (ENH_GEMM_ABLATE): 1 = no global->LDS loads, 2 = no MFMA, 3 = no LDS fragment reads
 };
 
 // global -> registers: one 128 x 64 (row layout) or 64 x 128 (kmaj layout) bf16 operand tile, 4 x 16 B per thread
@@ -236,116 +237,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs args) 
 
 
 // =================================================================================================
-// direct-to-LDS variant: global_load_lds (16 B / lane) writes the swizzled LDS image itself — the LDS destination
-// of a wave instruction is lane-linear (base + lane*16 B, verified in profiles/hw_probe_r01.txt), so the XOR swizzle
-// is applied to each lane's SOURCE address instead.  No staging VGPRs, no ds_write pass.  Requires every K-slice to
-// be a multiple of 64 (no zero-fill is possible); out-of-range rows / columns are clamped to the last valid one —
-// their products land in outputs that are never stored.
+// direct-to-LDS staging: global_load_lds (16 B / lane) writes the swizzled LDS image itself — the LDS destination of a wave
+// instruction is lane-linear (base + lane*16 B, verified in profiles/hw_probe_r01.txt), so the XOR swizzle is applied to each lane's
+// SOURCE address instead.  No staging VGPRs, no ds_write pass.  Requires every K-slice to be a multiple of 64 (no zero-fill is
+// possible); out-of-range rows / columns are clamped to the last valid one — their products land in outputs that are never stored.
+// (Earlier variants — a 2-buffer kernel with __syncthreads() drains and a 3-stage 256x128 kernel — lost the A/B comparisons recorded
+// in profiles/r01_gemm_ablation.txt and were removed.)
 // =================================================================================================
-template <bool TR>
-__device__ __forceinline__ void tile_glds_setup(const uint16_t* (&src)[4], const uint16_t* __restrict__ P, int64_t ld, int64_t x0,
-                                                int64_t X, int64_t k_begin, int wave, int lane) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int inst = wave * 4 + i;  // which 1-KiB slab of the 16-KiB tile this wave instruction fills
-    if (!TR) {
-      const int r = inst * 8 + (lane >> 3), pc = lane & 7;  // LDS row, physical 16-B chunk
-      const int c = pc ^ ((r >> 1) & 7);                    // logical chunk that must land there (lds_row_off)
-      int64_t row = x0 + r;
-      if (row > X - 1) row = X - 1;
-      src[i] = P + row * ld + k_begin + c * 8;
-    } else {
-      const int k = inst * 4 + (lane >> 4), pp = lane & 15;  // LDS k-row, physical 16-B piece
-      const int q = (pp >> 1) ^ ((k & 3) | (((k >> 3) & 1) << 2));  // logical 32-B chunk (lds_kmaj_off)
-      int64_t col = x0 + q * 16 + (pp & 1) * 8;
-      if (col > X - 8) col = X - 8;
-      src[i] = P + (k_begin + k) * ld + col;
-    }
-  }
-}
-template <bool TR>
-__device__ __forceinline__ void tile_glds_issue(const uint16_t* (&src)[4], unsigned char* tile, int64_t ld, int wave) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    __builtin_amdgcn_global_load_lds((const GLB_AS void*)src[i], (LDS_AS void*)(tile + (wave * 4 + i) * 1024), 16, 0, 0);
-    src[i] += TR ? (int64_t)G_BK * ld : (int64_t)G_BK;
-  }
-}
-
-template <bool TA, bool TB>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_glds_kernel(const GemmArgs args) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2 stages][A tile | B tile]
-  const int t = threadIdx.x;
-  const int lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int l16 = lane & 15, lg = lane >> 4;
-  int split, tile_m, tile_n;
-  gemm_tile_coords(args, split, tile_m, tile_n);
-  const int64_t m0 = (int64_t)tile_m * G_BM, n0 = (int64_t)tile_n * G_BN;
-  const int64_t k_begin = (int64_t)split * args.k_per_split;
-  int64_t k_end = k_begin + args.k_per_split;
-  if (k_end > args.K) k_end = args.K;
-  const int nk = (int)((k_end - k_begin) / G_BK);
-
-  const uint16_t* sa_src[4];
-  const uint16_t* sb_src[4];
-  tile_glds_setup<TA>(sa_src, args.A, args.lda, m0, args.M, k_begin, wave, lane);
-  tile_glds_setup<TB>(sb_src, args.B, args.ldb, n0, args.N, k_begin, wave, lane);
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  if (nk > 0) {
-    tile_glds_issue<TA>(sa_src, smem, args.lda, wave);
-    tile_glds_issue<TB>(sb_src, smem + G_TILE_BYTES, args.ldb, wave);
-  }
-  __syncthreads();  // hipcc drains vmcnt(0) before the barrier while an LDS-DMA is in flight
-  for (int kt = 0; kt < nk; ++kt) {
-    const int stage = kt & 1;
-    if (kt + 1 < nk) {
-      unsigned char* na = smem + (stage ^ 1) * (2 * G_TILE_BYTES);
-      tile_glds_issue<TA>(sa_src, na, args.lda, wave);
-      tile_glds_issue<TB>(sb_src, na + G_TILE_BYTES, args.ldb, wave);
-    }
-    const unsigned char* sa = smem + stage * (2 * G_TILE_BYTES);
-    const unsigned char* sb = sa + G_TILE_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      s16x8 fa[4], fb[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = tile_frag<TA>(sa, wm * 64 + i * 16, ks, lg, l16);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = tile_frag<TB>(sb, wn * 64 + j * 16, ks, lg, l16);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[j]), __builtin_bit_cast(bf16x8, fa[i]), acc[i][j], 0, 0, 0);
-    }
-    __syncthreads();
-  }
-  gemm_epilogue(args, acc, m0, n0, wm, wn, lg, l16);
-}
-
-
-// =================================================================================================
-// 3-stage pipelined variant ("p3"): 256 x 128 x 64 workgroup tile, 8 waves (4 x 2), one workgroup per CU.
-// A stage = three 16-KiB sub-tiles [A rows 0-127 | A rows 128-255 | B] in exactly the swizzled formats above,
-// filled by global_load_lds (6 x 1 KiB wave-instructions per wave).  The ring holds 3 stages (144 KiB LDS): while
-// stage kt is multiplied, stages kt+1 and kt+2 are in flight.  Waves wait with a COUNTED s_waitcnt vmcnt(6)
-// (their own 6 loads of the newest stage may stay outstanding) and meet at a raw s_barrier — the loads stay in flight
-// across barriers instead of being drained to vmcnt(0) at each one (cdna_hip_programming.md §5 "Pipelining across
-// barriers").  WAR safety: stage kt+2 reuses the buffer read during step kt-1, and every wave has passed this step's
-// barrier only after finishing its kt-1 reads.
-// =================================================================================================
-#define G3_BM 256
-#define G3_STAGE_BYTES (3 * G_TILE_BYTES)
-#define G3_STAGES 3
-
 template <bool TR>
 __device__ __forceinline__ const uint16_t* glds_src_ptr(const uint16_t* __restrict__ P, int64_t ld, int64_t x0, int64_t X,
                                                         int64_t k_begin, int slab, int lane) {
@@ -363,82 +261,6 @@ __device__ __forceinline__ const uint16_t* glds_src_ptr(const uint16_t* __restri
     return P + (k_begin + k) * ld + col;
   }
 }
-
-template <bool TA, bool TB>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_p3_kernel(const GemmArgs args) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [3 stages][A0 | A1 | B]
-  const int t = threadIdx.x;
-  const int lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = wave >> 1, wn = wave & 1;  // 4 x 2 waves, each 64 x 64
-  const int l16 = lane & 15, lg = lane >> 4;
-  int split, tile_m, tile_n;
-  gemm_tile_coords(args, split, tile_m, tile_n);
-  const int64_t m0 = (int64_t)tile_m * G3_BM, n0 = (int64_t)tile_n * G_BN;
-  const int64_t k_begin = (int64_t)split * args.k_per_split;
-  int64_t k_end = k_begin + args.k_per_split;
-  if (k_end > args.K) k_end = args.K;
-  const int nk = (int)((k_end - k_begin) / G_BK);
-
-  // this wave's 6 of the 48 one-KiB slabs of a stage: slab id g = wave*6 + i -> sub-tile g>>4, slab g&15
-  const uint16_t* src[6];
-  int lds_off[6];
-  int64_t step[6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    const int g = wave * 6 + i, sub = g >> 4, slab = g & 15;
-    lds_off[i] = sub * G_TILE_BYTES + slab * 1024;
-    if (sub < 2) {
-      src[i] = glds_src_ptr<TA>(args.A, args.lda, m0 + sub * 128, args.M, k_begin, slab, lane);
-      step[i] = TA ? (int64_t)G_BK * args.lda : (int64_t)G_BK;
-    } else {
-      src[i] = glds_src_ptr<TB>(args.B, args.ldb, n0, args.N, k_begin, slab, lane);
-      step[i] = TB ? (int64_t)G_BK * args.ldb : (int64_t)G_BK;
-    }
-  }
-#define G3_ISSUE(BUF)                                                                                                    \
-  do {                                                                                                                   \
-    unsigned char* base_ = smem + (BUF) * G3_STAGE_BYTES;                                                                \
-    _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) {                                                                   \
-      __builtin_amdgcn_global_load_lds((const GLB_AS void*)src[i_], (LDS_AS void*)(base_ + lds_off[i_]), 16, 0, 0);      \
-      src[i_] += step[i_];                                                                                               \
-    }                                                                                                                    \
-  } while (0)
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  if (nk > 0) G3_ISSUE(0);
-  if (nk > 1) G3_ISSUE(1);
-  int buf = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (kt + 2 < nk) G3_ISSUE(buf >= 1 ? buf - 1 : 2);  // (kt + 2) % 3
-    const unsigned char* sa = smem + buf * G3_STAGE_BYTES + (wm >> 1) * G_TILE_BYTES;
-    const unsigned char* sb = smem + buf * G3_STAGE_BYTES + 2 * G_TILE_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      s16x8 fa[4], fb[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = tile_frag<TA>(sa, (wm & 1) * 64 + i * 16, ks, lg, l16);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = tile_frag<TB>(sb, wn * 64 + j * 16, ks, lg, l16);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[j]), __builtin_bit_cast(bf16x8, fa[i]), acc[i][j], 0, 0, 0);
-    }
-    buf = buf == 2 ? 0 : buf + 1;
-  }
-  gemm_epilogue(args, acc, m0, n0, wm, wn, lg, l16);
-}
-
 
 // =================================================================================================
 // "pipe2": 128 x 128 x 64 tile, 4 waves, two LDS stages, direct-to-LDS loads — with the K-loop software-pipelined
@@ -792,14 +614,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_t256_kernel(const GemmArgs a
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-// kernel family: 0 = register-staged (any K % 8), 1 = glds 2-buffer, 2 = p3, 3 = pipe2, 4 = t256
+// kernel family: 0 = register-staged (any K % 8), 3 = pipe2, 4 = t256
 static int gemm_family(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K) {
-  static const int kernel_sel = [] {  // ENH_GEMM_KERNEL = reg | glds | p3 | pipe2 | t256 ; unset = per-shape choice
+  static const int kernel_sel = [] {  // ENH_GEMM_KERNEL = reg | pipe2 | t256 ; unset = per-shape choice
     const char* e = getenv("ENH_GEMM_KERNEL");
     if (!e) return -1;
     if (e[0] == 'r') return 0;
-    if (e[0] == 'g') return 1;
-    if (e[0] == 'p' && e[1] == '3') return 2;
     if (e[0] == 'p') return 3;
     if (e[0] == 't') return 4;
     return -1;
@@ -808,14 +628,12 @@ static int gemm_family(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K
   // per-shape choice (measured on MI355X, profiles/r01_gemm_ablation.txt): the 256x256 tile wins when the K loop is long
   // and the A operand is row-major (fc2 forward, dgrad of qkv / fc1); everything else runs the 128x128 pipe2 kernel.
   int family = !k64 ? 0 : (kernel_sel >= 0 ? kernel_sel : ((K >= 2048 && !trans_a) ? 4 : 3));
-  if (family == 2 && M < 256) family = 1;  // the 256-row tile would mostly multiply clamped rows
   if (family == 4 && (M < 256 || N < 256)) family = 3;
   return family;
 }
 
 extern "C" const char* enh_gemm_bf16_variant(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K) {
-  static const char* names[5] = {"gemm_bf16_kernel", "gemm_bf16_glds_kernel", "gemm_bf16_p3_kernel", "gemm_bf16_pipe2_kernel",
-                                 "gemm_bf16_t256_kernel"};
+  static const char* names[5] = {"gemm_bf16_kernel", "", "", "gemm_bf16_pipe2_kernel", "gemm_bf16_t256_kernel"};
   return names[gemm_family(trans_a, trans_b, M, N, K)];
 }
 
@@ -836,14 +654,13 @@ extern "C" int enh_gemm_bf16(const enh_bf16* A, int64_t lda, int trans_a, const 
   ENH_REQUIRE((!c_f32 || aligned16(c_f32)) && (!c_bf16 || (reinterpret_cast<uintptr_t>(c_bf16) & 7u) == 0), ENH_E_SHAPE, "enh_gemm_bf16: output alignment");
 
   const int family = gemm_family(trans_a, trans_b, M, N, K);
-  const int bm = family == 2 ? G3_BM : (family == 4 ? G4_BM : G_BM);
+  const int bm = family == 4 ? G4_BM : G_BM;
   const int bn = family == 4 ? G4_BN : G_BN;
 
   GemmArgs g;
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.M = M; g.N = N; g.K = K;
   g.bias = bias; g.act = act; g.aux = aux; g.ldaux = ldaux; g.res = res; g.ldres = ldres; g.res_rows = res_rows;
   g.accumulate = accumulate; g.c_f32 = c_f32; g.c_bf16 = c_bf16; g.ldc = ldc;
-  { const char* e = getenv("ENH_GEMM_ABLATE"); g.ablate = e ? atoi(e) : 0; }
   g.nbm = (int)((M + bm - 1) / bm);
   g.nbn = (int)((N + bn - 1) / bn);
   const int64_t tiles = (int64_t)g.nbm * g.nbn;
@@ -861,8 +678,6 @@ extern "C" int enh_gemm_bf16(const enh_bf16* A, int64_t lda, int trans_a, const 
     if (want > ksteps / 8) want = ksteps / 8;
     if (want > 64) want = 64;
     if (want >= 2) splits = (int)want;
-    static const int force = [] { const char* e = getenv("ENH_GEMM_SPLITS"); return e ? atoi(e) : 0; }();  // tuning hook
-    if (force > 0 && force <= ksteps) splits = force;
   }
   g.k_per_split = ((ksteps + splits - 1) / splits) * G_BK;
   splits = (int)((K + g.k_per_split - 1) / g.k_per_split);
@@ -871,14 +686,10 @@ extern "C" int enh_gemm_bf16(const enh_bf16* A, int64_t lda, int trans_a, const 
   const dim3 grid((unsigned)(tiles * splits));
   hipStream_t s = (hipStream_t)stream;
   static const bool attr_set = [] {
-    const int b2 = 4 * G_TILE_BYTES, b3 = G3_STAGES * G3_STAGE_BYTES;
+    const int b2 = 4 * G_TILE_BYTES;
 #define SET_ATTR(K_, B_) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&K_), hipFuncAttributeMaxDynamicSharedMemorySize, B_)
     SET_ATTR((gemm_bf16_kernel<false, false>), b2); SET_ATTR((gemm_bf16_kernel<false, true>), b2);
     SET_ATTR((gemm_bf16_kernel<true, false>), b2); SET_ATTR((gemm_bf16_kernel<true, true>), b2);
-    SET_ATTR((gemm_bf16_glds_kernel<false, false>), b2); SET_ATTR((gemm_bf16_glds_kernel<false, true>), b2);
-    SET_ATTR((gemm_bf16_glds_kernel<true, false>), b2); SET_ATTR((gemm_bf16_glds_kernel<true, true>), b2);
-    SET_ATTR((gemm_bf16_p3_kernel<false, false>), b3); SET_ATTR((gemm_bf16_p3_kernel<false, true>), b3);
-    SET_ATTR((gemm_bf16_p3_kernel<true, false>), b3); SET_ATTR((gemm_bf16_p3_kernel<true, true>), b3);
     SET_ATTR((gemm_bf16_pipe2_kernel<false, false>), b2); SET_ATTR((gemm_bf16_pipe2_kernel<false, true>), b2);
     SET_ATTR((gemm_bf16_pipe2_kernel<true, false>), b2); SET_ATTR((gemm_bf16_pipe2_kernel<true, true>), b2);
     SET_ATTR((gemm_bf16_t256_kernel<false, false>), 2 * G4_STAGE_BYTES); SET_ATTR((gemm_bf16_t256_kernel<false, true>), 2 * G4_STAGE_BYTES);
@@ -887,7 +698,7 @@ extern "C" int enh_gemm_bf16(const enh_bf16* A, int64_t lda, int trans_a, const 
     return true;
   }();
   (void)attr_set;
-  const size_t lds2 = 4 * G_TILE_BYTES, lds3 = G3_STAGES * G3_STAGE_BYTES;
+  const size_t lds2 = 4 * G_TILE_BYTES;
 #define LAUNCH(KERN, THREADS, LDS)                                                          \
   do {                                                                                      \
     if (!trans_a && !trans_b) KERN<false, false><<<grid, THREADS, LDS, s>>>(g);            \
@@ -897,8 +708,6 @@ extern "C" int enh_gemm_bf16(const enh_bf16* A, int64_t lda, int trans_a, const 
   } while (0)
   if (family == 4) LAUNCH(gemm_bf16_t256_kernel, 512, (size_t)(2 * G4_STAGE_BYTES));
   else if (family == 3) LAUNCH(gemm_bf16_pipe2_kernel, 256, lds2);
-  else if (family == 2) LAUNCH(gemm_bf16_p3_kernel, 512, lds3);
-  else if (family == 1) LAUNCH(gemm_bf16_glds_kernel, 256, lds2);
   else LAUNCH(gemm_bf16_kernel, 256, lds2);
 #undef LAUNCH
   return enh_check_launch("enh_gemm_bf16");
