@@ -96,6 +96,56 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const uint16_t* __rest
   }
 }
 
+// Wide variant (N % 8 == 0, 16-byte aligned rows): a lane owns 8 columns (one 16-byte load per row), a wave covers 512 contiguous
+// columns = 1 KiB of a row, and four rows are in flight per wave.
+__global__ __launch_bounds__(256) void colsum_bf16_wide_kernel(const uint16_t* __restrict__ x, int64_t M, int64_t N, int64_t ldx,
+                                                               int64_t rows_per_block, float* __restrict__ out) {
+  __shared__ float s_part[3][512];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t n0 = (int64_t)blockIdx.x * 512 + lane * 8;
+  const int64_t m_begin = (int64_t)blockIdx.y * rows_per_block;
+  int64_t m_end = m_begin + rows_per_block;
+  if (m_end > M) m_end = M;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (n0 < N) {
+    const uint16_t* col = x + n0;
+    int64_t m = m_begin + wave;
+    for (; m + 12 < m_end; m += 16) {
+      u32x4 v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = *reinterpret_cast<const u32x4*>(col + (size_t)(m + 4 * r) * ldx);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          acc[2 * k] += __uint_as_float(v[r][k] << 16);
+          acc[2 * k + 1] += __uint_as_float(v[r][k] & 0xffff0000u);
+        }
+    }
+    for (; m < m_end; m += 4) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(col + (size_t)m * ldx);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        acc[2 * k] += __uint_as_float(v[k] << 16);
+        acc[2 * k + 1] += __uint_as_float(v[k] & 0xffff0000u);
+      }
+    }
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s_part[wave - 1][lane * 8 + k] = acc[k];
+  }
+  __syncthreads();
+  if (wave == 0 && n0 < N) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float a = acc[k];
+      for (int ww = 0; ww < 3; ++ww) a += s_part[ww][lane * 8 + k];
+      atomicAdd(&out[n0 + k], a);
+    }
+  }
+}
+
 __global__ void cast_f32_bf16_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, int64_t n) {
   const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i + 3 < n) {
@@ -176,8 +226,13 @@ extern "C" int enh_colsum_bf16(const enh_bf16* x, int64_t M, int64_t N, int64_t 
   int64_t chunks = (M + 511) / 512;
   if (chunks > 256) chunks = 256;
   const int64_t rows_per_block = (M + chunks - 1) / chunks;
-  dim3 grid((unsigned)((N + 127) / 128), (unsigned)chunks);
-  colsum_bf16_kernel<<<grid, 256, 0, s>>>(x, M, N, ldx, rows_per_block, out);
+  if (N % 8 == 0 && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0) {
+    dim3 grid((unsigned)((N + 511) / 512), (unsigned)chunks);
+    colsum_bf16_wide_kernel<<<grid, 256, 0, s>>>(x, M, N, ldx, rows_per_block, out);
+  } else {
+    dim3 grid((unsigned)((N + 127) / 128), (unsigned)chunks);
+    colsum_bf16_kernel<<<grid, 256, 0, s>>>(x, M, N, ldx, rows_per_block, out);
+  }
   return enh_check_launch("enh_colsum_bf16");
 }
 

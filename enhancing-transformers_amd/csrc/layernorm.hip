@@ -57,8 +57,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   }
 }
 
-template <int NCH>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+// DY16: dy is bf16 (the dgrad GEMM's bf16 output) instead of f32.  The dres loads are issued together with dy / x, not after the row
+// reduction (D = 768: 128 VGPRs, still 4 waves / SIMD).  Measured at M = 131072, D = 768 with distinct buffers
+// (tools/ln_bench.py): 328 us = 4.9 TB/s of algorithmic traffic (16 B / element).
+template <int NCH, bool DY16>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy_any, const float* __restrict__ x,
                                                      const float* __restrict__ w, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ dres,
                                                      int64_t M, int D, float* __restrict__ dx32,
@@ -82,14 +85,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
   for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += stride) {
     const float mu = mean[row], rs = rstd[row];
     const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * D);
-    const float4* gr = reinterpret_cast<const float4*>(dy + (size_t)row * D);
-    float4 xh[NCH], g[NCH];
+    float4 xh[NCH], g[NCH], rr[NCH];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int c = lane + 64 * i;
       if (c < nch) {
-        const float4 xv = xr[c], dv = gr[c];
+        const float4 xv = xr[c];
+        float4 dv;
+        if (DY16) {
+          const uint2 r = reinterpret_cast<const uint2*>(static_cast<const uint16_t*>(dy_any) + (size_t)row * D)[c];
+          dv = make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u));
+        } else {
+          dv = reinterpret_cast<const float4*>(static_cast<const float*>(dy_any) + (size_t)row * D)[c];
+        }
+        if (dres) rr[i] = reinterpret_cast<const float4*>(dres + (size_t)row * D)[c];
         xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
         g[i] = make_float4(dv.x * gw[i].x, dv.y * gw[i].y, dv.z * gw[i].z, dv.w * gw[i].w);
         s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
@@ -113,7 +123,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         o.z = rs * (g[i].z - c1 - xh[i].z * c2);
         o.w = rs * (g[i].w - c1 - xh[i].w * c2);
         if (dres) {
-          const float4 r = reinterpret_cast<const float4*>(dres + (size_t)row * D)[c];
+          const float4 r = rr[i];
           o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
         }
         reinterpret_cast<float4*>(dx32 + (size_t)row * D)[c] = o;
@@ -194,21 +204,31 @@ extern "C" int enh_layernorm_forward(const float* x, const float* w, const float
   return enh_check_launch("enh_layernorm_forward");
 }
 
-extern "C" int enh_layernorm_backward(const float* dy, const float* x, const float* w, const float* mean,
+template <bool DY16>
+static void ln_bwd_launch(int grid, hipStream_t s, const void* dy, const float* x, const float* w, const float* mean, const float* rstd,
+                          const float* dres, int64_t M, int D, float* dx_f32, enh_bf16* dx_bf16, float* dw, float* db, float* dx_colsum) {
+  switch ((D + 255) / 256) {
+    case 1: ln_bwd_kernel<1, DY16><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum); break;
+    case 2: ln_bwd_kernel<2, DY16><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum); break;
+    case 3: ln_bwd_kernel<3, DY16><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum); break;
+    case 4: ln_bwd_kernel<4, DY16><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum); break;
+    case 5: ln_bwd_kernel<5, DY16><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum); break;
+    default: ln_bwd_kernel<8, DY16><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum); break;
+  }
+}
+
+extern "C" int enh_layernorm_backward(const float* dy, const enh_bf16* dy_bf16, const float* x, const float* w, const float* mean,
                                       const float* rstd, const float* dres, int64_t M, int D, float* dx_f32,
                                       enh_bf16* dx_bf16, float* dw, float* db, float* dx_colsum, void* stream) {
-  ENH_REQUIRE(dy && x && w && mean && rstd && dx_f32 && dw && db, ENH_E_BADARG, "enh_layernorm_backward: null pointer");
+  ENH_REQUIRE((dy != nullptr) != (dy_bf16 != nullptr), ENH_E_BADARG, "enh_layernorm_backward: pass exactly one of dy (f32) / dy_bf16");
+  ENH_REQUIRE(x && w && mean && rstd && dx_f32 && dw && db, ENH_E_BADARG, "enh_layernorm_backward: null pointer");
   ENH_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 2048, ENH_E_SHAPE, "enh_layernorm_backward: need D %% 4 == 0 and D <= 2048, got M=%lld D=%d", (long long)M, D);
   hipStream_t s = (hipStream_t)stream;
-  int64_t want = (M + 3) / 4;
-  const int grid = (int)(want < 2048 ? want : 2048);
-  switch ((D + 255) / 256) {
-    case 1: ln_bwd_kernel<1><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum); break;
-    case 2: ln_bwd_kernel<2><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum); break;
-    case 3: ln_bwd_kernel<3><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum); break;
-    case 4: ln_bwd_kernel<4><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum); break;
-    case 5: ln_bwd_kernel<5><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum); break;
-    default: ln_bwd_kernel<8><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum); break;
-  }
+  // Persistent grid: every workgroup ends with 3*D f32 atomics (dw, db, dx_colsum), so their number is kept at two workgroups per CU —
+  // measured 328 / 337 / 355 / 395 / 528 us at 512 / 768 / 1024 / 1280 / 4096 workgroups (M = 131072, D = 768).
+  const int64_t want = (M + 3) / 4;
+  const int grid = (int)(want < 512 ? want : 512);
+  if (dy_bf16) ln_bwd_launch<true>(grid, s, dy_bf16, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum);
+  else ln_bwd_launch<false>(grid, s, dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum);
   return enh_check_launch("enh_layernorm_backward");
 }

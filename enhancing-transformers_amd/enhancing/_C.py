@@ -33,7 +33,7 @@ SIGNATURES = {
     "enh_vq_backward": (_i32, [_vp, _vp, _vp, _vp, _f32, _vp, _i64, _i32, _i32, _f32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "enh_vq_lookup": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "enh_layernorm_forward": (_i32, [_vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp, _vp]),
-    "enh_layernorm_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "enh_layernorm_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "enh_gemm_bf16": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _i64, _i64, _i64, _vp, _i32, _vp, _i64, _vp, _i64, _i64,
                              _i32, _vp, _vp, _i64, _vp]),
     "enh_gemm_bf16_variant": (_c.c_char_p, [_i32, _i32, _i64, _i64, _i64]),
@@ -203,7 +203,8 @@ def layernorm_forward(x, w, b, eps: float = 1e-5, y_bf16=None, y_f32=None, mean=
 
 def layernorm_backward(dy, x, w, mean, rstd, dres, dx_f32, dx_bf16, dw, db, dx_colsum=None):
     M, D = x.shape
-    _check(lib().enh_layernorm_backward(_p(dy, F32, "dy"), _p(x, F32, "x"), _p(w, F32, "w"), _p(mean, F32, "mean"),
+    dy32, dy16 = (None, dy) if dy.dtype == BF16 else (dy, None)   # upstream gradient: f32, or the dgrad GEMM's bf16 output
+    _check(lib().enh_layernorm_backward(_p(dy32, F32, "dy"), _p(dy16, BF16, "dy_bf16"), _p(x, F32, "x"), _p(w, F32, "w"), _p(mean, F32, "mean"),
                                         _p(rstd, F32, "rstd"), _p(dres, F32, "dres"), M, D, _p(dx_f32, F32, "dx_f32"),
                                         _p(dx_bf16, BF16, "dx_bf16"), _p(dw, F32, "dw"), _p(db, F32, "db"), _p(dx_colsum, F32, "dx_colsum"),
                                         _stream()), "enh_layernorm_backward")

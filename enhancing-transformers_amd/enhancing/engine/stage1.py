@@ -123,7 +123,7 @@ class _Tower:
             exact = self.s.precision != "bf16"
             gA, gB = e(M, self.dim), e(M, self.dim)
             b.update(gA=gA, gA16=gA if exact else e(M, self.dim, dt=BF16), gB=gB, gB16=gB if exact else e(M, self.dim, dt=BF16),
-                     dA=e(M, self.dim), dhid16=e(M, self.mlp, dt=BF16), do16=e(M, self.inner, dt=BF16),
+                     dA=e(M, self.dim, dt=F32 if exact else BF16), dhid16=e(M, self.mlp, dt=BF16), do16=e(M, self.inner, dt=BF16),
                      dqkv16=e(M, 3 * self.inner, dt=BF16), delta=e(B, H, N))
         self._bufs[key] = b
         return b

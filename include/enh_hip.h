@@ -89,11 +89,12 @@ int enh_vq_lookup(const float* codebook, const int64_t* idx, int64_t M, int n_em
  * mean,rstd [M] f32 saved for backward (may be NULL for inference).  D % 4 == 0, D <= 2048. */
 int enh_layernorm_forward(const float* x, const float* w, const float* b, int64_t M, int D, float eps,
                           enh_bf16* y_bf16, float* y_f32, float* mean, float* rstd, void* stream);
-/* dx = LN-backward(dy) [+ dres];  dy [M,D] f32, dres optional f32 residual-stream gradient that is added;
+/* dx = LN-backward(dy) [+ dres];  the upstream gradient [M,D] is passed EITHER as dy (f32) OR as dy_bf16 (the bf16 output of the dgrad
+ * GEMM that produced it) — exactly one non-NULL;  dres optional f32 residual-stream gradient that is added;
  * dx_f32 [M,D] f32 and optional dx_bf16 copy; dw,db [D] f32 are ACCUMULATED (atomics; caller zeroes);
  * dx_colsum [D] f32, optional: += column sums of dx — the bias gradient of the Linear whose output feeds this
  * residual stream (to_out / fc2), fused here so no separate reduction pass over dx is needed. */
-int enh_layernorm_backward(const float* dy, const float* x, const float* w, const float* mean,
+int enh_layernorm_backward(const float* dy, const enh_bf16* dy_bf16, const float* x, const float* w, const float* mean,
                            const float* rstd, const float* dres, int64_t M, int D, float* dx_f32,
                            enh_bf16* dx_bf16, float* dw, float* db, float* dx_colsum, void* stream);
 

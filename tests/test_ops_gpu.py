@@ -144,6 +144,14 @@ def test_layernorm_fwd_bwd(C, M, D):
     assert rel(dx, xt.grad + dres) <= F32_TOL
     assert rel(dw, wt.grad) <= F32_TOL and rel(db, bt.grad) <= F32_TOL
     assert rel(dx16.float(), xt.grad + dres) <= BF16_TOL
+    # the same op fed with the dgrad GEMM's bf16 output: identical to the f32 entry on the bf16-rounded gradient
+    dy16 = dy.to(torch.bfloat16)
+    xt2, wt2, bt2 = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    torch.nn.functional.layer_norm(xt2, (D,), wt2, bt2, 1e-5).backward(dy16.float())
+    dw.zero_(); db.zero_(); dxs.zero_()
+    C.layernorm_backward(dy16.cuda(), xd, w.cuda(), mean, rstd, dres.cuda(), dx, dx16, dw, db, dxs)
+    assert rel(dx, xt2.grad + dres) <= F32_TOL and rel(dxs, (xt2.grad + dres).double().sum(0)) <= F32_TOL
+    assert rel(dw, wt2.grad) <= F32_TOL and rel(db, bt2.grad) <= F32_TOL
 
 
 # ---------------------------------------------------------------------------------------------
@@ -298,6 +306,21 @@ def test_patchify_unpatchify_loss(C):
     assert abs(sums[1].item() - (d ** 2).sum().item()) <= 1e-6 * (d ** 2).sum().item()
     gref = O.patchify(((0.3 * torch.sign(d) + 2.0 * d) / d.numel()).float(), p).reshape(-1, Cc * p * p)
     assert rel(dpix.float(), gref) <= BF16_TOL
+
+
+@pytest.mark.parametrize("M,N", [(5000, 192), (4099, 2304), (37, 3072), (1031, 520), (777, 130), (3, 8)])
+def test_colsum_shapes(C, M, N):
+    """wide kernel (N % 8 == 0: full, partial last 512-column block, fewer rows than one unrolled pass) and the 2-column fallback;
+    overwrite and accumulate entry modes"""
+    g = torch.Generator().manual_seed(M + N)
+    x = bf16r(torch.randn(M, N, generator=g))
+    xd = x.to(torch.bfloat16).cuda()
+    out = torch.full((N,), 7.0, device="cuda")
+    C.colsum(xd, M, N, out)
+    ref = x.double().sum(0)
+    assert rel(out, ref) <= F32_TOL
+    C.colsum(xd, M, N, out, True)
+    assert rel(out, 2 * ref) <= F32_TOL
 
 
 def test_colsum_cast_adamw(C):

@@ -88,8 +88,12 @@ mean = torch.empty(M, device=dev); rstd = torch.empty(M, device=dev)
 t = timeit(lambda: _C.layernorm_forward(x, w, bb, 1e-5, y16, None, mean, rstd))
 print(f"{'layernorm fwd':34s} {t*1e3:8.3f} ms  {M*DIM*6/t/1e12:6.2f} TB/s")
 dx = torch.empty_like(x); dx16 = torch.empty_like(y16); dw = torch.zeros(DIM, device=dev); db = torch.zeros(DIM, device=dev)
-t = timeit(lambda: _C.layernorm_backward(x, x, w, mean, rstd, x, dx, dx16, dw, db))
-print(f"{'layernorm bwd (+res)':34s} {t*1e3:8.3f} ms  {M*DIM*18/t/1e12:6.2f} TB/s")
+dy32 = torch.randn(M, DIM, device=dev); dres = torch.randn(M, DIM, device=dev); dxs = torch.zeros(DIM, device=dev)   # distinct buffers: real HBM traffic
+t = timeit(lambda: _C.layernorm_backward(dy32, x, w, mean, rstd, dres, dx, dx16, dw, db, dxs))
+print(f"{'layernorm bwd (f32 dy, +res)':34s} {t*1e3:8.3f} ms  {M*DIM*18/t/1e12:6.2f} TB/s")
+dy16 = dy32.to(torch.bfloat16)
+t = timeit(lambda: _C.layernorm_backward(dy16, x, w, mean, rstd, dres, dx, dx16, dw, db, dxs))
+print(f"{'layernorm bwd (bf16 dy, +res)':34s} {t*1e3:8.3f} ms  {M*DIM*16/t/1e12:6.2f} TB/s")
 n = 170_664_000
 p = torch.randn(n, device=dev); g = torch.randn(n, device=dev); m_ = torch.zeros(n, device=dev); v_ = torch.zeros(n, device=dev)
 p16 = torch.empty(n, dtype=torch.bfloat16, device=dev)
