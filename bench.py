@@ -95,7 +95,20 @@ def main():
                 0.05 * torch.randn(B, 3, size, size, device=dev, generator=g)).clamp_(0, 1).contiguous() for i in range(nbatch)]
     lr = 4.5e-6
 
+    adversarial = hasattr(model.loss, "discriminator")   # --config imagenet_vitvq_base_adv: the reference's two-optimizer protocol
+    if adversarial:
+        model.train()
+        model.learning_rate = lr
+        opts, _ = model.configure_optimizers()
+
     def step(i):
+        if adversarial:   # per optimizer: training_step (forward + backward) then its AdamW step, as Lightning 1.5 drives vitvqgan.py:101-127
+            batch = {"image": batches[i % nbatch]}
+            loss0 = model.training_step(batch, i, 0)
+            opts[0].step()
+            model.training_step(batch, i, 1)
+            opts[1].step()
+            return {"loss": loss0}
         out = eng.forward_backward(batches[i % nbatch], w_l1=0.0, w_l2=1.0, codebook_weight=1.0)
         eng.optimizer_step(lr)
         return out
@@ -143,8 +156,11 @@ def main():
         "value": round(img_per_s, 2), "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"{args.config}.yaml AE training step (1 fwd + 1 bwd + grad all-reduce + AdamW), loss = 1.0*L2 + 1.0*codebook "
-                               f"(LPIPS/GAN weights 0), K=8192 x 32 l2-normalised codes, fp32 master weights, bf16 MFMA operands / fp32 accumulate",
+        "config": {"workload": (f"{args.config}.yaml two-optimizer step exactly as the reference drives it: autoencoder fwd + bwd through the StyleGAN2 "
+                                f"discriminator (L2 + codebook + 0.1*vanilla GAN) + AdamW, then forward again + discriminator fwd/bwd on real and fake "
+                                f"(lazy R1 every 16 batches) + AdamW; LPIPS weight 0" if adversarial else
+                                f"{args.config}.yaml AE training step (1 fwd + 1 bwd + grad all-reduce + AdamW), loss = 1.0*L2 + 1.0*codebook "
+                                f"(LPIPS/GAN weights 0)") + ", K=8192 x 32 l2-normalised codes, fp32 master weights, bf16 MFMA operands / fp32 accumulate",
                    "per_gpu_batch": B, "global_batch": B * world, "image": f"{size}x{size}", "parallelism": f"dp{world}"},
         "final_loss": loss,
         "step_mfma_frac": round(img_per_s / world * STEP_TFLOP_PER_IMG_BASE / MFMA_BF16_PEAK_TFLOPS, 4) if is_base else None,

@@ -46,6 +46,8 @@ SIGNATURES = {
     "enh_fused_bias_act": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _f32, _f32, _vp]),
     "enh_channel_sum_f32": (_i32, [_vp, _i32, _i32, _i64, _vp, _i32, _vp]),
     "enh_upfirdn2d": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "enh_im2col_bf16": (_i32, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp]),
+    "enh_col2im_f32": (_i32, [_vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _i64, _vp]),
     "enh_gemm_f32": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _i64, _i64, _i64, _vp, _i32, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _i64, _vp]),
     "enh_attention_forward_f32": (_i32, [_vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp]),
     "enh_attention_backward_f32": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp]),
@@ -313,6 +315,28 @@ def upfirdn2d(x, kernel, up_x: int, up_y: int, down_x: int, down_y: int, pad_x0:
     out = torch.empty(major, out_h, out_w, dtype=F32, device=x.device)
     _check(lib().enh_upfirdn2d(_p(x), _p(kernel), _p(out), major, in_h, in_w, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1,
                                _stream()), "enh_upfirdn2d")
+    return out
+
+
+def conv_out_size(n: int, k: int, stride: int, pad: int) -> int:
+    return (n + 2 * pad - k) // stride + 1
+
+
+def im2col(x, sb: int, sc: int, B: int, C: int, H: int, W: int, k: int, stride: int, pad: int):
+    """x f32, element (b,c,h,w) at b*sb + c*sc + h*W + w  ->  bf16 cols [B*Ho*Wo, Kp], Kp = C*k*k rounded up to 8 (pad columns zero)."""
+    _p(x, F32, "x")
+    Ho, Wo = conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad)
+    ld = (C * k * k + 7) // 8 * 8
+    cols = torch.empty(B * Ho * Wo, ld, dtype=BF16, device=x.device)
+    _check(lib().enh_im2col_bf16(_p(x), sb, sc, B, C, H, W, k, stride, pad, Ho, Wo, _p(cols), ld, _stream()), "enh_im2col_bf16")
+    return cols
+
+
+def col2im(dcols, B: int, C: int, H: int, W: int, k: int, stride: int, pad: int, out, sb: int, sc: int):
+    """adjoint of im2col: bf16 dcols [B*Ho*Wo, Kp] -> f32 `out`, element (b,c,h,w) at b*sb + c*sc + h*W + w (overwritten)."""
+    _p(dcols, BF16, "dcols"); _p(out, F32, "dx")
+    Ho, Wo = conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad)
+    _check(lib().enh_col2im_f32(_p(dcols), dcols.stride(0), B, C, H, W, k, stride, pad, Ho, Wo, _p(out), sb, sc, _stream()), "enh_col2im_f32")
     return out
 
 

@@ -25,3 +25,37 @@ class FusedAdamW:
         s.step_count = int(sd["step"])
         s.m.copy_(sd["m"]); s.v.copy_(sd["v"])
         self.param_groups = sd["param_groups"]
+
+
+class FlatAdamW:
+    """The same fused AdamW launch over any ``ParamStore`` (here: the discriminator's, the second optimizer of reference
+    vitvqgan.py:163-164).  Under DDP the whole flat gradient buffer is averaged with ONE all-reduce right before the step."""
+
+    def __init__(self, store, lr: float, betas=(0.9, 0.99), eps: float = 1e-8, weight_decay: float = 1e-4) -> None:
+        self.store = store
+        self.param_groups = [dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)]
+        self.grad_scale = 1.0
+
+    def zero_grad(self, set_to_none: bool = False) -> None:
+        self.store.zero_grad()
+
+    def step(self) -> None:
+        import torch.distributed as dist
+        from .. import _C
+        s, g = self.store, self.param_groups[0]
+        scale = self.grad_scale
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(s.g)
+            scale /= dist.get_world_size()
+        s.step_count += 1
+        _C.adamw_step(s.p, s.g, s.m, s.v, None, s.step_count, g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], scale)
+
+    def state_dict(self) -> dict:
+        s = self.store
+        return dict(step=s.step_count, m=s.m.detach().cpu(), v=s.v.detach().cpu(), param_groups=self.param_groups)
+
+    def load_state_dict(self, sd: dict) -> None:
+        s = self.store
+        s.step_count = int(sd["step"])
+        s.m.copy_(sd["m"]); s.v.copy_(sd["v"])
+        self.param_groups = sd["param_groups"]

@@ -30,12 +30,14 @@ _ALIGN = 64  # elements; keeps every parameter view 16-byte aligned in both the 
 class ParamStore:
     """Flattens the trainable parameters of a module tree into contiguous device buffers."""
 
-    def __init__(self, module: nn.Module, device: torch.device, precision: str = "bf16") -> None:
+    def __init__(self, module: nn.Module, device: torch.device, precision: str = "bf16", prefixes: Optional[Tuple[str, ...]] = None) -> None:
+        """prefixes: restrict the store to parameters whose name starts with one of them (one store per optimizer)"""
         self.device = device
         self.precision = precision
         self.names: List[str] = []
         self.offsets: Dict[str, Tuple[int, int, torch.Size]] = {}
-        params = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
+        mine = (lambda n: True) if prefixes is None else (lambda n: n.startswith(prefixes))
+        params = [(n, p) for n, p in module.named_parameters() if p.requires_grad and mine(n)]
         total = 0
         for n, p in params:
             self.names.append(n)
@@ -59,7 +61,7 @@ class ParamStore:
             self.w[n], self.w16[n], self.grad[n] = view, self.p16[off:off + cnt].view(shp), p.grad
         # frozen tensors (position tables) just move to the device
         for n, p in module.named_parameters():
-            if not p.requires_grad:
+            if not p.requires_grad and mine(n):
                 p.data = p.data.to(device=device, dtype=F32).contiguous()
                 self.w[n] = p.data
         # GEMM operand view of every weight: the bf16 shadow (product path) or the fp32 master itself (exact mode)
@@ -233,7 +235,8 @@ class Stage1Engine:
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self.model = model
         enc, dec, q = model.encoder, model.decoder, model.quantizer
-        self.store = ParamStore(model, self.device, precision)
+        # the autoencoder optimizer's parameter group (reference vitvqgan.py:154-158); a discriminator inside model.loss has its own store
+        self.store = ParamStore(model, self.device, precision, prefixes=("encoder.", "decoder.", "pre_quant.", "post_quant.", "quantizer."))
         self.patch, self.size, self.C = enc.patch_size[0], enc.image_size[0], enc.channels
         self.n_tok = enc.num_patches
         self.pd = enc.patch_dim

@@ -45,20 +45,29 @@ class Trainer:
             eng.comm.broadcast_parameters(0)
             eng.store.refresh_shadows()
         data.setup(rank=self.rank, world=self.world)
-        (opt, *_), _scheds = model.configure_optimizers()
-        opt.grad_scale = 1.0 / self.accum
+        opts, _scheds = model.configure_optimizers()   # [autoencoder] or [autoencoder, discriminator]
+        opt = opts[0]
+        for o in opts:
+            o.grad_scale = 1.0 / self.accum
         sched = _scheds[0]["scheduler"] if _scheds else None
         base_lr = opt.param_groups[0]["lr"]
+        if self.world > 1 and len(opts) > 1:
+            import torch.distributed as dist
+            dist.broadcast(opts[1].store.p, 0)
         t0, seen = time.time(), 0
         for epoch in range(self.max_epochs):
             for batch_idx, batch in enumerate(data.train_dataloader()):
                 first = batch_idx % self.accum == 0
-                loss = model.training_step(batch, batch_idx, 0, zero_grad=first)
+                last = (batch_idx + 1) % self.accum == 0
+                # Lightning 1.5 order: per optimizer, training_step -> backward -> step, so the discriminator step sees the updated autoencoder
+                for oi, o in enumerate(opts):
+                    model.training_step(batch, batch_idx, oi, zero_grad=first)
+                    if last:
+                        if sched is not None:
+                            o.param_groups[0]["lr"] = base_lr * sched(self.global_step)
+                        o.step()
                 seen += batch["image"].shape[0] * self.world
-                if (batch_idx + 1) % self.accum == 0:
-                    if sched is not None:
-                        opt.param_groups[0]["lr"] = base_lr * sched(self.global_step)
-                    opt.step()
+                if last:
                     self.global_step += 1
                     model.global_step = self.global_step
                     if self.global_step % self.log_every == 0:
@@ -79,6 +88,6 @@ class Trainer:
                 ck = os.path.join(self.root, "ckpt")
                 os.makedirs(ck, exist_ok=True)
                 torch.save({"state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()}, "epoch": epoch,
-                            "global_step": self.global_step, "optimizer": opt.state_dict()}, os.path.join(ck, f"epoch={epoch:02d}.ckpt"))
+                            "global_step": self.global_step, "optimizer": opt.state_dict(), "optimizer_states": [o.state_dict() for o in opts]}, os.path.join(ck, f"epoch={epoch:02d}.ckpt"))
             if self.max_steps is not None and self.global_step >= self.max_steps:
                 break

@@ -6,10 +6,11 @@ Differences from the reference, all forced by the environment or by the tier's s
     *protocol* the reference relies on (``training_step(batch, batch_idx, optimizer_idx)``,
     ``validation_step``, ``configure_optimizers``, ``log`` / ``log_dict``, ``global_step``, ``learning_rate``);
     the in-repo trainer (``enhancing.engine.trainer``) drives it the way ``pl.Trainer.fit`` does.
-  * ``training_step(optimizer_idx=0)`` runs the fused forward+backward schedule and leaves the gradients in
-    ``param.grad`` (views of one flat buffer); it returns the detached loss.  Loss modules that need LPIPS or
-    the StyleGAN discriminator are outside this round's scope and raise on construction
-    unless their weights are zero.
+  * ``training_step`` runs forward AND backward and leaves the gradients in ``param.grad`` (views of one flat buffer per
+    optimizer); it returns the detached loss.  optimizer_idx 0 with a pixel + codebook loss is the fused schedule; with a
+    discriminator in the loss it is forward -> loss module -> autograd, and optimizer_idx 1 is the discriminator step (with the
+    frozen / trained parameter sets Lightning's ``toggle_optimizer`` would produce).  A loss that needs LPIPS raises on construction
+    (SURVEY.md §8f rank 2).
 """
 from __future__ import annotations
 
@@ -141,7 +142,7 @@ class ViTVQ(nn.Module):
         """the pixel + codebook losses of this package are fused into the unpatchify kernel; anything else goes through autograd"""
         from ...losses.vqperceptual import VQLPIPS
         return isinstance(self.loss, VQLPIPS) and float(getattr(self.loss, "perceptual_weight", 0.0)) == 0.0 and \
-            float(getattr(self.loss, "adversarial_weight", 0.0)) == 0.0
+            not hasattr(self.loss, "discriminator")
 
     def _loss_weights(self) -> Tuple[float, float, float]:
         L = self.loss
@@ -156,9 +157,16 @@ class ViTVQ(nn.Module):
             if zero_grad:
                 self.engine.store.zero_grad()
             xrec, qloss = self(x)
-            aeloss, log_dict_ae = self.loss(qloss, x.to(xrec.device), xrec, optimizer_idx, self.global_step, batch_idx,
-                                            last_layer=self.decoder.get_last_layer(), split="train")
-            aeloss.backward()
+            frozen = [p for p in self.loss.parameters() if p.requires_grad]   # Lightning's toggle_optimizer: only optimizer 0's parameters train
+            for p in frozen:
+                p.requires_grad_(False)
+            try:
+                aeloss, log_dict_ae = self.loss(qloss, x.to(xrec.device), xrec, optimizer_idx, self.global_step, batch_idx,
+                                                last_layer=self.decoder.get_last_layer(), split="train")
+                aeloss.backward()
+            finally:
+                for p in frozen:
+                    p.requires_grad_(True)
             self.log("train/total_loss", aeloss.detach())
             self.log_dict({k: v for k, v in log_dict_ae.items() if k != "train/total_loss"})
             return aeloss.detach()
@@ -174,29 +182,44 @@ class ViTVQ(nn.Module):
         if optimizer_idx == 1:
             if not hasattr(self.loss, "discriminator"):
                 return None
-            raise NotImplementedError("the StyleGAN discriminator step is outside this round's scope (SURVEY.md §8f rank 1)")
+            # reference vitvqgan.py:117-127; the reconstruction enters the discriminator loss detached, so no autoencoder graph is kept
+            xrec, qloss, _ = self.engine.reconstruct(x)
+            if zero_grad:
+                self.loss.disc_store(xrec.device).zero_grad()
+            discloss, log_dict_disc = self.loss(qloss, x.to(xrec.device), xrec, optimizer_idx, self.global_step, batch_idx,
+                                                last_layer=self.decoder.get_last_layer(), split="train")
+            if torch.is_tensor(discloss) and discloss.requires_grad:
+                discloss.backward()
+            self.log("train/disc_loss", log_dict_disc["train/disc_loss"])
+            self.log_dict({k: v for k, v in log_dict_disc.items() if k != "train/disc_loss"})
+            return log_dict_disc["train/disc_loss"]
 
     @torch.no_grad()
     def validation_step(self, batch, batch_idx: int) -> Dict:
-        """reference vitvqgan.py:129-150 (AE branch)"""
+        """reference vitvqgan.py:129-150"""
         x = self.get_input(batch, self.image_key)
         xrec, qloss = self(x)
         aeloss, log = self.loss(qloss, x.to(xrec.device), xrec, 0, self.global_step, batch_idx, last_layer=self.decoder.get_last_layer(), split="val")
         self.log("val/rec_loss", log["val/rec_loss"])
         self.log("val/total_loss", aeloss)
         self.log_dict({k: v for k, v in log.items() if k not in ("val/rec_loss", "val/total_loss")})
+        if hasattr(self.loss, "discriminator"):   # vitvqgan.py:144-148
+            _, log_disc = self.loss(qloss, x.to(xrec.device), xrec, 1, self.global_step, batch_idx, last_layer=self.decoder.get_last_layer(), split="val")
+            self.log_dict(log_disc)
         return self.logged
 
     def configure_optimizers(self):
         """reference vitvqgan.py:152-178: one AdamW(lr, betas=(0.9, 0.99), weight_decay=1e-4) over encoder + decoder +
         pre/post_quant + quantizer as a single group -> here ONE fused launch over the flat buffer."""
-        from ...engine.optim import FusedAdamW
+        from ...engine.optim import FlatAdamW, FusedAdamW
         optimizers = [FusedAdamW(self.engine, lr=self.learning_rate, betas=(0.9, 0.99), weight_decay=1e-4)]
+        if hasattr(self.loss, "discriminator"):   # vitvqgan.py:163-164: a second AdamW with the same hyper-parameters
+            optimizers.append(FlatAdamW(self.loss.disc_store(self.engine.device), lr=self.learning_rate, betas=(0.9, 0.99), weight_decay=1e-4))
         schedulers = []
         if self.scheduler is not None:
             self.scheduler.params.start = self.learning_rate
             sched = initialize_from_config(self.scheduler)
-            schedulers = [{"scheduler": sched, "interval": "step", "frequency": 1}]
+            schedulers = [{"scheduler": sched, "interval": "step", "frequency": 1} for _ in optimizers]
         return optimizers, schedulers
 
     @torch.no_grad()

@@ -172,6 +172,16 @@ int enh_channel_sum_f32(const float* x, int B, int C, int64_t inner, float* out,
 int enh_upfirdn2d(const float* in, const float* kernel, float* out, int64_t major, int in_h, int in_w, int kh, int kw, int up_x,
                   int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
 
+/* Equalised-lr convolution lowering (EqualConv2d, enhancing/losses/layers.py:163-185: conv2d(x, weight*scale, stride, padding),
+ * k in {1,3}, stride in {1,2}) onto enh_gemm_bf16:  cols[(b,ho,wo), c*k*k + kh*k + kw] = x[b,c,ho*stride-pad+kh,wo*stride-pad+kw]
+ * (zero outside the image), bf16, row stride ld = C*k*k rounded up to a multiple of 8 with the pad columns zeroed.  The image is
+ * addressed as x[b*stride_b + c*stride_c + h*W + w], so [B,C,H,W] and channel-major [C,B,H,W] activations are both accepted.
+ * enh_col2im_f32 is the adjoint (the convolution's input gradient given dcols = dy^T . W): dx is overwritten, no atomics. */
+int enh_im2col_bf16(const float* x, int64_t stride_b, int64_t stride_c, int B, int C, int H, int W, int k, int stride, int pad,
+                    int Ho, int Wo, enh_bf16* cols, int64_t ld, void* stream);
+int enh_col2im_f32(const enh_bf16* dcols, int64_t ld, int B, int C, int H, int W, int k, int stride, int pad, int Ho, int Wo,
+                   float* dx, int64_t stride_b, int64_t stride_c, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * fp32 "exact mode": the same contractions with fp32 operands and fixed ascending-k fp32 accumulation (no bf16 anywhere), for end-to-end
  * parity runs against the fp32 CPU oracle (SURVEY.md §8d metric 3).  Same argument meaning as the bf16 entries above; all tensors f32.

@@ -1,0 +1,118 @@
+"""CPU tests for the discriminator row: the oracle against the golden vectors produced by the reference's own
+layers.py, and the autograd wiring of the HIP-lowered discriminator with the kernels replaced by test-only torch stand-ins."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from util import disc_case, rel
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, "disc_tiny.npz"))
+
+
+def test_disc_oracle_matches_reference_golden(gold):
+    """parameters regenerated from the seed through THIS package's module classes (same construction order as the reference's, so the
+    same RNG stream) -> the oracle reproduces the reference's logits, R1 penalty, d-loss and gradients"""
+    import disc_oracle as O
+    D, real, fake = disc_case(gold)
+    size = int(gold["size"])
+    sd = {k: v.clone().requires_grad_("kernel" not in k) for k, v in D.state_dict().items()}
+    d_loss, lr, lf, r1 = O.discriminator_loss(sd, size, real, fake, True)
+    d_loss.backward()
+    assert rel(lr, torch.from_numpy(gold["logits_real"])) <= 1e-5 and rel(lf, torch.from_numpy(gold["logits_fake"])) <= 1e-5
+    assert abs(d_loss.item() - float(gold["d_loss"])) <= 1e-5 * abs(float(gold["d_loss"]))
+    assert abs(r1.item() - float(gold["r1"])) <= 1e-4 * float(gold["r1"])
+    for i, n in enumerate(gold["grad_names"]):
+        assert abs(sd[str(n)].grad.double().norm().item() - gold["grad_norms"][i]) <= 1e-4 * gold["grad_norms"][i], n
+    assert rel(sd["blocks.0.0.weight"].grad, torch.from_numpy(gold["g_rgb_w"])) <= 1e-4
+
+
+@pytest.mark.parametrize("B", [8, 6, 2])
+def test_discriminator_wiring_first_and_second_order(monkeypatch, B):
+    """kernels replaced by exact torch stand-ins: logits, d logits / d image, and the parameter gradients of (R1 penalty + d-loss)
+    — which differentiate THROUGH the first backward — must equal the fp32 oracle's to rounding"""
+    import disc_oracle as O
+    import hip_emulation
+    hip_emulation.install(monkeypatch, exact=True)
+    from enhancing.losses.layers import StyleDiscriminator
+    from enhancing.losses.op import conv2d_gradfix
+    torch.manual_seed(B)
+    D = StyleDiscriminator(size=16)
+    with torch.no_grad():
+        for n, p in D.named_parameters():
+            if n.endswith("bias"):
+                p.copy_(0.1 * torch.randn(p.shape))
+    x = torch.rand(B, 3, 16, 16)
+    x1 = x.clone().requires_grad_(True)
+    y1 = D(x1)
+    with conv2d_gradfix.no_weight_gradients():
+        g1, = torch.autograd.grad(y1.sum(), x1, create_graph=True)
+    (80 * g1.square().sum([1, 2, 3]).mean() + F.softplus(-y1).mean()).backward()
+    sd = {k: v.detach().clone().requires_grad_("kernel" not in k) for k, v in D.state_dict().items()}
+    x2 = x.clone().requires_grad_(True)
+    y2 = O.discriminator(sd, x2, 16)
+    g2, = torch.autograd.grad(y2.sum(), x2, create_graph=True)
+    (80 * g2.square().sum([1, 2, 3]).mean() + F.softplus(-y2).mean()).backward()
+    assert rel(y1, y2) <= 1e-5 and rel(g1, g2) <= 1e-5
+    for n, p in D.named_parameters():
+        assert rel(p.grad, sd[n].grad) <= 2e-5, n
+
+
+def test_layer_classes_keep_the_reference_nchw_api(monkeypatch):
+    import disc_ops_oracle as DO
+    import hip_emulation
+    hip_emulation.install(monkeypatch, exact=True)
+    from enhancing.losses.layers import ConvLayer, EqualLinear, StyleBlock
+    torch.manual_seed(0)
+    x = torch.randn(8, 16, 8, 8)
+    blk = StyleBlock(16, 24)
+    y = blk(x)
+    s = 1 / (16 * 9) ** 0.5
+    o = DO.fused_leaky_relu(F.conv2d(x, blk.conv1[0].weight * s, padding=1), blk.conv1[1].bias)
+    o = DO.fused_leaky_relu(F.conv2d(DO.upfirdn2d(o, blk.conv2[0].kernel, pad=(2, 2)), blk.conv2[1].weight * s, stride=2), blk.conv2[2].bias)
+    sk = F.conv2d(DO.upfirdn2d(x, blk.skip[0].kernel, pad=(1, 1)), blk.skip[1].weight * (1 / 4), stride=2)
+    assert y.shape == (8, 24, 4, 4) and rel(y, (o + sk) / 2 ** 0.5) <= 1e-5
+    c = ConvLayer(16, 8, 3, activate=False)   # bias on the convolution itself
+    assert rel(c(x), F.conv2d(x, c[0].weight * s, c[0].bias, padding=1)) <= 1e-5
+    lin = EqualLinear(40, 5, bias_init=0.3, lr_mul=0.5)
+    z = torch.randn(3, 40)
+    assert rel(lin(z), F.linear(z, lin.weight * lin.scale, lin.bias * lin.lr_mul)) <= 1e-5
+
+
+def test_loss_module_generator_and_discriminator_sides(monkeypatch):
+    """VQLPIPSWithDiscriminator.forward, both optimizer indices, against the oracle's restatement of vqperceptual.py:111-172: loss values,
+    log keys, lazy R1 only on batches with batch_idx % do_r1_every == 0, disc_start gating"""
+    import disc_oracle as O
+    import hip_emulation
+    hip_emulation.install(monkeypatch, exact=True)
+    from enhancing.losses.vqperceptual import VQLPIPSWithDiscriminator
+    torch.manual_seed(3)
+    L = VQLPIPSWithDiscriminator(disc_start=5, loglaplace_weight=0.5, loggaussian_weight=1.0, perceptual_weight=0.0, adversarial_weight=0.1,
+                                 disc_params={"size": 16}, do_r1_every=4)
+    L.train()
+    x, r = torch.rand(4, 3, 16, 16), torch.rand(4, 3, 16, 16)
+    q = torch.tensor(0.3)
+    sd = {k: v.detach().clone() for k, v in L.discriminator.state_dict().items()}
+    for step, factor in ((0, 0), (7, 1)):
+        rr = r.clone().requires_grad_(True)
+        loss, log = L(q, x, rr, 0, step, 0, split="train")
+        o_loss, o_g = O.generator_loss(sd, 16, q, x, r, 0.5, 1.0, 0.1, 1.0, factor)
+        assert abs(loss.item() - o_loss.item()) <= 1e-5 and abs(log["train/g_loss"].item() - o_g.item()) <= 1e-5
+        assert set(log) == {"train/total_loss", "train/quant_loss", "train/rec_loss", "train/loglaplace_loss", "train/loggaussian_loss",
+                            "train/perceptual_loss", "train/g_loss"}
+    for batch_idx, step, want_r1 in ((0, 7, True), (1, 7, False), (0, 0, False)):
+        d_loss, log = L(q, x, r, 1, step, batch_idx, split="train")
+        o_d, o_lr, o_lf, o_r1 = O.discriminator_loss(sd, 16, x, r, want_r1, 10.0, 4, 1 if step >= 5 else 0)
+        assert abs(float(d_loss.detach()) - float(o_d.detach())) <= 1e-4 * max(1.0, abs(float(o_d.detach())))
+        assert ("train/r1_reg" in log) == want_r1
+        assert abs(log["train/logits_real"].item() - o_lr.mean().item()) <= 1e-5
+        if want_r1:
+            assert abs(log["train/r1_reg"].item() - o_r1.item()) <= 1e-4 * o_r1.item()
+    L.eval()
+    _, log = L(q, x, r, 1, 7, 0, split="val")
+    assert "val/r1_reg" not in log and set(log) == {"val/disc_loss", "val/logits_real", "val/logits_fake"}

@@ -1,0 +1,148 @@
+"""GPU parity of the discriminator row: the convolution lowering (im2col / col2im / bf16 MFMA GEMM), the assembled
+StyleGAN2 discriminator against the golden vectors produced by the REFERENCE's own layers.py (fp32), and the two-optimizer step protocol.
+
+Tolerances.  Operator level: exact for the data movement, fp32-rounding for f32 outputs given IDENTICAL (bf16-representable) operands, the
+bf16 rounding floor for bf16 outputs.  Model level, against the reference's fp32 arithmetic: the discriminator rounds every convolution
+operand to bf16, and each rounding can flip leaky-ReLU gates of a random-initialised network, which moves gradients far more than values —
+predicted with the kernels emulated in torch (tests/hip_emulation.py, exact=False): logits 8e-3, d logits/d image 6e-2, R1 3e-3, parameter
+gradient norms 2e-2, single gradient tensors up to 1e-1.  The bounds below are about 2x those."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from util import bf16r, disc_case, rel
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def C():
+    from enhancing import _C
+    _C.lib()
+    return _C
+
+
+GEOMS = [  # layout, B, C, H, W, k, stride, pad
+    ("nchw", 2, 3, 16, 16, 1, 1, 0), ("cm", 2, 40, 12, 20, 3, 1, 1), ("cm", 3, 64, 17, 17, 3, 2, 0), ("cm", 2, 33, 15, 15, 1, 2, 0),
+    ("cm", 8, 513, 4, 4, 3, 1, 1), ("nchw", 1, 5, 70, 70, 3, 1, 1), ("cm", 1, 96, 35, 35, 3, 2, 0)]
+
+
+@pytest.mark.parametrize("layout,B,Cc,H,W,k,s,p", GEOMS)
+def test_im2col_col2im(C, layout, B, Cc, H, W, k, s, p):
+    g = torch.Generator().manual_seed(B * 100 + Cc)
+    img = torch.randn(B, Cc, H, W, generator=g)
+    x = (img if layout == "nchw" else img.permute(1, 0, 2, 3).contiguous()).cuda()
+    sb, sc = (Cc * H * W, H * W) if layout == "nchw" else (H * W, B * H * W)
+    cols = C.im2col(x, sb, sc, B, Cc, H, W, k, s, p)
+    Ho, Wo = C.conv_out_size(H, k, s, p), C.conv_out_size(W, k, s, p)
+    ref = F.unfold(img, k, padding=p, stride=s).permute(0, 2, 1).reshape(B * Ho * Wo, Cc * k * k)
+    assert cols.shape == (B * Ho * Wo, (Cc * k * k + 7) // 8 * 8)
+    assert torch.equal(cols[:, :Cc * k * k].cpu(), ref.to(torch.bfloat16))          # pure data movement + RNE rounding: bit-exact
+    assert not cols[:, Cc * k * k:].float().abs().sum().item()                        # alignment columns are zero
+    d = torch.randn(cols.shape, generator=g).to(torch.bfloat16)
+    out = torch.full((B, Cc, H, W) if layout == "nchw" else (Cc, B, H, W), 7.0, device="cuda")
+    C.col2im(d.cuda(), B, Cc, H, W, k, s, p, out, sb, sc)
+    want = F.fold(d[:, :Cc * k * k].float().reshape(B, Ho * Wo, Cc * k * k).permute(0, 2, 1), (H, W), k, padding=p, stride=s)
+    got = out.cpu() if layout == "nchw" else out.cpu().permute(1, 0, 2, 3)
+    assert rel(got, want) <= 1e-6
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,k,s,p", [(2, 3, 128, 16, 1, 1, 0), (2, 64, 128, 16, 3, 1, 1), (2, 64, 136, 17, 3, 2, 0), (8, 520, 64, 4, 3, 1, 1)])
+def test_conv2d_values_and_gradients(C, B, Cin, Cout, H, k, s, p):
+    """conv2d_gradfix.conv2d (the reference's NCHW signature) against F.conv2d on the same bf16-representable operands"""
+    from enhancing.losses.op import conv2d_gradfix
+    g = torch.Generator().manual_seed(Cin + Cout)
+    x = bf16r(torch.randn(B, Cin, H, H, generator=g))
+    w = bf16r(torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5)
+    b = torch.randn(Cout, generator=g)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br, stride=s, padding=p)
+    dy = bf16r(torch.randn(yr.shape, generator=g))
+    yr.backward(dy)
+    xd, wd, bd = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    y = conv2d_gradfix.conv2d(xd, wd, bias=bd, stride=s, padding=p)
+    y.backward(dy.cuda())
+    assert rel(y, yr) <= 1e-5 and rel(wd.grad, wr.grad) <= 1e-5 and rel(bd.grad, br.grad) <= 1e-5
+    assert rel(xd.grad, xr.grad) <= 4e-3      # dcols leaves the dgrad GEMM in bf16: up to k*k rounded terms per input pixel
+
+
+def test_discriminator_against_reference_golden(C, golden_dir):
+    from enhancing.engine.stage1 import ParamStore
+    from enhancing.losses.layers import vanilla_d_loss
+    from enhancing.losses.op import conv2d_gradfix
+    G = np.load(os.path.join(golden_dir, "disc_tiny.npz"))
+    D, real, fake = disc_case(G)
+    dev = torch.device("cuda")
+    D.to(dev)
+    store = ParamStore(D, dev, precision="fp32")
+    real, fake = real.to(dev), fake.to(dev)
+    x = real.clone().requires_grad_(True)
+    lr_, lf_ = D(x), D(fake)
+    e_logits = max(rel(lr_, torch.from_numpy(G["logits_real"])), rel(lf_, torch.from_numpy(G["logits_fake"])))
+    with conv2d_gradfix.no_weight_gradients():
+        gr, = torch.autograd.grad(lr_.sum(), x, create_graph=True)
+    r1 = gr.square().sum([1, 2, 3]).mean()
+    d_loss = vanilla_d_loss(lf_, lr_) + 10 * 16 * r1 / 2
+    store.zero_grad()
+    d_loss.backward()
+    e_dx = rel(gr, torch.from_numpy(G["dx_real"]))
+    e_r1 = abs(r1.item() - float(G["r1"])) / float(G["r1"])
+    e_loss = abs(d_loss.item() - float(G["d_loss"])) / abs(float(G["d_loss"]))
+    P = dict(D.named_parameters())
+    norms = {str(n): float(v) for n, v in zip(G["grad_names"], G["grad_norms"])}
+    e_norm = max(abs(P[n].grad.double().norm().item() - v) / v for n, v in norms.items())
+    e_t = {n: rel(P[n].grad, torch.from_numpy(G[k])) for n, k in (("final_conv.1.bias", "g_final_bias"), ("blocks.0.0.weight", "g_rgb_w"),
+                                                                    ("final_linear.1.weight", "g_lin1_w"))}
+    xf = fake.clone().requires_grad_(True)
+    g_loss = vanilla_d_loss(D(xf))
+    gf, = torch.autograd.grad(g_loss, xf)
+    e_gf = rel(gf, torch.from_numpy(G["g_fake"]))
+    print(f"discriminator vs reference golden: logits {e_logits:.2e}, dx {e_dx:.2e}, r1 {e_r1:.2e}, d_loss {e_loss:.2e}, grad norms {e_norm:.2e}, "
+          f"grads {e_t}, generator-side dx {e_gf:.2e}")
+    assert e_logits <= 2e-2 and e_dx <= 0.15 and e_r1 <= 2e-2 and e_loss <= 1e-2 and e_norm <= 6e-2 and e_gf <= 0.15
+    assert max(e_t.values()) <= 0.2, e_t
+    assert abs(g_loss.item() - float(G["g_loss"])) <= 1e-2
+
+
+def test_two_optimizer_training_step_protocol(C):
+    """ViTVQ.training_step with a discriminator in the loss (vitvqgan.py:101-127 under Lightning's toggle_optimizer): optimizer 0 trains
+    only the autoencoder (through the discriminator's input gradient), optimizer 1 only the discriminator (R1 on batch 0), both step."""
+    import vitvq_oracle as O
+    from enhancing.modules.stage1.vitvqgan import ViTVQ
+    from enhancing.utils.general import AttrDict
+    cfg = O.TINY_CFG
+    loss = {"target": "enhancing.losses.vqperceptual.VQLPIPSWithDiscriminator",
+            "params": dict(loglaplace_weight=0.0, loggaussian_weight=1.0, perceptual_weight=0.0, adversarial_weight=0.1, do_r1_every=2,
+                           disc_params={"size": cfg["image_size"]})}
+    m = ViTVQ("image", cfg["image_size"], cfg["patch_size"], AttrDict.wrap(cfg["encoder"]), AttrDict.wrap(cfg["decoder"]),
+              AttrDict.wrap(cfg["quantizer"]), AttrDict.wrap(loss))
+    m.load_state_dict({**O.make_params(cfg, seed=11), **{"loss." + k: v for k, v in m.loss.state_dict().items()}}, strict=True)
+    m.train()
+    opts, _ = m.configure_optimizers()
+    assert len(opts) == 2
+    ae, ds = m.engine.store, m.loss.disc_store(m.engine.device)
+    batch = {"image": O.make_images(5, 2, cfg["image_size"])}
+    for it in range(2):
+        p_ae, p_d, g_d = ae.p.clone(), ds.p.clone(), ds.g.clone()
+        l0 = m.training_step(batch, it, 0)
+        assert torch.isfinite(l0) and ae.g.abs().sum().item() > 0 and torch.equal(ds.g, g_d)            # discriminator frozen
+        assert "train/g_loss" in m.logged
+        opts[0].step()
+        ae.zero_grad()
+        l1 = m.training_step(batch, it, 1)
+        assert torch.isfinite(l1) and ds.g.abs().sum().item() > 0 and ae.g.abs().sum().item() == 0     # autoencoder untouched
+        assert ("train/r1_reg" in m.logged) == (it % 2 == 0)
+        m.logged.pop("train/r1_reg", None)
+        opts[1].step()
+        assert not torch.equal(ae.p, p_ae) and not torch.equal(ds.p, p_d)
+    # the generator-side gradient really comes through the discriminator: with adversarial_weight -> 0 the AE gradient changes
+    ae.zero_grad()
+    m.training_step(batch, 0, 0)
+    g_with = ae.g.clone()
+    m.loss.adversarial_weight = 1e-12
+    ae.zero_grad()
+    m.training_step(batch, 0, 0)
+    assert rel(g_with, ae.g) > 1e-3

@@ -64,7 +64,10 @@ def test_missing_loss_terms_fail_loudly(monkeypatch):
     with pytest.raises(NotImplementedError):
         VQLPIPS(perceptual_weight=0.1)
     with pytest.raises(NotImplementedError):
-        VQLPIPSWithDiscriminator(perceptual_weight=0.0, adversarial_weight=0.1)
+        VQLPIPSWithDiscriminator(perceptual_weight=0.1, adversarial_weight=0.0)
+    with pytest.raises(NotImplementedError):
+        VQLPIPSWithDiscriminator(perceptual_weight=0.0, adversarial_weight=0.1, use_adaptive_adv=True)
+    assert hasattr(VQLPIPSWithDiscriminator(perceptual_weight=0.0, adversarial_weight=0.1, disc_params={"size": 16}), "discriminator")
     L = VQLPIPSWithDiscriminator(loglaplace_weight=0.0, loggaussian_weight=1.0, perceptual_weight=0.0, adversarial_weight=0.0)
     x, r = torch.rand(2, 3, 8, 8), torch.rand(2, 3, 8, 8)
     loss, log = L(torch.tensor(0.5), x, r, 0, 0, 0, split="val")
