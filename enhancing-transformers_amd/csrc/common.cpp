@@ -22,4 +22,4 @@ int enh_check_launch(const char* what) {
 }
 
 extern "C" const char* enh_last_error(void) { return g_err; }
-extern "C" int enh_abi_version(void) { return 2; }
+extern "C" int enh_abi_version(void) { return ENH_ABI_VERSION; }

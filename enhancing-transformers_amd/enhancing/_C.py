@@ -58,6 +58,7 @@ SIGNATURES = {
 }
 
 _LIB = None
+ABI_VERSION = 2   # ENH_ABI_VERSION of the include/enh_hip.h these signatures were written against
 
 
 def lib():
@@ -71,6 +72,8 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError here == ABI drift: fail loudly
             fn.restype, fn.argtypes = res, args
+        if L.enh_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} reports ABI version {L.enh_abi_version()}, the bindings expect {ABI_VERSION}: rebuild the library")
         _LIB = L
     return _LIB
 

@@ -27,7 +27,9 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), f"{name} is declared in include/enh_hip.h but not exported"
         assert name in _C.SIGNATURES, f"{name} has no ctypes signature"
     assert sorted(_C.SIGNATURES) == declared
-    assert L.enh_abi_version() == 2
+    import re
+    hdr = open(os.path.join(ROOT, "include", "enh_hip.h")).read()
+    assert L.enh_abi_version() == _C.ABI_VERSION == int(re.search(r"#define ENH_ABI_VERSION (\d+)", hdr).group(1))
     assert L.enh_vq_workspace_bytes(131072, 8192, 4) > 8192 * 32 * 4
 
 
