@@ -80,3 +80,56 @@ def test_gradsync_reduces_unannounced_slices():
         assert sync.gap_elems == 0
     finally:
         dist.destroy_process_group()
+
+
+def _disc_worker(rank, world, port, q):
+    """the discriminator optimizer under DDP: per-rank gradients -> ONE all-reduce of the flat buffer -> fused AdamW with the mean"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in ("enhancing-transformers_amd", "oracle"):
+        sys.path.insert(0, os.path.join(root, p))
+    import vitvq_oracle as O
+    from enhancing import _C
+    from enhancing.engine.optim import FlatAdamW
+
+    def adamw_cpu(p, g, m, v, p16, step, lr, b1, b2, eps, wd, grad_scale):   # test-only stand-in for enh_adamw_step
+        O.adamw_step(p, g * grad_scale, m, v, step, lr, b1, b2, eps, wd)
+    _C.adamw_step = adamw_cpu
+
+    class Store:
+        def __init__(self):
+            self.p = torch.linspace(-1, 1, 4096)
+            self.g = torch.randn(4096, generator=torch.Generator().manual_seed(7 + rank))
+            self.m, self.v, self.step_count = torch.zeros(4096), torch.zeros(4096), 0
+
+        def zero_grad(self):
+            self.g.zero_()
+    s = Store()
+    local = s.g.clone()
+    opt = FlatAdamW(s, lr=1e-3)
+    opt.step()
+    q.put((rank, s.p.numpy().copy(), local.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_discriminator_optimizer_gloo_world2():
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import vitvq_oracle as O
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_disc_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=120) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    p_ref, m, v = torch.linspace(-1, 1, 4096), torch.zeros(4096), torch.zeros(4096)
+    O.adamw_step(p_ref, (torch.from_numpy(got[0][2]) + torch.from_numpy(got[1][2])) / 2, m, v, 1, 1e-3, 0.9, 0.99, 1e-8, 1e-4)
+    for _, p_new, _ in got:
+        assert torch.allclose(torch.from_numpy(p_new), p_ref, atol=1e-7)   # both ranks applied the MEAN gradient

@@ -1,5 +1,6 @@
 """CPU suite: the C-ABI library loads and exports every symbol include/enh_hip.h declares (no compute calls without a
 GPU), and the host-side mirror of the reference interface behaves (config factory, module tree, data contract)."""
+import json
 import os
 import re
 
@@ -107,3 +108,67 @@ def test_schedulers():
     s = LambdaWarmUpCosineScheduler(10, 100, 1e-6, 1e-4, 1e-5)
     assert abs(s(0) - 1.0) < 1e-9 and abs(s(10) - 10.0) < 1e-6 and abs(s(100) - 0.1) < 1e-6
     assert ExponentialDecayScheduler(0.1, 1, 1.0, 0.5)(100) == 0.5
+
+
+def test_trainer_drives_the_lightning_protocol_in_order(monkeypatch, tmp_path):
+    """Trainer.fit with a recording stand-in model: per batch and per optimizer `training_step -> step` (Lightning 1.5 order for the
+    two-optimizer GAN setup, reference main.py:51-61), gradient accumulation windows, the step-wise LR schedule, validation, and a
+    {"state_dict": ...} checkpoint per epoch (general.py:49-55)."""
+    from enhancing.engine import trainer as T
+    calls = []
+
+    class Opt:
+        def __init__(self, name):
+            self.name, self.param_groups, self.grad_scale = name, [dict(lr=1.0)], 1.0
+
+        def step(self):
+            calls.append((self.name + ".step", self.param_groups[0]["lr"], self.grad_scale))
+
+        def state_dict(self):
+            return {"name": self.name}
+
+    class Model:
+        logged, global_step = {}, 0
+        engine = type("E", (), {"store": None})()
+
+        def configure_optimizers(self):
+            return [Opt("ae"), Opt("disc")], [{"scheduler": lambda s: 1.0 / (1 + s)}, {"scheduler": lambda s: 1.0 / (1 + s)}]
+
+        def training_step(self, batch, batch_idx, optimizer_idx, zero_grad=True):
+            calls.append(("ts", batch_idx, optimizer_idx, zero_grad))
+            self.logged["train/total_loss"] = torch.tensor(0.5)
+
+        def validation_step(self, batch, batch_idx):
+            calls.append(("val", batch_idx))
+            self.logged["val/rec_loss"] = torch.tensor(0.25)
+
+        def state_dict(self):
+            return {"w": torch.ones(2)}
+
+    class Data:
+        dataset_configs = {"train": 1, "validation": 1}
+
+        def setup(self, rank, world):
+            calls.append(("setup", rank, world))
+
+        def train_dataloader(self):
+            return [{"image": torch.zeros(3, 3, 8, 8)} for _ in range(4)]
+
+        def val_dataloader(self):
+            return [{"image": torch.zeros(3, 3, 8, 8)} for _ in range(3)]
+
+    monkeypatch.setattr(T, "init_process_group_from_env", lambda *a, **k: (0, 0, 1))
+    monkeypatch.setattr(torch.cuda, "set_device", lambda *_: None)
+    tr = T.Trainer(max_epochs=1, accumulate_grad_batches=2, default_root_dir=str(tmp_path), log_every_n_steps=1, val_batches=2)
+    tr.fit(Model(), Data())
+    train = [c for c in calls if c[0] in ("ts", "ae.step", "disc.step")]
+    assert train == [
+        ("ts", 0, 0, True), ("ts", 0, 1, True),                                                      # first half of the window: no steps
+        ("ts", 1, 0, False), ("ae.step", 1.0, 0.5), ("ts", 1, 1, False), ("disc.step", 1.0, 0.5),      # optimizer 0 steps before optimizer 1 runs
+        ("ts", 2, 0, True), ("ts", 2, 1, True),
+        ("ts", 3, 0, False), ("ae.step", 0.5, 0.5), ("ts", 3, 1, False), ("disc.step", 0.5, 0.5)]      # lr = base * schedule(global_step = 1)
+    assert [c for c in calls if c[0] == "val"] == [("val", 0), ("val", 1)] and tr.global_step == 2
+    ck = torch.load(os.path.join(str(tmp_path), "ckpt", "epoch=00.ckpt"))
+    assert set(ck) >= {"state_dict", "epoch", "global_step", "optimizer", "optimizer_states"} and len(ck["optimizer_states"]) == 2
+    rows = [json.loads(l) for l in open(os.path.join(str(tmp_path), "metrics.jsonl"))]
+    assert rows[0]["step"] == 1 and rows[0]["train/total_loss"] == 0.5 and rows[-1]["val/rec_loss"] == 0.25
