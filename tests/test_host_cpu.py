@@ -172,3 +172,32 @@ def test_trainer_drives_the_lightning_protocol_in_order(monkeypatch, tmp_path):
     assert set(ck) >= {"state_dict", "epoch", "global_step", "optimizer", "optimizer_states"} and len(ck["optimizer_states"]) == 2
     rows = [json.loads(l) for l in open(os.path.join(str(tmp_path), "metrics.jsonl"))]
     assert rows[0]["step"] == 1 and rows[0]["train/total_loss"] == 0.5 and rows[-1]["val/rec_loss"] == 0.25
+
+
+def test_imagenet_folder_dataset_contract(tmp_path):
+    """reference dataloader/imagenet.py:15-54 on a miniature folder tree: class index = sorted folder order, sample = {'image' float [3,R,R]
+    in [0,1], 'class' [1]}, train = resize + random crop (+flip), validation = resize + centre crop (deterministic)"""
+    import numpy as np
+    from PIL import Image
+    from enhancing.dataloader import DataModuleFromConfig
+    rng = np.random.default_rng(0)
+    for split in ("train", "val"):
+        for ci, wnid in enumerate(("n02", "n01")):
+            d = tmp_path / split / wnid
+            d.mkdir(parents=True)
+            for k in range(3):
+                Image.fromarray(rng.integers(0, 256, (40 + 7 * k, 56 - 5 * ci, 3), dtype=np.uint8)).save(d / f"img{k}.png")
+            (d / "notes.txt").write_text("ignored")
+    node = lambda cls: {"target": f"enhancing.dataloader.imagenet.{cls}", "params": {"root": str(tmp_path), "resolution": 32}}
+    dm = DataModuleFromConfig(batch_size=4, num_workers=0, train=node("ImageNetTrain"), validation=node("ImageNetValidation"))
+    dm.setup()
+    tr, va = dm.datasets["train"], dm.datasets["validation"]
+    assert len(tr) == 6 and len(va) == 6 and tr.labels == [0, 0, 0, 1, 1, 1] and "n01" in tr.paths[0]
+    s = va[4]
+    assert s["image"].shape == (3, 32, 32) and s["image"].dtype == torch.float32 and 0.0 <= s["image"].min() and s["image"].max() <= 1.0
+    assert s["class"].shape == (1,) and int(s["class"]) == 1 and torch.equal(va[4]["image"], s["image"])
+    batch = next(iter(dm.val_dataloader()))
+    assert batch["image"].shape == (4, 3, 32, 32) and batch["class"].shape == (4, 1)
+    assert tr[0]["image"].shape == (3, 32, 32)
+    with pytest.raises(FileNotFoundError):
+        type(tr)(str(tmp_path / "nope"))
