@@ -612,9 +612,185 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_t256_kernel(const GemmArgs a
   gemm_epilogue32(args, acc, m0 + wm * 128, n0 + wn * 64, lane);
 }
 
+// =================================================================================================
+// "p8" (EXPERIMENTAL — written after round 1's GPU budget was spent: compiles for gfx950, NOT yet run; reachable only with
+// ENH_GEMM_KERNEL=8phase; tests/test_ops_gpu.py::test_gemm_p8_* are skipped unless ENH_TEST_EXPERIMENTAL=1).
+//
+// Why: t256 above waits vmcnt(0) once per K-tile — with two 64-KiB K-tile buffers nothing newer is in flight at that point, so the
+// global->LDS queue drains every K-tile and a load gets <= 0.75 K-tile (~0.7 us) to arrive.  cdna_hip_programming.md ("The 256^2
+// 8-phase template") measures that drain as the whole difference between ~900 and ~1320 TF/s.  The fix is not more LDS but FINER
+// SLOTS: the eight 16-KiB half-tiles {stage 0,1} x {A0, A1, B0, B1} are freed and refilled one at a time.  For a half-tile to be
+// released before its K-tile is finished, one phase must consume it completely — so a half-tile is not a contiguous 128-row block
+// but, for every wave, the rows of ONE of its quadrant operands:
+//      A half h = rows  wm*128 + h*64 + (0..63)  for wm = 0,1          B half h = cols  wn*64 + h*32 + (0..31)  for wn = 0..3
+// and a phase computes one 64x32 quadrant of the wave's 128x64 tile over the whole K-tile (8 MFMAs 32x32x16):
+//      P0: read A0, B0 (12 ds_read_b128) ; q(0,0)        P2: read A1 (8) ; q(1,1)  (B1 still in registers)
+//      P1: read B1 (4)                   ; q(0,1)        P3: no read     ; q(1,0)  (B0 still in registers)
+// Last reads: A0, B0 in P0, B1 in P1, A1 in P2.  A slot may be refilled two phases after its last read (both staggered wave groups
+// have retired their reads and passed a barrier by then), so every phase issues exactly ONE half-tile (2 global_load_lds per wave):
+//      P0(kt): B1(kt+1)     P1(kt): A1(kt+1)     P2(kt): A0(kt+2)     P3(kt): B0(kt+2)          -> 5-6 phases (1.25-1.5 K-tiles) of flight
+// and the waits are counted: vmcnt(6) = "everything except the three most recent half-tiles has landed", placed in P0, P2, P3 before
+// the phase's first barrier; the data each one retires is first read two phases later (one barrier more than strictly required).
+//      wait@P0(kt) retires A1(kt) [read P2(kt)]   wait@P2(kt) retires A0,B0(kt+1) [read P0(kt+1)]   wait@P3(kt) retires B1(kt+1) [read P1(kt+1)]
+// In the last two K-tiles some issues are skipped, so the count no longer covers the needed half-tile: vmcnt(0) there.
+// Same stagger as t256: waves 4-7 run one barrier behind waves 0-3, so on every SIMD one wave is in its MFMA segment while the other
+// issues its reads / loads.  Same LDS images per slot (row / kmaj2 swizzles), same fragment readers, same epilogue.
+// =================================================================================================
+__device__ __forceinline__ int p8_row_a(int h, int r) { return (r >> 6) * 128 + h * 64 + (r & 63); }   // slot row -> tile row
+__device__ __forceinline__ int p8_row_b(int h, int r) { return (r >> 5) * 64 + h * 32 + (r & 31); }
+
+template <bool TR, bool IS_A>
+__device__ __forceinline__ const uint16_t* p8_src_ptr(const uint16_t* __restrict__ P, int64_t ld, int64_t x0, int64_t X,
+                                                      int64_t k_begin, int h, int slab, int lane) {
+  if (!TR) {  // slab = 8 slot rows x 128 B
+    const int r = slab * 8 + (lane >> 3), pc = lane & 7;
+    const int c = pc ^ ((r >> 1) & 7);
+    int64_t row = x0 + (IS_A ? p8_row_a(h, r) : p8_row_b(h, r));
+    if (row > X - 1) row = X - 1;
+    return P + row * ld + k_begin + c * 8;
+  } else {    // slab = 4 k-rows x 256 B; a lane's 16 bytes = 8 consecutive slot columns (never straddling a 32-column group)
+    const int k = slab * 4 + (lane >> 4), pp = lane & 15;
+    const int q = (pp >> 1) ^ (((k & 3) << 1) | ((k >> 2) & 1));
+    const int cs = q * 16 + (pp & 1) * 8;
+    int64_t col = x0 + (IS_A ? p8_row_a(h, cs) : p8_row_b(h, cs));
+    if (col > X - 8) col = X - 8;
+    return P + (k_begin + k) * ld + col;
+  }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const GemmArgs args) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2 stages][A0 | A1 | B0 | B1], 16 KiB each
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 2, wn = wave & 3;  // 2 x 4 waves, each 128 (M) x 64 (N)
+  int split, tile_m, tile_n;
+  gemm_tile_coords(args, split, tile_m, tile_n);
+  const int64_t m0 = (int64_t)tile_m * G4_BM, n0 = (int64_t)tile_n * G4_BN;
+  const int64_t k_begin = (int64_t)split * args.k_per_split;
+  int64_t k_end = k_begin + args.k_per_split;
+  if (k_end > args.K) k_end = args.K;
+  const int nk = (int)((k_end - k_begin) / G_BK);
+
+  // every wave stages 2 of the 16 one-KiB slabs of EVERY half-tile kind (0 = A0, 1 = A1, 2 = B0, 3 = B1)
+  const uint16_t* src[8];
+  int lds_off[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int kind = i >> 1, slab = wave * 2 + (i & 1);
+    lds_off[i] = kind * G_TILE_BYTES + slab * 1024;
+    src[i] = kind < 2 ? p8_src_ptr<TA, true>(args.A, args.lda, m0, args.M, k_begin, kind, slab, lane)
+                      : p8_src_ptr<TB, false>(args.B, args.ldb, n0, args.N, k_begin, kind - 2, slab, lane);
+  }
+  const int64_t step_a = TA ? (int64_t)G_BK * args.lda : (int64_t)G_BK;
+  const int64_t step_b = TB ? (int64_t)G_BK * args.ldb : (int64_t)G_BK;
+
+#define P8_ISSUE(ST, KIND)                                                                                                          \
+  do {                                                                                                                              \
+    unsigned char* base_ = smem + (ST) * G4_STAGE_BYTES;                                                                            \
+    _Pragma("unroll") for (int u_ = 0; u_ < 2; ++u_) {                                                                              \
+      __builtin_amdgcn_global_load_lds((const GLB_AS void*)src[(KIND) * 2 + u_], (LDS_AS void*)(base_ + lds_off[(KIND) * 2 + u_]), 16, 0, 0); \
+      src[(KIND) * 2 + u_] += ((KIND) < 2 ? step_a : step_b);                                                                       \
+    }                                                                                                                               \
+  } while (0)
+#define P8_READ_A(ST, IH)                                                                                                           \
+  do {                                                                                                                              \
+    const unsigned char* sa_ = smem + (ST) * G4_STAGE_BYTES + (IH) * G_TILE_BYTES;                                                  \
+    _Pragma("unroll") for (int ib_ = 0; ib_ < 2; ++ib_)                                                                             \
+      _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) fa[ib_][s_] = frag32<TA>(sa_, wm * 64 + ib_ * 32, s_, lane);                 \
+  } while (0)
+#define P8_READ_B(FB, ST, J)                                                                                                        \
+  do {                                                                                                                              \
+    const unsigned char* sb_ = smem + (ST) * G4_STAGE_BYTES + (2 + (J)) * G_TILE_BYTES;                                             \
+    _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) FB[s_] = frag32<TB>(sb_, wn * 32, s_, lane);                                   \
+  } while (0)
+  // one quadrant: two accumulators alternate, so consecutive MFMAs never depend on each other
+#define P8_MMA(IH, J, FB)                                                                                                           \
+  do {                                                                                                                              \
+    _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_)                                                                                \
+      _Pragma("unroll") for (int ib_ = 0; ib_ < 2; ++ib_)                                                                           \
+        acc[(IH) * 2 + ib_][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, FB[s_]), __builtin_bit_cast(bf16x8, fa[ib_][s_]), acc[(IH) * 2 + ib_][J], 0, 0, 0); \
+  } while (0)
+#define P8_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define P8_BAR() __builtin_amdgcn_s_barrier()
+#define P8_WAIT_VM(STEADY)                                                                                                          \
+  do {                                                                                                                              \
+    if (STEADY) __builtin_amdgcn_s_waitcnt(0x0F76); /* vmcnt(6): all but the three newest half-tiles (2 loads each) have landed */ \
+    else __builtin_amdgcn_s_waitcnt(0x0F70);        /* vmcnt(0) */                                                                  \
+  } while (0)
+  // second half of a phase: close the read / issue segment, then the MFMA segment
+#define P8_MMA_SEG(IH, J, FB)                                                                                                       \
+  do {                                                                                                                              \
+    P8_FENCE(); P8_BAR();                                                                                                           \
+    __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0): this phase's fragments are in registers */                                   \
+    P8_FENCE();                                                                                                                     \
+    __builtin_amdgcn_s_setprio(1);                                                                                                  \
+    P8_MMA(IH, J, FB);                                                                                                              \
+    __builtin_amdgcn_s_setprio(0);                                                                                                  \
+    P8_FENCE(); P8_BAR();                                                                                                           \
+  } while (0)
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  s16x8 fa[2][4], fb0[4], fb1[4];
+
+  if (nk > 0) {
+    // prologue: stages 0 and 1 in the steady-state issue order (A0, B0, B1, A1), drained once
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      if (st < nk) { P8_ISSUE(st, 0); P8_ISSUE(st, 2); P8_ISSUE(st, 3); P8_ISSUE(st, 1); }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
+    P8_BAR();
+    const bool late = wave >= 4;  // wave-uniform
+    if (late) P8_BAR();           // stagger: the second wave of every SIMD runs one barrier behind
+    for (int kt = 0; kt < nk; ++kt) {
+      const int st = kt & 1;
+      const bool steady = kt + 2 < nk;       // all four issues of this K-tile and of the previous one exist
+      const bool next1 = kt >= 1 && kt + 1 < nk;
+      // ---- P0: q(0,0) ----
+      P8_READ_B(fb0, st, 0);
+      P8_FENCE();
+      P8_READ_A(st, 0);
+      if (next1) P8_ISSUE(st ^ 1, 3);        // B1(kt+1): its slot was last read in P1(kt-1)
+      P8_WAIT_VM(steady);                    // retires A1(kt), read in P2
+      P8_MMA_SEG(0, 0, fb0);
+      // ---- P1: q(0,1) ----
+      P8_READ_B(fb1, st, 1);
+      if (next1) P8_ISSUE(st ^ 1, 1);        // A1(kt+1): its slot was last read in P2(kt-1)
+      P8_MMA_SEG(0, 1, fb1);
+      // ---- P2: q(1,1) ----
+      P8_READ_A(st, 1);
+      if (steady) P8_ISSUE(st, 0);           // A0(kt+2): A0(kt) was last read in P0
+      P8_WAIT_VM(steady);                    // retires A0(kt+1), B0(kt+1), read in P0(kt+1)
+      P8_MMA_SEG(1, 1, fb1);
+      // ---- P3: q(1,0) ----
+      if (steady) P8_ISSUE(st, 2);           // B0(kt+2): B0(kt) was last read in P0
+      P8_WAIT_VM(steady);                    // retires B1(kt+1), read in P1(kt+1)
+      P8_MMA_SEG(1, 0, fb0);
+    }
+    if (!late) P8_BAR();  // barrier counts must match across the workgroup
+  }
+#undef P8_ISSUE
+#undef P8_READ_A
+#undef P8_READ_B
+#undef P8_MMA
+#undef P8_FENCE
+#undef P8_BAR
+#undef P8_WAIT_VM
+#undef P8_MMA_SEG
+  gemm_epilogue32(args, acc, m0 + wm * 128, n0 + wn * 64, lane);
+}
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-// kernel family: 0 = register-staged (any K % 8), 3 = pipe2, 4 = t256
+// kernel family: 0 = register-staged (any K % 8), 3 = pipe2, 4 = t256, 5 = p8 (experimental, only by ENH_GEMM_KERNEL=8phase)
 static int gemm_family(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K) {
   static const int kernel_sel = [] {  // ENH_GEMM_KERNEL = reg | pipe2 | t256 ; unset = per-shape choice
     const char* e = getenv("ENH_GEMM_KERNEL");
@@ -622,18 +798,19 @@ static int gemm_family(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K
     if (e[0] == 'r') return 0;
     if (e[0] == 'p') return 3;
     if (e[0] == 't') return 4;
+    if (e[0] == '8') return 5;
     return -1;
   }();
   const bool k64 = K % G_BK == 0 && (!trans_a || M >= 8) && (!trans_b || N >= 8);
   // per-shape choice (measured on MI355X, profiles/r01_gemm_ablation.txt): the 256x256 tile wins when the K loop is long
   // and the A operand is row-major (fc2 forward, dgrad of qkv / fc1); everything else runs the 128x128 pipe2 kernel.
   int family = !k64 ? 0 : (kernel_sel >= 0 ? kernel_sel : ((K >= 2048 && !trans_a) ? 4 : 3));
-  if (family == 4 && (M < 256 || N < 256)) family = 3;
+  if (family >= 4 && (M < 256 || N < 256)) family = 3;
   return family;
 }
 
 extern "C" const char* enh_gemm_bf16_variant(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K) {
-  static const char* names[5] = {"gemm_bf16_kernel", "", "", "gemm_bf16_pipe2_kernel", "gemm_bf16_t256_kernel"};
+  static const char* names[6] = {"gemm_bf16_kernel", "", "", "gemm_bf16_pipe2_kernel", "gemm_bf16_t256_kernel", "gemm_bf16_p8_kernel"};
   return names[gemm_family(trans_a, trans_b, M, N, K)];
 }
 
@@ -654,8 +831,8 @@ extern "C" int enh_gemm_bf16(const enh_bf16* A, int64_t lda, int trans_a, const 
   ENH_REQUIRE((!c_f32 || aligned16(c_f32)) && (!c_bf16 || (reinterpret_cast<uintptr_t>(c_bf16) & 7u) == 0), ENH_E_SHAPE, "enh_gemm_bf16: output alignment");
 
   const int family = gemm_family(trans_a, trans_b, M, N, K);
-  const int bm = family == 4 ? G4_BM : G_BM;
-  const int bn = family == 4 ? G4_BN : G_BN;
+  const int bm = family >= 4 ? G4_BM : G_BM;
+  const int bn = family >= 4 ? G4_BN : G_BN;
 
   GemmArgs g;
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.M = M; g.N = N; g.K = K;
@@ -667,13 +844,13 @@ extern "C" int enh_gemm_bf16(const enh_bf16* A, int64_t lda, int trans_a, const 
   ENH_REQUIRE(tiles < (1ll << 30), ENH_E_SHAPE, "enh_gemm_bf16: grid too large");
   // split-K (f32 atomics into a pre-initialised C) when a weight-gradient-shaped problem cannot fill 256 CUs
   const int64_t ksteps = (K + G_BK - 1) / G_BK;
-  const int64_t fill = family == 4 ? 256 : 512;  // resident workgroup slots
+  const int64_t fill = family >= 4 ? 256 : 512;  // resident workgroup slots
   int splits = 1;
   if (accumulate == 1 && c_f32 && !c_bf16 && !bias && act == ENH_ACT_NONE && !res && tiles < fill / 2 && K >= 2048) {
     // measured (profiles/r01_gemm_ablation.txt): the f32-atomic epilogue makes every extra K-slice expensive and a ragged
     // last round is worse still -> the largest split count whose workgroups fit ONE round of resident slots
     // (2 workgroups per CU for the 128x128 kernels, 1 for t256)
-    const int64_t slots = family == 4 ? 256 : 512;
+    const int64_t slots = family >= 4 ? 256 : 512;
     int64_t want = slots / tiles;
     if (want > ksteps / 8) want = ksteps / 8;
     if (want > 64) want = 64;
@@ -694,6 +871,8 @@ extern "C" int enh_gemm_bf16(const enh_bf16* A, int64_t lda, int trans_a, const 
     SET_ATTR((gemm_bf16_pipe2_kernel<true, false>), b2); SET_ATTR((gemm_bf16_pipe2_kernel<true, true>), b2);
     SET_ATTR((gemm_bf16_t256_kernel<false, false>), 2 * G4_STAGE_BYTES); SET_ATTR((gemm_bf16_t256_kernel<false, true>), 2 * G4_STAGE_BYTES);
     SET_ATTR((gemm_bf16_t256_kernel<true, false>), 2 * G4_STAGE_BYTES); SET_ATTR((gemm_bf16_t256_kernel<true, true>), 2 * G4_STAGE_BYTES);
+    SET_ATTR((gemm_bf16_p8_kernel<false, false>), 2 * G4_STAGE_BYTES); SET_ATTR((gemm_bf16_p8_kernel<false, true>), 2 * G4_STAGE_BYTES);
+    SET_ATTR((gemm_bf16_p8_kernel<true, false>), 2 * G4_STAGE_BYTES); SET_ATTR((gemm_bf16_p8_kernel<true, true>), 2 * G4_STAGE_BYTES);
 #undef SET_ATTR
     return true;
   }();
@@ -706,7 +885,8 @@ extern "C" int enh_gemm_bf16(const enh_bf16* A, int64_t lda, int trans_a, const 
     else if (trans_a && !trans_b) KERN<true, false><<<grid, THREADS, LDS, s>>>(g);         \
     else KERN<true, true><<<grid, THREADS, LDS, s>>>(g);                                   \
   } while (0)
-  if (family == 4) LAUNCH(gemm_bf16_t256_kernel, 512, (size_t)(2 * G4_STAGE_BYTES));
+  if (family == 5) LAUNCH(gemm_bf16_p8_kernel, 512, (size_t)(2 * G4_STAGE_BYTES));
+  else if (family == 4) LAUNCH(gemm_bf16_t256_kernel, 512, (size_t)(2 * G4_STAGE_BYTES));
   else if (family == 3) LAUNCH(gemm_bf16_pipe2_kernel, 256, lds2);
   else LAUNCH(gemm_bf16_kernel, 256, lds2);
 #undef LAUNCH

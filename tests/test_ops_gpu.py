@@ -10,6 +10,7 @@ Tolerances (relative Frobenius error vs the fp64/fp32 oracle fed the SAME bf16-r
   * fused attention (probabilities rounded to bf16 before P.V, bf16 output): <= 1.5 x floor (measured 1.10 x); its
     gradients (two chained bf16 roundings) <= 1e-2.
 """
+import os
 import numpy as np
 import pytest
 import torch
@@ -340,3 +341,22 @@ def test_colsum_cast_adamw(C):
         C.adamw_step(pd, gd, md, vd, p16, step, 4.5e-6)
     assert rel(pd, p) <= 1e-6 and rel(md, m) <= 1e-5 and rel(vd, v) <= 1e-5
     assert torch.equal(p16.cpu(), pd.cpu().to(torch.bfloat16))
+
+
+# ---------------------------------------------------------------------------------------------
+# experimental kernels (compiled in, off by default, not yet validated on hardware): opt in with ENH_TEST_EXPERIMENTAL=1
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.skipif(os.environ.get("ENH_TEST_EXPERIMENTAL", "0") != "1", reason="experimental 8-phase GEMM: set ENH_TEST_EXPERIMENTAL=1")
+def test_gemm_p8_experimental_reruns_the_gemm_suite():
+    """the kernel family is chosen once per process (ENH_GEMM_KERNEL), so the whole GEMM suite is re-run in a child process with the
+    8-phase kernel selected; shapes it does not cover (K % 64, M or N < 256) fall back exactly as they do for t256"""
+    import subprocess
+    import sys
+    env = dict(os.environ, ENH_GEMM_KERNEL="8phase", ENH_TEST_EXPERIMENTAL="0")
+    probe = ("import sys; sys.path.insert(0, 'enhancing-transformers_amd'); from enhancing import _C; "
+             "print(_C.lib().enh_gemm_bf16_variant(0, 0, 4096, 4096, 4096).decode())")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert subprocess.run([sys.executable, "-c", probe], env=env, cwd=root, capture_output=True, text=True).stdout.strip() == "gemm_bf16_p8_kernel"
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_ops_gpu.py", "-q", "-x", "-m", "gpu", "-k", "gemm", "-p", "no:cacheprovider"],
+                       env=env, cwd=root, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]
