@@ -250,6 +250,7 @@ class Stage1Engine:
         enc._engine = dec._engine = self
         self.world = 1
         self.comm = None  # enhancing.engine.ddp.GradSync when running data-parallel
+        self.sync_grads = True  # False on all but the last micro-batch of a gradient-accumulation window (DDP's no_sync)
 
     # ---- helpers -----------------------------------------------------------------------------
     def _io_bufs(self, B: int) -> dict:
@@ -377,7 +378,7 @@ class Stage1Engine:
         eb, h, zq16, idx = st["eb"], st["h"], st["zq16"], st["idx"]
         E = s.w["quantizer.embedding.weight"]
         db = self.dec.bufs(B, True)
-        notify = self.comm.layer_done if self.comm is not None else None
+        notify = self.comm.layer_done if self.comm is not None and self.sync_grads else None
         d_xf = io["d_xf_dec"]
         wpix = "decoder.to_pixel.1.weight"
         _C.mm(db["xf16"], dpix16, self.dec.dim, self.pd, M, g[wpix].view(self.dec.dim, self.pd), trans_a=True, trans_b=True, accumulate=True)

@@ -60,6 +60,7 @@ class Trainer:
                 first = batch_idx % self.accum == 0
                 last = (batch_idx + 1) % self.accum == 0
                 # Lightning 1.5 order: per optimizer, training_step -> backward -> step, so the discriminator step sees the updated autoencoder
+                eng.sync_grads = last   # accumulate locally, all-reduce the window's sum once (what DDP's no_sync gives Lightning)
                 for oi, o in enumerate(opts):
                     model.training_step(batch, batch_idx, oi, zero_grad=first)
                     if last:

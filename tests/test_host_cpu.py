@@ -115,7 +115,7 @@ def test_trainer_drives_the_lightning_protocol_in_order(monkeypatch, tmp_path):
     two-optimizer GAN setup, reference main.py:51-61), gradient accumulation windows, the step-wise LR schedule, validation, and a
     {"state_dict": ...} checkpoint per epoch (general.py:49-55)."""
     from enhancing.engine import trainer as T
-    calls = []
+    calls, syncs = [], []
 
     class Opt:
         def __init__(self, name):
@@ -136,6 +136,7 @@ def test_trainer_drives_the_lightning_protocol_in_order(monkeypatch, tmp_path):
 
         def training_step(self, batch, batch_idx, optimizer_idx, zero_grad=True):
             calls.append(("ts", batch_idx, optimizer_idx, zero_grad))
+            syncs.append(self.engine.sync_grads)
             self.logged["train/total_loss"] = torch.tensor(0.5)
 
         def validation_step(self, batch, batch_idx):
@@ -167,6 +168,7 @@ def test_trainer_drives_the_lightning_protocol_in_order(monkeypatch, tmp_path):
         ("ts", 1, 0, False), ("ae.step", 1.0, 0.5), ("ts", 1, 1, False), ("disc.step", 1.0, 0.5),      # optimizer 0 steps before optimizer 1 runs
         ("ts", 2, 0, True), ("ts", 2, 1, True),
         ("ts", 3, 0, False), ("ae.step", 0.5, 0.5), ("ts", 3, 1, False), ("disc.step", 0.5, 0.5)]      # lr = base * schedule(global_step = 1)
+    assert syncs == [False, False, True, True] * 2     # gradients are all-reduced only on the last micro-batch of a window (no_sync)
     assert [c for c in calls if c[0] == "val"] == [("val", 0), ("val", 1)] and tr.global_step == 2
     ck = torch.load(os.path.join(str(tmp_path), "ckpt", "epoch=00.ckpt"))
     assert set(ck) >= {"state_dict", "epoch", "global_step", "optimizer", "optimizer_states"} and len(ck["optimizer_states"]) == 2
