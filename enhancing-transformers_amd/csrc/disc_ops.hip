@@ -5,6 +5,7 @@
 // SURVEY.md §8f rank 1 ("next" row): the discriminator itself (equalised-lr convolutions on MFMA, minibatch-stddev, R1)
 // is not built yet; these two ops are what its activation / blur layers call.
 #include "common.h"
+#include <stdlib.h>
 
 // y = act(x + b[(i / step_b) % size_b]) * scale      (act = leaky-relu, reference "act*10+grad" cases 30 / 31)
 //   grad == 0: act(v) = v > 0 ? v : alpha * v
@@ -83,6 +84,91 @@ __global__ void upfirdn2d_kernel(const float* __restrict__ in, const float* __re
   out[idx] = acc;
 }
 
+// ---- EXPERIMENTAL fast paths (ENH_DISC_FAST=1; written after round 1's GPU budget was spent, compiled but not yet run) -------------
+// profiles/r01_adv_step_kernel_stats.csv: upfirdn2d_kernel is 24 % and channel_sum_kernel 6 % of the adversarial training step — the first
+// does 16 scalar loads per output, the second runs C (128..512) workgroups over a tensor of hundreds of MB.
+//
+// upfirdn2d with up = down = 1 (every use in the discriminator: Blur forward and both of its derivatives): a thread produces a
+// 2 (y) x 4 (x) output block from a (kh+1) x (kw+3) input window held in registers -> (kh+1)(kw+3)/8 loads per output instead of kh*kw.
+template <int KH, int KW>
+__global__ __launch_bounds__(256) void upfirdn2d_unit_kernel(const float* __restrict__ in, const float* __restrict__ kernel,
+                                                             float* __restrict__ out, int64_t major, int in_h, int in_w, int out_h,
+                                                             int out_w, int pad_x0, int pad_y0) {
+  __shared__ float s_k[KH * KW];
+  if (threadIdx.x < KH * KW) s_k[threadIdx.x] = kernel[(KH - 1 - threadIdx.x / KW) * KW + (KW - 1 - threadIdx.x % KW)];
+  __syncthreads();
+  const int bx = (out_w + 3) >> 2, by = (out_h + 1) >> 1;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= major * by * bx) return;
+  const int ox = (int)(idx % bx) * 4;
+  const int oy = (int)((idx / bx) % by) * 2;
+  const int64_t m = idx / ((int64_t)bx * by);
+  const float* plane = in + m * (int64_t)in_h * in_w;
+  float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+  for (int r = 0; r < KH + 1; ++r) {
+    const int iy = oy + r - pad_y0;
+    float row[KW + 3];
+    const bool yok = iy >= 0 && iy < in_h;
+#pragma unroll
+    for (int c = 0; c < KW + 3; ++c) {
+      const int ix = ox + c - pad_x0;
+      row[c] = (yok && ix >= 0 && ix < in_w) ? plane[(int64_t)iy * in_w + ix] : 0.f;
+    }
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+      const int ky = r - dy;  // output row oy + dy uses input row (oy + dy) + ky - pad
+      if (ky < 0 || ky >= KH) continue;
+#pragma unroll
+      for (int kx = 0; kx < KW; ++kx)
+#pragma unroll
+        for (int dx = 0; dx < 4; ++dx) acc[dy][dx] = fmaf(s_k[ky * KW + kx], row[dx + kx], acc[dy][dx]);
+    }
+  }
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy) {
+    if (oy + dy >= out_h) continue;
+    float* o = out + (m * out_h + oy + dy) * (int64_t)out_w + ox;
+    if (ox + 3 < out_w && (reinterpret_cast<uintptr_t>(o) & 15u) == 0) {
+      *reinterpret_cast<float4*>(o) = make_float4(acc[dy][0], acc[dy][1], acc[dy][2], acc[dy][3]);
+    } else {
+#pragma unroll
+      for (int dx = 0; dx < 4; ++dx)
+        if (ox + dx < out_w) o[dx] = acc[dy][dx];
+    }
+  }
+}
+
+// channel sums with the (batch, inner) space split over blockIdx.y: 16-byte loads when the rows are 16-byte aligned
+__global__ __launch_bounds__(256) void channel_sum_split_kernel(const float* __restrict__ x, int C, int64_t inner, int nchunk, int64_t chunk,
+                                                                float* __restrict__ out) {
+  __shared__ float s_part[4];
+  const int c = blockIdx.x;
+  const int b = blockIdx.y / nchunk, ch = blockIdx.y % nchunk;
+  const int64_t i0 = (int64_t)ch * chunk;
+  int64_t i1 = i0 + chunk;
+  if (i1 > inner) i1 = inner;
+  const float* p = x + ((int64_t)b * C + c) * inner;
+  float acc = 0.f;
+  if ((inner & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15u) == 0) {  // chunk is a multiple of 4 (launcher)
+    for (int64_t i = i0 + (int64_t)threadIdx.x * 4; i < i1; i += 1024) {
+      const float4 v = *reinterpret_cast<const float4*>(p + i);
+      acc += (v.x + v.y) + (v.z + v.w);
+    }
+  } else {
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) acc += p[i];
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(&out[c], (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]));
+}
+
+static bool disc_fast() {
+  static const bool on = [] { const char* e = getenv("ENH_DISC_FAST"); return e && e[0] == '1'; }();
+  return on;
+}
+
 extern "C" int enh_fused_bias_act(const float* x, const float* bias, const float* ref, float* y, int64_t n, int64_t step_b, int size_b,
                                   int act, int grad, float alpha, float scale, void* stream) {
   ENH_REQUIRE(x && y && n > 0, ENH_E_BADARG, "enh_fused_bias_act: bad argument");
@@ -102,6 +188,15 @@ extern "C" int enh_channel_sum_f32(const float* x, int B, int C, int64_t inner, 
     hipError_t e = hipMemsetAsync(out, 0, (size_t)C * sizeof(float), s);
     if (e != hipSuccess) { enh_set_error("enh_channel_sum_f32: memset failed"); return ENH_E_HIP_BASE - (int)e; }
   }
+  if (disc_fast()) {
+    int64_t chunk = (inner + 63) / 64;               // up to 64 slices of the inner axis per (batch, channel) row ...
+    if (chunk < 4096) chunk = 4096;                   // ... but never less than 16 KiB of work per workgroup
+    chunk = (chunk + 3) / 4 * 4;
+    const int nchunk = (int)((inner + chunk - 1) / chunk);
+    ENH_REQUIRE((int64_t)B * nchunk <= 65535, ENH_E_SHAPE, "enh_channel_sum_f32: grid too large");
+    channel_sum_split_kernel<<<dim3(C, B * nchunk), 256, 0, s>>>(x, C, inner, nchunk, chunk, out);
+    return enh_check_launch("enh_channel_sum_f32");
+  }
   const int by = B < 32 ? B : 32;
   channel_sum_kernel<<<dim3(C, by), 256, 0, s>>>(x, B, C, inner, out);
   return enh_check_launch("enh_channel_sum_f32");
@@ -115,6 +210,12 @@ extern "C" int enh_upfirdn2d(const float* in, const float* kernel, float* out, i
   const int out_h = (in_h * up_y + pad_y0 + pad_y1 - kh + down_y) / down_y;
   const int out_w = (in_w * up_x + pad_x0 + pad_x1 - kw + down_x) / down_x;
   ENH_REQUIRE(out_h > 0 && out_w > 0, ENH_E_SHAPE, "enh_upfirdn2d: empty output");
+  if (disc_fast() && up_x == 1 && up_y == 1 && down_x == 1 && down_y == 1 && kh == 4 && kw == 4) {
+    const int64_t blocks = major * ((out_h + 1) / 2) * ((out_w + 3) / 4);
+    upfirdn2d_unit_kernel<4, 4><<<(unsigned)((blocks + 255) / 256), 256, 0, (hipStream_t)stream>>>(in, kernel, out, major, in_h, in_w, out_h, out_w,
+                                                                                                  pad_x0, pad_y0);
+    return enh_check_launch("enh_upfirdn2d");
+  }
   const int64_t total = major * out_h * out_w;
   upfirdn2d_kernel<<<(int)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(in, kernel, out, major, in_h, in_w, out_h, out_w, kh, kw, up_x, up_y,
                                                                              down_x, down_y, pad_x0, pad_y0);
