@@ -203,3 +203,12 @@ def test_imagenet_folder_dataset_contract(tmp_path):
     assert tr[0]["image"].shape == (3, 32, 32)
     with pytest.raises(FileNotFoundError):
         type(tr)(str(tmp_path / "nope"))
+
+
+def test_p8_gemm_schedule_has_no_lds_hazards():
+    """the experimental 8-phase GEMM's issue / wait / barrier schedule, checked on a barrier-epoch model for 1..11 K-tiles (tools/p8_schedule_check.py)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("p8_schedule_check", os.path.join(ROOT, "tools", "p8_schedule_check.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    assert sum(m.check(nk) for nk in range(1, 12)) == 0
