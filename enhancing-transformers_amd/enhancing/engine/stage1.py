@@ -15,7 +15,6 @@ PyTorch is used for device memory, streams and ``torch.distributed`` only.
 """
 from __future__ import annotations
 
-import math
 from typing import Dict, List, Optional, Tuple
 
 import torch

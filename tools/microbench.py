@@ -1,7 +1,6 @@
 """Per-kernel timing at the BASELINE shapes (ViT-VQGAN base, per-GPU batch B) — dev tool, run on the GPU box."""
 import os
 import sys
-import time
 
 import torch
 
