@@ -741,12 +741,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const GemmArgs args) 
   s16x8 fa[2][4], fb0[4], fb1[4];
 
   if (nk > 0) {
-    // prologue: stages 0 and 1 in the steady-state issue order (A0, B0, B1, A1), drained once
+    // prologue: stages 0 and 1 in the steady-state issue order (A0, B0, B1, A1); only stage 0 has to have landed before the loop —
+    // stage 1's eight loads stay in flight and are retired by the counted waits of K-tile 0 like any later stage
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
       if (st < nk) { P8_ISSUE(st, 0); P8_ISSUE(st, 2); P8_ISSUE(st, 3); P8_ISSUE(st, 1); }
     }
-    __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
+    if (nk > 1) __builtin_amdgcn_s_waitcnt(0x0078);  // vmcnt(8) lgkmcnt(0)
+    else __builtin_amdgcn_s_waitcnt(0x0070);         // vmcnt(0) lgkmcnt(0)
     P8_BAR();
     const bool late = wave >= 4;  // wave-uniform
     if (late) P8_BAR();           // stagger: the second wave of every SIMD runs one barrier behind

@@ -15,11 +15,11 @@ KINDS = ("A0", "A1", "B0", "B1")
 
 def program(late: bool, nk: int):
     ev = []
-    for st in range(2):                                  # prologue: stages 0 and 1 in steady-state order, drained
+    for st in range(2):                                  # prologue: stages 0 and 1 in steady-state order; only stage 0 is waited for
         if st < nk:
             for kind in ("A0", "B0", "B1", "A1"):
                 ev.append(("ISSUE", (st, kind), st))
-    ev += [("WAITVM", 0), ("LGKM0",), ("BAR",)]
+    ev += [("WAITVM", 8 if nk > 1 else 0), ("LGKM0",), ("BAR",)]
     if late:
         ev.append(("BAR",))
     for kt in range(nk):
