@@ -790,9 +790,182 @@ __global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const GemmArgs args) 
   gemm_epilogue32(args, acc, m0 + wm * 128, n0 + wn * 64, lane);
 }
 
+// =================================================================================================
+// "p8p" (EXPERIMENTAL, never run — ENH_GEMM_KERNEL=9persist): the p8 schedule made persistent.  One workgroup per CU walks the
+// tiles b, b + gridDim.x, ... ; the half-tile issue stream of p8 simply CONTINUES across the tile boundary (each of the four kinds
+// counts its own K-tiles and re-derives its source pointers when it wraps), so the load queue never drains and the epilogue of one
+// tile runs while the first two K-tiles of the next are in flight — what a 12-K-tile problem (K = 768: 42 % of the training step)
+// needs from a 256x256 tile.  Synchronisation is p8's with a longer K sequence (tools/p8_schedule_check.py covers it as nk = the
+// workgroup's total K-tile count); gfx9 also counts the epilogue's stores / loads in vmcnt, which only makes the counted waits
+// conservative right after an epilogue.  No split-K (the launcher falls back to p8 then).  The macro block is a copy of p8's on
+// purpose: the two kernels are to be validated and tuned independently.
+// =================================================================================================
+__device__ __forceinline__ void gemm_tile_coords_v(const GemmArgs& args, int vbid, int& tile_m, int& tile_n) {
+  const int nwg = args.nbm * args.nbn;
+  int bid = vbid;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, pos = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+  }
+  const int per_group = 8 * args.nbn;
+  const int grp = bid / per_group, within = bid - grp * per_group;
+  const int rows = (args.nbm - grp * 8) < 8 ? (args.nbm - grp * 8) : 8;
+  tile_m = grp * 8 + within % rows;
+  tile_n = within / rows;
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(512) void gemm_bf16_p8p_kernel(const GemmArgs args) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2 stages][A0 | A1 | B0 | B1], 16 KiB each
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int ntiles = args.nbm * args.nbn;
+  const int G = (int)gridDim.x;  // a multiple of 8 whenever ntiles > G (launcher), so a workgroup never leaves its XCD's run of tiles
+  const int my_tiles = (ntiles - (int)blockIdx.x + G - 1) / G;
+  const int nk = (int)(args.K / G_BK);
+  const int gtot = my_tiles * nk;  // K-tiles this workgroup will consume, across all of its tiles
+
+  const uint16_t* src[8];
+  int lds_off[8];
+  int ktc[4] = {0, 0, 0, 0};  // per half-tile kind: K-tile (within its tile) of the NEXT issue ...
+  int tjc[4] = {0, 0, 0, 0};  // ... and which of this workgroup's tiles that issue belongs to
+#pragma unroll
+  for (int i = 0; i < 8; ++i) lds_off[i] = (i >> 1) * G_TILE_BYTES + (wave * 2 + (i & 1)) * 1024;
+  const int64_t step_a = TA ? (int64_t)G_BK * args.lda : (int64_t)G_BK;
+  const int64_t step_b = TB ? (int64_t)G_BK * args.ldb : (int64_t)G_BK;
+
+#define P9_SETPTR(KIND, J)                                                                                                          \
+  do {                                                                                                                              \
+    int tm_, tn_;                                                                                                                   \
+    gemm_tile_coords_v(args, (int)blockIdx.x + (J) * G, tm_, tn_);                                                                  \
+    _Pragma("unroll") for (int u_ = 0; u_ < 2; ++u_) {                                                                              \
+      if ((KIND) < 2) src[(KIND) * 2 + u_] = p8_src_ptr<TA, true>(args.A, args.lda, (int64_t)tm_ * G4_BM, args.M, 0, (KIND), wave * 2 + u_, lane);        \
+      else src[(KIND) * 2 + u_] = p8_src_ptr<TB, false>(args.B, args.ldb, (int64_t)tn_ * G4_BN, args.N, 0, (KIND) - 2, wave * 2 + u_, lane);              \
+    }                                                                                                                               \
+  } while (0)
+#define P9_ISSUE(ST, KIND)                                                                                                          \
+  do {                                                                                                                              \
+    unsigned char* base_ = smem + (ST) * G4_STAGE_BYTES;                                                                            \
+    _Pragma("unroll") for (int u_ = 0; u_ < 2; ++u_)                                                                                \
+      __builtin_amdgcn_global_load_lds((const GLB_AS void*)src[(KIND) * 2 + u_], (LDS_AS void*)(base_ + lds_off[(KIND) * 2 + u_]), 16, 0, 0); \
+    if (++ktc[KIND] == nk) {              /* this kind has issued the last K-tile of its tile: move to my next tile */                \
+      ktc[KIND] = 0;                                                                                                                \
+      ++tjc[KIND];                                                                                                                  \
+      if (tjc[KIND] < my_tiles) P9_SETPTR(KIND, tjc[KIND]);                                                                         \
+    } else {                                                                                                                        \
+      _Pragma("unroll") for (int u_ = 0; u_ < 2; ++u_) src[(KIND) * 2 + u_] += ((KIND) < 2 ? step_a : step_b);                     \
+    }                                                                                                                               \
+  } while (0)
+#define P9_READ_A(ST, IH)                                                                                                           \
+  do {                                                                                                                              \
+    const unsigned char* sa_ = smem + (ST) * G4_STAGE_BYTES + (IH) * G_TILE_BYTES;                                                  \
+    _Pragma("unroll") for (int ib_ = 0; ib_ < 2; ++ib_)                                                                             \
+      _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) fa[ib_][s_] = frag32<TA>(sa_, wm * 64 + ib_ * 32, s_, lane);                 \
+  } while (0)
+#define P9_READ_B(FB, ST, J)                                                                                                        \
+  do {                                                                                                                              \
+    const unsigned char* sb_ = smem + (ST) * G4_STAGE_BYTES + (2 + (J)) * G_TILE_BYTES;                                             \
+    _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) FB[s_] = frag32<TB>(sb_, wn * 32, s_, lane);                                   \
+  } while (0)
+#define P9_MMA(IH, J, FB)                                                                                                           \
+  do {                                                                                                                              \
+    _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_)                                                                                \
+      _Pragma("unroll") for (int ib_ = 0; ib_ < 2; ++ib_)                                                                           \
+        acc[(IH) * 2 + ib_][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, FB[s_]), __builtin_bit_cast(bf16x8, fa[ib_][s_]), acc[(IH) * 2 + ib_][J], 0, 0, 0); \
+  } while (0)
+#define P9_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define P9_BAR() __builtin_amdgcn_s_barrier()
+#define P9_WAIT_VM(STEADY)                                                                                                          \
+  do {                                                                                                                              \
+    if (STEADY) __builtin_amdgcn_s_waitcnt(0x0F76); /* vmcnt(6) */                                                                  \
+    else __builtin_amdgcn_s_waitcnt(0x0F70);        /* vmcnt(0) */                                                                  \
+  } while (0)
+#define P9_MMA_SEG(IH, J, FB)                                                                                                       \
+  do {                                                                                                                              \
+    P9_FENCE(); P9_BAR();                                                                                                           \
+    __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0) */                                                                            \
+    P9_FENCE();                                                                                                                     \
+    __builtin_amdgcn_s_setprio(1);                                                                                                  \
+    P9_MMA(IH, J, FB);                                                                                                              \
+    __builtin_amdgcn_s_setprio(0);                                                                                                  \
+    P9_FENCE(); P9_BAR();                                                                                                           \
+  } while (0)
+#define P9_ZERO_ACC()                                                                                                               \
+  do {                                                                                                                              \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                                                \
+      _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                                              \
+        _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) acc[i_][j_][r_] = 0.f;                                                    \
+  } while (0)
+
+  f32x16 acc[4][2];
+  P9_ZERO_ACC();
+  s16x8 fa[2][4], fb0[4], fb1[4];
+
+  if (gtot > 0) {
+    P9_SETPTR(0, 0); P9_SETPTR(1, 0); P9_SETPTR(2, 0); P9_SETPTR(3, 0);
+    // prologue: versions 0 and 1 of the stream, in its steady-state order; only version 0 has to have landed
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      if (v < gtot) { P9_ISSUE(v, 0); P9_ISSUE(v, 2); P9_ISSUE(v, 3); P9_ISSUE(v, 1); }
+    }
+    if (gtot > 1) __builtin_amdgcn_s_waitcnt(0x0078);  // vmcnt(8) lgkmcnt(0)
+    else __builtin_amdgcn_s_waitcnt(0x0070);           // vmcnt(0) lgkmcnt(0)
+    P9_BAR();
+    const bool late = wave >= 4;
+    if (late) P9_BAR();
+    int kt_in = 0, tile_j = 0;  // position of the K-tile being consumed
+    for (int g = 0; g < gtot; ++g) {
+      const int st = g & 1;
+      const bool steady = g + 2 < gtot;
+      const bool next1 = g >= 1 && g + 1 < gtot;
+      // ---- P0: q(0,0) ----
+      P9_READ_B(fb0, st, 0);
+      P9_FENCE();
+      P9_READ_A(st, 0);
+      if (next1) P9_ISSUE(st ^ 1, 3);
+      P9_WAIT_VM(steady);
+      P9_MMA_SEG(0, 0, fb0);
+      // ---- P1: q(0,1) ----
+      P9_READ_B(fb1, st, 1);
+      if (next1) P9_ISSUE(st ^ 1, 1);
+      P9_MMA_SEG(0, 1, fb1);
+      // ---- P2: q(1,1) ----
+      P9_READ_A(st, 1);
+      if (steady) P9_ISSUE(st, 0);
+      P9_WAIT_VM(steady);
+      P9_MMA_SEG(1, 1, fb1);
+      // ---- P3: q(1,0) ----
+      if (steady) P9_ISSUE(st, 2);
+      P9_WAIT_VM(steady);
+      P9_MMA_SEG(1, 0, fb0);
+      if (++kt_in == nk) {  // the tile is complete: store it (loads of my next tile are already in flight), start the next one
+        int tm, tn;
+        gemm_tile_coords_v(args, (int)blockIdx.x + tile_j * G, tm, tn);
+        gemm_epilogue32(args, acc, (int64_t)tm * G4_BM + wm * 128, (int64_t)tn * G4_BN + wn * 64, lane);
+        P9_ZERO_ACC();
+        kt_in = 0;
+        ++tile_j;
+      }
+    }
+    if (!late) P9_BAR();
+  }
+#undef P9_SETPTR
+#undef P9_ISSUE
+#undef P9_READ_A
+#undef P9_READ_B
+#undef P9_MMA
+#undef P9_FENCE
+#undef P9_BAR
+#undef P9_WAIT_VM
+#undef P9_MMA_SEG
+#undef P9_ZERO_ACC
+}
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-// kernel family: 0 = register-staged (any K % 8), 3 = pipe2, 4 = t256, 5 = p8 (experimental, only by ENH_GEMM_KERNEL=8phase)
+// kernel family: 0 = register-staged (any K % 8), 3 = pipe2, 4 = t256, 5 = p8, 6 = p8p (experimental, only by ENH_GEMM_KERNEL=8phase / 9persist)
 static int gemm_family(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K) {
   static const int kernel_sel = [] {  // ENH_GEMM_KERNEL = reg | pipe2 | t256 ; unset = per-shape choice
     const char* e = getenv("ENH_GEMM_KERNEL");
@@ -801,6 +974,7 @@ static int gemm_family(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K
     if (e[0] == 'p') return 3;
     if (e[0] == 't') return 4;
     if (e[0] == '8') return 5;
+    if (e[0] == '9') return 6;
     return -1;
   }();
   const bool k64 = K % G_BK == 0 && (!trans_a || M >= 8) && (!trans_b || N >= 8);
@@ -812,7 +986,7 @@ static int gemm_family(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K
 }
 
 extern "C" const char* enh_gemm_bf16_variant(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K) {
-  static const char* names[6] = {"gemm_bf16_kernel", "", "", "gemm_bf16_pipe2_kernel", "gemm_bf16_t256_kernel", "gemm_bf16_p8_kernel"};
+  static const char* names[7] = {"gemm_bf16_kernel", "", "", "gemm_bf16_pipe2_kernel", "gemm_bf16_t256_kernel", "gemm_bf16_p8_kernel", "gemm_bf16_p8p_kernel"};
   return names[gemm_family(trans_a, trans_b, M, N, K)];
 }
 
@@ -862,7 +1036,10 @@ extern "C" int enh_gemm_bf16(const enh_bf16* A, int64_t lda, int trans_a, const 
   splits = (int)((K + g.k_per_split - 1) / g.k_per_split);
   g.splits = splits;
   if (splits > 1) g.accumulate = 2;
-  const dim3 grid((unsigned)(tiles * splits));
+  int launch_family = family;
+  if (family == 6 && splits > 1) launch_family = 5;  // the persistent kernel has no split-K
+  // persistent: one workgroup per CU (256); fewer tiles than that -> one workgroup per tile
+  const dim3 grid(launch_family == 6 ? (unsigned)(tiles < 256 ? tiles : 256) : (unsigned)(tiles * splits));
   hipStream_t s = (hipStream_t)stream;
   static const bool attr_set = [] {
     const int b2 = 4 * G_TILE_BYTES;
@@ -875,6 +1052,8 @@ extern "C" int enh_gemm_bf16(const enh_bf16* A, int64_t lda, int trans_a, const 
     SET_ATTR((gemm_bf16_t256_kernel<true, false>), 2 * G4_STAGE_BYTES); SET_ATTR((gemm_bf16_t256_kernel<true, true>), 2 * G4_STAGE_BYTES);
     SET_ATTR((gemm_bf16_p8_kernel<false, false>), 2 * G4_STAGE_BYTES); SET_ATTR((gemm_bf16_p8_kernel<false, true>), 2 * G4_STAGE_BYTES);
     SET_ATTR((gemm_bf16_p8_kernel<true, false>), 2 * G4_STAGE_BYTES); SET_ATTR((gemm_bf16_p8_kernel<true, true>), 2 * G4_STAGE_BYTES);
+    SET_ATTR((gemm_bf16_p8p_kernel<false, false>), 2 * G4_STAGE_BYTES); SET_ATTR((gemm_bf16_p8p_kernel<false, true>), 2 * G4_STAGE_BYTES);
+    SET_ATTR((gemm_bf16_p8p_kernel<true, false>), 2 * G4_STAGE_BYTES); SET_ATTR((gemm_bf16_p8p_kernel<true, true>), 2 * G4_STAGE_BYTES);
 #undef SET_ATTR
     return true;
   }();
@@ -887,7 +1066,8 @@ extern "C" int enh_gemm_bf16(const enh_bf16* A, int64_t lda, int trans_a, const 
     else if (trans_a && !trans_b) KERN<true, false><<<grid, THREADS, LDS, s>>>(g);         \
     else KERN<true, true><<<grid, THREADS, LDS, s>>>(g);                                   \
   } while (0)
-  if (family == 5) LAUNCH(gemm_bf16_p8_kernel, 512, (size_t)(2 * G4_STAGE_BYTES));
+  if (launch_family == 6) LAUNCH(gemm_bf16_p8p_kernel, 512, (size_t)(2 * G4_STAGE_BYTES));
+  else if (launch_family == 5) LAUNCH(gemm_bf16_p8_kernel, 512, (size_t)(2 * G4_STAGE_BYTES));
   else if (family == 4) LAUNCH(gemm_bf16_t256_kernel, 512, (size_t)(2 * G4_STAGE_BYTES));
   else if (family == 3) LAUNCH(gemm_bf16_pipe2_kernel, 256, lds2);
   else LAUNCH(gemm_bf16_kernel, 256, lds2);

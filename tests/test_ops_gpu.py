@@ -346,17 +346,18 @@ def test_colsum_cast_adamw(C):
 # ---------------------------------------------------------------------------------------------
 # experimental kernels (compiled in, off by default, not yet validated on hardware): opt in with ENH_TEST_EXPERIMENTAL=1
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.skipif(os.environ.get("ENH_TEST_EXPERIMENTAL", "0") != "1", reason="experimental 8-phase GEMM: set ENH_TEST_EXPERIMENTAL=1")
-def test_gemm_p8_experimental_reruns_the_gemm_suite():
+@pytest.mark.skipif(os.environ.get("ENH_TEST_EXPERIMENTAL", "0") != "1", reason="experimental 8-phase GEMMs: set ENH_TEST_EXPERIMENTAL=1")
+@pytest.mark.parametrize("sel,symbol", [("8phase", "gemm_bf16_p8_kernel"), ("9persist", "gemm_bf16_p8p_kernel")])
+def test_gemm_p8_experimental_reruns_the_gemm_suite(sel, symbol):
     """the kernel family is chosen once per process (ENH_GEMM_KERNEL), so the whole GEMM suite is re-run in a child process with the
-    8-phase kernel selected; shapes it does not cover (K % 64, M or N < 256) fall back exactly as they do for t256"""
+    experimental kernel selected; shapes it does not cover (K % 64, M or N < 256; split-K for the persistent one) fall back"""
     import subprocess
     import sys
-    env = dict(os.environ, ENH_GEMM_KERNEL="8phase", ENH_TEST_EXPERIMENTAL="0")
+    env = dict(os.environ, ENH_GEMM_KERNEL=sel, ENH_TEST_EXPERIMENTAL="0")
     probe = ("import sys; sys.path.insert(0, 'enhancing-transformers_amd'); from enhancing import _C; "
              "print(_C.lib().enh_gemm_bf16_variant(0, 0, 4096, 4096, 4096).decode())")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    assert subprocess.run([sys.executable, "-c", probe], env=env, cwd=root, capture_output=True, text=True).stdout.strip() == "gemm_bf16_p8_kernel"
+    assert subprocess.run([sys.executable, "-c", probe], env=env, cwd=root, capture_output=True, text=True).stdout.strip() == symbol
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_ops_gpu.py", "-q", "-x", "-m", "gpu", "-k", "gemm", "-p", "no:cacheprovider"],
                        env=env, cwd=root, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:]

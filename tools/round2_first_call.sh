@@ -10,15 +10,18 @@ echo "== 1. regression (default kernels) =="
 timeout 300 python -m pytest tests -m gpu -q --no-header -p no:cacheprovider -x 2>&1 | tail -3
 echo "== 2. experimental 8-phase GEMM: correctness (GEMM suite re-run under ENH_GEMM_KERNEL=8phase), three times as a race screen =="
 for i in 1 2 3; do
-  ENH_TEST_EXPERIMENTAL=1 timeout 200 python -m pytest tests/test_ops_gpu.py -m gpu -q --no-header -p no:cacheprovider -k p8 2>&1 | tail -2
+  ENH_TEST_EXPERIMENTAL=1 timeout 200 python -m pytest tests/test_ops_gpu.py -m gpu -q --no-header -p no:cacheprovider -k "p8 and 8phase" 2>&1 | tail -2
 done
-echo "== 3. per-shape GEMM table: default vs 8phase (B = 128) =="
+ENH_TEST_EXPERIMENTAL=1 timeout 200 python -m pytest tests/test_ops_gpu.py -m gpu -q --no-header -p no:cacheprovider -k "p8 and 9persist" 2>&1 | tail -2
+echo "== 3. per-shape GEMM table: default | 8phase | 9persist (B = 128) =="
 MB_BATCH=128 timeout 120 python tools/microbench.py 2>/dev/null | sed -n 2,14p > "$OUT/gemm_default.txt"
 ENH_GEMM_KERNEL=8phase MB_BATCH=128 timeout 120 python tools/microbench.py 2>/dev/null | sed -n 2,14p > "$OUT/gemm_p8.txt"
-paste -d'|' <(cut -c1-34,68-90 "$OUT/gemm_default.txt") <(cut -c68-90 "$OUT/gemm_p8.txt")
-echo "== 4. whole step: default vs all-8phase (wherever it applies) =="
+ENH_GEMM_KERNEL=9persist MB_BATCH=128 timeout 120 python tools/microbench.py 2>/dev/null | sed -n 2,14p > "$OUT/gemm_p8p.txt"
+paste -d'|' <(cut -c1-34,68-90 "$OUT/gemm_default.txt") <(cut -c68-90 "$OUT/gemm_p8.txt") <(cut -c68-90 "$OUT/gemm_p8p.txt")
+echo "== 4. whole step: default vs 8phase vs 9persist (wherever they apply) =="
 timeout 150 python bench.py --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | cut -c1-130
 ENH_GEMM_KERNEL=8phase timeout 150 python bench.py --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | cut -c1-130
+ENH_GEMM_KERNEL=9persist timeout 150 python bench.py --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | cut -c1-130
 echo "== 5. experimental discriminator kernels: correctness, then the adversarial step with and without them =="
 ENH_TEST_EXPERIMENTAL=1 timeout 200 python -m pytest tests/test_disc_ops_gpu.py -m gpu -q --no-header -p no:cacheprovider -k fast_paths 2>&1 | tail -2
 timeout 150 python bench.py --config imagenet_vitvq_base_adv --batch 16 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | cut -c1-130
