@@ -212,3 +212,4 @@ def test_p8_gemm_schedule_has_no_lds_hazards():
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
     assert sum(m.check(nk) for nk in range(1, 12)) == 0
+    assert sum(m.check_stream(nk, mt) for nk in range(1, 9) for mt in range(1, 6)) == 0   # the persistent variant's tile / K-tile bookkeeping

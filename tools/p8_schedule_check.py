@@ -103,7 +103,42 @@ def check(nk: int):
     return errs
 
 
+def check_stream(nk: int, my_tiles: int) -> int:
+    """gemm_bf16_p8p_kernel's bookkeeping: with the per-kind (K-tile, tile) counters of P9_ISSUE, does every slot hold the half-tile of
+    the (tile, K-tile) that is being consumed when it is read?  Returns the number of mismatches."""
+    gtot = my_tiles * nk
+    ktc = {k: 0 for k in KINDS}
+    tjc = {k: 0 for k in KINDS}
+    slot, bad = {}, 0
+
+    def issue(st, kind):
+        slot[(st, kind)] = (tjc[kind], ktc[kind]) if tjc[kind] < my_tiles else None
+        ktc[kind] += 1
+        if ktc[kind] == nk:
+            ktc[kind] = 0
+            tjc[kind] += 1
+    for v in range(2):
+        if v < gtot:
+            for kind in ("A0", "B0", "B1", "A1"):
+                issue(v, kind)
+    for g in range(gtot):
+        st, steady, next1 = g & 1, g + 2 < gtot, g >= 1 and g + 1 < gtot
+        want = (g // nk, g % nk)
+        bad += slot[(st, "A0")] != want or slot[(st, "B0")] != want       # P0 reads
+        if next1:
+            issue(st ^ 1, "B1")
+        bad += slot[(st, "B1")] != want                                    # P1 read
+        if next1:
+            issue(st ^ 1, "A1")
+        bad += slot[(st, "A1")] != want                                    # P2 read
+        if steady:
+            issue(st, "A0")
+            issue(st, "B0")                                                # (P3)
+    return bad
+
+
 if __name__ == "__main__":
     total = sum(check(nk) for nk in range(1, 12))
-    print("hazards:", total)
+    total += sum(check_stream(nk, mt) for nk in range(1, 9) for mt in range(1, 6))
+    print("hazards + stream mismatches:", total)
     sys.exit(1 if total else 0)
