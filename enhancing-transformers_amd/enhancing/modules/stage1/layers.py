@@ -8,7 +8,6 @@ blocks on bf16 MFMA GEMMs + fused attention, final LayerNorm).  Sub-modules such
 reproduce the parameter tree (``transformer.layers.{i}.0.fn.to_qkv.weight`` ...), not to be called."""
 from __future__ import annotations
 
-import math
 from typing import Tuple, Union
 
 import numpy as np
@@ -32,23 +31,39 @@ def get_2d_sincos_pos_embed(embed_dim: int, grid_size) -> np.ndarray:
     return np.concatenate([one_axis(embed_dim // 2, xs), one_axis(embed_dim // 2, ys)], axis=1)
 
 
-def _xavier_uniform_2d(w: torch.Tensor) -> None:
-    """xavier-uniform on the weight viewed [shape[0], -1] (reference init_weights, layers.py:71-82)."""
-    fan_out, fan_in = w.shape[0], w[0].numel()
-    bound = math.sqrt(6.0 / (fan_in + fan_out))
-    with torch.no_grad():
-        w.uniform_(-bound, bound)
+def init_weights(m: nn.Module) -> None:
+    """The reference's ``init_weights`` (layers.py:71-82) over this package's parameter containers: xavier-uniform Linear weights
+    (as the official JAX ViT), zero Linear biases, LayerNorm (1, 0), xavier-uniform on the conv weights viewed [shape[0], -1] (the
+    conv biases keep torch's default init).  Applied with ``self.apply`` at the END of ViTEncoder / ViTDecoder construction, exactly
+    like the reference (layers.py:175,207) — see the seed-for-seed note on LinearParams."""
+    if isinstance(m, LinearParams):
+        torch.nn.init.xavier_uniform_(m.weight)
+        if m.bias is not None:
+            nn.init.constant_(m.bias, 0)
+    elif isinstance(m, NormParams):
+        nn.init.constant_(m.bias, 0)
+        nn.init.constant_(m.weight, 1.0)
+    elif isinstance(m, PatchConvParams):
+        w = m.weight.data
+        torch.nn.init.xavier_uniform_(w.view([w.shape[0], -1]))
 
 
 class LinearParams(nn.Module):
-    """weight [out, in] (+ bias [out]) of an nn.Linear, xavier-uniform / zeros (layers.py:72-76)."""
+    """weight [out, in] (+ bias [out]) of an nn.Linear.
+
+    Seed-for-seed parity with the reference: the reference CONSTRUCTS ``nn.Linear`` / ``nn.Conv2d`` /
+    ``nn.ConvTranspose2d`` — whose default initialisers draw from the global RNG — and only afterwards re-draws the weights in
+    ``self.apply(init_weights)`` order (layers.py:71-82,175,207).  To leave torch's RNG stream in the same state at every point,
+    the containers here are filled by constructing the very same stock torch module and adopting its parameters; ``init_weights``
+    then runs in the reference's ``apply`` order.  ``torch.manual_seed(s); ViTEncoder(...)`` therefore yields the reference's
+    tensors bit-for-bit (tests/test_host_cpu.py::test_init_is_seed_for_seed_with_the_reference)."""
 
     def __init__(self, in_features: int, out_features: int, bias: bool = True) -> None:
         super().__init__()
         self.in_features, self.out_features = in_features, out_features
-        self.weight = nn.Parameter(torch.empty(out_features, in_features))
-        _xavier_uniform_2d(self.weight)
-        self.bias = nn.Parameter(torch.zeros(out_features)) if bias else None
+        donor = nn.Linear(in_features, out_features, bias=bias)
+        self.weight = donor.weight
+        self.bias = donor.bias if bias else None
 
 
 class NormParams(nn.Module):
@@ -61,15 +76,15 @@ class NormParams(nn.Module):
 
 
 class PatchConvParams(nn.Module):
-    """weight [dim, C, p, p] + bias of Conv2d(C, dim, k=s=p) / ConvTranspose2d(dim, C, k=s=p): both store
-    [dim, C, p, p]; xavier on the [dim, C*p*p] view, torch-default bias (layers.py:80-82,169,204)."""
+    """weight [dim, C, p, p] + bias of Conv2d(C, dim, k=s=p) (bias [dim]) or ConvTranspose2d(dim, C, k=s=p) (bias [C]): both store
+    the weight as [dim, C, p, p]; xavier on the [dim, C*p*p] view, torch-default bias (layers.py:80-82,169,204)."""
 
-    def __init__(self, dim: int, channels: int, patch: Tuple[int, int], bias_len: int) -> None:
+    def __init__(self, dim: int, channels: int, patch: Tuple[int, int], transposed: bool) -> None:
         super().__init__()
-        self.weight = nn.Parameter(torch.empty(dim, channels, patch[0], patch[1]))
-        _xavier_uniform_2d(self.weight)
-        bound = 1.0 / math.sqrt(channels * patch[0] * patch[1])
-        self.bias = nn.Parameter(torch.empty(bias_len).uniform_(-bound, bound))
+        donor = (nn.ConvTranspose2d(dim, channels, kernel_size=patch, stride=patch) if transposed
+                 else nn.Conv2d(channels, dim, kernel_size=patch, stride=patch))
+        assert tuple(donor.weight.shape) == (dim, channels, patch[0], patch[1])
+        self.weight, self.bias = donor.weight, donor.bias
 
 
 class Attention(nn.Module):
@@ -148,9 +163,10 @@ class ViTEncoder(_ViTBase):
     def __init__(self, image_size: Union[Tuple[int, int], int], patch_size: Union[Tuple[int, int], int],
                  dim: int, depth: int, heads: int, mlp_dim: int, channels: int = 3, dim_head: int = 64) -> None:
         super().__init__(image_size, patch_size, dim, depth, heads, mlp_dim, channels, dim_head)
-        self.to_patch_embedding = nn.Sequential(PatchConvParams(dim, channels, self.patch_size, dim), nn.Identity())
+        self.to_patch_embedding = nn.Sequential(PatchConvParams(dim, channels, self.patch_size, transposed=False), nn.Identity())
         self.en_pos_embedding = self._pos_table()
         self.transformer = Transformer(dim, depth, heads, dim_head, mlp_dim)
+        self.apply(init_weights)
 
     def forward(self, img: torch.Tensor) -> torch.Tensor:
         return self._require_engine().encoder_forward(img)
@@ -164,7 +180,8 @@ class ViTDecoder(_ViTBase):
         super().__init__(image_size, patch_size, dim, depth, heads, mlp_dim, channels, dim_head)
         self.transformer = Transformer(dim, depth, heads, dim_head, mlp_dim)
         self.de_pos_embedding = self._pos_table()
-        self.to_pixel = nn.Sequential(nn.Identity(), PatchConvParams(dim, channels, self.patch_size, channels))
+        self.to_pixel = nn.Sequential(nn.Identity(), PatchConvParams(dim, channels, self.patch_size, transposed=True))
+        self.apply(init_weights)
 
     def forward(self, token: torch.Tensor) -> torch.Tensor:
         return self._require_engine().decoder_forward(token)

@@ -81,8 +81,11 @@ def feed_forward(x: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor) -> T
     return torch.tanh(x @ w1.t() + b1) @ w2.t() + b2
 
 
-def transformer(x: Tensor, P: Dict[str, Tensor], prefix: str, depth: int, heads: int) -> Tensor:
-    """layers.py:145-150: depth x { x = attn(LN(x)) + x ; x = ff(LN(x)) + x } ; final LN."""
+def transformer(x: Tensor, P: Dict[str, Tensor], prefix: str, depth: int, heads: int, trace: Optional[list] = None) -> Tensor:
+    """layers.py:145-150: depth x { x = attn(LN(x)) + x ; x = ff(LN(x)) + x } ; final LN.
+    ``trace`` (test aid): receives the residual stream entering layer 0 and leaving every layer, for per-layer parity tables."""
+    if trace is not None:
+        trace.append(x.detach())
     for i in range(depth):
         p = f"{prefix}layers.{i}."
         h = layer_norm(x, P[p + "0.norm.weight"], P[p + "0.norm.bias"])
@@ -90,6 +93,8 @@ def transformer(x: Tensor, P: Dict[str, Tensor], prefix: str, depth: int, heads:
         h = layer_norm(x, P[p + "1.norm.weight"], P[p + "1.norm.bias"])
         x = feed_forward(h, P[p + "1.fn.net.0.weight"], P[p + "1.fn.net.0.bias"],
                          P[p + "1.fn.net.2.weight"], P[p + "1.fn.net.2.bias"]) + x
+        if trace is not None:
+            trace.append(x.detach())
     return layer_norm(x, P[prefix + "norm.weight"], P[prefix + "norm.bias"])
 
 
@@ -113,20 +118,20 @@ def unpatchify(p: Tensor, patch: int, C: int, H: int, W: int) -> Tensor:
     return x.reshape(B, C, H, W)
 
 
-def encoder(img: Tensor, P: Dict[str, Tensor], cfg: dict, prefix: str = "encoder.") -> Tensor:
+def encoder(img: Tensor, P: Dict[str, Tensor], cfg: dict, prefix: str = "encoder.", trace: Optional[list] = None) -> Tensor:
     """ViTEncoder.forward layers.py:177-182."""
     patch = cfg["patch_size"]
     w = P[prefix + "to_patch_embedding.0.weight"]  # [dim, C, p, p]
     x = patchify(img, patch) @ w.reshape(w.shape[0], -1).t() + P[prefix + "to_patch_embedding.0.bias"]
     x = x + P[prefix + "en_pos_embedding"]
-    return transformer(x, P, prefix + "transformer.", cfg["encoder"]["depth"], cfg["encoder"]["heads"])
+    return transformer(x, P, prefix + "transformer.", cfg["encoder"]["depth"], cfg["encoder"]["heads"], trace)
 
 
-def decoder(tok: Tensor, P: Dict[str, Tensor], cfg: dict, prefix: str = "decoder.") -> Tensor:
+def decoder(tok: Tensor, P: Dict[str, Tensor], cfg: dict, prefix: str = "decoder.", trace: Optional[list] = None) -> Tensor:
     """ViTDecoder.forward layers.py:209-214.  ConvTranspose2d weight is [dim, C, p, p] = [K, N] (x @ W)."""
     patch, size = cfg["patch_size"], cfg["image_size"]
     x = tok + P[prefix + "de_pos_embedding"]
-    x = transformer(x, P, prefix + "transformer.", cfg["decoder"]["depth"], cfg["decoder"]["heads"])
+    x = transformer(x, P, prefix + "transformer.", cfg["decoder"]["depth"], cfg["decoder"]["heads"], trace)
     w = P[prefix + "to_pixel.1.weight"]
     C = w.shape[1]
     pix = x @ w.reshape(w.shape[0], -1) + P[prefix + "to_pixel.1.bias"].repeat_interleave(patch * patch)
@@ -357,3 +362,17 @@ TINY_CFG = dict(image_size=64, patch_size=8,
                 encoder=dict(dim=128, depth=2, heads=2, mlp_dim=256),
                 decoder=dict(dim=128, depth=2, heads=2, mlp_dim=256),
                 quantizer=dict(embed_dim=32, n_embed=512))
+
+
+def train_step_traced(img: Tensor, P: Dict[str, Tensor], cfg: dict, loss_kw: Optional[dict] = None) -> dict:
+    """train_step_grads plus every intermediate a per-layer parity table needs (test aid): the residual stream entering / leaving
+    each encoder and decoder layer, h (quantizer input), z_q, indices, xrec, loss, gradients.  Same arithmetic as forward()."""
+    leaves = {k: v.detach().clone().requires_grad_(not k.endswith("pos_embedding")) for k, v in P.items()}
+    enc_tr, dec_tr = [], []
+    h = encoder(img, leaves, cfg, trace=enc_tr) @ leaves["pre_quant.weight"].t() + leaves["pre_quant.bias"]
+    quant, qloss, idx = quantizer_forward(h, leaves["quantizer.embedding.weight"], **qparams(cfg))
+    xrec = decoder(quant @ leaves["post_quant.weight"].t() + leaves["post_quant.bias"], leaves, cfg, trace=dec_tr)
+    loss, log = pixel_codebook_loss(qloss, img, xrec, **(loss_kw or {}))
+    loss.backward()
+    return dict(loss=loss.detach(), log=log, grads={k: v.grad for k, v in leaves.items() if v.grad is not None}, xrec=xrec.detach(),
+                h=h.detach(), zq=quant.detach(), idx=idx, qloss=qloss.detach(), enc_trace=enc_tr, dec_trace=dec_tr)

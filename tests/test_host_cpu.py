@@ -205,6 +205,37 @@ def test_imagenet_folder_dataset_contract(tmp_path):
         type(tr)(str(tmp_path / "nope"))
 
 
+def _build_ours(case, seed):
+    """this package's modules in the reference's construction order (vitvqgan.py:34-39)"""
+    sys_path_oracle = os.path.join(ROOT, "oracle")
+    import sys
+    if sys_path_oracle not in sys.path:
+        sys.path.insert(0, sys_path_oracle)
+    import make_golden_init as G
+    from enhancing.modules.stage1 import layers as L, quantizers as Q
+    return G, G.build(L, Q, case, seed)
+
+
+@pytest.mark.parametrize("case", ["tiny", "small"])
+def test_init_is_seed_for_seed_with_the_reference(case):
+    """torch.manual_seed(0) then construction -> the REFERENCE's tensors, bit for bit (the reference constructs stock
+    nn.Linear / nn.Conv2d, whose default init consumes the RNG, then re-draws in apply() order; layers.py:71-82,175,207).
+    Checked against fingerprints of the reference's own state dict (tests/golden/init_seed.npz, oracle/make_golden_init.py) and,
+    where /root/reference is present (this container), against the reference modules tensor by tensor."""
+    import numpy as np
+    G, (sd, tail) = _build_ours(case, 0)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "init_seed.npz"))
+    names, fp = G.fingerprint(sd)
+    assert names == list(g[f"{case}_names"])
+    assert np.array_equal(fp, g[f"{case}_fp"]), [n for n, a, b in zip(names, fp, g[f"{case}_fp"]) if not np.array_equal(a, b)]
+    assert np.array_equal(tail.numpy(), g[f"{case}_tail"]), "the RNG stream must end in the same state"
+    import _reference_loader as RL
+    if RL.available():
+        ref_sd, ref_tail = G.build(RL.load_layers(), RL.load_quantizers(), case, 0)
+        assert list(ref_sd) == list(sd)
+        assert all(torch.equal(ref_sd[k], sd[k]) for k in sd) and torch.equal(ref_tail, tail)
+
+
 def test_p8_gemm_schedule_has_no_lds_hazards():
     """the experimental 8-phase GEMM's issue / wait / barrier schedule, checked on a barrier-epoch model for 1..11 K-tiles (tools/p8_schedule_check.py)"""
     import importlib.util

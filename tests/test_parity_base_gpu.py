@@ -1,0 +1,110 @@
+"""End-to-end parity of the MEASURED path (bf16 MFMA operands, fp32 accumulation / residual stream) at the BENCHMARKED
+configurations — BASELINE.json configs 2, 4 and 5 at their real widths and depths (768/12/12/3072 towers, K = 8192, 256 px;
+RQ depth 4; the large 512/8 + 1280/32 towers) — against the fp32 CPU oracle run with identical fp32 master weights.
+
+What is reported (printed as a table per test; `pytest -s` shows it, the numbers are copied to DESIGN.md §4):
+  * per-layer relative Frobenius error of the residual stream, encoder and decoder;
+  * h (quantizer input), xrec, loss;
+  * code match-rate END TO END (HIP codes from the bf16-operand h vs oracle codes from the fp32 h) and at the OP BOUNDARY
+    (oracle quantizer fed the HIP path's own h: must be 1.0 — every index bit-exact);
+  * one training step's parameter gradients (median / worst relative error).
+
+Tolerances.  north_star asks 1e-3 rel for bf16 activations.  Rounding an exact tensor to bf16 already costs 1.66e-3
+(util.bf16_floor), so that bound is unreachable for any quantity that passes through a bf16-stored GEMM operand; the bounds
+asserted here are the measured errors of this path at these sizes x ~1.5 (see the constants), i.e. regression bounds — the
+fp32 exact mode (test_model_gpu.py::test_exact_mode_*) is the instrument that meets 1e-3 (4e-7 measured).
+"""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from util import rel
+
+pytestmark = pytest.mark.gpu
+
+BASE = dict(image_size=256, patch_size=8, encoder=dict(dim=768, depth=12, heads=12, mlp_dim=3072),
+            decoder=dict(dim=768, depth=12, heads=12, mlp_dim=3072), quantizer=dict(embed_dim=32, n_embed=8192))
+LARGE = dict(image_size=256, patch_size=8, encoder=dict(dim=512, depth=8, heads=8, mlp_dim=2048),
+             decoder=dict(dim=1280, depth=32, heads=16, mlp_dim=5120), quantizer=dict(embed_dim=32, n_embed=8192))
+
+# regression bounds (measured on MI355X, round 2 — see DESIGN.md §4 for the table they come from)
+STREAM_TOL = 1.5e-2     # residual stream after any layer
+H_TOL, XREC_TOL = 2e-2, 3e-2
+GRAD_TOL = 6e-2         # worst parameter gradient
+MATCH_MIN = 0.80        # end-to-end code match-rate (bf16 h vs fp32 h feeding an 8192-way argmin)
+
+
+def _build(cfg, P):
+    from enhancing.modules.stage1.vitvqgan import ViTVQ
+    from enhancing.utils.general import AttrDict
+    loss = {"target": "enhancing.losses.vqperceptual.VQLPIPS",
+            "params": dict(codebook_weight=1.0, loglaplace_weight=0.0, loggaussian_weight=1.0, perceptual_weight=0.0)}
+    m = ViTVQ("image", cfg["image_size"], cfg["patch_size"], AttrDict.wrap(cfg["encoder"]), AttrDict.wrap(cfg["decoder"]),
+              AttrDict.wrap(cfg["quantizer"]), AttrDict.wrap(loss))
+    m.load_state_dict(P, strict=True)
+    assert m.engine.precision == "bf16"
+    return m
+
+
+def _run_case(label, cfg, B, seed, tols=None):
+    import vitvq_oracle as O
+    torch.set_num_threads(min(32, max(torch.get_num_threads(), 8)))
+    stream_tol, h_tol, xrec_tol, grad_tol, match_min = tols or (STREAM_TOL, H_TOL, XREC_TOL, GRAD_TOL, MATCH_MIN)
+    P = O.make_params(cfg, seed)
+    x = O.make_images(seed + 1, B, cfg["image_size"])
+    m = _build(cfg, P)
+    eng = m.engine
+    loss = m.training_step({"image": x}, 0, 0)
+    torch.cuda.synchronize()
+    ref = O.train_step_traced(x, P, cfg)
+    M = B * eng.n_tok
+    io = eng._io_bufs(B)
+    rows = []
+    for name, tower, tr in (("enc", eng.enc, ref["enc_trace"]), ("dec", eng.dec, ref["dec_trace"])):
+        xs = tower.bufs(B, True)["x"]
+        assert len(tr) == tower.depth + 1
+        for i, t in enumerate(tr):
+            rows.append((f"{name}.x[{i}]", rel(xs[i], t.reshape(M, -1))))
+    e_h, e_x = rel(io["h"], ref["h"].reshape(M, -1)), rel(io["xrec"], ref["xrec"])
+    codes = eng.encode_codes(x).cpu()   # no-grad path: same kernels, no saved activations
+    ref_idx = ref["idx"]
+    match_e2e = (codes == ref_idx).float().mean().item()
+    # op boundary: the oracle's quantizer on the HIP path's own h
+    h_gpu = eng._pre_quant(eng._encode_tokens(eng._check_img(x), save=False)["xf16"], B).clone()
+    _, _, idx_ob = O.quantizer_forward(h_gpu.cpu().view(B, eng.n_tok, -1), P["quantizer.embedding.weight"], **O.qparams(cfg))
+    match_ob = (codes == idx_ob).float().mean().item()
+    errs = {k: rel(p.grad, ref["grads"][k]) for k, p in m.named_parameters() if k in ref["grads"]}
+    worst = max(errs, key=errs.get)
+    print(f"\n== {label}: B={B}, bf16 MFMA operands vs fp32 CPU oracle ==")
+    for n, e in rows:
+        print(f"  {n:12s} rel {e:.2e}")
+    print(f"  h            rel {e_h:.2e}\n  xrec         rel {e_x:.2e}")
+    print(f"  loss {loss.item():.6f} vs {ref['loss'].item():.6f}   qloss {m.logged['train/quant_loss'].item():.6f} vs {ref['qloss'].item():.6f}")
+    print(f"  code match-rate end-to-end {match_e2e:.4f}   at the op boundary (identical h) {match_ob:.6f}   distinct codes used {ref_idx.unique().numel()}")
+    print(f"  gradients: median rel {np.median(list(errs.values())):.2e}, worst {worst} {errs[worst]:.2e}")
+    assert set(errs) == set(ref["grads"])
+    assert match_ob == 1.0, "indices must be bit-exact for identical quantizer input"
+    assert max(e for _, e in rows) <= stream_tol, rows
+    assert e_h <= h_tol and e_x <= xrec_tol
+    assert abs(loss.item() - ref["loss"].item()) <= 1e-2 * abs(ref["loss"].item())
+    assert match_e2e >= match_min
+    assert errs[worst] <= grad_tol, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+
+
+def test_base_config2_bf16_vs_oracle():
+    """BASELINE config 2: imagenet_vitvq_base.yaml towers — the configuration bench.py times."""
+    _run_case("imagenet_vitvq_base (config 2)", BASE, 2, 0)
+
+
+def test_base_rq4_config4_bf16_vs_oracle():
+    """BASELINE config 4: RQ-VAE base, ResidualQuantizer depth 4, one shared codebook."""
+    cfg = copy.deepcopy(BASE)
+    cfg["quantizer"].update(use_residual=True, num_quantizers=4)
+    _run_case("imagenet_rqvae_base (config 4)", cfg, 2, 3)
+
+
+def test_large_config5_towers_bf16_vs_oracle():
+    """BASELINE config 5 towers: imagenet_vitvq_large.yaml (encoder 512/8/8/2048, decoder 1280/32/16/5120), AE step only."""
+    _run_case("imagenet_vitvq_large towers (config 5)", LARGE, 1, 5)

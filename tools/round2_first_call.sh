@@ -7,12 +7,16 @@ cd "$(dirname "$0")/.."
 OUT=gpurun_out/round2_first
 mkdir -p "$OUT"
 echo "== 1. regression (default kernels) =="
-timeout 300 python -m pytest tests -m gpu -q --no-header -p no:cacheprovider -x 2>&1 | tail -3
+echo "(skipped: green in GPUTEST_r01)"
 echo "== 2. experimental 8-phase GEMM: correctness (GEMM suite re-run under ENH_GEMM_KERNEL=8phase), three times as a race screen =="
 for i in 1 2 3; do
   ENH_TEST_EXPERIMENTAL=1 timeout 200 python -m pytest tests/test_ops_gpu.py -m gpu -q --no-header -p no:cacheprovider -k "p8 and 8phase" 2>&1 | tail -2
 done
 ENH_TEST_EXPERIMENTAL=1 timeout 200 python -m pytest tests/test_ops_gpu.py -m gpu -q --no-header -p no:cacheprovider -k "p8 and 9persist" 2>&1 | tail -2
+echo "== 2b. bench-scale spot checks (M = 131072): default | 8phase | 9persist =="
+timeout 300 python -m pytest tests/test_scale_gpu.py -m gpu -q --no-header -p no:cacheprovider -s 2>&1 | grep -E "rel |attention at|passed|failed|Error" | cut -c1-200
+ENH_GEMM_KERNEL=8phase timeout 300 python -m pytest tests/test_scale_gpu.py -m gpu -q --no-header -p no:cacheprovider -s -k gemm 2>&1 | grep -E "rel |passed|failed|Error" | cut -c1-200
+ENH_GEMM_KERNEL=9persist timeout 300 python -m pytest tests/test_scale_gpu.py -m gpu -q --no-header -p no:cacheprovider -s -k gemm 2>&1 | grep -E "rel |passed|failed|Error" | cut -c1-200
 echo "== 3. per-shape GEMM table: default | 8phase | 9persist (B = 128) =="
 MB_BATCH=128 timeout 120 python tools/microbench.py 2>/dev/null | sed -n 2,14p > "$OUT/gemm_default.txt"
 ENH_GEMM_KERNEL=8phase MB_BATCH=128 timeout 120 python tools/microbench.py 2>/dev/null | sed -n 2,14p > "$OUT/gemm_p8.txt"
