@@ -36,7 +36,7 @@ def build(L, Q, case, seed):
 
 def fingerprint(sd):
     names = sorted(sd)
-    fp = np.array([[sd[n].double().sum().item(), (sd[n].double() ** 2).sum().item(), *sd[n].flatten()[:4].double().tolist()] for n in names])
+    fp = np.array([[sd[n].double().sum().item(), (sd[n].double() ** 2).sum().item(), *(sd[n].flatten()[:4].double().tolist() + [0.0] * 4)[:4]] for n in names])
     return names, fp
 
 
