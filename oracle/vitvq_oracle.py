@@ -151,13 +151,15 @@ def vq_distances(zn: Tensor, en: Tensor) -> Tensor:
     return torch.sum(zn ** 2, dim=1, keepdim=True) + torch.sum(en ** 2, dim=1) - 2 * torch.einsum("bd,nd->bn", zn, en)
 
 
-def vq_quantize(z: Tensor, E: Tensor, beta: float = 0.25, use_norm: bool = True) -> Tuple[Tensor, Tensor, Tensor]:
-    """VectorQuantizer.quantize quantizers.py:74-92 -> (z_qnorm, loss, indices[z.shape[:-1]] int64)."""
+def vq_quantize(z: Tensor, E: Tensor, beta: float = 0.25, use_norm: bool = True, force_idx: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
+    """VectorQuantizer.quantize quantizers.py:74-92 -> (z_qnorm, loss, indices[z.shape[:-1]] int64).
+    ``force_idx`` (test aid): skip the argmin and use the given indices, so that a mixed-precision path and this fp32 restatement
+    can be compared downstream of the SAME discrete decisions (arithmetic error separated from near-tie index flips)."""
     norm = l2norm if use_norm else (lambda t: t)
     d_e = E.shape[1]
     zn = norm(z.reshape(-1, d_e))
     en = norm(E)
-    idx = torch.argmin(vq_distances(zn, en), dim=1).view(*z.shape[:-1])
+    idx = torch.argmin(vq_distances(zn, en), dim=1).view(*z.shape[:-1]) if force_idx is None else force_idx.view(*z.shape[:-1])
     zq = F.embedding(idx, E).view(z.shape)
     zqn, zn2 = norm(zq), norm(z)
     loss = beta * torch.mean((zqn.detach() - zn2) ** 2) + torch.mean((zqn - zn2.detach()) ** 2)
@@ -165,16 +167,16 @@ def vq_quantize(z: Tensor, E: Tensor, beta: float = 0.25, use_norm: bool = True)
 
 
 def quantizer_forward(z: Tensor, E: Tensor, beta: float = 0.25, use_norm: bool = True,
-                      use_residual: bool = False, num_quantizers: Optional[int] = None):
-    """BaseQuantizer.forward quantizers.py:38-63 (residual loop + straight-through)."""
+                      use_residual: bool = False, num_quantizers: Optional[int] = None, force_idx: Optional[Tensor] = None):
+    """BaseQuantizer.forward quantizers.py:38-63 (residual loop + straight-through).  force_idx: see vq_quantize ([..., depth] if residual)."""
     if not use_residual:
-        z_q, loss, idx = vq_quantize(z, E, beta, use_norm)
+        z_q, loss, idx = vq_quantize(z, E, beta, use_norm, force_idx)
     else:
         z_q = torch.zeros_like(z)
         residual = z.detach().clone()
         losses, idxs = [], []
-        for _ in range(num_quantizers):
-            z_qi, l_i, i_i = vq_quantize(residual.clone(), E, beta, use_norm)
+        for d_ in range(num_quantizers):
+            z_qi, l_i, i_i = vq_quantize(residual.clone(), E, beta, use_norm, None if force_idx is None else force_idx[..., d_])
             residual.sub_(z_qi)          # in place, as quantizers.py:50 (creates the cross-depth grad path)
             z_q.add_(z_qi)
             idxs.append(i_i)
@@ -364,13 +366,13 @@ TINY_CFG = dict(image_size=64, patch_size=8,
                 quantizer=dict(embed_dim=32, n_embed=512))
 
 
-def train_step_traced(img: Tensor, P: Dict[str, Tensor], cfg: dict, loss_kw: Optional[dict] = None) -> dict:
+def train_step_traced(img: Tensor, P: Dict[str, Tensor], cfg: dict, loss_kw: Optional[dict] = None, force_idx: Optional[Tensor] = None) -> dict:
     """train_step_grads plus every intermediate a per-layer parity table needs (test aid): the residual stream entering / leaving
     each encoder and decoder layer, h (quantizer input), z_q, indices, xrec, loss, gradients.  Same arithmetic as forward()."""
     leaves = {k: v.detach().clone().requires_grad_(not k.endswith("pos_embedding")) for k, v in P.items()}
     enc_tr, dec_tr = [], []
     h = encoder(img, leaves, cfg, trace=enc_tr) @ leaves["pre_quant.weight"].t() + leaves["pre_quant.bias"]
-    quant, qloss, idx = quantizer_forward(h, leaves["quantizer.embedding.weight"], **qparams(cfg))
+    quant, qloss, idx = quantizer_forward(h, leaves["quantizer.embedding.weight"], force_idx=force_idx, **qparams(cfg))
     xrec = decoder(quant @ leaves["post_quant.weight"].t() + leaves["post_quant.bias"], leaves, cfg, trace=dec_tr)
     loss, log = pixel_codebook_loss(qloss, img, xrec, **(loss_kw or {}))
     loss.backward()

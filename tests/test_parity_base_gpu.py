@@ -12,7 +12,9 @@ What is reported (printed as a table per test; `pytest -s` shows it, the numbers
 Tolerances.  north_star asks 1e-3 rel for bf16 activations.  Rounding an exact tensor to bf16 already costs 1.66e-3
 (util.bf16_floor), so that bound is unreachable for any quantity that passes through a bf16-stored GEMM operand; the bounds
 asserted here are the measured errors of this path at these sizes x ~1.5 (see the constants), i.e. regression bounds — the
-fp32 exact mode (test_model_gpu.py::test_exact_mode_*) is the instrument that meets 1e-3 (4e-7 measured).
+activations / gradients are compared with the oracle run DOWNSTREAM OF THE SAME CODES (oracle `force_idx`), so that arithmetic
+error is not mixed with the O(1) effect of a flipped near-tie index; the freely-run oracle gives the end-to-end match-rate and the
+"incl. index flips" reconstruction error.  The fp32 exact mode (test_model_gpu.py::test_exact_mode_*) is the instrument that meets 1e-3 (4e-7 measured).
 """
 import copy
 
@@ -30,10 +32,12 @@ LARGE = dict(image_size=256, patch_size=8, encoder=dict(dim=512, depth=8, heads=
              decoder=dict(dim=1280, depth=32, heads=16, mlp_dim=5120), quantizer=dict(embed_dim=32, n_embed=8192))
 
 # regression bounds (measured on MI355X, round 2 — see DESIGN.md §4 for the table they come from)
-STREAM_TOL = 1.5e-2     # residual stream after any layer
-H_TOL, XREC_TOL = 2e-2, 3e-2
-GRAD_TOL = 6e-2         # worst parameter gradient
-MATCH_MIN = 0.80        # end-to-end code match-rate (bf16 h vs fp32 h feeding an 8192-way argmin)
+# measured (profiles/r02_parity_base_configs.txt): stream <= 5.4e-3 (saturating with depth), h 5.7e-3, xrec 6.1e-3, gradients <= 9.6e-3,
+# end-to-end match-rate 0.967 .. 0.981, op-boundary match-rate 1.0
+STREAM_TOL = 8e-3       # residual stream after any layer, oracle downstream of the same codes
+H_TOL, XREC_TOL = 9e-3, 1e-2
+GRAD_TOL = 1.5e-2       # worst parameter gradient
+MATCH_MIN = 0.95        # end-to-end code match-rate (bf16-operand h vs fp32 h feeding an 8192-way argmin)
 
 
 def _build(cfg, P):
@@ -56,11 +60,23 @@ def _run_case(label, cfg, B, seed, tols=None):
     x = O.make_images(seed + 1, B, cfg["image_size"])
     m = _build(cfg, P)
     eng = m.engine
-    loss = m.training_step({"image": x}, 0, 0)
+    out = eng.forward_backward(x, w_l1=0.0, w_l2=1.0, codebook_weight=1.0)   # = ViTVQ.training_step(optimizer_idx=0) with this loss config
     torch.cuda.synchronize()
-    ref = O.train_step_traced(x, P, cfg)
+    loss = out["loss"]
     M = B * eng.n_tok
     io = eng._io_bufs(B)
+    codes = (out["indices"].view(B, eng.n_tok, -1) if eng.q.use_residual else out["indices"].view(B, eng.n_tok)).cpu()
+    # (1) the oracle run freely: end-to-end match-rate and reconstruction error INCLUDING near-tie index flips
+    with torch.no_grad():
+        o_q, o_ql, o_idx, o_h = O.encode(x, P, cfg)
+        o_xrec_free = O.decode(o_q, P, cfg)
+    match_e2e = (codes == o_idx).float().mean().item()
+    e_x_free = rel(io["xrec"], o_xrec_free)
+    # (2) op boundary: the oracle's quantizer on the HIP path's own h -> every index must be bit-exact
+    _, _, idx_ob = O.quantizer_forward(io["h"].cpu().view(B, eng.n_tok, -1), P["quantizer.embedding.weight"], **O.qparams(cfg))
+    match_ob = (codes == idx_ob).float().mean().item()
+    # (3) the oracle's training step downstream of the SAME discrete codes: pure arithmetic error of activations and gradients
+    ref = O.train_step_traced(x, P, cfg, force_idx=codes)
     rows = []
     for name, tower, tr in (("enc", eng.enc, ref["enc_trace"]), ("dec", eng.dec, ref["dec_trace"])):
         xs = tower.bufs(B, True)["x"]
@@ -68,22 +84,21 @@ def _run_case(label, cfg, B, seed, tols=None):
         for i, t in enumerate(tr):
             rows.append((f"{name}.x[{i}]", rel(xs[i], t.reshape(M, -1))))
     e_h, e_x = rel(io["h"], ref["h"].reshape(M, -1)), rel(io["xrec"], ref["xrec"])
-    codes = eng.encode_codes(x).cpu()   # no-grad path: same kernels, no saved activations
-    ref_idx = ref["idx"]
-    match_e2e = (codes == ref_idx).float().mean().item()
-    # op boundary: the oracle's quantizer on the HIP path's own h
-    h_gpu = eng._pre_quant(eng._encode_tokens(eng._check_img(x), save=False)["xf16"], B).clone()
-    _, _, idx_ob = O.quantizer_forward(h_gpu.cpu().view(B, eng.n_tok, -1), P["quantizer.embedding.weight"], **O.qparams(cfg))
-    match_ob = (codes == idx_ob).float().mean().item()
     errs = {k: rel(p.grad, ref["grads"][k]) for k, p in m.named_parameters() if k in ref["grads"]}
     worst = max(errs, key=errs.get)
-    print(f"\n== {label}: B={B}, bf16 MFMA operands vs fp32 CPU oracle ==")
-    for n, e in rows:
-        print(f"  {n:12s} rel {e:.2e}")
-    print(f"  h            rel {e_h:.2e}\n  xrec         rel {e_x:.2e}")
-    print(f"  loss {loss.item():.6f} vs {ref['loss'].item():.6f}   qloss {m.logged['train/quant_loss'].item():.6f} vs {ref['qloss'].item():.6f}")
-    print(f"  code match-rate end-to-end {match_e2e:.4f}   at the op boundary (identical h) {match_ob:.6f}   distinct codes used {ref_idx.unique().numel()}")
-    print(f"  gradients: median rel {np.median(list(errs.values())):.2e}, worst {worst} {errs[worst]:.2e}")
+    lines = [f"== {label}: B={B}, bf16 MFMA operands vs fp32 CPU oracle =="]
+    lines += [f"  {n:12s} rel {e:.2e}" for n, e in rows]
+    lines += [f"  h            rel {e_h:.2e}", f"  xrec         rel {e_x:.2e}  (same codes)   {e_x_free:.2e} (oracle run freely, incl. index flips)",
+              f"  loss {loss.item():.6f} vs {ref['loss'].item():.6f}   qloss {out['quant_loss'].item():.6f} vs {ref['qloss'].item():.6f}",
+              f"  code match-rate end-to-end {match_e2e:.4f}   at the op boundary (identical h) {match_ob:.6f}   distinct codes used {o_idx.unique().numel()}",
+              f"  gradients (same codes): median rel {np.median(list(errs.values())):.2e}, worst {worst} {errs[worst]:.2e}",
+              "  worst five: " + ", ".join(f"{k} {v:.1e}" for k, v in sorted(errs.items(), key=lambda kv: -kv[1])[:5])]
+    print("\n" + "\n".join(lines))
+    import os
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "parity_base.txt"), "a") as f:
+            f.write("\n".join(lines) + "\n")
     assert set(errs) == set(ref["grads"])
     assert match_ob == 1.0, "indices must be bit-exact for identical quantizer input"
     assert max(e for _, e in rows) <= stream_tol, rows
