@@ -25,15 +25,14 @@ STEP_TFLOP_PER_IMG_BASE = 1.279      # 1 fwd + 1 bwd = 3x forward
 MFMA_BF16_PEAK_TFLOPS = 2500.0       # dense, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def cpu_baseline(max_seconds: float = 25.0):
-    """CPU oracle (port of the reference's PyTorch path) timed on the host cores: base config, batch 4."""
+def cpu_baseline(max_seconds: float = 40.0):
+    """CPU oracle (port of the reference's PyTorch path) timed on the host cores: base config, batch 2, fwd + bwd + AdamW in fp32.
+    The torch thread count is swept ONCE (one step per candidate) and recorded; the value is the MEDIAN of >= 3 post-warm-up steps at
+    the best count."""
+    import statistics
     import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import vitvq_oracle as O
-    # 256 torch threads on the 2-socket GPU host are pathologically slow for this op mix (measured: 355 s per batch-4
-    # step), so the baseline uses 32 threads — the count is reported in "cores"
-    cores = min(os.cpu_count() or 1, int(os.environ.get("ENH_CPU_BASELINE_THREADS", "32")))
-    torch.set_num_threads(cores)
     cfg = dict(image_size=256, patch_size=8, encoder=dict(dim=768, depth=12, heads=12, mlp_dim=3072),
                decoder=dict(dim=768, depth=12, heads=12, mlp_dim=3072), quantizer=dict(embed_dim=32, n_embed=8192))
     B = 2
@@ -41,19 +40,66 @@ def cpu_baseline(max_seconds: float = 25.0):
     m = {k: torch.zeros_like(v) for k, v in P.items()}
     v = {k: torch.zeros_like(v_) for k, v_ in P.items()}
     x = O.make_images(0, B, 256)
-    times, t_begin, step = [], time.time(), 0
-    while True:
-        step += 1
+    state = {"step": 0}
+
+    def one_step():
+        state["step"] += 1
         t0 = time.time()
         _, _, grads, _ = O.train_step_grads(x, P, cfg)
         for k, g in grads.items():
-            O.adamw_step(P[k], g, m[k], v[k], step, 4.5e-6)
-        times.append(time.time() - t0)
-        if step >= 2 or time.time() - t_begin > max_seconds:
+            O.adamw_step(P[k], g, m[k], v[k], state["step"], 4.5e-6)
+        return time.time() - t0
+
+    ncpu = os.cpu_count() or 1
+    env = os.environ.get("ENH_CPU_BASELINE_THREADS")
+    # all hardware threads of the 2-socket GPU host are pathologically slow for this op mix (measured in round 1: 355 s per batch-4
+    # step at 256 threads), so the sweep covers the moderate counts only
+    cands = [int(env)] if env else sorted({c for c in (16, 32, 64) if c <= ncpu} or {ncpu})
+    t_begin, sweep = time.time(), {}
+    torch.set_num_threads(cands[0])
+    one_step()  # warm-up (allocator, thread pool)
+    for c in cands:
+        torch.set_num_threads(c)
+        sweep[c] = one_step()
+        if time.time() - t_begin > max_seconds * 0.5:
             break
-    best = min(times[1:]) if len(times) > 1 else times[0]
-    return {"value": B / best, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{len(times)} AE train steps (fwd+bwd+AdamW, fp32) of ViT-VQGAN-base at batch {B}; best of the post-warm-up steps"}
+    cores = min(sweep, key=sweep.get)
+    torch.set_num_threads(cores)
+    times = []
+    while len(times) < 3 or (len(times) < 5 and time.time() - t_begin < max_seconds * 0.8):
+        times.append(one_step())
+    med = statistics.median(times)
+    return {"value": B / med, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"median of {len(times)} post-warm-up AE train steps (fwd+bwd+AdamW, fp32) of ViT-VQGAN-base at batch {B}; "
+                      f"thread sweep (s/step): {', '.join(f'{c}: {t:.2f}' for c, t in sweep.items())}",
+            "step_seconds": [round(t, 3) for t in times]}
+
+
+def vq_match_rate(h_dev, idx_dev, codebook_dev, depth: int, use_residual: bool):
+    """Second half of BASELINE.json's metric: the VQ argmin match-rate at the OP BOUNDARY — the quantizer input h the timed step just
+    produced on the GPU (M = per-GPU batch x 1024 tokens), quantized by the reference's formula on the host (oracle, the checker) vs the
+    indices the HIP kernel produced for the same h.  Any mismatch is audited as an fp32 near-tie (top-2 distance gap < 1e-6 in fp64),
+    SURVEY.md §8(d) metric 2."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import vitvq_oracle as O
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    h, idx, E = h_dev.detach().float().cpu(), idx_dev.detach().cpu().view(h_dev.shape[0], -1), codebook_dev.detach().float().cpu()
+    M, mism, worst_gap = h.shape[0], 0, 0.0
+    for s in range(0, M, 16384):
+        zz = h[s:s + 16384]
+        _, _, it = O.quantizer_forward(zz, E, 0.25, True, use_residual, depth if use_residual else None)
+        it = it.view(zz.shape[0], -1)
+        bad = (it != idx[s:s + 16384]).any(dim=1).nonzero().view(-1)
+        mism += len(bad)
+        if not use_residual:
+            en = torch.nn.functional.normalize(E.double(), dim=-1)
+            for j in bad.tolist()[:64]:
+                zn = torch.nn.functional.normalize(zz[j:j + 1].double(), dim=-1)
+                d = ((zn ** 2).sum(1, keepdim=True) + (en ** 2).sum(1) - 2 * zn @ en.t()).view(-1)
+                worst_gap = max(worst_gap, (d[it[j, 0]] - d[idx[s + j, 0]]).abs().item())
+    return {"value": 1.0 - mism / M, "tokens": M, "mismatches": mism, "worst_mismatch_gap_fp64": worst_gap,
+            "boundary": "identical quantizer input h (from the timed step's last batch); HIP indices vs the reference formula on the host"}
 
 
 def main():
@@ -152,7 +198,7 @@ def main():
             traffic = None
     is_base = args.config == "imagenet_vitvq_base"
     res = {
-        "metric": "images/sec ViT-VQGAN-base 256px stage-1 train" if is_base else f"images/sec {args.config} 256px stage-1 train",
+        "metric": "images/sec ViT-VQGAN-base 256px stage-1 train; VQ argmin match-rate" if is_base else f"images/sec {args.config} 256px stage-1 train",
         "value": round(img_per_s, 2), "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
@@ -172,6 +218,12 @@ def main():
                     for k, v in sorted(ks.items())},
     }
     if world == 1 and not args.no_cpu_baseline:
+        # checker legs (oracle on the host cores): the argmin match-rate on the h of the last timed step, then the CPU baseline
+        if "h" in out and "indices" in out:
+            q = model.quantizer
+            mr = vq_match_rate(out["h"], out["indices"], eng.store.w["quantizer.embedding.weight"], q.depth, bool(q.use_residual))
+            res["vq_match_rate"] = mr["value"]
+            res["vq_match"] = mr
         res["cpu_baseline"] = cpu_baseline()
     print(json.dumps(res), flush=True)
     if world > 1:

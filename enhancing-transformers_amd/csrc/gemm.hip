@@ -9,7 +9,9 @@
 // index is the slow storage index are staged as-is and read from LDS with the hardware transpose read
 // ds_read_b64_tr_b16 (semantics verified on MI355X, profiles/hw_probe_r01.txt).
 //
-// Kernel families (enh_gemm_bf16_variant() reports the per-shape choice; ENH_GEMM_KERNEL = reg | pipe2 | t256 overrides):
+// Kernel families (enh_gemm_bf16_variant() reports the per-shape choice; enh_gemm_set_kernel() overrides it):
+//   gemm_bf16_w256_kernel   256x256x64 tile, 4 waves (2x2, each 4x4 v_mfma_f32_32x32x16_bf16 = 128x128, one wave per SIMD), round 2; every shape
+//                           with M, N multiples of 256 that fills the chip (with split-K if needed).
 //   gemm_bf16_pipe2_kernel  128x128x64 tile, 4 waves (2x2, each 4x4 v_mfma_f32_16x16x32_bf16), two 32-KiB LDS stages filled by
 //                           global_load_lds, K-loop software-pipelined around one mid-iteration barrier; 2 workgroups per CU.  Default.
 //   gemm_bf16_t256_kernel   256x256x64 tile, 8 waves (2x4, each 4x2 v_mfma_f32_32x32x16_bf16), two 64-KiB stages, staggered two-group
@@ -47,7 +49,8 @@ struct GemmArgs {
   int64_t k_per_split;  // multiple of G_BK
   const float* bias; int act; const uint16_t* aux; int64_t ldaux;
   const float* res; int64_t ldres; int64_t res_rows;
-  int accumulate;       // 1: += C_old ; 2: split-K partial -> f32 atomicAdd into c_f32
+  int accumulate;       // 1: += C_old ; 2: split-K partial -> f32 atomicAdd into c_f32 ; 3: split-K partial -> workspace slab (two-pass, deterministic)
+  float* ws;            // split-K workspace [splits][M][N] f32 (accumulate == 3)
   float* c_f32; uint16_t* c_bf16; int64_t ldc;
   int nbm, nbn;
   int splits;  // number of K-slices (1 = no split-K; otherwise a multiple of 8)
@@ -105,49 +108,120 @@ __device__ __forceinline__ s16x8 tile_frag(const unsigned char* tile, int base, 
   }
 }
 
-// ---- epilogue: lane (lg, l16) holds C[m = .. + l16][n = .. + lg*4 + 0..3] (MFMA issued with swapped operands) ----
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& args, f32x4 (&acc)[4][4], int64_t m0, int64_t n0, int wm, int wn,
-                                              int lg, int l16) {
+// ---- epilogue -----------------------------------------------------------------------------------------------
+// One body for every kernel: 4 consecutive output columns of one row.  The fused options (bias / tanh / tanh' / residual / accumulate / f32 and
+// bf16 stores / split-K partials) are RUNTIME arguments of the C ABI, but a kernel whose epilogue tests them per element pays for it: with one
+// wave per SIMD nothing hides the instruction fetch after each (wave-uniform) branch — the 256 x 256 kernel lost 19 us per tile, more than its
+// K loop at K = 768.  So the combinations the training step uses are compile-time MODES selected once per kernel; anything else takes the
+// generic (branchy) mode.
+enum { EPI_GENERIC = 0, EPI_BF16, EPI_BF16_BIAS_TANH, EPI_BF16_DTANH, EPI_F32_BIAS_RES, EPI_F32, EPI_WS, EPI_ATOMIC, EPI_NMODES };
+
+__host__ __device__ __forceinline__ int epi_mode(const GemmArgs& a) {
+  if (a.accumulate == 3) return EPI_WS;
+  if (a.accumulate == 2) return EPI_ATOMIC;
+  if (a.accumulate == 0) {
+    const bool only16 = a.c_bf16 && !a.c_f32, only32 = a.c_f32 && !a.c_bf16;
+    if (only16 && !a.bias && a.act == ENH_ACT_NONE && !a.res) return EPI_BF16;
+    if (only16 && a.bias && a.act == ENH_ACT_TANH && !a.res) return EPI_BF16_BIAS_TANH;
+    if (only16 && !a.bias && a.act == ENH_ACT_DTANH && !a.res) return EPI_BF16_DTANH;
+    if (only32 && a.bias && a.act == ENH_ACT_NONE && a.res) return EPI_F32_BIAS_RES;
+    if (only32 && !a.bias && a.act == ENH_ACT_NONE && !a.res) return EPI_F32;
+  }
+  return EPI_GENERIC;
+}
+
+// The operands an epilogue READS (residual / position row, saved tanh output, previous C) are fetched by epi_load for a whole group of
+// elements BEFORE any of them is consumed: a load issued and awaited per element exposes the full memory latency 64 times per wave.
+struct EpiIn { float4 res; float4 old; uint2 aux; };
+
+template <int MODE>
+__device__ __forceinline__ EpiIn epi_load(const GemmArgs& args, int64_t m, int64_t n) {
+  constexpr bool G = MODE == EPI_GENERIC;
+  EpiIn in;
+  in.res = make_float4(0.f, 0.f, 0.f, 0.f); in.old = in.res; in.aux = make_uint2(0u, 0u);
+  if (MODE == EPI_BF16_DTANH || (G && args.act == ENH_ACT_DTANH)) in.aux = *reinterpret_cast<const uint2*>(args.aux + m * args.ldaux + n);
+  if (MODE == EPI_F32_BIAS_RES || (G && args.res)) {
+    const int64_t mr = args.res_rows == args.M ? m : m % args.res_rows;   // residual stream (res_rows = M) or position table (row mod n_tokens)
+    in.res = *reinterpret_cast<const float4*>(args.res + mr * args.ldres + n);
+  }
+  if (G && args.accumulate == 1 && args.c_f32) in.old = *reinterpret_cast<const float4*>(args.c_f32 + m * args.ldc + n);
+  return in;
+}
+
+template <int MODE>
+__device__ __forceinline__ void epi4(const GemmArgs& args, float (&v)[4], const EpiIn& in, int64_t m, int64_t n, int split) {
+  constexpr bool G = MODE == EPI_GENERIC;
+  if (MODE == EPI_WS || (G && args.accumulate == 3)) {   // split-K partial -> workspace slab [split][M][N] (reduced by splitk_reduce_kernel in a fixed order)
+    const f32x4 o_ = {v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(args.ws + ((int64_t)split * args.M + m) * args.N + n) = o_;
+    return;
+  }
+  float* cp = (G ? args.c_f32 != nullptr : (MODE == EPI_F32_BIAS_RES || MODE == EPI_F32 || MODE == EPI_ATOMIC)) ? args.c_f32 + m * args.ldc + n : nullptr;
+  if (MODE == EPI_ATOMIC || (G && args.accumulate == 2)) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) atomicAdd(cp + r, v[r]);
+    return;
+  }
+  if (MODE == EPI_BF16_BIAS_TANH || MODE == EPI_F32_BIAS_RES || (G && args.bias)) {
+    const float4 b4 = *reinterpret_cast<const float4*>(args.bias + n);
+    v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+  }
+  if (MODE == EPI_BF16_BIAS_TANH || (G && args.act == ENH_ACT_TANH)) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
+  } else if (MODE == EPI_BF16_DTANH || (G && args.act == ENH_ACT_DTANH)) {
+    const float h0 = bf16_bits_to_f32((uint16_t)(in.aux.x & 0xffffu)), h1 = bf16_bits_to_f32((uint16_t)(in.aux.x >> 16));
+    const float h2 = bf16_bits_to_f32((uint16_t)(in.aux.y & 0xffffu)), h3 = bf16_bits_to_f32((uint16_t)(in.aux.y >> 16));
+    v[0] *= 1.f - h0 * h0; v[1] *= 1.f - h1 * h1; v[2] *= 1.f - h2 * h2; v[3] *= 1.f - h3 * h3;
+  }
+  if (MODE == EPI_F32_BIAS_RES || (G && args.res)) { v[0] += in.res.x; v[1] += in.res.y; v[2] += in.res.z; v[3] += in.res.w; }
+  if (G && args.accumulate == 1 && cp) { v[0] += in.old.x; v[1] += in.old.y; v[2] += in.old.z; v[3] += in.old.w; }
+  if (cp) { const f32x4 o_ = {v[0], v[1], v[2], v[3]}; if (ENH_NT_EPILOGUE) __builtin_nontemporal_store(o_, reinterpret_cast<f32x4*>(cp)); else *reinterpret_cast<f32x4*>(cp) = o_; }
+  if (MODE == EPI_BF16 || MODE == EPI_BF16_BIAS_TANH || MODE == EPI_BF16_DTANH || (G && args.c_bf16)) {
+    const u32x2 o_ = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    if (ENH_NT_EPILOGUE) __builtin_nontemporal_store(o_, reinterpret_cast<u32x2*>(args.c_bf16 + m * args.ldc + n)); else *reinterpret_cast<u32x2*>(args.c_bf16 + m * args.ldc + n) = o_;
+  }
+}
+
+// run LOOPS<MODE>(...) with the mode chosen once (wave-uniform switch)
+#define EPI_DISPATCH(CALL)                                                     \
+  do {                                                                         \
+    switch (epi_mode(args)) {                                                  \
+      case EPI_BF16: { constexpr int EM = EPI_BF16; CALL; } break;             \
+      case EPI_BF16_BIAS_TANH: { constexpr int EM = EPI_BF16_BIAS_TANH; CALL; } break; \
+      case EPI_BF16_DTANH: { constexpr int EM = EPI_BF16_DTANH; CALL; } break; \
+      case EPI_F32_BIAS_RES: { constexpr int EM = EPI_F32_BIAS_RES; CALL; } break; \
+      case EPI_F32: { constexpr int EM = EPI_F32; CALL; } break;               \
+      case EPI_WS: { constexpr int EM = EPI_WS; CALL; } break;                 \
+      case EPI_ATOMIC: { constexpr int EM = EPI_ATOMIC; CALL; } break;         \
+      default: { constexpr int EM = EPI_GENERIC; CALL; } break;                \
+    }                                                                          \
+  } while (0)
+
+// 16x16 accumulator layout (pipe2 / fallback): lane (lg, l16) holds C[m = .. + l16][n = .. + lg*4 + 0..3] (MFMA issued with swapped operands)
+template <int MODE>
+__device__ __forceinline__ void gemm_epilogue_loops(const GemmArgs& args, f32x4 (&acc)[4][4], int64_t m0, int64_t n0, int wm, int wn, int lg, int l16, int split) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int64_t m = m0 + wm * 64 + i * 16 + l16;
     if (m >= args.M) continue;
+    EpiIn in[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int64_t n = n0 + wn * 64 + j * 16 + lg * 4;
-      if (n >= args.N) continue;  // N % 4 == 0: the 4 columns are in or out together
+      if (n < args.N) in[j] = epi_load<MODE>(args, m, n);  // N % 4 == 0: the 4 columns are in or out together
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t n = n0 + wn * 64 + j * 16 + lg * 4;
+      if (n >= args.N) continue;
       float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      float* cp = args.c_f32 ? args.c_f32 + m * args.ldc + n : nullptr;
-      if (args.accumulate == 2) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) atomicAdd(cp + r, v[r]);
-        continue;
-      }
-      if (args.bias) {
-        const float4 b4 = *reinterpret_cast<const float4*>(args.bias + n);
-        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-      }
-      if (args.act == ENH_ACT_TANH) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
-      } else if (args.act == ENH_ACT_DTANH) {
-        const uint2 a2 = *reinterpret_cast<const uint2*>(args.aux + m * args.ldaux + n);
-        const float h0 = bf16_bits_to_f32((uint16_t)(a2.x & 0xffffu)), h1 = bf16_bits_to_f32((uint16_t)(a2.x >> 16));
-        const float h2 = bf16_bits_to_f32((uint16_t)(a2.y & 0xffffu)), h3 = bf16_bits_to_f32((uint16_t)(a2.y >> 16));
-        v[0] *= 1.f - h0 * h0; v[1] *= 1.f - h1 * h1; v[2] *= 1.f - h2 * h2; v[3] *= 1.f - h3 * h3;
-      }
-      if (args.res) {
-        const float4 r4 = *reinterpret_cast<const float4*>(args.res + (m % args.res_rows) * args.ldres + n);
-        v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
-      }
-      if (args.accumulate == 1 && cp) {
-        const float4 o4 = *reinterpret_cast<const float4*>(cp);
-        v[0] += o4.x; v[1] += o4.y; v[2] += o4.z; v[3] += o4.w;
-      }
-      if (cp) { const f32x4 o_ = {v[0], v[1], v[2], v[3]}; if (ENH_NT_EPILOGUE) __builtin_nontemporal_store(o_, reinterpret_cast<f32x4*>(cp)); else *reinterpret_cast<f32x4*>(cp) = o_; }
-      if (args.c_bf16) { const u32x2 o_ = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])}; if (ENH_NT_EPILOGUE) __builtin_nontemporal_store(o_, reinterpret_cast<u32x2*>(args.c_bf16 + m * args.ldc + n)); else *reinterpret_cast<u32x2*>(args.c_bf16 + m * args.ldc + n) = o_; }
+      epi4<MODE>(args, v, in[j], m, n, split);
     }
   }
+}
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& args, f32x4 (&acc)[4][4], int64_t m0, int64_t n0, int wm, int wn, int lg, int l16, int split) {
+  EPI_DISPATCH((gemm_epilogue_loops<EM>(args, acc, m0, n0, wm, wn, lg, l16, split)));
 }
 
 // tile scheduling shared by both kernels
@@ -232,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs args) 
     __syncthreads();
   }
 
-  gemm_epilogue(args, acc, m0, n0, wm, wn, lg, l16);
+  gemm_epilogue(args, acc, m0, n0, wm, wn, lg, l16, split);
 }
 
 
@@ -378,7 +452,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_pipe2_kernel(const GemmArgs 
 #undef P2_ISSUE
 #undef P2_READ
 #undef P2_MMA
-  gemm_epilogue(args, acc, m0, n0, wm, wn, lg, l16);
+  gemm_epilogue(args, acc, m0, n0, wm, wn, lg, l16, split);
 }
 
 
@@ -429,52 +503,37 @@ __device__ __forceinline__ s16x8 frag32(const unsigned char* tile, int base, int
   }
 }
 
-// epilogue for the swapped 32x32 accumulator layout: acc[i][j][r] = C[m0 + i*32 + (lane&31)][n0 + j*32 + 8*(r>>2) + 4*(lane>>5) + (r&3)]
-__device__ __forceinline__ void gemm_epilogue32(const GemmArgs& args, f32x16 (&acc)[4][2], int64_t mw, int64_t nw, int lane) {
+// epilogue for the swapped 32x32 accumulator layout: acc[i][j][r] = C[mw + i*32 + (lane&31)][nw + j*32 + 8*(r>>2) + 4*(lane>>5) + (r&3)]
+template <int MODE, int NJ, bool BOUNDS>
+__device__ __forceinline__ void gemm_epilogue32_loops(const GemmArgs& args, f32x16 (&acc)[4][NJ], int64_t mw, int64_t nw, int lane, int split) {
   const int l31 = lane & 31, hi = lane >> 5;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int64_t m = mw + i * 32 + l31;
-    if (m >= args.M) continue;
+    if (BOUNDS && m >= args.M) continue;
+    EpiIn in[NJ][4];   // one row-block's inputs (residual / aux / old C) are all requested before the first one is used
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         const int64_t n = nw + j * 32 + 8 * g4 + 4 * hi;
-        if (n >= args.N) continue;
+        if (!BOUNDS || n < args.N) in[j][g4] = epi_load<MODE>(args, m, n);
+      }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int64_t n = nw + j * 32 + 8 * g4 + 4 * hi;
+        if (BOUNDS && n >= args.N) continue;
         float v[4] = {acc[i][j][g4 * 4 + 0], acc[i][j][g4 * 4 + 1], acc[i][j][g4 * 4 + 2], acc[i][j][g4 * 4 + 3]};
-        float* cp = args.c_f32 ? args.c_f32 + m * args.ldc + n : nullptr;
-        if (args.accumulate == 2) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) atomicAdd(cp + r, v[r]);
-          continue;
-        }
-        if (args.bias) {
-          const float4 b4 = *reinterpret_cast<const float4*>(args.bias + n);
-          v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-        }
-        if (args.act == ENH_ACT_TANH) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
-        } else if (args.act == ENH_ACT_DTANH) {
-          const uint2 a2 = *reinterpret_cast<const uint2*>(args.aux + m * args.ldaux + n);
-          const float h0 = bf16_bits_to_f32((uint16_t)(a2.x & 0xffffu)), h1 = bf16_bits_to_f32((uint16_t)(a2.x >> 16));
-          const float h2 = bf16_bits_to_f32((uint16_t)(a2.y & 0xffffu)), h3 = bf16_bits_to_f32((uint16_t)(a2.y >> 16));
-          v[0] *= 1.f - h0 * h0; v[1] *= 1.f - h1 * h1; v[2] *= 1.f - h2 * h2; v[3] *= 1.f - h3 * h3;
-        }
-        if (args.res) {
-          const float4 r4 = *reinterpret_cast<const float4*>(args.res + (m % args.res_rows) * args.ldres + n);
-          v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
-        }
-        if (args.accumulate == 1 && cp) {
-          const float4 o4 = *reinterpret_cast<const float4*>(cp);
-          v[0] += o4.x; v[1] += o4.y; v[2] += o4.z; v[3] += o4.w;
-        }
-        if (cp) { const f32x4 o_ = {v[0], v[1], v[2], v[3]}; if (ENH_NT_EPILOGUE) __builtin_nontemporal_store(o_, reinterpret_cast<f32x4*>(cp)); else *reinterpret_cast<f32x4*>(cp) = o_; }
-        if (args.c_bf16) { const u32x2 o_ = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])}; if (ENH_NT_EPILOGUE) __builtin_nontemporal_store(o_, reinterpret_cast<u32x2*>(args.c_bf16 + m * args.ldc + n)); else *reinterpret_cast<u32x2*>(args.c_bf16 + m * args.ldc + n) = o_; }
+        epi4<MODE>(args, v, in[j][g4], m, n, split);
       }
     }
   }
+}
+template <int NJ, bool BOUNDS>   // BOUNDS = false: the kernel only runs shapes that are whole tiles (a per-element range check is 64 more branches per wave)
+__device__ __forceinline__ void gemm_epilogue32(const GemmArgs& args, f32x16 (&acc)[4][NJ], int64_t mw, int64_t nw, int lane, int split) {
+  EPI_DISPATCH((gemm_epilogue32_loops<EM, NJ, BOUNDS>(args, acc, mw, nw, lane, split)));
 }
 
 template <bool TA, bool TB>
@@ -609,391 +668,245 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_t256_kernel(const GemmArgs a
 #undef T4_MMA
 #undef T4_FENCE
 #undef T4_WAIT_LDS
-  gemm_epilogue32(args, acc, m0 + wm * 128, n0 + wn * 64, lane);
+  gemm_epilogue32<2, true>(args, acc, m0 + wm * 128, n0 + wn * 64, lane, split);
 }
 
 // =================================================================================================
-// "p8" (EXPERIMENTAL — written after round 1's GPU budget was spent: compiles for gfx950, NOT yet run; reachable only with
-// ENH_GEMM_KERNEL=8phase; tests/test_ops_gpu.py::test_gemm_p8_* are skipped unless ENH_TEST_EXPERIMENTAL=1).
-//
-// Why: t256 above waits vmcnt(0) once per K-tile — with two 64-KiB K-tile buffers nothing newer is in flight at that point, so the
-// global->LDS queue drains every K-tile and a load gets <= 0.75 K-tile (~0.7 us) to arrive.  cdna_hip_programming.md ("The 256^2
-// 8-phase template") measures that drain as the whole difference between ~900 and ~1320 TF/s.  The fix is not more LDS but FINER
-// SLOTS: the eight 16-KiB half-tiles {stage 0,1} x {A0, A1, B0, B1} are freed and refilled one at a time.  For a half-tile to be
-// released before its K-tile is finished, one phase must consume it completely — so a half-tile is not a contiguous 128-row block
-// but, for every wave, the rows of ONE of its quadrant operands:
-//      A half h = rows  wm*128 + h*64 + (0..63)  for wm = 0,1          B half h = cols  wn*64 + h*32 + (0..31)  for wn = 0..3
-// and a phase computes one 64x32 quadrant of the wave's 128x64 tile over the whole K-tile (8 MFMAs 32x32x16):
-//      P0: read A0, B0 (12 ds_read_b128) ; q(0,0)        P2: read A1 (8) ; q(1,1)  (B1 still in registers)
-//      P1: read B1 (4)                   ; q(0,1)        P3: no read     ; q(1,0)  (B0 still in registers)
-// Last reads: A0, B0 in P0, B1 in P1, A1 in P2.  A slot may be refilled two phases after its last read (both staggered wave groups
-// have retired their reads and passed a barrier by then), so every phase issues exactly ONE half-tile (2 global_load_lds per wave):
-//      P0(kt): B1(kt+1)     P1(kt): A1(kt+1)     P2(kt): A0(kt+2)     P3(kt): B0(kt+2)          -> 5-6 phases (1.25-1.5 K-tiles) of flight
-// and the waits are counted: vmcnt(6) = "everything except the three most recent half-tiles has landed", placed in P0, P2, P3 before
-// the phase's first barrier; the data each one retires is first read two phases later (one barrier more than strictly required).
-//      wait@P0(kt) retires A1(kt) [read P2(kt)]   wait@P2(kt) retires A0,B0(kt+1) [read P0(kt+1)]   wait@P3(kt) retires B1(kt+1) [read P1(kt+1)]
-// In the last two K-tiles some issues are skipped, so the count no longer covers the needed half-tile: vmcnt(0) there.
-// Same stagger as t256: waves 4-7 run one barrier behind waves 0-3, so on every SIMD one wave is in its MFMA segment while the other
-// issues its reads / loads.  Same LDS images per slot (row / kmaj2 swizzles), same fragment readers, same epilogue.
+// "w256": 256 x 256 x 64 workgroup tile, FOUR waves (2 x 2) of 128 x 128 — one wave per SIMD, 256 accumulator registers (AGPRs) + ~170 VGPRs.
+// Round-2 design, measured step by step in tools/probe/gemm_lab.cpp (profiles/r02_gemm_lab.txt):
+//   * one wave per SIMD reads each LDS byte once per 128 x 128 sub-tile: 32 fragment reads per 64 MFMAs (t256's 128 x 64 waves need 48), and
+//     there is no second wave group to keep in phase — ONE barrier per K stage instead of eight;
+//   * an in-order wave stalls the matrix pipe whenever an instruction takes longer to issue than the ~28 cycles of cover one MFMA gives, so
+//     nothing is issued in bursts: fragment reads go one per MFMA under the first 8 MFMAs of every k16 step (all four waves hit the one LDS
+//     at once: a burst of 32 reads costs ~128 cycles), global_load_lds one per two MFMAs (texture addresser ~64 B/clk per CU);
+//     measured MFMA utilisation inside the K loop: 96 % without loads, 90 % with L2-resident operands, 70-80 % streaming from HBM;
+//   * operands are staged as WHOLE 128-byte lines (64-deep K stages): fetching each line as two 64-byte halves one stage apart (a 4-slot
+//     ring of 32-deep stages, which would allow a deeper prefetch) costs 7-11 % utilisation on HBM-streamed operands, while one stage less
+//     of prefetch depth costs only 1-2 %;
+//   * two 64-KiB slots [A0 | A1 | B0 | B1] (row / kmaj2 images as t256).  The barrier sits after the reads of the last k-step: the slot is
+//     then free and the loads of stage j+2 are spread over the next 32 MFMAs; every load gets 32-64 MFMAs (1-2 K-steps x 4) to land and the
+//     wait at the next barrier is vmcnt(0) with nothing newer in flight — a count, not a drain.
+// Shapes: M, N multiples of 256, every K slice a multiple of 64 with at least two stages; everything else runs pipe2 / the fallback.
 // =================================================================================================
-__device__ __forceinline__ int p8_row_a(int h, int r) { return (r >> 6) * 128 + h * 64 + (r & 63); }   // slot row -> tile row
-__device__ __forceinline__ int p8_row_b(int h, int r) { return (r >> 5) * 64 + h * 32 + (r & 31); }
-
-template <bool TR, bool IS_A>
-__device__ __forceinline__ const uint16_t* p8_src_ptr(const uint16_t* __restrict__ P, int64_t ld, int64_t x0, int64_t X,
-                                                      int64_t k_begin, int h, int slab, int lane) {
-  if (!TR) {  // slab = 8 slot rows x 128 B
-    const int r = slab * 8 + (lane >> 3), pc = lane & 7;
-    const int c = pc ^ ((r >> 1) & 7);
-    int64_t row = x0 + (IS_A ? p8_row_a(h, r) : p8_row_b(h, r));
-    if (row > X - 1) row = X - 1;
-    return P + row * ld + k_begin + c * 8;
-  } else {    // slab = 4 k-rows x 256 B; a lane's 16 bytes = 8 consecutive slot columns (never straddling a 32-column group)
-    const int k = slab * 4 + (lane >> 4), pp = lane & 15;
+#define W2_SLOT (4 * G_TILE_BYTES)
+// staging source of the lane for slab parity p (slabs 2u + p): !TR: 8 rows x 128 B per slab ; TR: 4 k-rows x 256 B per slab
+template <bool TR>
+__device__ __forceinline__ const uint16_t* w256_src(const uint16_t* __restrict__ P, int64_t ld, int64_t x0, int64_t k_begin, int p, int lane) {
+  if (!TR) {
+    const int r = p * 8 + (lane >> 3), pc = lane & 7;
+    const int c = pc ^ ((r >> 1) & 7);             // (slab*8 + r) >> 1 & 7 depends on the slab only through its parity
+    return P + (x0 + r) * ld + k_begin + c * 8;
+  } else {
+    const int k = p * 4 + (lane >> 4), pp = lane & 15;
     const int q = (pp >> 1) ^ (((k & 3) << 1) | ((k >> 2) & 1));
-    const int cs = q * 16 + (pp & 1) * 8;
-    int64_t col = x0 + (IS_A ? p8_row_a(h, cs) : p8_row_b(h, cs));
-    if (col > X - 8) col = X - 8;
-    return P + (k_begin + k) * ld + col;
+    return P + (k_begin + k) * ld + x0 + q * 16 + (pp & 1) * 8;
   }
 }
 
-template <bool TA, bool TB>
-__global__ __launch_bounds__(512) void gemm_bf16_p8_kernel(const GemmArgs args) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2 stages][A0 | A1 | B0 | B1], 16 KiB each
+// EPI: the epilogue mode is a template parameter of THIS kernel (chosen on the host): an in-kernel 8-way switch over unrolled epilogues made the
+// code 10x larger and the whole kernel ~10 % slower (measured, same main loop)
+template <bool TA, bool TB, int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_bf16_w256_kernel(const GemmArgs args) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2 slots][A0 | A1 | B0 | B1], 16 KiB each
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = wave >> 2, wn = wave & 3;  // 2 x 4 waves, each 128 (M) x 64 (N)
+  const int wm = wave >> 1, wn = wave & 1;  // 2 x 2 waves, each 128 (M) x 128 (N)
   int split, tile_m, tile_n;
   gemm_tile_coords(args, split, tile_m, tile_n);
-  const int64_t m0 = (int64_t)tile_m * G4_BM, n0 = (int64_t)tile_n * G4_BN;
+  const int64_t m0 = (int64_t)tile_m * 256, n0 = (int64_t)tile_n * 256;
   const int64_t k_begin = (int64_t)split * args.k_per_split;
   int64_t k_end = k_begin + args.k_per_split;
   if (k_end > args.K) k_end = args.K;
-  const int nk = (int)((k_end - k_begin) / G_BK);
+  const int nst = (int)((k_end - k_begin) / G_BK);   // >= 2 (launcher)
 
-  // every wave stages 2 of the 16 one-KiB slabs of EVERY half-tile kind (0 = A0, 1 = A1, 2 = B0, 3 = B1)
-  const uint16_t* src[8];
-  int lds_off[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int kind = i >> 1, slab = wave * 2 + (i & 1);
-    lds_off[i] = kind * G_TILE_BYTES + slab * 1024;
-    src[i] = kind < 2 ? p8_src_ptr<TA, true>(args.A, args.lda, m0, args.M, k_begin, kind, slab, lane)
-                      : p8_src_ptr<TB, false>(args.B, args.ldb, n0, args.N, k_begin, kind - 2, slab, lane);
-  }
-  const int64_t step_a = TA ? (int64_t)G_BK * args.lda : (int64_t)G_BK;
-  const int64_t step_b = TB ? (int64_t)G_BK * args.ldb : (int64_t)G_BK;
+  // staging: wave w fills sub-tile w of every slot (0, 1: A halves ; 2, 3: B halves): 16 one-KiB slabs per stage, two source patterns
+  const bool stage_a = wave < 2;   // wave-uniform
+  const uint16_t* gsrc_e = stage_a ? w256_src<TA>(args.A, args.lda, m0 + wave * 128, k_begin, 0, lane) : w256_src<TB>(args.B, args.ldb, n0 + (wave - 2) * 128, k_begin, 0, lane);
+  const uint16_t* gsrc_o = stage_a ? w256_src<TA>(args.A, args.lda, m0 + wave * 128, k_begin, 1, lane) : w256_src<TB>(args.B, args.ldb, n0 + (wave - 2) * 128, k_begin, 1, lane);
+  const bool my_tr = stage_a ? TA : TB;
+  const int64_t my_ld = stage_a ? args.lda : args.ldb;
+  const int64_t pair_step = (my_tr ? 8 : 16) * my_ld;              // elements between slabs u and u + 2
+  const int64_t stage_step = my_tr ? (int64_t)G_BK * my_ld : (int64_t)G_BK;
+  unsigned char* const my_sub = smem + wave * G_TILE_BYTES;
 
-#define P8_ISSUE(ST, KIND)                                                                                                          \
-  do {                                                                                                                              \
-    unsigned char* base_ = smem + (ST) * G4_STAGE_BYTES;                                                                            \
-    _Pragma("unroll") for (int u_ = 0; u_ < 2; ++u_) {                                                                              \
-      __builtin_amdgcn_global_load_lds((const GLB_AS void*)src[(KIND) * 2 + u_], (LDS_AS void*)(base_ + lds_off[(KIND) * 2 + u_]), 16, 0, 0); \
-      src[(KIND) * 2 + u_] += ((KIND) < 2 ? step_a : step_b);                                                                       \
-    }                                                                                                                               \
-  } while (0)
-#define P8_READ_A(ST, IH)                                                                                                           \
-  do {                                                                                                                              \
-    const unsigned char* sa_ = smem + (ST) * G4_STAGE_BYTES + (IH) * G_TILE_BYTES;                                                  \
-    _Pragma("unroll") for (int ib_ = 0; ib_ < 2; ++ib_)                                                                             \
-      _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) fa[ib_][s_] = frag32<TA>(sa_, wm * 64 + ib_ * 32, s_, lane);                 \
-  } while (0)
-#define P8_READ_B(FB, ST, J)                                                                                                        \
-  do {                                                                                                                              \
-    const unsigned char* sb_ = smem + (ST) * G4_STAGE_BYTES + (2 + (J)) * G_TILE_BYTES;                                             \
-    _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) FB[s_] = frag32<TB>(sb_, wn * 32, s_, lane);                                   \
-  } while (0)
-  // one quadrant: two accumulators alternate, so consecutive MFMAs never depend on each other
-#define P8_MMA(IH, J, FB)                                                                                                           \
-  do {                                                                                                                              \
-    _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_)                                                                                \
-      _Pragma("unroll") for (int ib_ = 0; ib_ < 2; ++ib_)                                                                           \
-        acc[(IH) * 2 + ib_][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, FB[s_]), __builtin_bit_cast(bf16x8, fa[ib_][s_]), acc[(IH) * 2 + ib_][J], 0, 0, 0); \
-  } while (0)
-#define P8_FENCE() __builtin_amdgcn_sched_barrier(0)
-#define P8_BAR() __builtin_amdgcn_s_barrier()
-#define P8_WAIT_VM(STEADY)                                                                                                          \
-  do {                                                                                                                              \
-    if (STEADY) __builtin_amdgcn_s_waitcnt(0x0F76); /* vmcnt(6): all but the three newest half-tiles (2 loads each) have landed */ \
-    else __builtin_amdgcn_s_waitcnt(0x0F70);        /* vmcnt(0) */                                                                  \
-  } while (0)
-  // second half of a phase: close the read / issue segment, then the MFMA segment
-#define P8_MMA_SEG(IH, J, FB)                                                                                                       \
-  do {                                                                                                                              \
-    P8_FENCE(); P8_BAR();                                                                                                           \
-    __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0): this phase's fragments are in registers */                                   \
-    P8_FENCE();                                                                                                                     \
-    __builtin_amdgcn_s_setprio(1);                                                                                                  \
-    P8_MMA(IH, J, FB);                                                                                                              \
-    __builtin_amdgcn_s_setprio(0);                                                                                                  \
-    P8_FENCE(); P8_BAR();                                                                                                           \
-  } while (0)
-
-  f32x16 acc[4][2];
+  f32x16 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  s16x8 fa[2][4], fb0[4], fb1[4];
+  s16x8 fa0[4], fb0[4], fa1[4], fb1[4];
 
-  if (nk > 0) {
-    // prologue: stages 0 and 1 in the steady-state issue order (A0, B0, B1, A1); only stage 0 has to have landed before the loop —
-    // stage 1's eight loads stay in flight and are retired by the counted waits of K-tile 0 like any later stage
+#define W2_ISSUE_ONE(SLOT, U)                                                                                                     \
+  __builtin_amdgcn_global_load_lds((const GLB_AS void*)((((U) & 1) ? gsrc_o : gsrc_e) + ((U) >> 1) * pair_step),                  \
+                                   (LDS_AS void*)(my_sub + (SLOT) * W2_SLOT + (U) * 1024), 16, 0, 0)
+#define W2_ADVANCE() do { gsrc_e += stage_step; gsrc_o += stage_step; } while (0)
+  // fragment u of k16-step S from slot SLOT: u = 0..3 the wave's A row-blocks, 4..7 its B column-blocks.  Transposed operands are read with the
+  // asm transpose read (the compiler's wait-count pass knows nothing about them: explicit lgkmcnt(0) at every k-step boundary below)
+#define W2_READ_ONE(FA, FB, SLOT, S, U)                                                                                           \
+  do {                                                                                                                            \
+    if ((U) < 4) FA[(U) & 3] = frag32<TA>(smem + (SLOT) * W2_SLOT + wm * G_TILE_BYTES, ((U) & 3) * 32, S, lane);                  \
+    else FB[(U) & 3] = frag32<TB>(smem + (SLOT) * W2_SLOT + (2 + wn) * G_TILE_BYTES, ((U) & 3) * 32, S, lane);                    \
+  } while (0)
+#define W2_MM(Q, FA, FB)                                                                                                          \
+  acc[(Q) >> 2][(Q) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, FB[(Q) & 3]), __builtin_bit_cast(bf16x8, FA[(Q) >> 2]), acc[(Q) >> 2][(Q) & 3], 0, 0, 0)
+#define W2_FENCE() __builtin_amdgcn_sched_barrier(0)
+  // one k16 step: 16 MFMAs on (FA, FB); under MFMAs 0-7 one fragment read each (k-step RS of slot RSLOT into RA / RB); under every odd MFMA one
+  // global_load_lds (pieces G0 .. G0+7 into slot GSLOT).  The step opens with lgkmcnt(0): its fragments were read >= 8 MFMAs ago.
+#define W2_KSTEP(FA, FB, RA, RB, RSLOT, RS, DO_READ, GSLOT, G0, DO_ISSUE)                                                         \
+  do {                                                                                                                            \
+    if (TA || TB) __builtin_amdgcn_s_waitcnt(0xC07F); /* asm transpose reads are invisible to the compiler's wait-count pass */      \
+    W2_FENCE();                                                                                                                   \
+    _Pragma("unroll") for (int q_ = 0; q_ < 16; ++q_) {                                                                           \
+      W2_MM(q_, FA, FB);                                                                                                          \
+      if ((DO_READ) && q_ < 8) { W2_READ_ONE(RA, RB, RSLOT, RS, q_); }                                                            \
+      if ((DO_ISSUE) && (q_ & 1)) { W2_ISSUE_ONE(GSLOT, (G0) + (q_ >> 1)); }                                                      \
+      W2_FENCE();                                                                                                                 \
+    }                                                                                                                             \
+  } while (0)
+
+  // prologue: stage 0 -> slot 0 completely; pieces 0-7 of stage 1 -> slot 1 (pieces 8-15 follow under the first k-step)
 #pragma unroll
-    for (int st = 0; st < 2; ++st) {
-      if (st < nk) { P8_ISSUE(st, 0); P8_ISSUE(st, 2); P8_ISSUE(st, 3); P8_ISSUE(st, 1); }
-    }
-    if (nk > 1) __builtin_amdgcn_s_waitcnt(0x0078);  // vmcnt(8) lgkmcnt(0)
-    else __builtin_amdgcn_s_waitcnt(0x0070);         // vmcnt(0) lgkmcnt(0)
-    P8_BAR();
-    const bool late = wave >= 4;  // wave-uniform
-    if (late) P8_BAR();           // stagger: the second wave of every SIMD runs one barrier behind
-    for (int kt = 0; kt < nk; ++kt) {
-      const int st = kt & 1;
-      const bool steady = kt + 2 < nk;       // all four issues of this K-tile and of the previous one exist
-      const bool next1 = kt >= 1 && kt + 1 < nk;
-      // ---- P0: q(0,0) ----
-      P8_READ_B(fb0, st, 0);
-      P8_FENCE();
-      P8_READ_A(st, 0);
-      if (next1) P8_ISSUE(st ^ 1, 3);        // B1(kt+1): its slot was last read in P1(kt-1)
-      P8_WAIT_VM(steady);                    // retires A1(kt), read in P2
-      P8_MMA_SEG(0, 0, fb0);
-      // ---- P1: q(0,1) ----
-      P8_READ_B(fb1, st, 1);
-      if (next1) P8_ISSUE(st ^ 1, 1);        // A1(kt+1): its slot was last read in P2(kt-1)
-      P8_MMA_SEG(0, 1, fb1);
-      // ---- P2: q(1,1) ----
-      P8_READ_A(st, 1);
-      if (steady) P8_ISSUE(st, 0);           // A0(kt+2): A0(kt) was last read in P0
-      P8_WAIT_VM(steady);                    // retires A0(kt+1), B0(kt+1), read in P0(kt+1)
-      P8_MMA_SEG(1, 1, fb1);
-      // ---- P3: q(1,0) ----
-      if (steady) P8_ISSUE(st, 2);           // B0(kt+2): B0(kt) was last read in P0
-      P8_WAIT_VM(steady);                    // retires B1(kt+1), read in P1(kt+1)
-      P8_MMA_SEG(1, 0, fb0);
-    }
-    if (!late) P8_BAR();  // barrier counts must match across the workgroup
+  for (int u = 0; u < 16; ++u) W2_ISSUE_ONE(0, u);
+  W2_ADVANCE();
+#pragma unroll
+  for (int u = 0; u < 8; ++u) W2_ISSUE_ONE(1, u);
+  __builtin_amdgcn_s_waitcnt(0x0F78);   // vmcnt(8): stage 0 landed
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int u = 0; u < 8; ++u) W2_READ_ONE(fa0, fb0, 0, 0, u);
+  W2_FENCE();
+
+  // invariant at the top of iteration j: the source pointers are at stage j+1, whose pieces 0-7 are already issued into slot (j+1)&1
+  int j = 0;
+  for (; j + 2 < nst; ++j) {
+    const int slot = j & 1;
+    W2_KSTEP(fa0, fb0, fa1, fb1, slot, 1, true, slot ^ 1, 8, true);      // + pieces 8-15 of stage j+1
+    W2_ADVANCE();
+    W2_KSTEP(fa1, fb1, fa0, fb0, slot, 2, true, 0, 0, false);
+    W2_KSTEP(fa0, fb0, fa1, fb1, slot, 3, true, 0, 0, false);
+    __builtin_amdgcn_s_waitcnt(0x0070);    // vmcnt(0): stage j+1 landed (nothing newer outstanding) ; lgkmcnt(0): this slot is read out
+    __builtin_amdgcn_s_barrier();
+    W2_FENCE();
+    W2_KSTEP(fa1, fb1, fa0, fb0, slot ^ 1, 0, true, slot, 0, true);      // + pieces 0-7 of stage j+2 into the slot just vacated
   }
-#undef P8_ISSUE
-#undef P8_READ_A
-#undef P8_READ_B
-#undef P8_MMA
-#undef P8_FENCE
-#undef P8_BAR
-#undef P8_WAIT_VM
-#undef P8_MMA_SEG
-  gemm_epilogue32(args, acc, m0 + wm * 128, n0 + wn * 64, lane);
+  {  // tail: stages nst-2 and nst-1
+    const int slot = j & 1;
+    W2_KSTEP(fa0, fb0, fa1, fb1, slot, 1, true, slot ^ 1, 8, true);      // + pieces 8-15 of stage nst-1
+    W2_KSTEP(fa1, fb1, fa0, fb0, slot, 2, true, 0, 0, false);
+    W2_KSTEP(fa0, fb0, fa1, fb1, slot, 3, true, 0, 0, false);
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    __builtin_amdgcn_s_barrier();
+    W2_FENCE();
+    W2_KSTEP(fa1, fb1, fa0, fb0, slot ^ 1, 0, true, 0, 0, false);
+    W2_KSTEP(fa0, fb0, fa1, fb1, slot ^ 1, 1, true, 0, 0, false);
+    W2_KSTEP(fa1, fb1, fa0, fb0, slot ^ 1, 2, true, 0, 0, false);
+    W2_KSTEP(fa0, fb0, fa1, fb1, slot ^ 1, 3, true, 0, 0, false);
+    W2_KSTEP(fa1, fb1, fa0, fb0, 0, 0, false, 0, 0, false);
+  }
+#undef W2_ISSUE_ONE
+#undef W2_ADVANCE
+#undef W2_READ_ONE
+#undef W2_MM
+#undef W2_FENCE
+#undef W2_KSTEP
+  gemm_epilogue32_loops<EPI, 4, false>(args, acc, m0 + wm * 128, n0 + wn * 128, lane, split);
 }
 
-// =================================================================================================
-// "p8p" (EXPERIMENTAL, never run — ENH_GEMM_KERNEL=9persist): the p8 schedule made persistent.  One workgroup per CU walks the
-// tiles b, b + gridDim.x, ... ; the half-tile issue stream of p8 simply CONTINUES across the tile boundary (each of the four kinds
-// counts its own K-tiles and re-derives its source pointers when it wraps), so the load queue never drains and the epilogue of one
-// tile runs while the first two K-tiles of the next are in flight — what a 12-K-tile problem (K = 768: 42 % of the training step)
-// needs from a 256x256 tile.  Synchronisation is p8's with a longer K sequence (tools/p8_schedule_check.py covers it as nk = the
-// workgroup's total K-tile count); gfx9 also counts the epilogue's stores / loads in vmcnt, which only makes the counted waits
-// conservative right after an epilogue.  No split-K (the launcher falls back to p8 then).  The macro block is a copy of p8's on
-// purpose: the two kernels are to be validated and tuned independently.
-// =================================================================================================
-__device__ __forceinline__ void gemm_tile_coords_v(const GemmArgs& args, int vbid, int& tile_m, int& tile_n) {
-  const int nwg = args.nbm * args.nbn;
-  int bid = vbid;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, pos = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+// split-K second pass: C[m][n] (+)= sum over the splits of the partial slabs, in a fixed order (deterministic, no atomics)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, int64_t MN, int64_t N, float* __restrict__ c, int64_t ldc, int accumulate) {
+  const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 >= MN) return;
+  f32x4 s = *reinterpret_cast<const f32x4*>(ws + i4);
+  for (int k = 1; k < splits; ++k) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(ws + (int64_t)k * MN + i4);
+    s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
   }
-  const int per_group = 8 * args.nbn;
-  const int grp = bid / per_group, within = bid - grp * per_group;
-  const int rows = (args.nbm - grp * 8) < 8 ? (args.nbm - grp * 8) : 8;
-  tile_m = grp * 8 + within % rows;
-  tile_n = within / rows;
-}
-
-template <bool TA, bool TB>
-__global__ __launch_bounds__(512) void gemm_bf16_p8p_kernel(const GemmArgs args) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2 stages][A0 | A1 | B0 | B1], 16 KiB each
-  const int t = threadIdx.x;
-  const int lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-  const int ntiles = args.nbm * args.nbn;
-  const int G = (int)gridDim.x;  // a multiple of 8 whenever ntiles > G (launcher), so a workgroup never leaves its XCD's run of tiles
-  const int my_tiles = (ntiles - (int)blockIdx.x + G - 1) / G;
-  const int nk = (int)(args.K / G_BK);
-  const int gtot = my_tiles * nk;  // K-tiles this workgroup will consume, across all of its tiles
-
-  const uint16_t* src[8];
-  int lds_off[8];
-  int ktc[4] = {0, 0, 0, 0};  // per half-tile kind: K-tile (within its tile) of the NEXT issue ...
-  int tjc[4] = {0, 0, 0, 0};  // ... and which of this workgroup's tiles that issue belongs to
-#pragma unroll
-  for (int i = 0; i < 8; ++i) lds_off[i] = (i >> 1) * G_TILE_BYTES + (wave * 2 + (i & 1)) * 1024;
-  const int64_t step_a = TA ? (int64_t)G_BK * args.lda : (int64_t)G_BK;
-  const int64_t step_b = TB ? (int64_t)G_BK * args.ldb : (int64_t)G_BK;
-
-#define P9_SETPTR(KIND, J)                                                                                                          \
-  do {                                                                                                                              \
-    int tm_, tn_;                                                                                                                   \
-    gemm_tile_coords_v(args, (int)blockIdx.x + (J) * G, tm_, tn_);                                                                  \
-    _Pragma("unroll") for (int u_ = 0; u_ < 2; ++u_) {                                                                              \
-      if ((KIND) < 2) src[(KIND) * 2 + u_] = p8_src_ptr<TA, true>(args.A, args.lda, (int64_t)tm_ * G4_BM, args.M, 0, (KIND), wave * 2 + u_, lane);        \
-      else src[(KIND) * 2 + u_] = p8_src_ptr<TB, false>(args.B, args.ldb, (int64_t)tn_ * G4_BN, args.N, 0, (KIND) - 2, wave * 2 + u_, lane);              \
-    }                                                                                                                               \
-  } while (0)
-#define P9_ISSUE(ST, KIND)                                                                                                          \
-  do {                                                                                                                              \
-    unsigned char* base_ = smem + (ST) * G4_STAGE_BYTES;                                                                            \
-    _Pragma("unroll") for (int u_ = 0; u_ < 2; ++u_)                                                                                \
-      __builtin_amdgcn_global_load_lds((const GLB_AS void*)src[(KIND) * 2 + u_], (LDS_AS void*)(base_ + lds_off[(KIND) * 2 + u_]), 16, 0, 0); \
-    if (++ktc[KIND] == nk) {              /* this kind has issued the last K-tile of its tile: move to my next tile */                \
-      ktc[KIND] = 0;                                                                                                                \
-      ++tjc[KIND];                                                                                                                  \
-      if (tjc[KIND] < my_tiles) P9_SETPTR(KIND, tjc[KIND]);                                                                         \
-    } else {                                                                                                                        \
-      _Pragma("unroll") for (int u_ = 0; u_ < 2; ++u_) src[(KIND) * 2 + u_] += ((KIND) < 2 ? step_a : step_b);                     \
-    }                                                                                                                               \
-  } while (0)
-#define P9_READ_A(ST, IH)                                                                                                           \
-  do {                                                                                                                              \
-    const unsigned char* sa_ = smem + (ST) * G4_STAGE_BYTES + (IH) * G_TILE_BYTES;                                                  \
-    _Pragma("unroll") for (int ib_ = 0; ib_ < 2; ++ib_)                                                                             \
-      _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) fa[ib_][s_] = frag32<TA>(sa_, wm * 64 + ib_ * 32, s_, lane);                 \
-  } while (0)
-#define P9_READ_B(FB, ST, J)                                                                                                        \
-  do {                                                                                                                              \
-    const unsigned char* sb_ = smem + (ST) * G4_STAGE_BYTES + (2 + (J)) * G_TILE_BYTES;                                             \
-    _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) FB[s_] = frag32<TB>(sb_, wn * 32, s_, lane);                                   \
-  } while (0)
-#define P9_MMA(IH, J, FB)                                                                                                           \
-  do {                                                                                                                              \
-    _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_)                                                                                \
-      _Pragma("unroll") for (int ib_ = 0; ib_ < 2; ++ib_)                                                                           \
-        acc[(IH) * 2 + ib_][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, FB[s_]), __builtin_bit_cast(bf16x8, fa[ib_][s_]), acc[(IH) * 2 + ib_][J], 0, 0, 0); \
-  } while (0)
-#define P9_FENCE() __builtin_amdgcn_sched_barrier(0)
-#define P9_BAR() __builtin_amdgcn_s_barrier()
-#define P9_WAIT_VM(STEADY)                                                                                                          \
-  do {                                                                                                                              \
-    if (STEADY) __builtin_amdgcn_s_waitcnt(0x0F76); /* vmcnt(6) */                                                                  \
-    else __builtin_amdgcn_s_waitcnt(0x0F70);        /* vmcnt(0) */                                                                  \
-  } while (0)
-#define P9_MMA_SEG(IH, J, FB)                                                                                                       \
-  do {                                                                                                                              \
-    P9_FENCE(); P9_BAR();                                                                                                           \
-    __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0) */                                                                            \
-    P9_FENCE();                                                                                                                     \
-    __builtin_amdgcn_s_setprio(1);                                                                                                  \
-    P9_MMA(IH, J, FB);                                                                                                              \
-    __builtin_amdgcn_s_setprio(0);                                                                                                  \
-    P9_FENCE(); P9_BAR();                                                                                                           \
-  } while (0)
-#define P9_ZERO_ACC()                                                                                                               \
-  do {                                                                                                                              \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                                                \
-      _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                                              \
-        _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) acc[i_][j_][r_] = 0.f;                                                    \
-  } while (0)
-
-  f32x16 acc[4][2];
-  P9_ZERO_ACC();
-  s16x8 fa[2][4], fb0[4], fb1[4];
-
-  if (gtot > 0) {
-    P9_SETPTR(0, 0); P9_SETPTR(1, 0); P9_SETPTR(2, 0); P9_SETPTR(3, 0);
-    // prologue: versions 0 and 1 of the stream, in its steady-state order; only version 0 has to have landed
-#pragma unroll
-    for (int v = 0; v < 2; ++v) {
-      if (v < gtot) { P9_ISSUE(v, 0); P9_ISSUE(v, 2); P9_ISSUE(v, 3); P9_ISSUE(v, 1); }
-    }
-    if (gtot > 1) __builtin_amdgcn_s_waitcnt(0x0078);  // vmcnt(8) lgkmcnt(0)
-    else __builtin_amdgcn_s_waitcnt(0x0070);           // vmcnt(0) lgkmcnt(0)
-    P9_BAR();
-    const bool late = wave >= 4;
-    if (late) P9_BAR();
-    int kt_in = 0, tile_j = 0;  // position of the K-tile being consumed
-    for (int g = 0; g < gtot; ++g) {
-      const int st = g & 1;
-      const bool steady = g + 2 < gtot;
-      const bool next1 = g >= 1 && g + 1 < gtot;
-      // ---- P0: q(0,0) ----
-      P9_READ_B(fb0, st, 0);
-      P9_FENCE();
-      P9_READ_A(st, 0);
-      if (next1) P9_ISSUE(st ^ 1, 3);
-      P9_WAIT_VM(steady);
-      P9_MMA_SEG(0, 0, fb0);
-      // ---- P1: q(0,1) ----
-      P9_READ_B(fb1, st, 1);
-      if (next1) P9_ISSUE(st ^ 1, 1);
-      P9_MMA_SEG(0, 1, fb1);
-      // ---- P2: q(1,1) ----
-      P9_READ_A(st, 1);
-      if (steady) P9_ISSUE(st, 0);
-      P9_WAIT_VM(steady);
-      P9_MMA_SEG(1, 1, fb1);
-      // ---- P3: q(1,0) ----
-      if (steady) P9_ISSUE(st, 2);
-      P9_WAIT_VM(steady);
-      P9_MMA_SEG(1, 0, fb0);
-      if (++kt_in == nk) {  // the tile is complete: store it (loads of my next tile are already in flight), start the next one
-        int tm, tn;
-        gemm_tile_coords_v(args, (int)blockIdx.x + tile_j * G, tm, tn);
-        gemm_epilogue32(args, acc, (int64_t)tm * G4_BM + wm * 128, (int64_t)tn * G4_BN + wn * 64, lane);
-        P9_ZERO_ACC();
-        kt_in = 0;
-        ++tile_j;
-      }
-    }
-    if (!late) P9_BAR();
+  const int64_t m = i4 / N, n = i4 - m * N;
+  float* cp = c + m * ldc + n;
+  if (accumulate) {
+    const f32x4 o = *reinterpret_cast<const f32x4*>(cp);
+    s[0] += o[0]; s[1] += o[1]; s[2] += o[2]; s[3] += o[3];
   }
-#undef P9_SETPTR
-#undef P9_ISSUE
-#undef P9_READ_A
-#undef P9_READ_B
-#undef P9_MMA
-#undef P9_FENCE
-#undef P9_BAR
-#undef P9_WAIT_VM
-#undef P9_MMA_SEG
-#undef P9_ZERO_ACC
+  *reinterpret_cast<f32x4*>(cp) = s;
 }
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-// kernel family: 0 = register-staged (any K % 8), 3 = pipe2, 4 = t256, 5 = p8, 6 = p8p (experimental, only by ENH_GEMM_KERNEL=8phase / 9persist)
-static int gemm_family(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K) {
-  static const int kernel_sel = [] {  // ENH_GEMM_KERNEL = reg | pipe2 | t256 ; unset = per-shape choice
-    const char* e = getenv("ENH_GEMM_KERNEL");
-    if (!e) return -1;
-    if (e[0] == 'r') return 0;
-    if (e[0] == 'p') return 3;
-    if (e[0] == 't') return 4;
-    if (e[0] == '8') return 5;
-    if (e[0] == '9') return 6;
-    return -1;
-  }();
+// kernel family: 0 = register-staged fallback (any K % 8), 3 = pipe2 (128x128), 4 = t256 (256x256, 8 waves), 7 = w256 (256x256, 4 waves)
+static int g_kernel_override = -1;   // set by enh_gemm_set_kernel(): explicit state behind an explicit call, no environment lookups in the library
+
+extern "C" int enh_gemm_set_kernel(int family) {
+  ENH_REQUIRE(family == -1 || family == 0 || family == 3 || family == 4 || family == 7, ENH_E_BADARG, "enh_gemm_set_kernel: family must be -1 (auto), 0, 3, 4 or 7");
+  g_kernel_override = family;
+  return ENH_OK;
+}
+
+struct GemmPlan { int family, splits; int64_t k_per_split; };
+
+static GemmPlan gemm_plan(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, bool splittable) {
   const bool k64 = K % G_BK == 0 && (!trans_a || M >= 8) && (!trans_b || N >= 8);
-  // per-shape choice (measured on MI355X, profiles/r01_gemm_ablation.txt): the 256x256 tile wins when the K loop is long
-  // and the A operand is row-major (fc2 forward, dgrad of qkv / fc1); everything else runs the 128x128 pipe2 kernel.
-  int family = !k64 ? 0 : (kernel_sel >= 0 ? kernel_sel : ((K >= 2048 && !trans_a) ? 4 : 3));
-  if (family >= 4 && (M < 256 || N < 256)) family = 3;
-  return family;
+  const int64_t ksteps = (K + G_BK - 1) / G_BK;
+  GemmPlan pl = {0, 1, ksteps * G_BK};
+  if (!k64) return pl;
+  // split-K (weight-gradient-shaped problems that cannot fill 256 CUs): as many K slices as fit ONE round of resident workgroups, each at least
+  // 8 stages long (more slices only add partial-sum traffic, a ragged second round costs more: profiles/r01_gemm_ablation.txt)
+  auto split_for = [&](int64_t tiles, int64_t slots, int64_t cap) -> int {
+    if (!splittable || tiles >= slots / 2 || K < 2048) return 1;
+    int64_t want = slots / tiles;
+    if (want > ksteps / 8) want = ksteps / 8;
+    if (want > cap) want = cap;
+    if (want < 2) return 1;
+    const int64_t per = (ksteps + want - 1) / want;
+    return (int)((ksteps + per - 1) / per);
+  };
+  const bool w256_ok = M % 256 == 0 && N % 256 == 0 && ksteps >= 2;
+  const bool t256_ok = M >= 256 && N >= 256;
+  int family = g_kernel_override >= 0 ? g_kernel_override : -1;
+  if (family == 7 && !w256_ok) family = -1;
+  if (family == 4 && !t256_ok) family = -1;
+  if (family < 0) {
+    // w256 whenever its tiles (times K slices) occupy at least 3/4 of the CUs; else the 128x128 pipe2 kernel (four times as many workgroups)
+    family = 3;
+    if (w256_ok) {
+      const int64_t tiles = (M / 256) * (N / 256);
+      const int sp = split_for(tiles, 256, 64);
+      const int64_t per = (ksteps + sp - 1) / sp;
+      if (tiles * sp >= 192 && ksteps - (sp - 1) * per >= 2) family = 7;
+    }
+  }
+  pl.family = family;
+  const int64_t bm = family >= 4 ? 256 : 128;
+  const int64_t tiles = ((M + bm - 1) / bm) * ((N + bm - 1) / bm);
+  pl.splits = split_for(tiles, family >= 4 ? 256 : 512, 64);
+  const int64_t per = (ksteps + pl.splits - 1) / pl.splits;
+  pl.k_per_split = per * G_BK;
+  pl.splits = (int)((ksteps + per - 1) / per);
+  if (family == 7 && ksteps - (pl.splits - 1) * per < 2) { pl.splits = 1; pl.k_per_split = ksteps * G_BK; }   // every slice needs two stages
+  return pl;
+}
+
+static bool gemm_splittable(int accumulate, const float* c_f32, const enh_bf16* c_bf16, const float* bias, int act, const float* res) {
+  return accumulate == 1 && c_f32 && !c_bf16 && !bias && act == ENH_ACT_NONE && !res;
 }
 
 extern "C" const char* enh_gemm_bf16_variant(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K) {
-  static const char* names[7] = {"gemm_bf16_kernel", "", "", "gemm_bf16_pipe2_kernel", "gemm_bf16_t256_kernel", "gemm_bf16_p8_kernel", "gemm_bf16_p8p_kernel"};
-  return names[gemm_family(trans_a, trans_b, M, N, K)];
+  static const char* names[8] = {"gemm_bf16_kernel", "", "", "gemm_bf16_pipe2_kernel", "gemm_bf16_t256_kernel", "", "", "gemm_bf16_w256_kernel"};
+  // weight-gradient-shaped calls (both operands contraction-major) are the ones issued with accumulate -> report their split-K plan
+  return names[gemm_plan(trans_a, trans_b, M, N, K, trans_a && trans_b).family];
 }
 
-extern "C" int enh_gemm_bf16(const enh_bf16* A, int64_t lda, int trans_a, const enh_bf16* B, int64_t ldb, int trans_b,
-                             int64_t M, int64_t N, int64_t K, const float* bias, int act, const enh_bf16* aux,
-                             int64_t ldaux, const float* res, int64_t ldres, int64_t res_rows, int accumulate,
-                             float* c_f32, enh_bf16* c_bf16, int64_t ldc, void* stream) {
+extern "C" size_t enh_gemm_bf16_workspace_bytes(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K) {
+  const GemmPlan pl = gemm_plan(trans_a, trans_b, M, N, K, true);
+  return pl.splits > 1 ? (size_t)pl.splits * (size_t)M * (size_t)N * sizeof(float) : 0;
+}
+
+extern "C" int enh_gemm_bf16_ws(const enh_bf16* A, int64_t lda, int trans_a, const enh_bf16* B, int64_t ldb, int trans_b,
+                                int64_t M, int64_t N, int64_t K, const float* bias, int act, const enh_bf16* aux,
+                                int64_t ldaux, const float* res, int64_t ldres, int64_t res_rows, int accumulate,
+                                float* c_f32, enh_bf16* c_bf16, int64_t ldc, void* workspace, size_t workspace_bytes, void* stream) {
   ENH_REQUIRE(A && B && (c_f32 || c_bf16), ENH_E_BADARG, "enh_gemm_bf16: null pointer");
   ENH_REQUIRE(M > 0 && N > 0 && K > 0, ENH_E_BADARG, "enh_gemm_bf16: M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
   ENH_REQUIRE(K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && aligned16(A) && aligned16(B), ENH_E_SHAPE,
@@ -1005,41 +918,36 @@ extern "C" int enh_gemm_bf16(const enh_bf16* A, int64_t lda, int trans_a, const 
   ENH_REQUIRE(!res || (res_rows > 0 && ldres % 4 == 0), ENH_E_BADARG, "enh_gemm_bf16: res needs res_rows > 0 and ldres %% 4 == 0");
   ENH_REQUIRE(accumulate == 0 || (accumulate == 1 && c_f32), ENH_E_BADARG, "enh_gemm_bf16: accumulate needs an f32 output");
   ENH_REQUIRE((!c_f32 || aligned16(c_f32)) && (!c_bf16 || (reinterpret_cast<uintptr_t>(c_bf16) & 7u) == 0), ENH_E_SHAPE, "enh_gemm_bf16: output alignment");
+  ENH_REQUIRE(!workspace || aligned16(workspace), ENH_E_SHAPE, "enh_gemm_bf16: workspace must be 16-byte aligned");
 
-  const int family = gemm_family(trans_a, trans_b, M, N, K);
+  const GemmPlan pl = gemm_plan(trans_a, trans_b, M, N, K, gemm_splittable(accumulate, c_f32, c_bf16, bias, act, res));
+  const int family = pl.family;
   const int bm = family >= 4 ? G4_BM : G_BM;
   const int bn = family >= 4 ? G4_BN : G_BN;
 
   GemmArgs g;
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.M = M; g.N = N; g.K = K;
   g.bias = bias; g.act = act; g.aux = aux; g.ldaux = ldaux; g.res = res; g.ldres = ldres; g.res_rows = res_rows;
-  g.accumulate = accumulate; g.c_f32 = c_f32; g.c_bf16 = c_bf16; g.ldc = ldc;
+  g.accumulate = accumulate; g.c_f32 = c_f32; g.c_bf16 = c_bf16; g.ldc = ldc; g.ws = nullptr;
   g.nbm = (int)((M + bm - 1) / bm);
   g.nbn = (int)((N + bn - 1) / bn);
   const int64_t tiles = (int64_t)g.nbm * g.nbn;
   ENH_REQUIRE(tiles < (1ll << 30), ENH_E_SHAPE, "enh_gemm_bf16: grid too large");
-  // split-K (f32 atomics into a pre-initialised C) when a weight-gradient-shaped problem cannot fill 256 CUs
-  const int64_t ksteps = (K + G_BK - 1) / G_BK;
-  const int64_t fill = family >= 4 ? 256 : 512;  // resident workgroup slots
-  int splits = 1;
-  if (accumulate == 1 && c_f32 && !c_bf16 && !bias && act == ENH_ACT_NONE && !res && tiles < fill / 2 && K >= 2048) {
-    // measured (profiles/r01_gemm_ablation.txt): the f32-atomic epilogue makes every extra K-slice expensive and a ragged
-    // last round is worse still -> the largest split count whose workgroups fit ONE round of resident slots
-    // (2 workgroups per CU for the 128x128 kernels, 1 for t256)
-    const int64_t slots = family >= 4 ? 256 : 512;
-    int64_t want = slots / tiles;
-    if (want > ksteps / 8) want = ksteps / 8;
-    if (want > 64) want = 64;
-    if (want >= 2) splits = (int)want;
+  g.k_per_split = pl.k_per_split;
+  g.splits = pl.splits;
+  bool two_pass = false;
+  if (pl.splits > 1) {
+    // with a workspace: partial slabs + a fixed-order second pass (deterministic); without: f32 atomics into C (N % 4 == 0 and a dense slab need ldc == N
+    // only for the workspace form)
+    const size_t need = (size_t)pl.splits * (size_t)M * (size_t)N * sizeof(float);
+    if (workspace && family == 7) {
+      ENH_REQUIRE(workspace_bytes >= need, ENH_E_WORKSPACE, "enh_gemm_bf16: workspace of %zu bytes needed, %zu given", need, workspace_bytes);
+      g.accumulate = 3; g.ws = (float*)workspace; two_pass = true;
+    } else {
+      g.accumulate = 2;
+    }
   }
-  g.k_per_split = ((ksteps + splits - 1) / splits) * G_BK;
-  splits = (int)((K + g.k_per_split - 1) / g.k_per_split);
-  g.splits = splits;
-  if (splits > 1) g.accumulate = 2;
-  int launch_family = family;
-  if (family == 6 && splits > 1) launch_family = 5;  // the persistent kernel has no split-K
-  // persistent: one workgroup per CU (256); fewer tiles than that -> one workgroup per tile
-  const dim3 grid(launch_family == 6 ? (unsigned)(tiles < 256 ? tiles : 256) : (unsigned)(tiles * splits));
+  const dim3 grid((unsigned)(tiles * pl.splits));
   hipStream_t s = (hipStream_t)stream;
   static const bool attr_set = [] {
     const int b2 = 4 * G_TILE_BYTES;
@@ -1050,10 +958,6 @@ extern "C" int enh_gemm_bf16(const enh_bf16* A, int64_t lda, int trans_a, const 
     SET_ATTR((gemm_bf16_pipe2_kernel<true, false>), b2); SET_ATTR((gemm_bf16_pipe2_kernel<true, true>), b2);
     SET_ATTR((gemm_bf16_t256_kernel<false, false>), 2 * G4_STAGE_BYTES); SET_ATTR((gemm_bf16_t256_kernel<false, true>), 2 * G4_STAGE_BYTES);
     SET_ATTR((gemm_bf16_t256_kernel<true, false>), 2 * G4_STAGE_BYTES); SET_ATTR((gemm_bf16_t256_kernel<true, true>), 2 * G4_STAGE_BYTES);
-    SET_ATTR((gemm_bf16_p8_kernel<false, false>), 2 * G4_STAGE_BYTES); SET_ATTR((gemm_bf16_p8_kernel<false, true>), 2 * G4_STAGE_BYTES);
-    SET_ATTR((gemm_bf16_p8_kernel<true, false>), 2 * G4_STAGE_BYTES); SET_ATTR((gemm_bf16_p8_kernel<true, true>), 2 * G4_STAGE_BYTES);
-    SET_ATTR((gemm_bf16_p8p_kernel<false, false>), 2 * G4_STAGE_BYTES); SET_ATTR((gemm_bf16_p8p_kernel<false, true>), 2 * G4_STAGE_BYTES);
-    SET_ATTR((gemm_bf16_p8p_kernel<true, false>), 2 * G4_STAGE_BYTES); SET_ATTR((gemm_bf16_p8p_kernel<true, true>), 2 * G4_STAGE_BYTES);
 #undef SET_ATTR
     return true;
   }();
@@ -1066,11 +970,36 @@ extern "C" int enh_gemm_bf16(const enh_bf16* A, int64_t lda, int trans_a, const 
     else if (trans_a && !trans_b) KERN<true, false><<<grid, THREADS, LDS, s>>>(g);         \
     else KERN<true, true><<<grid, THREADS, LDS, s>>>(g);                                   \
   } while (0)
-  if (launch_family == 6) LAUNCH(gemm_bf16_p8p_kernel, 512, (size_t)(2 * G4_STAGE_BYTES));
-  else if (launch_family == 5) LAUNCH(gemm_bf16_p8_kernel, 512, (size_t)(2 * G4_STAGE_BYTES));
-  else if (family == 4) LAUNCH(gemm_bf16_t256_kernel, 512, (size_t)(2 * G4_STAGE_BYTES));
+  if (family == 7) {
+    typedef void (*w256_fn)(const GemmArgs);
+#define W2_ROW(TA_, TB_) {gemm_bf16_w256_kernel<TA_, TB_, EPI_GENERIC>, gemm_bf16_w256_kernel<TA_, TB_, EPI_BF16>, gemm_bf16_w256_kernel<TA_, TB_, EPI_BF16_BIAS_TANH>, \
+                          gemm_bf16_w256_kernel<TA_, TB_, EPI_BF16_DTANH>, gemm_bf16_w256_kernel<TA_, TB_, EPI_F32_BIAS_RES>, gemm_bf16_w256_kernel<TA_, TB_, EPI_F32>,   \
+                          gemm_bf16_w256_kernel<TA_, TB_, EPI_WS>, gemm_bf16_w256_kernel<TA_, TB_, EPI_ATOMIC>}
+    static const w256_fn table[4][EPI_NMODES] = {W2_ROW(false, false), W2_ROW(false, true), W2_ROW(true, false), W2_ROW(true, true)};
+#undef W2_ROW
+    static const bool w2_attr = [] {
+      for (int l = 0; l < 4; ++l)
+        for (int e = 0; e < EPI_NMODES; ++e)
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(table[l][e]), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W2_SLOT);
+      return true;
+    }();
+    (void)w2_attr;
+    hipLaunchKernelGGL(table[(trans_a ? 2 : 0) + (trans_b ? 1 : 0)][epi_mode(g)], grid, dim3(256), (size_t)(2 * W2_SLOT), s, g);
+  } else if (family == 4) LAUNCH(gemm_bf16_t256_kernel, 512, (size_t)(2 * G4_STAGE_BYTES));
   else if (family == 3) LAUNCH(gemm_bf16_pipe2_kernel, 256, lds2);
   else LAUNCH(gemm_bf16_kernel, 256, lds2);
 #undef LAUNCH
+  if (two_pass) {
+    const int64_t MN = M * N;
+    splitk_reduce_kernel<<<dim3((unsigned)((MN / 4 + 255) / 256)), 256, 0, s>>>(g.ws, pl.splits, MN, N, c_f32, ldc, accumulate);
+  }
   return enh_check_launch("enh_gemm_bf16");
+}
+
+extern "C" int enh_gemm_bf16(const enh_bf16* A, int64_t lda, int trans_a, const enh_bf16* B, int64_t ldb, int trans_b,
+                             int64_t M, int64_t N, int64_t K, const float* bias, int act, const enh_bf16* aux,
+                             int64_t ldaux, const float* res, int64_t ldres, int64_t res_rows, int accumulate,
+                             float* c_f32, enh_bf16* c_bf16, int64_t ldc, void* stream) {
+  return enh_gemm_bf16_ws(A, lda, trans_a, B, ldb, trans_b, M, N, K, bias, act, aux, ldaux, res, ldres, res_rows, accumulate, c_f32, c_bf16, ldc,
+                          nullptr, 0, stream);
 }

@@ -36,6 +36,10 @@ SIGNATURES = {
     "enh_layernorm_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "enh_gemm_bf16": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _i64, _i64, _i64, _vp, _i32, _vp, _i64, _vp, _i64, _i64,
                              _i32, _vp, _vp, _i64, _vp]),
+    "enh_gemm_bf16_ws": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _i64, _i64, _i64, _vp, _i32, _vp, _i64, _vp, _i64, _i64,
+                                _i32, _vp, _vp, _i64, _vp, _sz, _vp]),
+    "enh_gemm_bf16_workspace_bytes": (_sz, [_i32, _i32, _i64, _i64, _i64]),
+    "enh_gemm_set_kernel": (_i32, [_i32]),
     "enh_gemm_bf16_variant": (_c.c_char_p, [_i32, _i32, _i64, _i64, _i64]),
     "enh_attention_forward": (_i32, [_vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp]),
     "enh_attention_backward": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp]),
@@ -58,7 +62,7 @@ SIGNATURES = {
 }
 
 _LIB = None
-ABI_VERSION = 2   # ENH_ABI_VERSION of the include/enh_hip.h these signatures were written against
+ABI_VERSION = 3   # ENH_ABI_VERSION of the include/enh_hip.h these signatures were written against
 
 
 def lib():
@@ -75,6 +79,16 @@ def lib():
         if L.enh_abi_version() != ABI_VERSION:
             raise RuntimeError(f"{LIB_PATH} reports ABI version {L.enh_abi_version()}, the bindings expect {ABI_VERSION}: rebuild the library")
         _LIB = L
+        # kernel-family override for A/B measurements: explicit library state behind enh_gemm_set_kernel(); the environment is read HERE, in
+        # the binding, never inside the library (reg = 0, pipe2 = 3, t256 = 4, w256 = 7)
+        sel = os.environ.get("ENH_GEMM_KERNEL")
+        if sel:
+            fam = {"reg": 0, "pipe2": 3, "t256": 4, "w256": 7}.get(sel)
+            if fam is None:
+                raise RuntimeError(f"ENH_GEMM_KERNEL={sel!r}: expected reg | pipe2 | t256 | w256")
+            _check_rc = L.enh_gemm_set_kernel(fam)
+            if _check_rc != 0:
+                raise RuntimeError(L.enh_last_error().decode())
     return _LIB
 
 
@@ -226,16 +240,35 @@ def gemm(a, b, M: int, N: int, K: int, trans_a: bool = False, trans_b: bool = Fa
     ldb = b.stride(0) if ldb is None else ldb
     out = out_f32 if out_f32 is not None else out_bf16
     ldc = out.stride(0) if ldc is None else ldc
+    # split-K weight gradients: partial slabs in a caller-owned workspace + a fixed-order second pass (deterministic; no f32 atomics)
+    ws, ws_bytes = None, 0
+    if accumulate and trans_a and trans_b and out_f32 is not None and out_bf16 is None and bias is None and res is None and act == ACT_NONE and ldc == N:
+        ws_bytes = lib().enh_gemm_bf16_workspace_bytes(1, 1, M, N, K)
+        if ws_bytes:
+            ws = _gemm_workspace(a.device, ws_bytes)
     args = (_p(a, BF16, "A"), lda, int(trans_a), _p(b, BF16, "B"), ldb, int(trans_b), M, N, K, _p(bias, F32, "bias"),
             act, _p(aux, BF16, "aux"), aux.stride(0) if aux is not None else 0, _p(res, F32, "res"),
             res.stride(0) if res is not None else 0, res_rows if res is not None else 0, int(accumulate),
-            _p(out_f32, F32, "out_f32"), _p(out_bf16, BF16, "out_bf16"), ldc, _stream())
+            _p(out_f32, F32, "out_f32"), _p(out_bf16, BF16, "out_bf16"), ldc, _p(ws), ws_bytes if ws is not None else 0, _stream())
     if TIMER is None:
-        _check(lib().enh_gemm_bf16(*args), "enh_gemm_bf16")
+        _check(lib().enh_gemm_bf16_ws(*args), "enh_gemm_bf16")
     else:  # label with the symbol rocprofv3 will report, e.g. "gemm_bf16_pipe2_kernel<false, true>"
         fam = lib().enh_gemm_bf16_variant(int(trans_a), int(trans_b), M, N, K).decode()
         TIMER.run(f"{fam}<{'true' if trans_a else 'false'}, {'true' if trans_b else 'false'}>", 2.0 * M * N * K,
-                  lambda: _check(lib().enh_gemm_bf16(*args), "enh_gemm_bf16"))
+                  lambda: _check(lib().enh_gemm_bf16_ws(*args), "enh_gemm_bf16"))
+
+
+_GEMM_WS = {}
+
+
+def _gemm_workspace(device, nbytes: int):
+    """one grow-only split-K workspace per device (the library never allocates: SURVEY.md §8b ownership rule); all GEMMs of a process run on
+    one stream, so a single buffer is safe"""
+    t = _GEMM_WS.get(device)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _GEMM_WS[device] = t
+    return t
 
 
 # ------------------------------------------------------------------------------------------------

@@ -36,7 +36,7 @@ extern "C" {
 typedef uint16_t enh_bf16; /* raw bfloat16 bits */
 
 const char* enh_last_error(void);
-#define ENH_ABI_VERSION 2   /* bumped whenever a signature below changes; the bindings check it at load */
+#define ENH_ABI_VERSION 3   /* bumped whenever a signature below changes; the bindings check it at load */
 int enh_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -120,9 +120,24 @@ int enh_gemm_bf16(const enh_bf16* A, int64_t lda, int trans_a, const enh_bf16* B
                   int64_t ldaux, const float* res, int64_t ldres, int64_t res_rows, int accumulate,
                   float* c_f32, enh_bf16* c_bf16, int64_t ldc, void* stream);
 
+/* The same with a caller-owned split-K workspace.  Weight-gradient-shaped calls (accumulate = 1, f32 output only, no bias / act / res) whose
+ * output tiles cannot fill the chip are split along K; with a workspace of enh_gemm_bf16_workspace_bytes() the K slices write partial slabs
+ * [splits][M][N] and a second pass adds them to C in a fixed order: bit-reproducible, no f32 atomics (needs ldc == N).  workspace = NULL
+ * (what enh_gemm_bf16 passes) falls back to f32 atomicAdd into C.  Replaces the autograd wgrad of every nn.Linear (layers.py:99-101,118,120). */
+int enh_gemm_bf16_ws(const enh_bf16* A, int64_t lda, int trans_a, const enh_bf16* B, int64_t ldb, int trans_b,
+                     int64_t M, int64_t N, int64_t K, const float* bias, int act, const enh_bf16* aux,
+                     int64_t ldaux, const float* res, int64_t ldres, int64_t res_rows, int accumulate,
+                     float* c_f32, enh_bf16* c_bf16, int64_t ldc, void* workspace, size_t workspace_bytes, void* stream);
+/* bytes of workspace the split-K plan of this shape needs (0 = the shape is not split) */
+size_t enh_gemm_bf16_workspace_bytes(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K);
+
 /* name of the kernel family enh_gemm_bf16 launches for this shape (measurement aid: lets callers label timings with
- * the symbol a profiler will report); the choice is per shape, overridable with ENH_GEMM_KERNEL */
+ * the symbol a profiler will report); the choice is per shape */
 const char* enh_gemm_bf16_variant(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K);
+/* A/B measurement aid: force a kernel family for every later call that it can serve (-1 = per-shape choice [default], 0 = register-staged
+ * fallback, 3 = pipe2 128x128, 4 = t256 256x256 / 8 waves, 7 = w256 256x256 / 4 waves).  Process-global, set explicitly by the caller (the Python
+ * binding maps the ENH_GEMM_KERNEL environment variable onto it); the library itself reads no environment. */
+int enh_gemm_set_kernel(int family);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused attention — Attention.forward layers.py:122-132 without materialising the N x N matrix

@@ -234,13 +234,3 @@ def test_init_is_seed_for_seed_with_the_reference(case):
         ref_sd, ref_tail = G.build(RL.load_layers(), RL.load_quantizers(), case, 0)
         assert list(ref_sd) == list(sd)
         assert all(torch.equal(ref_sd[k], sd[k]) for k in sd) and torch.equal(ref_tail, tail)
-
-
-def test_p8_gemm_schedule_has_no_lds_hazards():
-    """the experimental 8-phase GEMM's issue / wait / barrier schedule, checked on a barrier-epoch model for 1..11 K-tiles (tools/p8_schedule_check.py)"""
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("p8_schedule_check", os.path.join(ROOT, "tools", "p8_schedule_check.py"))
-    m = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(m)
-    assert sum(m.check(nk) for nk in range(1, 12)) == 0
-    assert sum(m.check_stream(nk, mt) for nk in range(1, 9) for mt in range(1, 6)) == 0   # the persistent variant's tile / K-tile bookkeeping

@@ -71,6 +71,7 @@ struct W4Args {
   int64_t M, N, K;
   float* c_f32; uint16_t* c_bf16; int64_t ldc;
   int nbm, nbn;
+  unsigned long long* clk;   // [2 * blocks]: shader-clock cycles, 100 MHz realtime ticks of the K loop
 };
 
 __device__ __forceinline__ void w4_tile_coords(const W4Args& a, int& tile_m, int& tile_n) {
@@ -91,7 +92,8 @@ __device__ __forceinline__ void w4_tile_coords(const W4Args& a, int& tile_m, int
 template <int FLAGS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_w4_kernel(const W4Args args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr bool LOADS = !(FLAGS & 1), READS = !(FLAGS & 2), MFMA = !(FLAGS & 4), STORE = !(FLAGS & 8);
+  constexpr int GPHASE = (FLAGS >> 8) & 3;   // MFMA slot (mod 4) under which this build issues its global_load_lds
+  constexpr bool LOADS = !(FLAGS & 1), READS = !(FLAGS & 2), MFMA = !(FLAGS & 4), STORE = !(FLAGS & 8), VMWAIT = !(FLAGS & 16), HOT = (FLAGS & 32) != 0, STAG = (FLAGS & 64) != 0, FULL = (FLAGS & 128) != 0, SHALLOW = (FLAGS & 1024) != 0;
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -107,12 +109,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   {
     const uint16_t* P = wave < 2 ? args.A : args.B;
     gld = wave < 2 ? args.lda : args.ldb;
-    const int64_t x0 = wave < 2 ? m0 + wave * 128 : n0 + (wave - 2) * 128;
+    const int64_t x0 = HOT ? (wave & 1) * 128 : (wave < 2 ? m0 + wave * 128 : n0 + (wave - 2) * 128);   // HOT: every tile stages the same (L2-resident) rows
     const int r = lane >> 2, pc = lane & 3;           // row within the 16-row slab, physical chunk
     const int c = pc ^ ((r >> 2) & 3);                // logical chunk stored there (slab base rows are multiples of 16: (r>>2)&3 unaffected)
     gsrc = P + (x0 + r) * gld + c * 8;
+    // FULL (timing experiment, results wrong): the same byte volume fetched as 8 rows x 128 B per instruction (whole cache lines)
+    if (FULL) gsrc = P + (x0 / 2 + (lane >> 3)) * gld + (lane & 7) * 8;
   }
-  const int64_t slab_step = 16 * gld;                 // elements between consecutive 16-row slabs
+  const int64_t slab_step = (FULL ? 8 : 16) * gld;    // elements between consecutive slabs
   unsigned char* const my_sub = smem + wave * W4_SUB;
 
   f32x16 acc[4][4];
@@ -130,17 +134,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // fragment (32 rows x 16 k) of sub-tile row-block i at k-step s (0,1): lane -> row i*32 + l31, chunk s*2 + hi
 #define W4_ISSUE_ONE(SLOT, U)                                                                                                     \
   do {                                                                                                                            \
-    if (LOADS)                                                                                                                    \
+    if (LOADS || prologue)                                                                                                        \
       __builtin_amdgcn_global_load_lds((const GLB_AS void*)(gsrc + (U) * slab_step), (LDS_AS void*)(my_sub + (SLOT) * W4_SLOT + (U) * 1024), 16, 0, 0); \
   } while (0)
 #define W4_ISSUE_STAGE(SLOT)                                                                                                      \
   do {                                                                                                                            \
     _Pragma("unroll") for (int u_ = 0; u_ < 8; ++u_) W4_ISSUE_ONE(SLOT, u_);                                                      \
-    gsrc += 32;                                                                                                                   \
+    gsrc += (FULL ? 64 : 32);                                                                                                                   \
   } while (0)
 #define W4_READ(FA, FB, SLOT, S)                                                                                                  \
   do {                                                                                                                            \
-    if (READS) {                                                                                                                  \
+    if (READS || prologue) {                                                                                                                  \
       const unsigned char* sa_ = smem + (SLOT) * W4_SLOT + wm * W4_SUB;                                                           \
       const unsigned char* sb_ = smem + (SLOT) * W4_SLOT + (2 + wn) * W4_SUB;                                                     \
       _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) FA[i_] = *reinterpret_cast<const s16x8*>(sa_ + row32_off(i_ * 32 + l31, (S) * 2 + hi)); \
@@ -162,79 +166,97 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     if (MFMA) acc[(Q) >> 2][(Q) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, FB[(Q) & 3]), __builtin_bit_cast(bf16x8, FA[(Q) >> 2]), acc[(Q) >> 2][(Q) & 3], 0, 0, 0); \
   } while (0)
 #define W4_FENCE() __builtin_amdgcn_sched_barrier(0)
-  // first half of a stage: MFMAs on k-step 0 (F0) with the reads of k-step 1 (F1) issued under the first MFMAs
-#define W4_HALF_A(SLOT)                                                                                                           \
+  // one fragment read (u = 0..3: A row-blocks, 4..7: B row-blocks)
+#define W4_READ_ONE(FA, FB, SLOT, S, U)                                                                                           \
   do {                                                                                                                            \
-    W4_MM(0, fa0, fb0); W4_MM(1, fa0, fb0);                                                                                       \
-    W4_FENCE();                                                                                                                   \
-    W4_READ(fa1, fb1, SLOT, 1);                                                                                                   \
-    W4_FENCE();                                                                                                                   \
-    _Pragma("unroll") for (int q_ = 2; q_ < 16; ++q_) W4_MM(q_, fa0, fb0);                                                        \
-    W4_FENCE();                                                                                                                   \
+    if (READS || prologue) {                                                                                                      \
+      if ((U) < 4) FA[(U) & 3] = *reinterpret_cast<const s16x8*>(smem + (SLOT) * W4_SLOT + wm * W4_SUB + row32_off(((U) & 3) * 32 + l31, (S) * 2 + hi)); \
+      else FB[(U) & 3] = *reinterpret_cast<const s16x8*>(smem + (SLOT) * W4_SLOT + (2 + wn) * W4_SUB + row32_off(((U) & 3) * 32 + l31, (S) * 2 + hi)); \
+    }                                                                                                                             \
   } while (0)
-  // second half: MFMAs on k-step 1 (F1); the refill of the vacated slot is spread one load per MFMA, then the reads of the next
-  // stage's k-step 0 (F0)
-#define W4_HALF_B(SLOT, NEXT_SLOT, ISSUE, READ_NEXT)                                                                              \
+  // half a stage = 16 MFMAs on fragments (FA, FB): under MFMAs 0-7 one fragment read each (the NEXT half's fragments, from RSLOT /
+  // k-step RS into RA / RB), under MFMAs 8-15 one global_load_lds per two MFMAs (four 1-KiB pieces G0..G0+3 of the stage being staged
+  // into slot GSLOT).  Spreading matters: the four waves share one LDS (a burst of 32 reads takes ~128 cycles) and one texture
+  // addresser (~64 B/clk: a 1-KiB load per wave = 64 cycles for the four of them) — bursts stall the in-order waves and idle the MFMA pipe
+#define W4_HALF(GPH, FA, FB, RA, RB, RSLOT, RS, DO_READ, GSLOT, G0, DO_ISSUE)                                                          \
   do {                                                                                                                            \
-    _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) {                                                                            \
-      W4_MM(q_, fa1, fb1);                                                                                                        \
-      if (ISSUE) { W4_ISSUE_ONE(SLOT, q_); }                                                                                      \
+    _Pragma("unroll") for (int q_ = 0; q_ < 16; ++q_) {                                                                           \
+      W4_MM(q_, FA, FB);                                                                                                          \
+      if ((DO_READ) && q_ < 8) { W4_READ_ONE(RA, RB, RSLOT, RS, q_); }                                                            \
+      if ((DO_ISSUE) && (q_ & 3) == (GPH)) { W4_ISSUE_ONE(GSLOT, (G0) + (q_ >> 2)); }                                            \
       W4_FENCE();                                                                                                                 \
     }                                                                                                                             \
-    if (ISSUE) gsrc += 32;                                                                                                        \
-    W4_MM(8, fa1, fb1); W4_MM(9, fa1, fb1);                                                                                       \
-    W4_FENCE();                                                                                                                   \
-    if (READ_NEXT) { W4_READ(fa0, fb0, NEXT_SLOT, 0); }                                                                           \
-    W4_FENCE();                                                                                                                   \
-    _Pragma("unroll") for (int q_ = 10; q_ < 16; ++q_) W4_MM(q_, fa1, fb1);                                                       \
-    W4_FENCE();                                                                                                                   \
   } while (0)
 
-  // prologue: stages 0..3 fill the four slots; only stage 0 has to have landed (requires nst >= 4)
-  W4_ISSUE_STAGE(0); W4_ISSUE_STAGE(1); W4_ISSUE_STAGE(2); W4_ISSUE_STAGE(3);
-  __builtin_amdgcn_s_waitcnt(0x4F78);       // vmcnt(24)
+  // prologue: stages 0..2 fill slots 0..2 completely, the first half (pieces 0-3) of stage 3 goes to slot 3 (its second half is issued in
+  // the first half of stage 0, as in steady state); only stage 0 has to have landed (requires nst >= 4)
+  bool prologue = true;   // ablation builds still stage / read REAL data once, so the MFMAs see realistic operands (DVFS is data dependent)
+  W4_ISSUE_STAGE(0); W4_ISSUE_STAGE(1); W4_ISSUE_STAGE(2);
+  _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) W4_ISSUE_ONE(3, u_);
+  if (LOADS) __builtin_amdgcn_s_waitcnt(0x4F74);       // vmcnt(20): stage 0 landed
+  else __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0)
   __builtin_amdgcn_s_barrier();
   W4_READ(fa0, fb0, 0, 0);
+  if (!READS) { W4_READ(fa1, fb1, 0, 1); }
   W4_FENCE();
+  prologue = false;
 
-  int j = 0;
-  for (; j + 4 < nst; ++j) {               // steady state: stages j+1 .. j+3 in flight, stage j+4 issued in the second half
-    const int slot = j & 3;
-    W4_HALF_A(slot);
-    __builtin_amdgcn_s_waitcnt(0x4070);    // vmcnt(16): my loads of stage j+1 have landed ; lgkmcnt(0): my reads of this slot are complete
-    __builtin_amdgcn_s_barrier();
-    W4_FENCE();
-    W4_HALF_B(slot, (j + 1) & 3, true, true);
+  const unsigned long long t0c = __builtin_readcyclecounter(), t0r = __builtin_amdgcn_s_memrealtime();
+#define W4_KLOOP(GPH_)                                                                                                            \
+  do {                                                                                                                            \
+  int j = 0; \
+  for (; j + 4 < nst; ++j) { \
+    const int slot = j & 3; \
+    W4_HALF(GPH_, fa0, fb0, fa1, fb1, slot, 1, true, (j + 3) & 3, 4, true); \
+    gsrc += (FULL ? 64 : 32); \
+    if (VMWAIT && SHALLOW) __builtin_amdgcn_s_waitcnt(0x0078); \
+    else if (VMWAIT) __builtin_amdgcn_s_waitcnt(0x4070); \
+    else __builtin_amdgcn_s_waitcnt(0xC07F); \
+    __builtin_amdgcn_s_barrier(); \
+    W4_FENCE(); \
+    W4_HALF(GPH_, fa1, fb1, fa0, fb0, (j + 1) & 3, 0, true, slot, 0, true); \
+  } \
+  { \
+    W4_HALF(GPH_, fa0, fb0, fa1, fb1, j & 3, 1, true, (j + 3) & 3, 4, true); \
+    __builtin_amdgcn_s_waitcnt(0x4070); \
+    __builtin_amdgcn_s_barrier(); \
+    W4_FENCE(); \
+    W4_HALF(GPH_, fa1, fb1, fa0, fb0, (j + 1) & 3, 0, true, 0, 0, false); \
+    ++j; \
+    W4_HALF(GPH_, fa0, fb0, fa1, fb1, j & 3, 1, true, 0, 0, false); \
+    __builtin_amdgcn_s_waitcnt(0x0078); \
+    __builtin_amdgcn_s_barrier(); \
+    W4_FENCE(); \
+    W4_HALF(GPH_, fa1, fb1, fa0, fb0, (j + 1) & 3, 0, true, 0, 0, false); \
+    ++j; \
+    W4_HALF(GPH_, fa0, fb0, fa1, fb1, j & 3, 1, true, 0, 0, false); \
+    __builtin_amdgcn_s_waitcnt(0x0070); \
+    __builtin_amdgcn_s_barrier(); \
+    W4_FENCE(); \
+    W4_HALF(GPH_, fa1, fb1, fa0, fb0, (j + 1) & 3, 0, true, 0, 0, false); \
+    ++j; \
+    W4_HALF(GPH_, fa0, fb0, fa1, fb1, j & 3, 1, true, 0, 0, false); \
+    __builtin_amdgcn_s_waitcnt(0xC07F); \
+    W4_FENCE(); \
+    W4_HALF(GPH_, fa1, fb1, fa0, fb0, 0, 0, false, 0, 0, false); \
+  } \
+  } while (0)
+  // STAG builds: wave w issues its global_load_lds under MFMA slots = w (mod 4), so the four waves (in lock step after every barrier)
+  // never contend for the texture addresser; otherwise every wave uses slot GPHASE
+  if (STAG) {
+    if (wave == 0) W4_KLOOP(0); else if (wave == 1) W4_KLOOP(1); else if (wave == 2) W4_KLOOP(2); else W4_KLOOP(3);
+  } else {
+    W4_KLOOP(GPHASE);
   }
-  // tail: the last four stages, nothing left to issue
-  {
-    W4_HALF_A(j & 3);
-    __builtin_amdgcn_s_waitcnt(0x4070);    // vmcnt(16)
-    __builtin_amdgcn_s_barrier();
-    W4_FENCE();
-    W4_HALF_B(j & 3, (j + 1) & 3, false, true);
-    ++j;
-    W4_HALF_A(j & 3);
-    __builtin_amdgcn_s_waitcnt(0x0078);    // vmcnt(8)
-    __builtin_amdgcn_s_barrier();
-    W4_FENCE();
-    W4_HALF_B(j & 3, (j + 1) & 3, false, true);
-    ++j;
-    W4_HALF_A(j & 3);
-    __builtin_amdgcn_s_waitcnt(0x0070);    // vmcnt(0)
-    __builtin_amdgcn_s_barrier();
-    W4_FENCE();
-    W4_HALF_B(j & 3, (j + 1) & 3, false, true);
-    ++j;
-    W4_HALF_A(j & 3);
-    __builtin_amdgcn_s_waitcnt(0xC07F);    // lgkmcnt(0)
-    W4_FENCE();
-    W4_HALF_B(j & 3, 0, false, false);
+  if (args.clk && t == 0) {
+    args.clk[2 * blockIdx.x] = __builtin_readcyclecounter() - t0c;
+    args.clk[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - t0r;
   }
 #undef W4_MM
 #undef W4_FENCE
-#undef W4_HALF_A
-#undef W4_HALF_B
+#undef W4_READ_ONE
+#undef W4_HALF
+#undef W4_KLOOP
 #undef W4_ISSUE_ONE
 #undef W4_ISSUE_STAGE
 #undef W4_READ
@@ -271,6 +293,577 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
 }
 
+
+// -------------------------------------------------------------------------------------------------------------------
+// w2x kernel: 256 (M) x 128 (N) tile, 4 waves (2 x 2, 128 x 64 each, 128 accumulator registers), TWO workgroups per CU (two waves per
+// SIMD: one workgroup's prologue / epilogue / load-issue stalls are covered by the other's MFMAs), 3-slot ring of 32-deep K stages
+// (24 KiB each: A 256 rows x 64 B | B 128 rows x 64 B) filled by global_load_lds two stages ahead, one barrier per stage.
+// -------------------------------------------------------------------------------------------------------------------
+#define X2_SLOT 24576
+template <int FLAGS>
+__global__ __launch_bounds__(256, 2) void gemm_w2x_kernel(const W4Args args) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr bool LOADS = !(FLAGS & 1), READS = !(FLAGS & 2), MFMA = !(FLAGS & 4), STORE = !(FLAGS & 8);
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  int tile_m, tile_n;
+  w4_tile_coords(args, tile_m, tile_n);
+  const int64_t m0 = (int64_t)tile_m * 256, n0 = (int64_t)tile_n * 128;
+  const int nst = (int)(args.K / 32);
+
+  // staging: 24 slabs of 16 rows (0-15: A, 16-23: B); wave w stages slabs w*6 .. w*6+5
+  const uint16_t* gsrc[6];
+#pragma unroll
+  for (int u = 0; u < 6; ++u) {
+    const int sl = wave * 6 + u;
+    const int r = lane >> 2, pc = lane & 3;
+    const int c = pc ^ ((r >> 2) & 3);
+    gsrc[u] = sl < 16 ? args.A + (m0 + sl * 16 + r) * args.lda + c * 8 : args.B + (n0 + (sl - 16) * 16 + r) * args.ldb + c * 8;
+  }
+  unsigned char* const my_dst = smem + wave * 6 * 1024;
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  s16x8 fa0[4], fb0[2], fa1[4], fb1[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) fa0[i] = fa1[i] = (s16x8){1, 2, 3, 4, 5, 6, 7, 8};
+#pragma unroll
+  for (int i = 0; i < 2; ++i) fb0[i] = fb1[i] = (s16x8){1, 2, 3, 4, 5, 6, 7, 8};
+  const int l31 = lane & 31, hi = lane >> 5;
+  bool prologue = true;
+
+#define X2_ISSUE_ONE(SLOT, U)                                                                                                     \
+  do {                                                                                                                            \
+    if (LOADS || prologue) {                                                                                                      \
+      __builtin_amdgcn_global_load_lds((const GLB_AS void*)gsrc[U], (LDS_AS void*)(my_dst + (SLOT) * X2_SLOT + (U) * 1024), 16, 0, 0); \
+      gsrc[U] += 32;                                                                                                              \
+    }                                                                                                                             \
+  } while (0)
+  // fragment u of k-step S from slot SLOT: u = 0..3 A row-blocks of this wave's 128 rows, u = 4,5 B row-blocks of its 64 columns
+#define X2_READ_ONE(FA, FB, SLOT, S, U)                                                                                           \
+  do {                                                                                                                            \
+    if (READS || prologue) {                                                                                                      \
+      if ((U) < 4) FA[(U) & 3] = *reinterpret_cast<const s16x8*>(smem + (SLOT) * X2_SLOT + row32_off(wm * 128 + ((U) & 3) * 32 + l31, (S) * 2 + hi)); \
+      else FB[(U) & 1] = *reinterpret_cast<const s16x8*>(smem + (SLOT) * X2_SLOT + 16384 + row32_off(wn * 64 + ((U) & 1) * 32 + l31, (S) * 2 + hi)); \
+    }                                                                                                                             \
+  } while (0)
+#define X2_MM(Q, FA, FB)                                                                                                          \
+  do {                                                                                                                            \
+    if (MFMA) acc[(Q) >> 1][(Q) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, FB[(Q) & 1]), __builtin_bit_cast(bf16x8, FA[(Q) >> 1]), acc[(Q) >> 1][(Q) & 1], 0, 0, 0); \
+  } while (0)
+#define X2_FENCE() __builtin_amdgcn_sched_barrier(0)
+  // half a stage: 8 MFMAs; under MFMAs 0-5 one fragment read each (next half's fragments), under MFMAs 1, 4, 7 one global_load_lds
+#define X2_HALF(FA, FB, RA, RB, RSLOT, RS, DO_READ, GSLOT, G0, DO_ISSUE)                                                          \
+  do {                                                                                                                            \
+    _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) {                                                                            \
+      X2_MM(q_, FA, FB);                                                                                                          \
+      if ((DO_READ) && q_ < 6) { X2_READ_ONE(RA, RB, RSLOT, RS, q_); }                                                            \
+      if ((DO_ISSUE) && (q_ % 3) == 1) { X2_ISSUE_ONE(GSLOT, (G0) + q_ / 3); }                                                    \
+      X2_FENCE();                                                                                                                 \
+    }                                                                                                                             \
+  } while (0)
+
+  // prologue: stages 0, 1 completely, pieces 0-2 of stage 2 (its pieces 3-5 go out in the first half of stage 0, as in steady state)
+  _Pragma("unroll") for (int u_ = 0; u_ < 6; ++u_) X2_ISSUE_ONE(0, u_);
+  _Pragma("unroll") for (int u_ = 0; u_ < 6; ++u_) X2_ISSUE_ONE(1, u_);
+  _Pragma("unroll") for (int u_ = 0; u_ < 3; ++u_) X2_ISSUE_ONE(2, u_);
+  if (LOADS) __builtin_amdgcn_s_waitcnt(0x0F79);       // vmcnt(9): stage 0 landed
+  else __builtin_amdgcn_s_waitcnt(0x0F70);
+  __builtin_amdgcn_s_barrier();
+  _Pragma("unroll") for (int u_ = 0; u_ < 6; ++u_) X2_READ_ONE(fa0, fb0, 0, 0, u_);
+  if (!READS) { _Pragma("unroll") for (int u_ = 0; u_ < 6; ++u_) X2_READ_ONE(fa1, fb1, 0, 1, u_); }
+  X2_FENCE();
+  prologue = false;
+
+  const unsigned long long t0c = __builtin_readcyclecounter(), t0r = __builtin_amdgcn_s_memrealtime();
+  int j = 0, slot = 0, slot1 = 1, slot2 = 2;   // slot = j % 3, slot1 = (j+1) % 3, slot2 = (j+2) % 3
+  for (; j + 3 < nst; ++j) {
+    X2_HALF(fa0, fb0, fa1, fb1, slot, 1, true, slot2, 3, true);      // pieces 3-5 of stage j+2 -> slot (j+2)%3
+    __builtin_amdgcn_s_waitcnt(0x0076);                              // vmcnt(6): my loads of stage j+1 landed ; lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    X2_FENCE();
+    X2_HALF(fa1, fb1, fa0, fb0, slot1, 0, true, slot, 0, true);      // pieces 0-2 of stage j+3 -> the slot just vacated
+    const int s_ = slot; slot = slot1; slot1 = slot2; slot2 = s_;
+  }
+  // tail: j = nst-3, nst-2, nst-1
+  X2_HALF(fa0, fb0, fa1, fb1, slot, 1, true, slot2, 3, true);        // pieces 3-5 of stage nst-1
+  __builtin_amdgcn_s_waitcnt(0x0076);
+  __builtin_amdgcn_s_barrier();
+  X2_FENCE();
+  X2_HALF(fa1, fb1, fa0, fb0, slot1, 0, true, 0, 0, false);
+  X2_HALF(fa0, fb0, fa1, fb1, slot1, 1, true, 0, 0, false);
+  __builtin_amdgcn_s_waitcnt(0x0070);                                // vmcnt(0)
+  __builtin_amdgcn_s_barrier();
+  X2_FENCE();
+  X2_HALF(fa1, fb1, fa0, fb0, slot2, 0, true, 0, 0, false);
+  X2_HALF(fa0, fb0, fa1, fb1, slot2, 1, true, 0, 0, false);
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  X2_FENCE();
+  X2_HALF(fa1, fb1, fa0, fb0, 0, 0, false, 0, 0, false);
+  if (args.clk && t == 0) {
+    args.clk[2 * blockIdx.x] = __builtin_readcyclecounter() - t0c;
+    args.clk[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - t0r;
+  }
+#undef X2_ISSUE_ONE
+#undef X2_READ_ONE
+#undef X2_MM
+#undef X2_FENCE
+#undef X2_HALF
+  if (STORE) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t m = m0 + wm * 128 + i * 32 + l31;
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int64_t n = n0 + wn * 64 + jj * 32 + 8 * g4 + 4 * hi;
+          const float v0 = acc[i][jj][g4 * 4 + 0], v1 = acc[i][jj][g4 * 4 + 1], v2 = acc[i][jj][g4 * 4 + 2], v3 = acc[i][jj][g4 * 4 + 3];
+          if (args.c_f32) { const f32x4 o = {v0, v1, v2, v3}; *reinterpret_cast<f32x4*>(args.c_f32 + m * args.ldc + n) = o; }
+          if (args.c_bf16) {
+            const u32x2 o = {(uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16), (uint32_t)f2bf(v2) | ((uint32_t)f2bf(v3) << 16)};
+            *reinterpret_cast<u32x2*>(args.c_bf16 + m * args.ldc + n) = o;
+          }
+        }
+      }
+    }
+  } else {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[i][jj][r];
+    if (s == 1234.5678f) args.c_f32[0] = s;
+  }
+}
+
+template <int FLAGS>
+static void launch_w2x(const W4Args& a0, hipStream_t s) {
+  static bool set = false;
+  if (!set) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w2x_kernel<FLAGS>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * X2_SLOT)); set = true; }
+  W4Args a = a0;
+  a.nbn = (int)(a.N / 128);
+  gemm_w2x_kernel<FLAGS><<<dim3(a.nbm * a.nbn), 256, 3 * X2_SLOT, s>>>(a);
+}
+
+
+// -------------------------------------------------------------------------------------------------------------------
+// w4b kernel: as w4 (256 x 256 tile, four waves of 128 x 128, one per SIMD) but with 64-deep K stages loaded as WHOLE 128-byte lines
+// (HBM-streamed operands lose ~10 % MFMA utilisation when every line is fetched as two 64-byte halves a stage apart), two 64-KiB slots
+// [A rows 0-127 | A rows 128-255 | B cols 0-127 | B cols 128-255] in the product library's "row" image (128-B rows, chunk ^ ((r>>1)&7)).
+// One barrier per stage, placed after the reads of the last k-step: the slot is then free and its refill (next-next stage) is spread
+// over the following 32 MFMAs (one load per two MFMAs); fragment reads go one per MFMA under the first 8 MFMAs of every k-step.
+// -------------------------------------------------------------------------------------------------------------------
+#define WB_SLOT 65536
+#define WB_SUB 16384
+__device__ __forceinline__ int row64_off(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
+
+template <int FLAGS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_w4b_kernel(const W4Args args) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr bool LOADS = !(FLAGS & 1), READS = !(FLAGS & 2), MFMA = !(FLAGS & 4), STORE = !(FLAGS & 8), HOT = (FLAGS & 32) != 0, COAL = (FLAGS & 64) != 0, STAGGER = (FLAGS & 128) != 0;
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  int tile_m, tile_n;
+  w4_tile_coords(args, tile_m, tile_n);
+  const int64_t m0 = (int64_t)tile_m * 256, n0 = (int64_t)tile_n * 256;
+  const int nst = (int)(args.K / 64);
+  if (STAGGER && blockIdx.x < 256) {
+    // de-synchronise the CUs: the first workgroup of every CU starts 0, 1/4, 1/2 or 3/4 of a tile period late, so that the chip's epilogues
+    // (a burst of 32-64 MB of stores when all 256 CUs finish a tile together) are spread over time; later workgroups inherit the phase
+    const int phase = (blockIdx.x >> 3) & 7;
+    const int sleeps = phase * nst * 2800 / 8 / 1024;   // s_sleep 16 = 1024 cycles ; tile period ~ nst * 2800 cycles
+    for (int i = 0; i < sleeps; ++i) __builtin_amdgcn_s_sleep(16);
+  }
+
+  // staging: wave w fills sub-tile w (16 slabs of 8 rows x 128 B per stage).  Slab u, lane -> row u*8 + (lane>>3), physical chunk lane&7,
+  // logical chunk (lane&7) ^ ((row>>1)&7) = (lane&7) ^ ((u*4 + (lane>>4)) & 7): two source patterns (u even / odd)
+  const uint16_t* gsrc_e; const uint16_t* gsrc_o;
+  int64_t gld;
+  {
+    const uint16_t* P = wave < 2 ? args.A : args.B;
+    gld = wave < 2 ? args.lda : args.ldb;
+    const int64_t x0 = HOT ? (wave & 1) * 128 : (wave < 2 ? m0 + wave * 128 : n0 + (wave - 2) * 128);
+    const int r = lane >> 3, pc = lane & 7;
+    gsrc_e = P + (x0 + r) * gld + ((pc ^ ((lane >> 4) & 7)) * 8);
+    gsrc_o = P + (x0 + 8 + r) * gld + ((pc ^ ((4 + (lane >> 4)) & 7)) * 8);
+  }
+  const int64_t pair_step = 16 * gld;
+  unsigned char* const my_sub = smem + wave * WB_SUB;
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  s16x8 fa0[4], fb0[4], fa1[4], fb1[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { fa0[i] = fb0[i] = fa1[i] = fb1[i] = (s16x8){1, 2, 3, 4, 5, 6, 7, 8}; }
+  const int l31 = lane & 31, hi = lane >> 5;
+  bool prologue = true;
+
+#define WB_ISSUE_ONE(SLOT, U)                                                                                                     \
+  do {                                                                                                                            \
+    if (LOADS || prologue)                                                                                                        \
+      __builtin_amdgcn_global_load_lds((const GLB_AS void*)((((U) & 1) ? gsrc_o : gsrc_e) + ((U) >> 1) * pair_step),             \
+                                       (LDS_AS void*)(my_sub + (SLOT) * WB_SLOT + (U) * 1024), 16, 0, 0);                        \
+  } while (0)
+#define WB_ADVANCE() do { gsrc_e += 64; gsrc_o += 64; } while (0)
+#define WB_READ_ONE(FA, FB, SLOT, S, U)                                                                                           \
+  do {                                                                                                                            \
+    if (READS || prologue) {                                                                                                      \
+      if ((U) < 4) FA[(U) & 3] = *reinterpret_cast<const s16x8*>(smem + (SLOT) * WB_SLOT + wm * WB_SUB + row64_off(((U) & 3) * 32 + l31, (S) * 2 + hi)); \
+      else FB[(U) & 3] = *reinterpret_cast<const s16x8*>(smem + (SLOT) * WB_SLOT + (2 + wn) * WB_SUB + row64_off(((U) & 3) * 32 + l31, (S) * 2 + hi)); \
+    }                                                                                                                             \
+  } while (0)
+#define WB_MM(Q, FA, FB)                                                                                                          \
+  do {                                                                                                                            \
+    if (MFMA) acc[(Q) >> 2][(Q) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, FB[(Q) & 3]), __builtin_bit_cast(bf16x8, FA[(Q) >> 2]), acc[(Q) >> 2][(Q) & 3], 0, 0, 0); \
+  } while (0)
+#define WB_FENCE() __builtin_amdgcn_sched_barrier(0)
+  // one k-step: 16 MFMAs on (FA, FB); one fragment read under each of MFMAs 0-7 (fragments of k-step RS of slot RSLOT into RA / RB);
+  // one global_load_lds under every odd MFMA (pieces G0 .. G0+7 into slot GSLOT)
+#define WB_KSTEP(FA, FB, RA, RB, RSLOT, RS, DO_READ, GSLOT, G0, DO_ISSUE)                                                         \
+  do {                                                                                                                            \
+    _Pragma("unroll") for (int q_ = 0; q_ < 16; ++q_) {                                                                           \
+      WB_MM(q_, FA, FB);                                                                                                          \
+      if ((DO_READ) && q_ < 8) { WB_READ_ONE(RA, RB, RSLOT, RS, q_); }                                                            \
+      if ((DO_ISSUE) && (q_ & 1)) { WB_ISSUE_ONE(GSLOT, (G0) + (q_ >> 1)); }                                                      \
+      WB_FENCE();                                                                                                                 \
+    }                                                                                                                             \
+  } while (0)
+
+  // prologue: stage 0 -> slot 0 completely; pieces 0-7 of stage 1 -> slot 1 (pieces 8-15 follow under k-step 0 of stage 0)
+  _Pragma("unroll") for (int u_ = 0; u_ < 16; ++u_) WB_ISSUE_ONE(0, u_);
+  WB_ADVANCE();
+  _Pragma("unroll") for (int u_ = 0; u_ < 8; ++u_) WB_ISSUE_ONE(1, u_);
+  if (LOADS) __builtin_amdgcn_s_waitcnt(0x0F78);   // vmcnt(8): stage 0 landed
+  else __builtin_amdgcn_s_waitcnt(0x0F70);
+  __builtin_amdgcn_s_barrier();
+  _Pragma("unroll") for (int u_ = 0; u_ < 8; ++u_) WB_READ_ONE(fa0, fb0, 0, 0, u_);
+  if (!READS) { _Pragma("unroll") for (int u_ = 0; u_ < 8; ++u_) WB_READ_ONE(fa1, fb1, 0, 1, u_); }
+  WB_FENCE();
+  prologue = false;
+
+  const unsigned long long t0c = __builtin_readcyclecounter(), t0r = __builtin_amdgcn_s_memrealtime();
+  // invariant at the top of iteration j: gsrc points at stage j+1 whose pieces 0-7 are already issued (slot (j+1)&1)
+  int j = 0;
+  for (; j + 2 < nst; ++j) {
+    const int slot = j & 1;
+    WB_KSTEP(fa0, fb0, fa1, fb1, slot, 1, true, slot ^ 1, 8, true);      // pieces 8-15 of stage j+1
+    WB_ADVANCE();
+    WB_KSTEP(fa1, fb1, fa0, fb0, slot, 2, true, 0, 0, false);
+    WB_KSTEP(fa0, fb0, fa1, fb1, slot, 3, true, 0, 0, false);
+    __builtin_amdgcn_s_waitcnt(0x0070);    // vmcnt(0): stage j+1 landed (issued >= 32 MFMAs ago, nothing newer outstanding) ; lgkmcnt(0): slot read out
+    __builtin_amdgcn_s_barrier();
+    WB_FENCE();
+    WB_KSTEP(fa1, fb1, fa0, fb0, slot ^ 1, 0, true, slot, 0, true);      // pieces 0-7 of stage j+2 -> the slot just vacated
+  }
+  // tail: stages nst-2 and nst-1 (requires nst >= 2)
+  {
+    const int slot = j & 1;
+    WB_KSTEP(fa0, fb0, fa1, fb1, slot, 1, true, slot ^ 1, 8, true);      // pieces 8-15 of stage nst-1
+    WB_KSTEP(fa1, fb1, fa0, fb0, slot, 2, true, 0, 0, false);
+    WB_KSTEP(fa0, fb0, fa1, fb1, slot, 3, true, 0, 0, false);
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    __builtin_amdgcn_s_barrier();
+    WB_FENCE();
+    WB_KSTEP(fa1, fb1, fa0, fb0, slot ^ 1, 0, true, 0, 0, false);
+    WB_KSTEP(fa0, fb0, fa1, fb1, slot ^ 1, 1, true, 0, 0, false);
+    WB_KSTEP(fa1, fb1, fa0, fb0, slot ^ 1, 2, true, 0, 0, false);
+    WB_KSTEP(fa0, fb0, fa1, fb1, slot ^ 1, 3, true, 0, 0, false);
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    WB_FENCE();
+    WB_KSTEP(fa1, fb1, fa0, fb0, 0, 0, false, 0, 0, false);
+  }
+  if (args.clk && t == 0) {
+    args.clk[2 * blockIdx.x] = __builtin_readcyclecounter() - t0c;
+    args.clk[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - t0r;
+  }
+#undef WB_ISSUE_ONE
+#undef WB_ADVANCE
+#undef WB_READ_ONE
+#undef WB_MM
+#undef WB_FENCE
+#undef WB_KSTEP
+  if (STORE && COAL) {
+    // coalesced epilogue: the wave's 128 x 128 f32 tile goes through its private 32 KiB of LDS in two halves of 64 rows (row pitch
+    // 512 B, 16-B chunks XOR-swizzled by the row) and leaves as whole 128-byte lines: every store instruction covers 2 rows x 512 B (f32)
+    // or 2 rows x 256 B (bf16).  The plain epilogue writes 16-B pieces of 32 different rows per instruction: 8x the L2 write requests.
+    __builtin_amdgcn_s_barrier();   // every wave is done reading the operand ring
+    unsigned char* stg = smem + wave * 32768;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+        const int i = h * 2 + ii;
+        const int row = ii * 32 + l31;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const int cb = (jj * 32 + 8 * g4 + 4 * hi) * 4;
+            const f32x4 o = {acc[i][jj][g4 * 4 + 0], acc[i][jj][g4 * 4 + 1], acc[i][jj][g4 * 4 + 2], acc[i][jj][g4 * 4 + 3]};
+            *reinterpret_cast<f32x4*>(stg + row * 512 + (cb ^ ((row & 31) << 4))) = o;
+          }
+      }
+      // (wave-private region: only the wave's own LDS writes have to have landed)
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+#pragma unroll 4
+      for (int p = 0; p < 32; ++p) {
+        const int row = p * 2 + (lane >> 5), ch = lane & 31;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * 512 + ((ch << 4) ^ ((row & 31) << 4)));
+        const int64_t m = m0 + wm * 128 + h * 64 + row, n = n0 + wn * 128 + ch * 4;
+        if (args.c_f32) *reinterpret_cast<f32x4*>(args.c_f32 + m * args.ldc + n) = v;
+        if (args.c_bf16) {
+          const u32x2 o = {(uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16), (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16)};
+          *reinterpret_cast<u32x2*>(args.c_bf16 + m * args.ldc + n) = o;
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0xC07F);   // staging reads done before the second half overwrites the region
+    }
+  } else if (STORE) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t m = m0 + wm * 128 + i * 32 + l31;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int64_t n = n0 + wn * 128 + jj * 32 + 8 * g4 + 4 * hi;
+          const float v0 = acc[i][jj][g4 * 4 + 0], v1 = acc[i][jj][g4 * 4 + 1], v2 = acc[i][jj][g4 * 4 + 2], v3 = acc[i][jj][g4 * 4 + 3];
+          if (args.c_f32) { const f32x4 o = {v0, v1, v2, v3}; *reinterpret_cast<f32x4*>(args.c_f32 + m * args.ldc + n) = o; }
+          if (args.c_bf16) {
+            const u32x2 o = {(uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16), (uint32_t)f2bf(v2) | ((uint32_t)f2bf(v3) << 16)};
+            *reinterpret_cast<u32x2*>(args.c_bf16 + m * args.ldc + n) = o;
+          }
+        }
+      }
+    }
+  } else {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[i][jj][r];
+    if (s == 1234.5678f) args.c_f32[0] = s;
+  }
+}
+
+template <int FLAGS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_w4p_kernel(const W4Args args) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr bool LOADS = !(FLAGS & 1), READS = !(FLAGS & 2), MFMA = !(FLAGS & 4), STORE = !(FLAGS & 8), HOT = (FLAGS & 32) != 0, COAL = (FLAGS & 64) != 0, STAGGER = (FLAGS & 128) != 0;
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntiles = args.nbm * args.nbn;
+  int64_t m0 = 0, n0 = 0;
+  const int nst = (int)(args.K / 64);
+  // staging: wave w fills sub-tile w (16 slabs of 8 rows x 128 B per stage).  Slab u, lane -> row u*8 + (lane>>3), physical chunk lane&7,
+  // logical chunk (lane&7) ^ ((row>>1)&7) = (lane&7) ^ ((u*4 + (lane>>4)) & 7): two source patterns (u even / odd)
+  const uint16_t* gsrc_e; const uint16_t* gsrc_o;
+  const uint16_t* const Pw = wave < 2 ? args.A : args.B;
+  const int64_t gld = wave < 2 ? args.lda : args.ldb;
+  // virtual block id -> tile (XCD-aware grouped order) ; sets the staging pointers of this wave for that tile
+#define WP_SET_TILE(VB, M0, N0)                                                                                                   \
+  do {                                                                                                                            \
+    int bid_ = (VB);                                                                                                              \
+    { const int q_ = ntiles >> 3, r_ = ntiles & 7, xcd_ = bid_ & 7, pos_ = bid_ >> 3;                                             \
+      bid_ = (xcd_ < r_ ? xcd_ * (q_ + 1) : r_ * (q_ + 1) + (xcd_ - r_) * q_) + pos_; }                                           \
+    const int per_group_ = 8 * args.nbn;                                                                                          \
+    const int grp_ = bid_ / per_group_, within_ = bid_ - grp_ * per_group_;                                                       \
+    const int rows_ = (args.nbm - grp_ * 8) < 8 ? (args.nbm - grp_ * 8) : 8;                                                      \
+    M0 = (int64_t)(grp_ * 8 + within_ % rows_) * 256;                                                                             \
+    N0 = (int64_t)(within_ / rows_) * 256;                                                                                        \
+    const int64_t x0_ = wave < 2 ? M0 + wave * 128 : N0 + (wave - 2) * 128;                                                       \
+    const int r_l = lane >> 3, pc_ = lane & 7;                                                                                    \
+    gsrc_e = Pw + (x0_ + r_l) * gld + ((pc_ ^ ((lane >> 4) & 7)) * 8);                                                            \
+    gsrc_o = Pw + (x0_ + 8 + r_l) * gld + ((pc_ ^ ((4 + (lane >> 4)) & 7)) * 8);                                                  \
+  } while (0)
+  const int64_t pair_step = 16 * gld;
+  unsigned char* const my_sub = smem + wave * WB_SUB;
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  s16x8 fa0[4], fb0[4], fa1[4], fb1[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { fa0[i] = fb0[i] = fa1[i] = fb1[i] = (s16x8){1, 2, 3, 4, 5, 6, 7, 8}; }
+  const int l31 = lane & 31, hi = lane >> 5;
+  bool prologue = true;
+  (void)prologue;
+
+#define WB_ISSUE_ONE(SLOT, U)                                                                                                     \
+  do {                                                                                                                            \
+    if (LOADS || prologue)                                                                                                        \
+      __builtin_amdgcn_global_load_lds((const GLB_AS void*)((((U) & 1) ? gsrc_o : gsrc_e) + ((U) >> 1) * pair_step),             \
+                                       (LDS_AS void*)(my_sub + (SLOT) * WB_SLOT + (U) * 1024), 16, 0, 0);                        \
+  } while (0)
+#define WB_ADVANCE() do { gsrc_e += 64; gsrc_o += 64; } while (0)
+#define WB_READ_ONE(FA, FB, SLOT, S, U)                                                                                           \
+  do {                                                                                                                            \
+    if (READS || prologue) {                                                                                                      \
+      if ((U) < 4) FA[(U) & 3] = *reinterpret_cast<const s16x8*>(smem + (SLOT) * WB_SLOT + wm * WB_SUB + row64_off(((U) & 3) * 32 + l31, (S) * 2 + hi)); \
+      else FB[(U) & 3] = *reinterpret_cast<const s16x8*>(smem + (SLOT) * WB_SLOT + (2 + wn) * WB_SUB + row64_off(((U) & 3) * 32 + l31, (S) * 2 + hi)); \
+    }                                                                                                                             \
+  } while (0)
+#define WB_MM(Q, FA, FB)                                                                                                          \
+  do {                                                                                                                            \
+    if (MFMA) acc[(Q) >> 2][(Q) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, FB[(Q) & 3]), __builtin_bit_cast(bf16x8, FA[(Q) >> 2]), acc[(Q) >> 2][(Q) & 3], 0, 0, 0); \
+  } while (0)
+#define WB_FENCE() __builtin_amdgcn_sched_barrier(0)
+  // one k-step: 16 MFMAs on (FA, FB); one fragment read under each of MFMAs 0-7 (fragments of k-step RS of slot RSLOT into RA / RB);
+  // one global_load_lds under every odd MFMA (pieces G0 .. G0+7 into slot GSLOT)
+#define WB_KSTEP(FA, FB, RA, RB, RSLOT, RS, DO_READ, GSLOT, G0, DO_ISSUE)                                                         \
+  do {                                                                                                                            \
+    _Pragma("unroll") for (int q_ = 0; q_ < 16; ++q_) {                                                                           \
+      WB_MM(q_, FA, FB);                                                                                                          \
+      if ((DO_READ) && q_ < 8) { WB_READ_ONE(RA, RB, RSLOT, RS, q_); }                                                            \
+      if ((DO_ISSUE) && (q_ & 1)) { WB_ISSUE_ONE(GSLOT, (G0) + (q_ >> 1)); }                                                      \
+      WB_FENCE();                                                                                                                 \
+    }                                                                                                                             \
+  } while (0)
+
+#define WP_PROLOGUE_LOADS()                                                                                                       \
+  do {                                                                                                                            \
+    _Pragma("unroll") for (int u_ = 0; u_ < 16; ++u_) WB_ISSUE_ONE(0, u_);                                                        \
+    WB_ADVANCE();                                                                                                                 \
+    _Pragma("unroll") for (int u_ = 0; u_ < 8; ++u_) WB_ISSUE_ONE(1, u_);                                                         \
+  } while (0)
+  unsigned long long tsum_c = 0, tsum_r = 0;
+  if (STAGGER) {
+    const int phase = (blockIdx.x >> 3) & 7;
+    const int sleeps = phase * nst * 2800 / 8 / 1024;
+    for (int i = 0; i < sleeps; ++i) __builtin_amdgcn_s_sleep(16);
+  }
+  int vb = blockIdx.x;
+  WP_SET_TILE(vb, m0, n0);
+  WP_PROLOGUE_LOADS();
+  __builtin_amdgcn_s_waitcnt(0x0F78);   // vmcnt(8): stage 0 landed
+  for (;;) {
+  __builtin_amdgcn_s_barrier();
+  _Pragma("unroll") for (int u_ = 0; u_ < 8; ++u_) WB_READ_ONE(fa0, fb0, 0, 0, u_);
+  WB_FENCE();
+  prologue = false;
+  const unsigned long long t0c = __builtin_readcyclecounter(), t0r = __builtin_amdgcn_s_memrealtime();
+  // invariant at the top of iteration j: gsrc points at stage j+1 whose pieces 0-7 are already issued (slot (j+1)&1)
+  int j = 0;
+  for (; j + 2 < nst; ++j) {
+    const int slot = j & 1;
+    WB_KSTEP(fa0, fb0, fa1, fb1, slot, 1, true, slot ^ 1, 8, true);      // pieces 8-15 of stage j+1
+    WB_ADVANCE();
+    WB_KSTEP(fa1, fb1, fa0, fb0, slot, 2, true, 0, 0, false);
+    WB_KSTEP(fa0, fb0, fa1, fb1, slot, 3, true, 0, 0, false);
+    __builtin_amdgcn_s_waitcnt(0x0070);    // vmcnt(0): stage j+1 landed (issued >= 32 MFMAs ago, nothing newer outstanding) ; lgkmcnt(0): slot read out
+    __builtin_amdgcn_s_barrier();
+    WB_FENCE();
+    WB_KSTEP(fa1, fb1, fa0, fb0, slot ^ 1, 0, true, slot, 0, true);      // pieces 0-7 of stage j+2 -> the slot just vacated
+  }
+  // tail: stages nst-2 and nst-1 (requires nst >= 2)
+  {
+    const int slot = j & 1;
+    WB_KSTEP(fa0, fb0, fa1, fb1, slot, 1, true, slot ^ 1, 8, true);      // pieces 8-15 of stage nst-1
+    WB_KSTEP(fa1, fb1, fa0, fb0, slot, 2, true, 0, 0, false);
+    WB_KSTEP(fa0, fb0, fa1, fb1, slot, 3, true, 0, 0, false);
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    __builtin_amdgcn_s_barrier();
+    WB_FENCE();
+    WB_KSTEP(fa1, fb1, fa0, fb0, slot ^ 1, 0, true, 0, 0, false);
+    WB_KSTEP(fa0, fb0, fa1, fb1, slot ^ 1, 1, true, 0, 0, false);
+    WB_KSTEP(fa1, fb1, fa0, fb0, slot ^ 1, 2, true, 0, 0, false);
+    WB_KSTEP(fa0, fb0, fa1, fb1, slot ^ 1, 3, true, 0, 0, false);
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    WB_FENCE();
+    WB_KSTEP(fa1, fb1, fa0, fb0, 0, 0, false, 0, 0, false);
+  }
+  tsum_c += __builtin_readcyclecounter() - t0c;
+  tsum_r += __builtin_amdgcn_s_memrealtime() - t0r;
+  // ---- tile boundary: every wave is done with the ring -> next tile's first loads go out, overlapped with this tile's stores ----
+  __builtin_amdgcn_s_barrier();
+  const int64_t em0 = m0, en0 = n0;
+  vb += gridDim.x;
+  const bool more = vb < ntiles;
+#define WP_STORE_ROWBLOCK(I)                                                                                                      \
+  do {                                                                                                                            \
+    const int64_t m_ = em0 + wm * 128 + (I) * 32 + l31;                                                                           \
+    _Pragma("unroll") for (int jj = 0; jj < 4; ++jj)                                                                              \
+      _Pragma("unroll") for (int g4 = 0; g4 < 4; ++g4) {                                                                          \
+        const int64_t n_ = en0 + wn * 128 + jj * 32 + 8 * g4 + 4 * hi;                                                            \
+        const float v0 = acc[I][jj][g4 * 4 + 0], v1 = acc[I][jj][g4 * 4 + 1], v2 = acc[I][jj][g4 * 4 + 2], v3 = acc[I][jj][g4 * 4 + 3]; \
+        if (args.c_f32) { const f32x4 o = {v0, v1, v2, v3}; *reinterpret_cast<f32x4*>(args.c_f32 + m_ * args.ldc + n_) = o; }    \
+        if (args.c_bf16) {                                                                                                        \
+          const u32x2 o = {(uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16), (uint32_t)f2bf(v2) | ((uint32_t)f2bf(v3) << 16)};      \
+          *reinterpret_cast<u32x2*>(args.c_bf16 + m_ * args.ldc + n_) = o;                                                        \
+        }                                                                                                                         \
+      }                                                                                                                           \
+  } while (0)
+  if (STORE) { WP_STORE_ROWBLOCK(0); WP_STORE_ROWBLOCK(1); WP_STORE_ROWBLOCK(2); }
+  WB_FENCE();
+  if (more) {
+    WP_SET_TILE(vb, m0, n0);
+    WP_PROLOGUE_LOADS();
+  }
+  WB_FENCE();
+  if (STORE) { WP_STORE_ROWBLOCK(3); }
+  if (!more) break;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j2 = 0; j2 < 4; ++j2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j2][r] = 0.f;
+  __builtin_amdgcn_s_waitcnt(0x4F78);   // vmcnt(24): stage 0 of the next tile landed (newer: 8 loads + the 16 stores of row-block 3)
+  }  // tile loop
+  if (args.clk && t == 0) { args.clk[2 * blockIdx.x] = tsum_c; args.clk[2 * blockIdx.x + 1] = tsum_r; }
+#undef WB_ISSUE_ONE
+#undef WB_ADVANCE
+#undef WB_READ_ONE
+#undef WB_MM
+#undef WB_FENCE
+#undef WB_KSTEP
+#undef WP_SET_TILE
+#undef WP_PROLOGUE_LOADS
+#undef WP_STORE_ROWBLOCK
+}
+
+template <int FLAGS>
+static void launch_w4p(const W4Args& a, hipStream_t s) {
+  static bool set = false;
+  if (!set) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w4p_kernel<FLAGS>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WB_SLOT)); set = true; }
+  const int nt = a.nbm * a.nbn;
+  const char* e = getenv("LAB_GRID");
+  const int cap = e ? atoi(e) : 256;
+  gemm_w4p_kernel<FLAGS><<<dim3(nt < cap ? nt : cap), 256, 2 * WB_SLOT, s>>>(a);
+}
+
+template <int FLAGS>
+static void launch_w4b(const W4Args& a, hipStream_t s) {
+  static bool set = false;
+  if (!set) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w4b_kernel<FLAGS>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WB_SLOT)); set = true; }
+  gemm_w4b_kernel<FLAGS><<<dim3(a.nbm * a.nbn), 256, 2 * WB_SLOT, s>>>(a);
+}
+
 template <int FLAGS>
 static void launch_w4(const W4Args& a, hipStream_t s) {
   static bool set = false;
@@ -302,6 +895,32 @@ static void run_variant(void* p) {
     case 3: launch_w4<3>(c->a, 0); break;
     case 11: launch_w4<11>(c->a, 0); break;   // MFMA only, no epilogue
     case 8: launch_w4<8>(c->a, 0); break;     // full main loop, no epilogue
+    case 16: launch_w4<16>(c->a, 0); break;   // no vmcnt waits in the steady state (results wrong; timing only)
+    case 32: launch_w4<32>(c->a, 0); break;
+    case 0x300: launch_w4<0x300>(c->a, 0); break;
+    case 64: launch_w4<64>(c->a, 0); break;
+    case 128: launch_w4<128>(c->a, 0); break;
+    case 1024: launch_w4<1024>(c->a, 0); break;
+    case 1152: launch_w4<1152>(c->a, 0); break;
+    case 160: launch_w4<160>(c->a, 0); break;
+    case 96: launch_w4<96>(c->a, 0); break;
+    case 66: launch_w4<66>(c->a, 0); break;
+    case 0x320: launch_w4<0x320>(c->a, 0); break;   // every tile stages the same rows (L2-resident source)
+    case 200: launch_w4b<0>(c->a, 0); break;
+    case 201: launch_w4b<1>(c->a, 0); break;
+    case 202: launch_w4b<2>(c->a, 0); break;
+    case 208: launch_w4b<8>(c->a, 0); break;
+    case 232: launch_w4b<32>(c->a, 0); break;
+    case 264: launch_w4b<64>(c->a, 0); break;
+    case 300: launch_w4p<0>(c->a, 0); break;
+    case 308: launch_w4p<8>(c->a, 0); break;
+    case 428: launch_w4p<128>(c->a, 0); break;
+    case 392: launch_w4b<192>(c->a, 0); break;
+    case 1000: launch_w2x<0>(c->a, 0); break;
+    case 1001: launch_w2x<1>(c->a, 0); break;
+    case 1002: launch_w2x<2>(c->a, 0); break;
+    case 1008: launch_w2x<8>(c->a, 0); break;
+    case 1011: launch_w2x<11>(c->a, 0); break;
     case 100: {
       int rc = enh_gemm_bf16((const enh_bf16*)c->a.A, c->a.lda, 0, (const enh_bf16*)c->a.B, c->a.ldb, 0, c->a.M, c->a.N, c->a.K, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0,
                              c->a.c_f32, (enh_bf16*)c->a.c_bf16, c->a.ldc, nullptr);
@@ -321,6 +940,10 @@ int main(int argc, char** argv) {
   fill_kernel<<<2048, 256>>>(B, (size_t)N * K, 0x89abcdeu, 1.0f);
   CK(hipDeviceSynchronize());
   Ctx c;
+  unsigned long long* dclk;
+  const int nblk = (int)((M / 256) * (N / 256));
+  CK(hipMalloc(&dclk, (size_t)nblk * 32));
+  c.a.clk = dclk;
   c.a.A = A; c.a.lda = K; c.a.B = B; c.a.ldb = K; c.a.M = M; c.a.N = N; c.a.K = K; c.a.c_f32 = C32; c.a.c_bf16 = C16; c.a.ldc = N;
   c.a.nbm = (int)(M / 256); c.a.nbn = (int)(N / 256);
   const double fl = 2.0 * M * N * K;
@@ -349,15 +972,27 @@ int main(int argc, char** argv) {
   };
   struct V { int id; const char* name; bool checkable; };
   const V vs[] = {{100, "library", true}, {0, "w4", true}, {1, "w4-noload", false}, {2, "w4-noread", false}, {3, "w4-noload-noread", false},
-                  {8, "w4-noepi", false}, {11, "w4-mfma-only", false}};
+                  {8, "w4-noepi", false}, {11, "w4-mfma-only", false}, {16, "w4-novmwait", false}, {32, "w4-hot", false}, {0x300, "w4-g3", true}, {0x320, "w4-g3-hot", false}, {200, "w4b", true}, {201, "w4b-noload", false}, {202, "w4b-noread", false}, {208, "w4b-noepi", false}, {232, "w4b-hot", false}, {264, "w4b-coal", true}, {300, "w4p", true}, {308, "w4p-noepi", false}, {428, "w4p-stagger", true}, {392, "w4b-coal-stagger", true}, {1000, "w2x", true}, {1001, "w2x-noload", false}, {1002, "w2x-noread", false}, {1008, "w2x-noepi", false}, {1011, "w2x-mfma-only", false}, {128, "w4-fullline", false}, {1024, "w4-shallow", true}, {1152, "w4-fullline-shallow", false}, {160, "w4-fullline-hot", false}, {64, "w4-stag", true}, {96, "w4-stag-hot", false}, {66, "w4-stag-noread", false}};
   printf("M=%lld N=%lld K=%lld out=%s\n", (long long)M, (long long)N, (long long)K, f32out ? "f32" : "bf16");
+  std::vector<V> order(std::begin(vs), std::end(vs));
+  order.push_back({100, "library", false});   // the library again at the END of every repetition: position in the sequence matters (clock ramp)
   for (int rep = 0; rep < 2; ++rep)
-    for (const V& v : vs) {
+    for (const V& v : order) {
       if (argc > 6 && !strstr(argv[6], v.name) ) continue;
       c.variant = v.id;
       if (f32out) CK(hipMemset(C32, 0xff, (size_t)M * N * 4)); else CK(hipMemset(C16, 0xff, (size_t)M * N * 2));
       const double ms = time_ms(run_variant, &c, iters);
-      printf("  %-18s %8.3f ms  %7.1f TF/s\n", v.name, ms, fl / ms / 1e9);
+      double mhz = 0, kus = 0;
+      const int nb = (v.id >= 1000 && v.id < 1024) ? nblk * 2 : nblk;
+      if (v.id != 100) {
+        std::vector<unsigned long long> hclk((size_t)nb * 2);
+        CK(hipMemcpy(hclk.data(), dclk, (size_t)nb * 16, hipMemcpyDeviceToHost));
+        double cyc = 0, rt = 0;
+        for (int i = 0; i < nb; ++i) { cyc += (double)hclk[2 * i]; rt += (double)hclk[2 * i + 1]; }
+        mhz = cyc / rt * 100.0; kus = rt / nb / 100.0;
+      }
+      printf("  %-18s %8.3f ms  %7.1f TF/s   shader clock %6.0f MHz, K-loop %7.1f us/block, MFMA util in loop %4.1f%%\n", v.name, ms, fl / ms / 1e9, mhz, kus,
+             mhz > 0 ? 100.0 * (double)(K / 16) * ((v.id >= 1000 && v.id < 1024) ? 8 : 16) * 32 / ((kus * mhz)) : 0.0);
       if (v.checkable && rep == 0) check(v.name);
     }
   return 0;
