@@ -14,8 +14,6 @@
 //                           with M, N multiples of 256 that fills the chip (with split-K if needed).
 //   gemm_bf16_pipe2_kernel  128x128x64 tile, 4 waves (2x2, each 4x4 v_mfma_f32_16x16x32_bf16), two 32-KiB LDS stages filled by
 //                           global_load_lds, K-loop software-pipelined around one mid-iteration barrier; 2 workgroups per CU.  Default.
-//   gemm_bf16_t256_kernel   256x256x64 tile, 8 waves (2x4, each 4x2 v_mfma_f32_32x32x16_bf16), two 64-KiB stages, staggered two-group
-//                           schedule; chosen for long-K forward / dgrad shapes (half the staged bytes per flop).
 //   gemm_bf16_kernel        register-staged 128x128x64 fallback for K not a multiple of 64 (zero-fills partial tiles).
 // All LDS images are XOR-swizzled so that staging writes, ds_read_b128 fragments and the transpose reads are bank-conflict free under
 // the gfx950 bank model (MI355X_MICROARCH.md §LDS; checked by tools/lds_bank_check.py; SQ_LDS_BANK_CONFLICT = 0 measured).
@@ -457,16 +455,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_pipe2_kernel(const GemmArgs 
 
 
 // =================================================================================================
-// "t256": 256 x 256 x 64 workgroup tile, 8 waves (2 x 4), each 128 x 64 = 4 x 2 tiles of v_mfma_f32_32x32x16_bf16.
-// Motivation (measured, profiles/r01_gemm_ablation.txt): the 128 x 128 tile is bound by global->LDS ingest
-// (~30 B/clk/CU sustained; 64 FLOP per staged byte needs 64 B/clk/CU at MFMA peak).  256 x 256 doubles the
-// intensity to 128 FLOP/B.  A stage = four 16-KiB sub-tiles [A rows 0-127 | A rows 128-255 | B 0-127 | B 128-255];
-// two stages = 128 KiB LDS, one workgroup per CU.  Schedule = pipe2 with the K-step split into four k16 sub-steps and
-// two alternating fragment sets (6 fragments each): the reads of sub-step s+1 are issued before the 8 MFMAs of
-// sub-step s; after sub-step 2 every wave holds the rest of stage kt in registers -> lgkmcnt(0) + vmcnt(0) + barrier,
-// global_load_lds of stage kt+2 into the freed buffer, first fragments of stage kt+1, then sub-step 3's MFMAs.
-// The contraction-major ("kmaj") sub-tiles use a second swizzle (q ^ (2*(k&3) | (k>>2)&1)) that keeps the 32-column
-// transpose reads of this fragment shape conflict-free.
+// helpers of the 256 x 256 kernel: 32x32x16 fragment readers over the "row" image and over a second contraction-major image ("kmaj2":
+// chunk q ^ (2*(k&3) | (k>>2)&1)) that keeps the 32-column transpose reads of that fragment shape conflict-free.  (The 8-wave "t256" kernel these
+// were written for in round 1 lost to the 4-wave w256 on every shape — fc2 forward 940 vs 957, dgrad 958/991 vs 995/1017 TF/s — and was removed
+// together with the two 8-phase variants that had never run; numbers in profiles/r02_gemm_lab.txt.)
 // =================================================================================================
 #define G4_BM 256
 #define G4_BN 256
@@ -534,141 +526,6 @@ __device__ __forceinline__ void gemm_epilogue32_loops(const GemmArgs& args, f32x
 template <int NJ, bool BOUNDS>   // BOUNDS = false: the kernel only runs shapes that are whole tiles (a per-element range check is 64 more branches per wave)
 __device__ __forceinline__ void gemm_epilogue32(const GemmArgs& args, f32x16 (&acc)[4][NJ], int64_t mw, int64_t nw, int lane, int split) {
   EPI_DISPATCH((gemm_epilogue32_loops<EM, NJ, BOUNDS>(args, acc, mw, nw, lane, split)));
-}
-
-template <bool TA, bool TB>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_t256_kernel(const GemmArgs args) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2 stages][A0 | A1 | B0 | B1]
-  const int t = threadIdx.x;
-  const int lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = wave >> 2, wn = wave & 3;  // 2 x 4 waves, each 128 (M) x 64 (N)
-  int split, tile_m, tile_n;
-  gemm_tile_coords(args, split, tile_m, tile_n);
-  const int64_t m0 = (int64_t)tile_m * G4_BM, n0 = (int64_t)tile_n * G4_BN;
-  const int64_t k_begin = (int64_t)split * args.k_per_split;
-  int64_t k_end = k_begin + args.k_per_split;
-  if (k_end > args.K) k_end = args.K;
-  const int nk = (int)((k_end - k_begin) / G_BK);
-
-  const uint16_t* src[8];
-  int lds_off[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int g = wave * 8 + i, sub = g >> 4, slab = g & 15;
-    lds_off[i] = sub * G_TILE_BYTES + slab * 1024;
-    src[i] = sub < 2 ? glds_src_ptr2<TA>(args.A, args.lda, m0 + sub * 128, args.M, k_begin, slab, lane)
-                     : glds_src_ptr2<TB>(args.B, args.ldb, n0 + (sub - 2) * 128, args.N, k_begin, slab, lane);
-  }
-  const int64_t step_a = TA ? (int64_t)G_BK * args.lda : (int64_t)G_BK;
-  const int64_t step_b = TB ? (int64_t)G_BK * args.ldb : (int64_t)G_BK;
-  // waves 0-3 stage A slabs (sub-tiles 0,1), waves 4-7 stage B slabs (sub-tiles 2,3): g>>4 = wave>>1 ... per-wave uniform
-  const int64_t my_step = wave < 4 ? step_a : step_b;
-#define T4_ISSUE(BUF)                                                                                                    \
-  do {                                                                                                                   \
-    unsigned char* base_ = smem + (BUF) * G4_STAGE_BYTES;                                                                \
-    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                                                   \
-      __builtin_amdgcn_global_load_lds((const GLB_AS void*)src[i_], (LDS_AS void*)(base_ + lds_off[i_]), 16, 0, 0);      \
-      src[i_] += my_step;                                                                                                \
-    }                                                                                                                    \
-  } while (0)
-#define T4_READ(FA, FB, BUF, S)                                                                                          \
-  do {                                                                                                                   \
-    const unsigned char* sa_ = smem + (BUF) * G4_STAGE_BYTES + wm * G_TILE_BYTES;                                        \
-    const unsigned char* sb_ = smem + (BUF) * G4_STAGE_BYTES + (2 + (wn >> 1)) * G_TILE_BYTES;                           \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) FA[i_] = frag32<TA>(sa_, i_ * 32, S, lane);                         \
-    _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) FB[j_] = frag32<TB>(sb_, (wn & 1) * 64 + j_ * 32, S, lane);         \
-  } while (0)
-#define T4_MMA(FA, FB)                                                                                                   \
-  do {                                                                                                                   \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                                     \
-      _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                                   \
-        acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, FB[j_]), __builtin_bit_cast(bf16x8, FA[i_]), acc[i_][j_], 0, 0, 0); \
-  } while (0)
-#define T4_FENCE() __builtin_amdgcn_sched_barrier(0)
-#define T4_WAIT_LDS() __builtin_amdgcn_s_waitcnt(0xC07F) /* lgkmcnt(0) */
-
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  s16x8 fae[4], fbe[2], fao[4], fbo[2];
-
-  // ---- staggered two-group schedule ----------------------------------------------------------------------------
-  // Each k16 sub-step is split into a READ segment (fragment ds_reads of the NEXT sub-step + a share of the
-  // global_load_lds traffic) and an MMA segment (8 MFMAs), every segment closed by s_barrier.  Waves 4-7 (the second
-  // wave of every SIMD) run ONE barrier behind waves 0-3, so on each SIMD one wave is always inside an MMA segment
-  // while its partner issues LDS / VMEM work: the matrix pipe is fed continuously and read / load issue is hidden.
-  //   stage kt lives in buffer kt & 1; its sub-step-0 fragments are read in R3 of step kt-1, sub-steps 1..3 in R0..R2;
-  //   stage kt+2 is loaded into the same buffer: first half issued in R3(kt) — by then both groups have completed
-  //   their last reads of stage kt (lgkmcnt(0) before the barrier closing R2) — second half in R0(kt+1); every wave
-  //   waits vmcnt(0) at the end of R2(kt+1), i.e. before the barriers that precede any R3(kt+1) read of that stage.
-  const bool late = wave >= 4;  // wave-uniform (readfirstlane above)
-#define T4_BAR() __builtin_amdgcn_s_barrier()
-#define T4_HALF(BUF, H)                                                                                                  \
-  do {                                                                                                                   \
-    unsigned char* base_ = smem + (BUF) * G4_STAGE_BYTES;                                                                \
-    _Pragma("unroll") for (int i_ = (H) * 4; i_ < (H) * 4 + 4; ++i_) {                                                   \
-      __builtin_amdgcn_global_load_lds((const GLB_AS void*)src[i_], (LDS_AS void*)(base_ + lds_off[i_]), 16, 0, 0);      \
-      src[i_] += my_step;                                                                                                \
-    }                                                                                                                    \
-  } while (0)
-#define T4_MMA_SEG(FA, FB)                                                                                               \
-  do {                                                                                                                   \
-    T4_WAIT_LDS();                                                                                                       \
-    T4_FENCE();                                                                                                          \
-    __builtin_amdgcn_s_setprio(1);                                                                                       \
-    T4_MMA(FA, FB);                                                                                                      \
-    __builtin_amdgcn_s_setprio(0);                                                                                       \
-    T4_FENCE();                                                                                                          \
-    T4_BAR();                                                                                                            \
-  } while (0)
-
-  if (nk > 0) {
-    T4_ISSUE(0);
-    if (nk > 1) T4_ISSUE(1);
-    __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
-    T4_BAR();
-    T4_READ(fae, fbe, 0, 0);
-    if (late) T4_BAR();  // stagger: the second wave of every SIMD runs one barrier behind
-    int buf = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-      // ---- sub-step 0 ----
-      T4_READ(fao, fbo, buf, 1);
-      if (kt >= 1 && kt + 1 < nk) T4_HALF(buf ^ 1, 1);   // second half of stage kt+1 (first half went out in R3(kt-1))
-      T4_FENCE(); T4_BAR();
-      T4_MMA_SEG(fae, fbe);
-      // ---- sub-step 1 ----
-      T4_READ(fae, fbe, buf, 2);
-      T4_FENCE(); T4_BAR();
-      T4_MMA_SEG(fao, fbo);
-      // ---- sub-step 2 ----
-      T4_READ(fao, fbo, buf, 3);
-      T4_FENCE();
-      __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0): my share of stage kt+1 has landed ; lgkmcnt(0): my reads of stage kt are done
-      T4_BAR();
-      T4_MMA_SEG(fae, fbe);
-      // ---- sub-step 3 ----
-      if (kt + 1 < nk) T4_READ(fae, fbe, buf ^ 1, 0);
-      if (kt + 2 < nk) T4_HALF(buf, 0);                   // first half of stage kt+2 into the buffer stage kt just vacated
-      T4_FENCE(); T4_BAR();
-      T4_MMA_SEG(fao, fbo);
-      buf ^= 1;
-    }
-    if (!late) T4_BAR();  // barrier counts must match across the workgroup
-  }
-#undef T4_BAR
-#undef T4_HALF
-#undef T4_MMA_SEG
-#undef T4_ISSUE
-#undef T4_READ
-#undef T4_MMA
-#undef T4_FENCE
-#undef T4_WAIT_LDS
-  gemm_epilogue32<2, true>(args, acc, m0 + wm * 128, n0 + wn * 64, lane, split);
 }
 
 // =================================================================================================
@@ -835,11 +692,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-// kernel family: 0 = register-staged fallback (any K % 8), 3 = pipe2 (128x128), 4 = t256 (256x256, 8 waves), 7 = w256 (256x256, 4 waves)
+// kernel family: 0 = register-staged fallback (any K % 8), 3 = pipe2 (128x128), 7 = w256 (256x256, 4 waves)
 static int g_kernel_override = -1;   // set by enh_gemm_set_kernel(): explicit state behind an explicit call, no environment lookups in the library
 
 extern "C" int enh_gemm_set_kernel(int family) {
-  ENH_REQUIRE(family == -1 || family == 0 || family == 3 || family == 4 || family == 7, ENH_E_BADARG, "enh_gemm_set_kernel: family must be -1 (auto), 0, 3, 4 or 7");
+  ENH_REQUIRE(family == -1 || family == 0 || family == 3 || family == 7, ENH_E_BADARG, "enh_gemm_set_kernel: family must be -1 (auto), 0, 3 or 7");
   g_kernel_override = family;
   return ENH_OK;
 }
@@ -863,10 +720,8 @@ static GemmPlan gemm_plan(int trans_a, int trans_b, int64_t M, int64_t N, int64_
     return (int)((ksteps + per - 1) / per);
   };
   const bool w256_ok = M % 256 == 0 && N % 256 == 0 && ksteps >= 2;
-  const bool t256_ok = M >= 256 && N >= 256;
   int family = g_kernel_override >= 0 ? g_kernel_override : -1;
   if (family == 7 && !w256_ok) family = -1;
-  if (family == 4 && !t256_ok) family = -1;
   if (family < 0) {
     // w256 whenever its tiles (times K slices) occupy at least 3/4 of the CUs; else the 128x128 pipe2 kernel (four times as many workgroups)
     family = 3;
@@ -878,9 +733,9 @@ static GemmPlan gemm_plan(int trans_a, int trans_b, int64_t M, int64_t N, int64_
     }
   }
   pl.family = family;
-  const int64_t bm = family >= 4 ? 256 : 128;
+  const int64_t bm = family == 7 ? 256 : 128;
   const int64_t tiles = ((M + bm - 1) / bm) * ((N + bm - 1) / bm);
-  pl.splits = split_for(tiles, family >= 4 ? 256 : 512, 64);
+  pl.splits = split_for(tiles, family == 7 ? 256 : 512, 64);
   const int64_t per = (ksteps + pl.splits - 1) / pl.splits;
   pl.k_per_split = per * G_BK;
   pl.splits = (int)((ksteps + per - 1) / per);
@@ -893,7 +748,7 @@ static bool gemm_splittable(int accumulate, const float* c_f32, const enh_bf16* 
 }
 
 extern "C" const char* enh_gemm_bf16_variant(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K) {
-  static const char* names[8] = {"gemm_bf16_kernel", "", "", "gemm_bf16_pipe2_kernel", "gemm_bf16_t256_kernel", "", "", "gemm_bf16_w256_kernel"};
+  static const char* names[8] = {"gemm_bf16_kernel", "", "", "gemm_bf16_pipe2_kernel", "", "", "", "gemm_bf16_w256_kernel"};
   // weight-gradient-shaped calls (both operands contraction-major) are the ones issued with accumulate -> report their split-K plan
   return names[gemm_plan(trans_a, trans_b, M, N, K, trans_a && trans_b).family];
 }
@@ -922,8 +777,8 @@ extern "C" int enh_gemm_bf16_ws(const enh_bf16* A, int64_t lda, int trans_a, con
 
   const GemmPlan pl = gemm_plan(trans_a, trans_b, M, N, K, gemm_splittable(accumulate, c_f32, c_bf16, bias, act, res));
   const int family = pl.family;
-  const int bm = family >= 4 ? G4_BM : G_BM;
-  const int bn = family >= 4 ? G4_BN : G_BN;
+  const int bm = family == 7 ? G4_BM : G_BM;
+  const int bn = family == 7 ? G4_BN : G_BN;
 
   GemmArgs g;
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.M = M; g.N = N; g.K = K;
@@ -956,8 +811,6 @@ extern "C" int enh_gemm_bf16_ws(const enh_bf16* A, int64_t lda, int trans_a, con
     SET_ATTR((gemm_bf16_kernel<true, false>), b2); SET_ATTR((gemm_bf16_kernel<true, true>), b2);
     SET_ATTR((gemm_bf16_pipe2_kernel<false, false>), b2); SET_ATTR((gemm_bf16_pipe2_kernel<false, true>), b2);
     SET_ATTR((gemm_bf16_pipe2_kernel<true, false>), b2); SET_ATTR((gemm_bf16_pipe2_kernel<true, true>), b2);
-    SET_ATTR((gemm_bf16_t256_kernel<false, false>), 2 * G4_STAGE_BYTES); SET_ATTR((gemm_bf16_t256_kernel<false, true>), 2 * G4_STAGE_BYTES);
-    SET_ATTR((gemm_bf16_t256_kernel<true, false>), 2 * G4_STAGE_BYTES); SET_ATTR((gemm_bf16_t256_kernel<true, true>), 2 * G4_STAGE_BYTES);
 #undef SET_ATTR
     return true;
   }();
@@ -985,8 +838,7 @@ extern "C" int enh_gemm_bf16_ws(const enh_bf16* A, int64_t lda, int trans_a, con
     }();
     (void)w2_attr;
     hipLaunchKernelGGL(table[(trans_a ? 2 : 0) + (trans_b ? 1 : 0)][epi_mode(g)], grid, dim3(256), (size_t)(2 * W2_SLOT), s, g);
-  } else if (family == 4) LAUNCH(gemm_bf16_t256_kernel, 512, (size_t)(2 * G4_STAGE_BYTES));
-  else if (family == 3) LAUNCH(gemm_bf16_pipe2_kernel, 256, lds2);
+  } else if (family == 3) LAUNCH(gemm_bf16_pipe2_kernel, 256, lds2);
   else LAUNCH(gemm_bf16_kernel, 256, lds2);
 #undef LAUNCH
   if (two_pass) {

@@ -80,12 +80,12 @@ def lib():
             raise RuntimeError(f"{LIB_PATH} reports ABI version {L.enh_abi_version()}, the bindings expect {ABI_VERSION}: rebuild the library")
         _LIB = L
         # kernel-family override for A/B measurements: explicit library state behind enh_gemm_set_kernel(); the environment is read HERE, in
-        # the binding, never inside the library (reg = 0, pipe2 = 3, t256 = 4, w256 = 7)
+        # the binding, never inside the library (reg = 0, pipe2 = 3, w256 = 7)
         sel = os.environ.get("ENH_GEMM_KERNEL")
         if sel:
-            fam = {"reg": 0, "pipe2": 3, "t256": 4, "w256": 7}.get(sel)
+            fam = {"reg": 0, "pipe2": 3, "w256": 7}.get(sel)
             if fam is None:
-                raise RuntimeError(f"ENH_GEMM_KERNEL={sel!r}: expected reg | pipe2 | t256 | w256")
+                raise RuntimeError(f"ENH_GEMM_KERNEL={sel!r}: expected reg | pipe2 | w256")
             _check_rc = L.enh_gemm_set_kernel(fam)
             if _check_rc != 0:
                 raise RuntimeError(L.enh_last_error().decode())

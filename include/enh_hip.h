@@ -135,7 +135,7 @@ size_t enh_gemm_bf16_workspace_bytes(int trans_a, int trans_b, int64_t M, int64_
  * the symbol a profiler will report); the choice is per shape */
 const char* enh_gemm_bf16_variant(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K);
 /* A/B measurement aid: force a kernel family for every later call that it can serve (-1 = per-shape choice [default], 0 = register-staged
- * fallback, 3 = pipe2 128x128, 4 = t256 256x256 / 8 waves, 7 = w256 256x256 / 4 waves).  Process-global, set explicitly by the caller (the Python
+ * fallback, 3 = pipe2 128x128, 7 = w256 256x256 / 4 waves).  Process-global, set explicitly by the caller (the Python
  * binding maps the ENH_GEMM_KERNEL environment variable onto it); the library itself reads no environment. */
 int enh_gemm_set_kernel(int family);
 

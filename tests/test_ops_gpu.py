@@ -368,7 +368,7 @@ def test_colsum_cast_adamw(C):
 # ---------------------------------------------------------------------------------------------
 # every GEMM kernel family on every shape it can serve (the per-shape default only exercises one of them)
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("sel,symbol", [("w256", "gemm_bf16_w256_kernel"), ("t256", "gemm_bf16_t256_kernel"), ("pipe2", "gemm_bf16_pipe2_kernel")])
+@pytest.mark.parametrize("sel,symbol", [("w256", "gemm_bf16_w256_kernel"), ("pipe2", "gemm_bf16_pipe2_kernel")])
 def test_gemm_suite_under_each_kernel_family(sel, symbol):
     """the family override is process-global (enh_gemm_set_kernel, mapped from ENH_GEMM_KERNEL by the binding), so the GEMM tests are re-run
     in a child process per family; shapes a family cannot serve fall back to the per-shape choice"""
