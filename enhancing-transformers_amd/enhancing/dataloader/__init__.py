@@ -24,6 +24,7 @@ class DataModuleFromConfig:
             self.dataset_configs["test"] = test
         self.datasets = None
         self.rank, self.world = 0, 1
+        self._samplers = {}
 
     def prepare_data(self):
         for cfg in self.dataset_configs.values():
@@ -41,7 +42,19 @@ class DataModuleFromConfig:
             self.setup()
         ds = self.datasets[key]
         workers = 0 if getattr(ds, "in_process", False) else self.num_workers
-        return DataLoader(ds, batch_size=self.batch_size, num_workers=workers, shuffle=shuffle and not getattr(ds, "in_process", False))
+        shuffle = shuffle and not getattr(ds, "in_process", False)
+        sampler = None
+        if self.world > 1 and not hasattr(ds, "set_shard"):
+            # data-parallel runs: every rank must see a DISJOINT slice of each epoch (Lightning's strategy="ddp" injects a DistributedSampler,
+            # reference main.py:53-56); datasets that shard themselves (set_shard) were handled in setup()
+            from torch.utils.data.distributed import DistributedSampler
+            sampler = DistributedSampler(ds, num_replicas=self.world, rank=self.rank, shuffle=shuffle)
+            self._samplers[key] = sampler
+        return DataLoader(ds, batch_size=self.batch_size, num_workers=workers, shuffle=shuffle and sampler is None, sampler=sampler)
+
+    def set_epoch(self, epoch: int) -> None:
+        for s in self._samplers.values():
+            s.set_epoch(epoch)
 
     def train_dataloader(self):
         return self._loader("train", True)

@@ -252,6 +252,11 @@ class Stage1Engine:
         self.sync_grads = True  # False on all but the last micro-batch of a gradient-accumulation window (DDP's no_sync)
 
     # ---- helpers -----------------------------------------------------------------------------
+    def _invalidate_saved(self) -> None:
+        """every entry point that overwrites the per-batch-size io buffers (h, patches, pix, xrec) or the no-save arena makes an outstanding
+        forward_train un-differentiable: bump the serial so its backward refuses instead of silently using stale h / patches"""
+        self._fwd_serial = getattr(self, "_fwd_serial", 0) + 1
+
     def _io_bufs(self, B: int) -> dict:
         if B not in self._io:
             dev, M = self.device, B * self.n_tok
@@ -298,6 +303,7 @@ class Stage1Engine:
     # ---- inference API (reference vitvqgan.py:44-90) -------------------------------------------
     @torch.no_grad()
     def encode_codes(self, img: torch.Tensor) -> torch.Tensor:
+        self._invalidate_saved()
         img = self._check_img(img)
         B = img.shape[0]
         b = self._encode_tokens(img, save=False)
@@ -308,6 +314,7 @@ class Stage1Engine:
     @torch.no_grad()
     def reconstruct(self, img: torch.Tensor):
         """forward without saving activations -> (xrec [B,C,H,W] f32, qloss scalar, indices)."""
+        self._invalidate_saved()
         img = self._check_img(img)
         B, io = img.shape[0], self._io_bufs(img.shape[0])
         b = self._encode_tokens(img, save=False)
@@ -323,6 +330,7 @@ class Stage1Engine:
     @torch.no_grad()
     def decode_from_quant(self, quant: torch.Tensor) -> torch.Tensor:
         """decode(quant) for quant [B, N, embed_dim] f32 (reference vitvqgan.py:68-72)."""
+        self._invalidate_saved()
         B = quant.shape[0]
         io = self._io_bufs(B)
         zq16 = quant.reshape(B * self.n_tok, self.ed).to(device=self.device, dtype=self.adt).contiguous()
@@ -332,6 +340,7 @@ class Stage1Engine:
 
     @torch.no_grad()
     def encoder_forward(self, img: torch.Tensor) -> torch.Tensor:
+        self._invalidate_saved()
         img = self._check_img(img)
         b = self._encode_tokens(img, save=False, want_f32=True)
         return b["xf32"].view(img.shape[0], self.n_tok, self.enc.dim).clone()
@@ -339,6 +348,7 @@ class Stage1Engine:
     @torch.no_grad()
     def decoder_forward(self, tok: torch.Tensor) -> torch.Tensor:
         """ViTDecoder.forward(token) for token [B, N, dim] f32 (post_quant output) — reference layers.py:209-214."""
+        self._invalidate_saved()
         B, s, io, M = tok.shape[0], self.store, self._io_bufs(tok.shape[0]), tok.shape[0] * self.n_tok
         x0 = self.dec.input_buffer(B, False)
         torch.add(tok.reshape(M, self.dec.dim).to(device=self.device, dtype=F32), s.w["decoder.de_pos_embedding"].view(self.n_tok, self.dec.dim).repeat(B, 1), out=x0)

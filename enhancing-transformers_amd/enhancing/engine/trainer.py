@@ -20,7 +20,12 @@ class Trainer:
                  accumulate_grad_batches: int = 1, callbacks=None, logger=None, max_steps: Optional[int] = None,
                  default_root_dir: str = "experiments", log_every_n_steps: int = 10, val_batches: int = 4) -> None:
         self.max_epochs, self.max_steps = max_epochs, max_steps
-        self.precision = precision  # accepted for CLI compatibility: compute is always bf16-operand MFMA / fp32 accumulate
+        # Lightning's `precision` (reference main.py:52): 16 = --use_amp = mixed precision.  On MI355X the mixed-precision dtype is bf16 (fp32 master
+        # weights / accumulation; bf16 keeps fp32's exponent range, so Lightning's fp16 GradScaler has nothing to do and its semantics are the
+        # identity); 32 = no AMP = the fp32 "exact" engine mode.  The model's engine precision must AGREE with it: fit() checks and raises.
+        if precision not in (16, 32, "bf16", "16", "32"):
+            raise ValueError(f"precision must be 16 (mixed, bf16 on this hardware) or 32, got {precision!r}")
+        self.precision = 32 if str(precision) == "32" else 16
         self.accum = max(int(accumulate_grad_batches), 1)
         self.strategy = strategy
         self.root = default_root_dir
@@ -39,7 +44,12 @@ class Trainer:
     def fit(self, model, data) -> None:
         self.rank, self.local_rank, self.world = init_process_group_from_env()
         torch.cuda.set_device(self.local_rank)
+        want = "bf16" if self.precision == 16 else "fp32"
+        if getattr(model, "_engine", None) is None and hasattr(model, "precision") and model.precision is None:
+            model.precision = want          # engine not bound yet: bind it in the requested mode
         eng = model.engine
+        if getattr(eng, "precision", want) != want:
+            raise RuntimeError(f"Trainer(precision={self.precision}) asks for the {want} engine mode but the model is bound to {eng.precision}")
         if self.world > 1:
             eng.comm = GradSync(eng.store)
             eng.comm.broadcast_parameters(0)
@@ -56,16 +66,23 @@ class Trainer:
             dist.broadcast(opts[1].store.p, 0)
         t0, seen = time.time(), 0
         for epoch in range(self.max_epochs):
-            for batch_idx, batch in enumerate(data.train_dataloader()):
+            loader = data.train_dataloader()
+            if hasattr(data, "set_epoch"):
+                data.set_epoch(epoch)          # DistributedSampler reshuffle (what Lightning does for strategy="ddp")
+            n_batches = len(loader) if hasattr(loader, "__len__") else None
+            for batch_idx, batch in enumerate(loader):
                 first = batch_idx % self.accum == 0
-                last = (batch_idx + 1) % self.accum == 0
+                # Lightning also steps on the LAST batch of an epoch when the window is incomplete (a trailing partial window is not dropped)
+                last = (batch_idx + 1) % self.accum == 0 or (n_batches is not None and batch_idx + 1 == n_batches)
                 # Lightning 1.5 order: per optimizer, training_step -> backward -> step, so the discriminator step sees the updated autoencoder
                 eng.sync_grads = last   # accumulate locally, all-reduce the window's sum once (what DDP's no_sync gives Lightning)
                 for oi, o in enumerate(opts):
                     model.training_step(batch, batch_idx, oi, zero_grad=first)
                     if last:
                         if sched is not None:
-                            o.param_groups[0]["lr"] = base_lr * sched(self.global_step)
+                            # LambdaLR(lr_lambda=scheduler.schedule), vitvqgan.py:172 (a bare callable is taken as the lr_lambda itself)
+                            mult = sched.schedule(self.global_step) if hasattr(sched, "schedule") else sched(self.global_step)
+                            o.param_groups[0]["lr"] = base_lr * mult
                         o.step()
                 seen += batch["image"].shape[0] * self.world
                 if last:

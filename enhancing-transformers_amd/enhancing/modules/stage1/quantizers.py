@@ -43,6 +43,32 @@ class _QuantizeFn(torch.autograd.Function):
         return dz.view(shp), d_cb, None, None, None, None
 
 
+class _LookupFn(torch.autograd.Function):
+    """z_qnorm = norm(E[idx]) through enh_vq_lookup; backward = the l2-normalise Jacobian scattered into the codebook gradient."""
+
+    @staticmethod
+    def forward(ctx, codebook, idx, use_norm):
+        cb = codebook.detach().contiguous()
+        flat = idx.reshape(-1, 1).contiguous()
+        out, _ = _C.vq_lookup(cb, flat, use_norm, want_bf16=False)
+        ctx.save_for_backward(cb, flat)
+        ctx.use_norm = use_norm
+        ctx.mark_non_differentiable(idx)
+        return out.view(*idx.shape, cb.shape[1])
+
+    @staticmethod
+    def backward(ctx, g):
+        cb, flat = ctx.saved_tensors
+        e = cb[flat.view(-1)]
+        g = g.reshape(-1, cb.shape[1]).float()
+        if ctx.use_norm:
+            nrm = e.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+            en = e / nrm
+            g = (g - en * (en * g).sum(-1, keepdim=True)) / nrm
+        d_cb = torch.zeros_like(cb).index_add_(0, flat.view(-1), g)
+        return d_cb, None, None
+
+
 class BaseQuantizer(nn.Module):
     def __init__(self, embed_dim: int, n_embed: int, straight_through: bool = True, use_norm: bool = True,
                  use_residual: bool = False, num_quantizers: Optional[int] = None) -> None:
@@ -69,6 +95,8 @@ class VectorQuantizer(BaseQuantizer):
             raise ValueError("the fused gfx950 quantizer kernel requires embed_dim == 32")
         if use_residual and not num_quantizers:
             raise ValueError("use_residual=True needs num_quantizers")
+        if use_residual and int(num_quantizers) > 8:
+            raise ValueError("the fused gfx950 residual quantizer keeps at most 8 depths in registers (enh_vq_backward): num_quantizers <= 8")
         self.beta = beta
 
     @property
@@ -79,9 +107,13 @@ class VectorQuantizer(BaseQuantizer):
         return _QuantizeFn.apply(z, self.embedding.weight, float(self.beta), self.depth, bool(self.use_residual), bool(self.use_norm))
 
     def quantize(self, z: torch.Tensor):
-        """single-level quantize (reference quantizers.py:74-92): (normalised code, loss, indices)."""
-        zq, loss, idx = _QuantizeFn.apply(z, self.embedding.weight, float(self.beta), 1, False, bool(self.use_norm))
-        return zq, loss, idx
+        """single-level quantize (reference quantizers.py:74-92): (z_qnorm, loss, indices) where z_qnorm = norm(embedding(indices)) — the
+        NORMALISED CODE itself, not the straight-through value forward() returns (quantizers.py:85-92).  Indices and loss come from the fused
+        kernel; z_qnorm from the lookup kernel, differentiable with respect to the codebook like the reference's (normalise Jacobian +
+        scatter-add, evaluated with torch ops in backward: this entry point is API surface, not the training hot path)."""
+        _, loss, idx = _QuantizeFn.apply(z, self.embedding.weight, float(self.beta), 1, False, bool(self.use_norm))
+        zqn = _LookupFn.apply(self.embedding.weight, idx, bool(self.use_norm))
+        return zqn.view(z.shape), loss, idx
 
     def lookup(self, code: torch.Tensor) -> torch.Tensor:
         """decode_codes front half (reference vitvqgan.py:82-87): n(E[code]) summed over the depth axis."""
@@ -90,3 +122,12 @@ class VectorQuantizer(BaseQuantizer):
         out, _ = _C.vq_lookup(self.embedding.weight.detach().contiguous(), code.reshape(-1, depth).contiguous(), self.use_norm,
                               want_bf16=False)
         return out.view(*shp, self.embed_dim)
+
+
+class GumbelQuantizer(BaseQuantizer):
+    """reference quantizers.py:95-126 (Gumbel-softmax relaxation, used by ViTVQGumbel).  Outside the hot-path scope of this build (no
+    shipped stage-1 config selects it): the class exists so that a config naming it fails with a clear message instead of an AttributeError."""
+
+    def __init__(self, *args, **kwargs) -> None:
+        raise NotImplementedError("GumbelQuantizer / ViTVQGumbel are not part of the MI355X stage-1 hot path (VectorQuantizer with use_residual for "
+                                  "RQ-VAE is); see DESIGN.md 'out of scope'")

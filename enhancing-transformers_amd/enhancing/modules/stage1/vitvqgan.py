@@ -103,6 +103,7 @@ class ViTVQ(nn.Module):
         """h = pre_quant(encoder(x)) as f32 [B, N, embed_dim] (the quantizer's input: op-boundary parity point)."""
         eng = self.engine
         x = eng._check_img(x)
+        eng._invalidate_saved()
         with torch.no_grad():
             b = eng._encode_tokens(x, save=False)
             h = eng._pre_quant(b["xf16"], x.shape[0])

@@ -25,6 +25,8 @@ if __name__ == '__main__':
     parser.add_argument('-b', '--batch_frequency', type=int, default=750)
     parser.add_argument('-m', '--max_images', type=int, default=4)
     parser.add_argument('--max_steps', type=int, default=None, help="(extension) stop after this many optimizer steps")
+    parser.add_argument('--fp32', default=False, action='store_true',
+                        help="(extension) run the fp32 'exact' engine mode = Lightning precision 32; cannot be combined with --use_amp")
     args = parser.parse_args()
 
     if args.num_gpus > 1 and "RANK" not in os.environ:
@@ -43,7 +45,12 @@ if __name__ == '__main__':
     model.learning_rate = args.base_lr
     data = initialize_from_config(config.dataset)
     data.prepare_data()
-    trainer = Trainer(max_epochs=args.epochs, precision=16 if args.use_amp else 32, gpus=args.num_gpus, num_nodes=args.num_nodes,
+    # reference main.py:52: precision = 16 if --use_amp else 32.  Here mixed precision (bf16 MFMA operands, fp32 master weights / accumulation; no
+    # loss scaling needed in bf16) is the product path and therefore ALSO the default; --use_amp selects it explicitly, --fp32 selects the fp32
+    # exact mode (what the reference runs without --use_amp), and asking for both is an error instead of being silently resolved
+    if args.use_amp and args.fp32:
+        sys.exit("--use_amp (mixed precision) and --fp32 (no mixed precision) contradict each other")
+    trainer = Trainer(max_epochs=args.epochs, precision=32 if args.fp32 else 16, gpus=args.num_gpus, num_nodes=args.num_nodes,
                       strategy="ddp" if args.num_nodes > 1 or args.num_gpus > 1 else None, accumulate_grad_batches=args.update_every,
                       max_steps=args.max_steps, default_root_dir=os.path.join(ROOT, "experiments", args.config))
     trainer.fit(model, data)

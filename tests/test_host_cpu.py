@@ -104,10 +104,46 @@ def test_synthetic_data_contract():
 
 
 def test_schedulers():
-    from enhancing.utils.scheduler import ExponentialDecayScheduler, LambdaWarmUpCosineScheduler
-    s = LambdaWarmUpCosineScheduler(10, 100, 1e-6, 1e-4, 1e-5)
-    assert abs(s(0) - 1.0) < 1e-9 and abs(s(10) - 10.0) < 1e-6 and abs(s(100) - 0.1) < 1e-6
-    assert ExponentialDecayScheduler(0.1, 1, 1.0, 0.5)(100) == 0.5
+    """reference scheduler.py API: constructor names, schedule() = multiplier of start (LambdaLR), __call__ = absolute value"""
+    from enhancing.utils.scheduler import ExponentialDecayScheduler, LambdaWarmUpCosineScheduler, LambdaWarmUpLinearScheduler
+    s = LambdaWarmUpCosineScheduler(warm_up_steps=10, max_decay_steps=100, min_=1e-6, max_=1e-4, start=1e-5)
+    assert abs(s.schedule(0) - 1.0) < 1e-9 and abs(s.schedule(10) - 10.0) < 1e-6 and abs(s.schedule(100) - 0.1) < 1e-6
+    assert abs(s(10) - 1e-4) < 1e-12                                  # __call__ multiplies by start
+    e = ExponentialDecayScheduler(start=1.0, end=0.5, decay_every_step=10, scale_factor=0.01)
+    assert e.schedule(0) == 1.0 and abs(e.schedule(10) - 0.9048374) < 1e-6 and e.schedule(15) == e.schedule(10)   # held between multiples
+    assert e.schedule(1000) == 0.5 and e(1000) == 0.5
+    lin = LambdaWarmUpLinearScheduler(warm_up_steps=10, max_decay_steps=100, min_=0.0, max_=1e-4, start=1e-5)
+    assert abs(lin.schedule(50) - 5.0) < 1e-9
+    with pytest.raises(TypeError):
+        LambdaWarmUpCosineScheduler(warmup_steps=10, max_decay_steps=100, min_=0, max_=1, start=1)      # the reference's spelling is warm_up_steps
+
+
+def test_real_datasets_are_sharded_across_ranks():
+    """a dataset without set_shard gets a DistributedSampler when world > 1 -> disjoint per-rank index sets that cover the data"""
+    import torch
+    from enhancing.dataloader import DataModuleFromConfig
+
+    class Plain(torch.utils.data.Dataset):
+        def __len__(self): return 40
+        def __getitem__(self, i): return {"image": torch.full((3, 2, 2), float(i)), "class": torch.tensor([i])}
+
+    seen = []
+    for rank in range(2):
+        dm = DataModuleFromConfig(batch_size=4, num_workers=0)
+        dm.dataset_configs["train"] = None
+        dm.datasets, dm.rank, dm.world = {"train": Plain()}, rank, 2
+        loader = dm.train_dataloader()
+        dm.set_epoch(3)
+        seen.append(sorted(int(c) for b in loader for c in b["class"].view(-1)))
+    assert len(seen[0]) == len(seen[1]) == 20 and not set(seen[0]) & set(seen[1]) and sorted(seen[0] + seen[1]) == list(range(40))
+
+
+def test_gumbel_and_deep_rq_fail_loudly():
+    from enhancing.modules.stage1.quantizers import GumbelQuantizer, VectorQuantizer
+    with pytest.raises(NotImplementedError):
+        GumbelQuantizer(32, 1024)
+    with pytest.raises(ValueError, match="num_quantizers <= 8"):
+        VectorQuantizer(32, 1024, use_residual=True, num_quantizers=9)
 
 
 def test_trainer_drives_the_lightning_protocol_in_order(monkeypatch, tmp_path):

@@ -344,3 +344,33 @@ def test_exact_mode_baseline_config1_small_256px():
     print(f"config 1 (small, 256px, B=2) exact mode vs CPU oracle: h rel {rel(h, o_h):.2e}, xrec rel {rel(xrec, o_xrec):.2e}, code match {match:.6f}")
     assert rel(h, o_h) <= EXACT_ACT_TOL and rel(xrec, o_xrec) <= EXACT_ACT_TOL
     assert match == 1.0
+
+
+def test_quantize_returns_the_normalised_code_like_the_reference(tiny):
+    """VectorQuantizer.quantize (reference quantizers.py:74-92) -> (z_qnorm, loss, indices): the NORMALISED CODE, differentiable w.r.t. the codebook;
+    forward() returns the straight-through value instead (quantizers.py:61)."""
+    import vitvq_oracle as O
+    cfg, P, x, m = tiny
+    h = m.pre_quant_tokens(x)
+    E = P["quantizer.embedding.weight"]
+    zqn, loss, idx = m.quantizer.quantize(h)
+    Et = E.clone().requires_grad_(True)
+    zqn_o, loss_o, idx_o = O.vq_quantize(h.cpu(), Et)
+    assert torch.equal(idx.cpu(), idx_o)
+    assert (zqn.cpu() - zqn_o.detach()).abs().max().item() <= 1.2e-7, "z_qnorm must equal norm(E[idx]) to the last bit or two"
+    assert abs(loss.item() - loss_o.item()) <= 1e-6
+    g = torch.randn(zqn.shape, generator=torch.Generator().manual_seed(0))
+    m.quantizer.embedding.weight.grad = None
+    (zqn * g.to(zqn.device)).sum().backward()
+    (zqn_o * g).sum().backward()
+    assert rel(m.quantizer.embedding.weight.grad, Et.grad) <= 1e-5
+
+
+def test_inference_between_forward_and_backward_is_refused(tiny):
+    """the no-grad entry points share the per-batch-size buffers with an outstanding differentiable forward -> its backward must refuse"""
+    cfg, P, x, _ = tiny
+    m = _build(cfg, P)
+    xrec, _ = m(x)
+    m.encode_codes(x)
+    with pytest.raises(RuntimeError, match="overwritten"):
+        xrec.sum().backward()
