@@ -36,20 +36,6 @@ __global__ void fused_bias_act_kernel(const float* __restrict__ x, const float* 
   else for (int k = 0; k < 4 && i0 + k < n; ++k) y[i0 + k] = v[k];
 }
 
-// out[c] (+)= sum over batch and the inner axis of x [B, C, inner]  (bias gradient of the op above)
-__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x, int B, int C, int64_t inner, float* __restrict__ out) {
-  __shared__ float s_part[4];
-  const int c = blockIdx.x;
-  float acc = 0.f;
-  for (int bb = blockIdx.y; bb < B; bb += gridDim.y) {
-    const float* p = x + ((int64_t)bb * C + c) * inner;
-    for (int64_t i = threadIdx.x; i < inner; i += 256) acc += p[i];
-  }
-  acc = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(&out[c], (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]));
-}
 
 // upfirdn2d on [major, in_h, in_w] planes (minor = 1, as the reference reshapes NCHW at upfirdn2d.py:100):
 //   out[m][oy][ox] = sum_{ky,kx} kernel[kh-1-ky][kw-1-kx] * P[oy*down_y + ky][ox*down_x + kx],
@@ -84,9 +70,9 @@ __global__ void upfirdn2d_kernel(const float* __restrict__ in, const float* __re
   out[idx] = acc;
 }
 
-// ---- EXPERIMENTAL fast paths (ENH_DISC_FAST=1; written after round 1's GPU budget was spent, compiled but not yet run) -------------
-// profiles/r01_adv_step_kernel_stats.csv: upfirdn2d_kernel is 24 % and channel_sum_kernel 6 % of the adversarial training step — the first
-// does 16 scalar loads per output, the second runs C (128..512) workgroups over a tensor of hundreds of MB.
+// ---- register-blocked blur and split channel sums (validated on MI355X in round 2: same parity tests, adversarial step 68.8 -> 89.0 images/s) ------
+// profiles/r01_adv_step_kernel_stats.csv: the one-output-per-thread blur was 24 % and the per-channel reduction 6 % of the adversarial training
+// step — the first did 16 scalar loads per output, the second ran C (128..512) workgroups over a tensor of hundreds of MB.
 //
 // upfirdn2d with up = down = 1 (every use in the discriminator: Blur forward and both of its derivatives): a thread produces a
 // 2 (y) x 4 (x) output block from a (kh+1) x (kw+3) input window held in registers -> (kh+1)(kw+3)/8 loads per output instead of kh*kw.
@@ -164,11 +150,6 @@ __global__ __launch_bounds__(256) void channel_sum_split_kernel(const float* __r
   if (threadIdx.x == 0) atomicAdd(&out[c], (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]));
 }
 
-static bool disc_fast() {
-  static const bool on = [] { const char* e = getenv("ENH_DISC_FAST"); return e && e[0] == '1'; }();
-  return on;
-}
-
 extern "C" int enh_fused_bias_act(const float* x, const float* bias, const float* ref, float* y, int64_t n, int64_t step_b, int size_b,
                                   int act, int grad, float alpha, float scale, void* stream) {
   ENH_REQUIRE(x && y && n > 0, ENH_E_BADARG, "enh_fused_bias_act: bad argument");
@@ -188,17 +169,12 @@ extern "C" int enh_channel_sum_f32(const float* x, int B, int C, int64_t inner, 
     hipError_t e = hipMemsetAsync(out, 0, (size_t)C * sizeof(float), s);
     if (e != hipSuccess) { enh_set_error("enh_channel_sum_f32: memset failed"); return ENH_E_HIP_BASE - (int)e; }
   }
-  if (disc_fast()) {
-    int64_t chunk = (inner + 63) / 64;               // up to 64 slices of the inner axis per (batch, channel) row ...
-    if (chunk < 4096) chunk = 4096;                   // ... but never less than 16 KiB of work per workgroup
-    chunk = (chunk + 3) / 4 * 4;
-    const int nchunk = (int)((inner + chunk - 1) / chunk);
-    ENH_REQUIRE((int64_t)B * nchunk <= 65535, ENH_E_SHAPE, "enh_channel_sum_f32: grid too large");
-    channel_sum_split_kernel<<<dim3(C, B * nchunk), 256, 0, s>>>(x, C, inner, nchunk, chunk, out);
-    return enh_check_launch("enh_channel_sum_f32");
-  }
-  const int by = B < 32 ? B : 32;
-  channel_sum_kernel<<<dim3(C, by), 256, 0, s>>>(x, B, C, inner, out);
+  int64_t chunk = (inner + 63) / 64;               // up to 64 slices of the inner axis per (batch, channel) row ...
+  if (chunk < 4096) chunk = 4096;                   // ... but never less than 16 KiB of work per workgroup
+  chunk = (chunk + 3) / 4 * 4;
+  const int nchunk = (int)((inner + chunk - 1) / chunk);
+  ENH_REQUIRE((int64_t)B * nchunk <= 65535, ENH_E_SHAPE, "enh_channel_sum_f32: grid too large");
+  channel_sum_split_kernel<<<dim3(C, B * nchunk), 256, 0, s>>>(x, C, inner, nchunk, chunk, out);
   return enh_check_launch("enh_channel_sum_f32");
 }
 
@@ -210,7 +186,7 @@ extern "C" int enh_upfirdn2d(const float* in, const float* kernel, float* out, i
   const int out_h = (in_h * up_y + pad_y0 + pad_y1 - kh + down_y) / down_y;
   const int out_w = (in_w * up_x + pad_x0 + pad_x1 - kw + down_x) / down_x;
   ENH_REQUIRE(out_h > 0 && out_w > 0, ENH_E_SHAPE, "enh_upfirdn2d: empty output");
-  if (disc_fast() && up_x == 1 && up_y == 1 && down_x == 1 && down_y == 1 && kh == 4 && kw == 4) {
+  if (up_x == 1 && up_y == 1 && down_x == 1 && down_y == 1 && kh == 4 && kw == 4) {
     const int64_t blocks = major * ((out_h + 1) / 2) * ((out_w + 3) / 4);
     upfirdn2d_unit_kernel<4, 4><<<(unsigned)((blocks + 255) / 256), 256, 0, (hipStream_t)stream>>>(in, kernel, out, major, in_h, in_w, out_h, out_w,
                                                                                                   pad_x0, pad_y0);

@@ -690,6 +690,162 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   *reinterpret_cast<f32x4*>(cp) = s;
 }
 
+// =================================================================================================
+// Implicit-GEMM 3x3 convolution (stride 1, padding 1) on channels-last bf16 activations — the convolution of the LPIPS VGG16 trunk
+// (lpips 0.1.4 pretrained_networks.vgg16 = torchvision vgg16.features; reference call sites enhancing/losses/vqperceptual.py:29,43,74,115) and of
+// its input gradient.  No `cols` tensor exists: the A operand of the GEMM
+//      out[(b,h,w), co] = sum over (kh, kw, ci) of x[b, h+kh-1, w+kw-1, ci] * wt[co][(kh*3 + kw)*Cin + ci]
+// is GATHERED in the load stage — row (b,h,w), 8 consecutive channels of one tap per 16-byte load, zeros outside the image — into the same
+// swizzled LDS image the dense kernels use; the weights are stored tap-major [Cout][9*Cin] once (they are frozen).  The input gradient is the same
+// kernel on the flipped / transposed weights.  Register-staged double buffer (the gather needs per-lane predication, which global_load_lds cannot
+// do), 128 x 128 x 64 tile, 4 waves of 64 x 64, 2 workgroups per CU.  Cin, Cout multiples of 8; any M = B*H*W.
+//   mode 0: out = relu(acc + bias[co])                  -> bf16      (forward)
+//   mode 1: out = (acc + add[m,co]) * (aux[m,co] > 0)   -> bf16      (input gradient; add = gradient arriving from the LPIPS head at this
+//                                                                     activation (optional), aux = the saved post-ReLU activation)
+//   mode 2: out = acc                                   -> bf16      (input gradient in front of a max-pool: routed / masked by the pool backward)
+// =================================================================================================
+struct ConvArgs {
+  const uint16_t* X; const uint16_t* Wt;
+  int64_t M; int H, W, Cin, Cout; int64_t K;
+  const float* bias; int mode; const uint16_t* aux; const uint16_t* add;
+  uint16_t* out;
+  int nbm, nbn;
+};
+
+__global__ __launch_bounds__(256, 2) void conv3x3_igemm_kernel(const ConvArgs args) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2 stages][A tile | B tile]
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l16 = lane & 15, lg = lane >> 4;
+  const int tile_m = blockIdx.x % args.nbm, tile_n = blockIdx.x / args.nbm;
+  const int64_t m0 = (int64_t)tile_m * G_BM, n0 = (int64_t)tile_n * G_BN;
+  const int nk = (int)((args.K + G_BK - 1) / G_BK);
+
+  // this thread gathers chunk c (8 channels) of rows r0 + 32*i: the pixel of a row does not change along K
+  const int c = t & 7, r0 = t >> 3;
+  int ph[4], pw[4];
+  int64_t pbase[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t row = m0 + r0 + 32 * i;
+    if (row < args.M) {
+      const int64_t hw = (int64_t)args.H * args.W;
+      const int64_t b = row / hw, rem = row - b * hw;
+      ph[i] = (int)(rem / args.W); pw[i] = (int)(rem - (int64_t)ph[i] * args.W);
+      pbase[i] = row * args.Cin;     // element offset of pixel (b,h,w), channel 0
+    } else { ph[i] = -4; pw[i] = -4; pbase[i] = 0; }   // every tap of an out-of-range row falls outside the image -> zeros
+  }
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  u32x4 ra[4], rb[4];
+  auto gather = [&](int64_t k0) {
+    const int64_t kk = k0 + c * 8;
+    const int tap = (int)(kk / args.Cin), ch = (int)(kk - (int64_t)tap * args.Cin);
+    const int dh = tap / 3 - 1, dw = tap - (tap / 3) * 3 - 1;
+    const int64_t doff = ((int64_t)dh * args.W + dw) * args.Cin + ch;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int hh = ph[i] + dh, ww = pw[i] + dw;
+      const bool ok = kk < args.K && hh >= 0 && hh < args.H && ww >= 0 && ww < args.W;
+      ra[i] = ok ? *reinterpret_cast<const u32x4*>(args.X + pbase[i] + doff) : zero4;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t co = n0 + r0 + 32 * i;
+      rb[i] = (co < args.Cout && kk < args.K) ? *reinterpret_cast<const u32x4*>(args.Wt + co * args.K + kk) : zero4;
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  gather(0);
+  tile_sstore<false>(ra, smem, t);
+  tile_sstore<false>(rb, smem + G_TILE_BYTES, t);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int stage = kt & 1;
+    if (kt + 1 < nk) gather((int64_t)(kt + 1) * G_BK);
+    const unsigned char* sa = smem + stage * (2 * G_TILE_BYTES);
+    const unsigned char* sb = sa + G_TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      s16x8 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = tile_frag<false>(sa, wm * 64 + i * 16, ks, lg, l16);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = tile_frag<false>(sb, wn * 64 + j * 16, ks, lg, l16);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[j]), __builtin_bit_cast(bf16x8, fa[i]), acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      unsigned char* na = smem + (stage ^ 1) * (2 * G_TILE_BYTES);
+      tile_sstore<false>(ra, na, t);
+      tile_sstore<false>(rb, na + G_TILE_BYTES, t);
+    }
+    __syncthreads();
+  }
+  // epilogue: lane (lg, l16) holds out[m = m0 + wm*64 + i*16 + l16][n = n0 + wn*64 + j*16 + lg*4 + 0..3]
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t m = m0 + wm * 64 + i * 16 + l16;
+    if (m >= args.M) continue;
+    uint2 ax[4], ad[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t n = n0 + wn * 64 + j * 16 + lg * 4;
+      ax[j] = make_uint2(0u, 0u); ad[j] = make_uint2(0u, 0u);
+      if (args.mode == 1 && n < args.Cout) {
+        ax[j] = *reinterpret_cast<const uint2*>(args.aux + m * args.Cout + n);
+        if (args.add) ad[j] = *reinterpret_cast<const uint2*>(args.add + m * args.Cout + n);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t n = n0 + wn * 64 + j * 16 + lg * 4;
+      if (n >= args.Cout) continue;   // Cout % 8 == 0: the 4 columns are in or out together
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (args.mode == 0) {
+        const float4 b4 = *reinterpret_cast<const float4*>(args.bias + n);
+        v[0] = fmaxf(v[0] + b4.x, 0.f); v[1] = fmaxf(v[1] + b4.y, 0.f); v[2] = fmaxf(v[2] + b4.z, 0.f); v[3] = fmaxf(v[3] + b4.w, 0.f);
+      } else if (args.mode == 1) {
+        const uint32_t a0 = ax[j].x, a1 = ax[j].y, d0 = ad[j].x, d1 = ad[j].y;
+        v[0] = (a0 & 0x7fffu) && !(a0 & 0x8000u) ? v[0] + bf16_bits_to_f32((uint16_t)(d0 & 0xffffu)) : 0.f;
+        v[1] = ((a0 >> 16) & 0x7fffu) && !(a0 >> 31) ? v[1] + bf16_bits_to_f32((uint16_t)(d0 >> 16)) : 0.f;
+        v[2] = (a1 & 0x7fffu) && !(a1 & 0x8000u) ? v[2] + bf16_bits_to_f32((uint16_t)(d1 & 0xffffu)) : 0.f;
+        v[3] = ((a1 >> 16) & 0x7fffu) && !(a1 >> 31) ? v[3] + bf16_bits_to_f32((uint16_t)(d1 >> 16)) : 0.f;
+      }
+      const u32x2 o_ = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+      *reinterpret_cast<u32x2*>(args.out + m * args.Cout + n) = o_;
+    }
+  }
+}
+
+extern "C" int enh_conv3x3_nhwc_bf16(const enh_bf16* x, const enh_bf16* wt, int B, int H, int W, int Cin, int Cout, const float* bias, int mode,
+                                     const enh_bf16* aux, const enh_bf16* add, enh_bf16* out, void* stream) {
+  ENH_REQUIRE(x && wt && out && B > 0 && H > 0 && W > 0, ENH_E_BADARG, "enh_conv3x3_nhwc_bf16: bad argument");
+  ENH_REQUIRE(Cin > 0 && Cout > 0 && Cin % 8 == 0 && Cout % 8 == 0, ENH_E_SHAPE, "enh_conv3x3_nhwc_bf16: Cin and Cout must be multiples of 8 (Cin=%d Cout=%d)", Cin, Cout);
+  ENH_REQUIRE((mode == 0 && bias) || (mode == 1 && aux) || mode == 2, ENH_E_BADARG, "enh_conv3x3_nhwc_bf16: mode 0 needs bias, mode 1 needs aux, mode 2 neither");
+  ConvArgs a;
+  a.X = x; a.Wt = wt; a.M = (int64_t)B * H * W; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.K = 9ll * Cin;
+  a.bias = bias; a.mode = mode; a.aux = aux; a.add = add; a.out = out;
+  a.nbm = (int)((a.M + G_BM - 1) / G_BM); a.nbn = (Cout + G_BN - 1) / G_BN;
+  ENH_REQUIRE((int64_t)a.nbm * a.nbn < (1ll << 30), ENH_E_SHAPE, "enh_conv3x3_nhwc_bf16: grid too large");
+  static const bool attr_set = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G_TILE_BYTES);
+    return true;
+  }();
+  (void)attr_set;
+  conv3x3_igemm_kernel<<<dim3((unsigned)(a.nbm * a.nbn)), 256, 4 * G_TILE_BYTES, (hipStream_t)stream>>>(a);
+  return enh_check_launch("enh_conv3x3_nhwc_bf16");
+}
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // kernel family: 0 = register-staged fallback (any K % 8), 3 = pipe2 (128x128), 7 = w256 (256x256, 4 waves)

@@ -58,11 +58,18 @@ SIGNATURES = {
     "enh_colsum_f32": (_i32, [_vp, _i64, _i64, _i64, _vp, _i32, _vp]),
     "enh_patch_perm_f32": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "enh_unpatchify_loss_f32": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp]),
+    "enh_conv3x3_nhwc_bf16": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "enh_vgg_conv1": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "enh_vgg_conv1_backward": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "enh_maxpool2_nhwc_bf16": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "enh_maxpool2_nhwc_bf16_backward": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "enh_lpips_head": (_i32, [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _i32, _vp]),
+    "enh_lpips_head_backward": (_i32, [_vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp]),
     "enh_adamw_step": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
 }
 
 _LIB = None
-ABI_VERSION = 3   # ENH_ABI_VERSION of the include/enh_hip.h these signatures were written against
+ABI_VERSION = 4   # ENH_ABI_VERSION of the include/enh_hip.h these signatures were written against
 
 
 def lib():
@@ -441,3 +448,47 @@ def unpatchify_loss_any(pix, target, B, C, H, W, p, w_l1, w_l2, xrec, sums, dpix
     else:
         _check(lib().enh_unpatchify_loss_f32(_p(pix, F32, "pix"), _p(target, F32, "target"), B, C, H, W, p, w_l1, w_l2, _p(xrec, F32, "xrec"),
                                              _p(sums, F64, "sums"), _p(dpix, F32, "dpix"), _stream()), "enh_unpatchify_loss_f32")
+
+
+# ------------------------------------------------------------------------------------------------
+# LPIPS (lpips 0.1.4, net="vgg"): channels-last bf16 activations
+# ------------------------------------------------------------------------------------------------
+def conv3x3_nhwc(x, wt, B: int, H: int, W: int, Cin: int, Cout: int, out, bias=None, mode: int = 0, aux=None, add=None):
+    _timed("conv3x3_igemm_kernel", 2.0 * B * H * W * Cout * 9 * Cin,
+           lambda: _check(lib().enh_conv3x3_nhwc_bf16(_p(x, BF16, "x"), _p(wt, BF16, "wt"), B, H, W, Cin, Cout, _p(bias, F32, "bias"), mode, _p(aux, BF16, "aux"),
+                                                      _p(add, BF16, "add"), _p(out, BF16, "out"), _stream()), "enh_conv3x3_nhwc_bf16"))
+    return out
+
+
+def vgg_conv1(img, w, bias, shift, scale, normalize: bool, out):
+    B, _, H, W = img.shape
+    _check(lib().enh_vgg_conv1(_p(img, F32, "img"), _p(w, F32, "w"), _p(bias, F32, "bias"), _p(shift, F32, "shift"), _p(scale, F32, "scale"), int(normalize), B, H, W,
+                               _p(out, BF16, "out"), _stream()), "enh_vgg_conv1")
+    return out
+
+
+def vgg_conv1_backward(gpre, w, scale, normalize: bool, B: int, H: int, W: int, dimg):
+    _check(lib().enh_vgg_conv1_backward(_p(gpre, BF16, "gpre"), _p(w, F32, "w"), _p(scale, F32, "scale"), int(normalize), B, H, W, _p(dimg, F32, "dimg"), _stream()),
+           "enh_vgg_conv1_backward")
+    return dimg
+
+
+def maxpool2_nhwc(x, B: int, H: int, W: int, C: int, y):
+    _check(lib().enh_maxpool2_nhwc_bf16(_p(x, BF16, "x"), B, H, W, C, _p(y, BF16, "y"), _stream()), "enh_maxpool2_nhwc_bf16")
+    return y
+
+
+def maxpool2_nhwc_backward(x, gy, add, B: int, H: int, W: int, C: int, gx):
+    _check(lib().enh_maxpool2_nhwc_bf16_backward(_p(x, BF16, "x"), _p(gy, BF16, "gy"), _p(add, BF16, "add"), B, H, W, C, _p(gx, BF16, "gx"), _stream()),
+           "enh_maxpool2_nhwc_bf16_backward")
+    return gx
+
+
+def lpips_head(feat, lin, B: int, HW: int, C: int, val_ws, out, accumulate: bool):
+    _check(lib().enh_lpips_head(_p(feat, BF16, "feat"), _p(lin, F32, "lin"), B, HW, C, _p(val_ws, F32, "val_ws"), _p(out, F32, "out"), int(accumulate), _stream()),
+           "enh_lpips_head")
+
+
+def lpips_head_backward(feat, lin, gout, B: int, HW: int, C: int, dfeat1):
+    _check(lib().enh_lpips_head_backward(_p(feat, BF16, "feat"), _p(lin, F32, "lin"), _p(gout, F32, "gout"), B, HW, C, _p(dfeat1, BF16, "dfeat1"), _stream()),
+           "enh_lpips_head_backward")

@@ -1,30 +1,16 @@
 """Stage-1 loss modules with the reference's names, constructor arguments, call signature and log keys
 (reference enhancing/losses/vqperceptual.py:17-172).
 
-In scope: the pixel terms (L1 / L2) and the codebook term — row a20 of SURVEY.md §8 — and, from the "next" rows (§8f rank 1),
-the adversarial term with the StyleGAN2 discriminator and its lazy R1 penalty.  The LPIPS perceptual term (third-party ``lpips`` +
-un-obtainable pretrained VGG16 weights, §8f rank 2) is not built: constructing a loss with a non-zero perceptual weight raises,
-so a config can never silently train with a term missing.  ``ENH_ALLOW_MISSING_TERMS=1`` turns the
-error into a warning and treats the missing terms as zero (used to load the reference's yaml files as they are)."""
+Pixel terms (L1 / L2) and the codebook term are row a20 of SURVEY.md §8; the adversarial term with the StyleGAN2 discriminator and its lazy R1 penalty
+is §8f rank 1; the LPIPS perceptual term (§8f rank 2) is ``enhancing.losses.lpips.LPIPS`` — lpips 0.1.4's ``LPIPS(net="vgg")`` topology on HIP kernels,
+constructed only when ``perceptual_weight != 0`` (the reference constructs it unconditionally, vqperceptual.py:29,74; skipping an unused 14.7 M-parameter
+VGG16 changes no result).  Without pretrained weights on disk the term runs on a random-init trunk and says so (see lpips.py)."""
 from __future__ import annotations
 
-import os
-import warnings
 from typing import Optional, Tuple
 
 import torch
 import torch.nn as nn
-
-
-def _missing(term: str, weight: float) -> None:
-    if weight == 0:
-        return
-    msg = (f"{term} (weight {weight}) is not implemented in this round (SURVEY.md §8f); it would be treated as 0. "
-           f"Set the weight to 0 or export ENH_ALLOW_MISSING_TERMS=1 to proceed without it.")
-    if os.environ.get("ENH_ALLOW_MISSING_TERMS", "0") == "1":
-        warnings.warn(msg)
-    else:
-        raise NotImplementedError(msg)
 
 
 class DummyLoss(nn.Module):
@@ -38,7 +24,9 @@ class VQLPIPS(nn.Module):
     def __init__(self, codebook_weight: float = 1.0, loglaplace_weight: float = 1.0, loggaussian_weight: float = 1.0,
                  perceptual_weight: float = 1.0) -> None:
         super().__init__()
-        _missing("LPIPS perceptual loss", perceptual_weight)
+        if perceptual_weight != 0:
+            from .lpips import LPIPS
+            self.perceptual_loss = LPIPS(net="vgg", verbose=False)     # vqperceptual.py:29
         self.codebook_weight = codebook_weight
         self.loglaplace_weight = loglaplace_weight
         self.loggaussian_weight = loggaussian_weight
@@ -51,8 +39,8 @@ class VQLPIPS(nn.Module):
         diff = reconstructions - inputs
         loglaplace_loss = diff.abs().mean()
         loggaussian_loss = diff.pow(2).mean()
-        perceptual_loss = torch.zeros((), device=diff.device)
-        nll_loss = self.loglaplace_weight * loglaplace_loss + self.loggaussian_weight * loggaussian_loss
+        perceptual_loss = self._perceptual(inputs, reconstructions)
+        nll_loss = self.loglaplace_weight * loglaplace_loss + self.loggaussian_weight * loggaussian_loss + self.perceptual_weight * perceptual_loss
         loss = nll_loss + self.codebook_weight * codebook_loss
         log = {"{}/total_loss".format(split): loss.clone().detach(),
                "{}/quant_loss".format(split): codebook_loss.detach(),
@@ -63,11 +51,19 @@ class VQLPIPS(nn.Module):
         return loss, log
 
 
+    def _perceptual(self, inputs: torch.Tensor, reconstructions: torch.Tensor) -> torch.Tensor:
+        """self.perceptual_loss(inputs*2-1, reconstructions*2-1).mean() (vqperceptual.py:43,115); the 2x-1 map is lpips' own normalize=True, fused
+        into the first convolution kernel"""
+        if self.perceptual_weight == 0 or not hasattr(self, "perceptual_loss"):
+            return torch.zeros((), device=reconstructions.device)
+        return self.perceptual_loss(inputs, reconstructions, normalize=True).mean()
+
+
 class VQLPIPSWithDiscriminator(VQLPIPS):
     """Reference vqperceptual.py:59-172: generator-side loss (optimizer_idx 0: pixel + [LPIPS] + disc_factor * adversarial_weight *
     g_loss + codebook) and discriminator-side loss (optimizer_idx 1: d_loss on real / detached fake + lazy R1 every `do_r1_every`
     batches, differentiated through the discriminator's backward).  The StyleGAN2 discriminator runs on this library's HIP kernels
-    (losses/layers.py).  Deviations, both loud: the LPIPS term is still missing (perceptual_weight must be 0); with
+    (losses/layers.py), the LPIPS term on those of losses/lpips.py.  Deviation: with
     adversarial_weight == 0 no discriminator is built (the reference would build and train one whose output never reaches the
     autoencoder), so such configs keep the single-optimizer fused step."""
 
@@ -114,8 +110,8 @@ class VQLPIPSWithDiscriminator(VQLPIPS):
             diff = reconstructions - inputs
             loglaplace_loss = diff.abs().mean()
             loggaussian_loss = diff.pow(2).mean()
-            perceptual_loss = torch.zeros((), device=diff.device)
-            nll_loss = self.loglaplace_weight * loglaplace_loss + self.loggaussian_weight * loggaussian_loss
+            perceptual_loss = self._perceptual(inputs, reconstructions)
+            nll_loss = self.loglaplace_weight * loglaplace_loss + self.loggaussian_weight * loggaussian_loss + self.perceptual_weight * perceptual_loss
             logits_fake = self.discriminator(reconstructions)
             g_loss = self.disc_loss(logits_fake)
             loss = nll_loss + disc_factor * self.adversarial_weight * g_loss + self.codebook_weight * codebook_loss

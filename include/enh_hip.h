@@ -36,7 +36,7 @@ extern "C" {
 typedef uint16_t enh_bf16; /* raw bfloat16 bits */
 
 const char* enh_last_error(void);
-#define ENH_ABI_VERSION 3   /* bumped whenever a signature below changes; the bindings check it at load */
+#define ENH_ABI_VERSION 4   /* bumped whenever a signature below changes; the bindings check it at load */
 int enh_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -213,6 +213,32 @@ int enh_colsum_f32(const float* x, int64_t M, int64_t N, int64_t ldx, float* out
 int enh_patch_perm_f32(const float* src, float* dst, int B, int C, int H, int W, int p, int to_patches, void* stream);
 int enh_unpatchify_loss_f32(const float* pix, const float* target, int B, int C, int H, int W, int p, float w_l1, float w_l2, float* xrec,
                             double* sums, float* dpix, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * LPIPS perceptual term (lpips 0.1.4, net = "vgg": pinned third-party dependency of the reference, requirements.txt:2; call sites
+ * enhancing/losses/vqperceptual.py:29,43,74,115).  Activations are channels-last bf16 [B,H,W,C].
+ * ------------------------------------------------------------------------------------------------ */
+/* 3x3 convolution, stride 1, zero padding 1, as an implicit GEMM (no im2col tensor).  x [B,H,W,Cin], wt [Cout][9*Cin] tap-major
+ * (wt[co][(kh*3+kw)*Cin + ci] = weight[co][ci][kh][kw]), out [B,H,W,Cout]; Cin, Cout multiples of 8.
+ *   mode 0: out = relu(acc + bias[co])                            (torchvision vgg16.features conv + ReLU)
+ *   mode 1: out = (acc + add[m,co]) * (aux[m,co] > 0)             (input gradient: wt = flipped / transposed weights, aux = the saved post-ReLU
+ *                                                                  activation this gradient is for, add = optional extra gradient at that activation)
+ *   mode 2: out = acc                                             (input gradient in front of a max-pool) */
+int enh_conv3x3_nhwc_bf16(const enh_bf16* x, const enh_bf16* wt, int B, int H, int W, int Cin, int Cout, const float* bias, int mode,
+                          const enh_bf16* aux, const enh_bf16* add, enh_bf16* out, void* stream);
+/* ScalingLayer + first convolution: img [B,3,H,W] f32 -> relu(conv3x3(((a img + b) - shift) / scale, w [64,3,3,3]) + bias) as [B,H,W,64] bf16, with
+ * (a, b) = (2, -1) if normalize (images in [0,1]: lpips' normalize=True, = the inputs*2-1 of vqperceptual.py:43) else (1, 0); lpips ScalingLayer: shift
+ * (-.030,-.088,-.188), scale (.458,.448,.450) ; and its gradient w.r.t. img given the gradient at the convolution output before the ReLU */
+int enh_vgg_conv1(const float* img, const float* w, const float* bias, const float* shift, const float* scale, int normalize, int B, int H, int W, enh_bf16* out, void* stream);
+int enh_vgg_conv1_backward(const enh_bf16* gpre, const float* w, const float* scale, int normalize, int B, int H, int W, float* dimg, void* stream);
+/* 2x2 / stride-2 max-pool ; backward gx = (x > 0) * (gy routed to the first maximum of each window + add)  (add optional) */
+int enh_maxpool2_nhwc_bf16(const enh_bf16* x, int B, int H, int W, int C, enh_bf16* y, void* stream);
+int enh_maxpool2_nhwc_bf16_backward(const enh_bf16* x, const enh_bf16* gy, const enh_bf16* add, int B, int H, int W, int C, enh_bf16* gx, void* stream);
+/* LPIPS head of one slice: feat [2B,h,w,C] (images 0..B-1 = references, B..2B-1 = reconstructions), lin [C] = the slice's 1x1 "lin" weights;
+ * out[b] (+)= mean over pixels of sum_c lin[c] (f0/(|f0|+1e-10) - f1/(|f1|+1e-10))_c^2 ; val_ws [B*h*w] f32 scratch (deterministic two-stage sum).
+ * Backward: gradient w.r.t. the reconstruction features only, dfeat1 [B,h,w,C] bf16, given gout[B] */
+int enh_lpips_head(const enh_bf16* feat, const float* lin, int B, int64_t HW, int C, float* val_ws, float* out, int accumulate, void* stream);
+int enh_lpips_head_backward(const enh_bf16* feat, const float* lin, const float* gout, int B, int64_t HW, int C, enh_bf16* dfeat1, void* stream);
 
 #ifdef __cplusplus
 }

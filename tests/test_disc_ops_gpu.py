@@ -98,15 +98,3 @@ def test_module_api(ops):
     y = m(torch.randn(2, 8, 4, 4, device="cuda"))
     y.sum().backward()
     assert m.bias.grad is not None and m.bias.grad.shape == (8,)
-
-
-@pytest.mark.skipif(os.environ.get("ENH_TEST_EXPERIMENTAL", "0") != "1", reason="experimental fast discriminator kernels: set ENH_TEST_EXPERIMENTAL=1")
-def test_fast_paths_experimental_rerun_the_discriminator_suites():
-    """ENH_DISC_FAST is read once per process: re-run the op and model suites of the discriminator in a child process with it set"""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, ENH_DISC_FAST="1", ENH_TEST_EXPERIMENTAL="0")
-    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_disc_ops_gpu.py", "tests/test_disc_model_gpu.py", "-q", "-x", "-m", "gpu",
-                        "-p", "no:cacheprovider"], env=env, cwd=root, capture_output=True, text=True)
-    assert r.returncode == 0, r.stdout[-3000:]

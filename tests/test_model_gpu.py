@@ -26,7 +26,7 @@ def _build(cfg, P, loss_params=None):
         loss["params"].update(loss_params)
     m = ViTVQ("image", cfg["image_size"], cfg["patch_size"], AttrDict.wrap(cfg["encoder"]), AttrDict.wrap(cfg["decoder"]),
               AttrDict.wrap(cfg["quantizer"]), AttrDict.wrap(loss))
-    missing = m.load_state_dict(P, strict=True)
+    m.load_state_dict(P, strict=not any(k.startswith("loss.") for k in m.state_dict()))   # a loss with parameters (LPIPS / discriminator) keeps its own
     m.engine  # bind to the GPU
     return m
 
@@ -374,3 +374,31 @@ def test_inference_between_forward_and_backward_is_refused(tiny):
     m.encode_codes(x)
     with pytest.raises(RuntimeError, match="overwritten"):
         xrec.sum().backward()
+
+
+def test_training_step_with_the_lpips_term_vs_oracle():
+    """optimizer_idx 0 with VQLPIPS(perceptual_weight=0.1): forward -> loss module (pixel + LPIPS + codebook) -> autograd through the HIP LPIPS and the
+    engine's backward (reference vitvqgan.py:103-115, vqperceptual.py:41-46), against the fp32 oracle with the same (random) LPIPS weights"""
+    import warnings
+    import lpips_oracle as LO
+    import vitvq_oracle as O
+    cfg = O.TINY_CFG
+    P = O.make_params(cfg, seed=11)
+    x = O.make_images(5, 2, cfg["image_size"])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = _build(cfg, P, loss_params=dict(perceptual_weight=0.1))
+    lsd = {k: v.detach().cpu().clone() for k, v in m.loss.perceptual_loss.state_dict().items()}
+    loss = m.training_step({"image": x}, 0, 0)
+    leaves = {k: v.detach().clone().requires_grad_(not k.endswith("pos_embedding")) for k, v in P.items()}
+    o_xrec, o_q = O.forward(x, leaves, cfg)
+    o_p = LO.lpips_distance(x, o_xrec, lsd, normalize=True).mean()
+    o_loss = ((o_xrec - x) ** 2).mean() + 0.1 * o_p + o_q
+    o_loss.backward()
+    print(f"LPIPS step: loss {loss.item():.6f} vs {o_loss.item():.6f}, perceptual {m.logged['train/perceptual_loss'].item():.6f} vs {o_p.item():.6f}")
+    assert abs(loss.item() - o_loss.item()) <= 1e-2 * abs(o_loss.item())
+    assert abs(m.logged["train/perceptual_loss"].item() - o_p.item()) <= 2e-2 * abs(o_p.item())
+    errs = {k: rel(p.grad, leaves[k].grad) for k, p in m.named_parameters() if k in leaves and leaves[k].grad is not None}
+    worst = max(errs, key=errs.get)
+    print(f"  worst grad {worst} {errs[worst]:.2e}, median {np.median(list(errs.values())):.2e}")
+    assert errs[worst] <= 2e-2, sorted(errs.items(), key=lambda kv: -kv[1])[:5]      # measured 6.7e-3
