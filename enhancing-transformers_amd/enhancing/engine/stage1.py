@@ -247,6 +247,7 @@ class Stage1Engine:
         self.ed = q.embed_dim
         self._io: Dict[int, dict] = {}
         enc._engine = dec._engine = self
+        dec.get_last_layer()._enh_engine = self      # lets the loss module ask for ||d(.)/d last_layer|| (adaptive adversarial weight)
         self.world = 1
         self.comm = None  # enhancing.engine.ddp.GradSync when running data-parallel
         self.sync_grads = True  # False on all but the last micro-batch of a gradient-accumulation window (DDP's no_sync)
@@ -436,6 +437,18 @@ class Stage1Engine:
         nll = w_l1 * l1 + w_l2 * l2
         return dict(loss=nll + codebook_weight * ql, quant_loss=ql, rec_loss=nll, loglaplace_loss=l1, loggaussian_loss=l2,
                     xrec=io["xrec"], indices=st["idx"], h=st["h"])
+
+    @torch.no_grad()
+    def last_layer_grad_norm(self, g_xrec: torch.Tensor) -> torch.Tensor:
+        """|| d L / d decoder.to_pixel.weight ||_F for a loss whose gradient at the reconstruction is g_xrec [B,C,H,W], for the OUTSTANDING forward_train
+        (the saved final-LayerNorm output is the other GEMM operand).  What VQLPIPSWithDiscriminator.calculate_adaptive_factor obtains with
+        torch.autograd.grad(loss, last_layer) in the reference (vqperceptual.py:95-103); nothing is accumulated into the gradient buffers."""
+        B = g_xrec.shape[0]
+        io, db, M = self._io_bufs(B), self.dec.bufs(B, True), B * self.n_tok
+        _C.patchify_any(g_xrec.to(dtype=F32).contiguous(), self.patch, io["dpix16"])
+        tmp = torch.zeros(self.dec.dim, self.pd, dtype=F32, device=self.device)
+        _C.mm(db["xf16"], io["dpix16"], self.dec.dim, self.pd, M, tmp, trans_a=True, trans_b=True, accumulate=True)
+        return tmp.norm()
 
     def differentiable_forward(self, img: torch.Tensor):
         """(xrec, qloss) connected to autograd: `.backward()` on any function of them runs backward_from and leaves the

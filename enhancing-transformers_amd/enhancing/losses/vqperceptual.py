@@ -73,9 +73,6 @@ class VQLPIPSWithDiscriminator(VQLPIPS):
         super().__init__(codebook_weight, loglaplace_weight, loggaussian_weight, perceptual_weight)
         from .layers import StyleDiscriminator, hinge_d_loss, least_square_d_loss, vanilla_d_loss
         assert disc_loss in ["hinge", "vanilla", "least_square"], f"Unknown GAN loss '{disc_loss}'."
-        if use_adaptive_adv:
-            raise NotImplementedError("use_adaptive_adv needs autograd.grad w.r.t. the decoder's last layer, which the fused engine does not "
-                                      "expose as an autograd leaf; no reference config enables it")
         if adversarial_weight != 0:
             self.discriminator = StyleDiscriminator(**dict(disc_params or {}))
         self.disc_loss = {"hinge": hinge_d_loss, "vanilla": vanilla_d_loss, "least_square": least_square_d_loss}[disc_loss]
@@ -85,6 +82,18 @@ class VQLPIPSWithDiscriminator(VQLPIPS):
         self.r1_gamma = r1_gamma
         self.do_r1_every = do_r1_every
         self._disc_store = None
+
+    def calculate_adaptive_factor(self, nll_loss: torch.Tensor, g_loss: torch.Tensor, last_layer, reconstructions: torch.Tensor) -> torch.Tensor:
+        """reference vqperceptual.py:95-103: ||d nll / d last_layer|| / (||d g_loss / d last_layer|| + 1e-4), clamped to [0, 1e4], detached.  The decoder's
+        last layer is not an autograd leaf of the fused engine, so each norm is obtained from the gradient at the reconstruction (autograd) times the
+        saved last-layer input (one small GEMM in the engine, Stage1Engine.last_layer_grad_norm)."""
+        eng = getattr(last_layer, "_enh_engine", None)
+        if eng is None:
+            raise RuntimeError("use_adaptive_adv: last_layer must be ViTDecoder.get_last_layer() of a model bound to the HIP engine")
+        nll_g, = torch.autograd.grad(nll_loss, reconstructions, retain_graph=True)
+        g_g, = torch.autograd.grad(g_loss, reconstructions, retain_graph=True)
+        adapt = eng.last_layer_grad_norm(nll_g) / (eng.last_layer_grad_norm(g_g) + 1e-4)
+        return adapt.clamp(0.0, 1e4).detach()
 
     # the discriminator's parameters live in one flat fp32 buffer (fused AdamW, one all-reduce), created on first use
     def disc_store(self, device: torch.device):
@@ -114,7 +123,14 @@ class VQLPIPSWithDiscriminator(VQLPIPS):
             nll_loss = self.loglaplace_weight * loglaplace_loss + self.loggaussian_weight * loggaussian_loss + self.perceptual_weight * perceptual_loss
             logits_fake = self.discriminator(reconstructions)
             g_loss = self.disc_loss(logits_fake)
-            loss = nll_loss + disc_factor * self.adversarial_weight * g_loss + self.codebook_weight * codebook_loss
+            d_weight = self.adversarial_weight
+            if self.use_adaptive_adv:
+                if reconstructions.requires_grad:
+                    d_weight = d_weight * self.calculate_adaptive_factor(nll_loss, g_loss, last_layer, reconstructions)
+                else:                                  # the reference's `except RuntimeError: assert not self.training; d_weight = 0` (vqperceptual.py:127-129)
+                    assert not self.training
+                    d_weight = torch.tensor(0.0, device=reconstructions.device)
+            loss = nll_loss + disc_factor * d_weight * g_loss + self.codebook_weight * codebook_loss
             log = {"{}/total_loss".format(split): loss.clone().detach(),
                    "{}/quant_loss".format(split): codebook_loss.detach(),
                    "{}/rec_loss".format(split): nll_loss.detach(),
@@ -122,6 +138,8 @@ class VQLPIPSWithDiscriminator(VQLPIPS):
                    "{}/loggaussian_loss".format(split): loggaussian_loss.detach(),
                    "{}/perceptual_loss".format(split): perceptual_loss.detach(),
                    "{}/g_loss".format(split): g_loss.detach()}
+            if self.use_adaptive_adv:
+                log["{}/d_weight".format(split)] = d_weight.detach() if torch.is_tensor(d_weight) else torch.tensor(float(d_weight))
             return loss, log
 
         if optimizer_idx == 1:   # discriminator update (vqperceptual.py:148-172)

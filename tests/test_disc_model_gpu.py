@@ -146,3 +146,43 @@ def test_two_optimizer_training_step_protocol(C):
     ae.zero_grad()
     m.training_step(batch, 0, 0)
     assert rel(g_with, ae.g) > 1e-3
+
+
+def test_adaptive_adversarial_weight(C):
+    """use_adaptive_adv (reference vqperceptual.py:95-103,125-126): d_weight = adversarial_weight * ||d nll/d last_layer|| / (||d g_loss/d last_layer|| + 1e-4).
+    The engine's last-layer norm (gradient at the reconstruction x saved last-layer input) must equal the norm of the gradient its own backward writes
+    for the same upstream gradient, and the logged d_weight must be the ratio of the two norms."""
+    import vitvq_oracle as O
+    from enhancing.modules.stage1.vitvqgan import ViTVQ
+    from enhancing.utils.general import AttrDict
+    cfg = O.TINY_CFG
+    loss = {"target": "enhancing.losses.vqperceptual.VQLPIPSWithDiscriminator",
+            "params": dict(loglaplace_weight=0.0, loggaussian_weight=1.0, perceptual_weight=0.0, adversarial_weight=0.1, use_adaptive_adv=True,
+                           disc_params={"size": cfg["image_size"]})}
+    m = ViTVQ("image", cfg["image_size"], cfg["patch_size"], AttrDict.wrap(cfg["encoder"]), AttrDict.wrap(cfg["decoder"]),
+              AttrDict.wrap(cfg["quantizer"]), AttrDict.wrap(loss))
+    m.load_state_dict({**O.make_params(cfg, seed=11), **{"loss." + k: v for k, v in m.loss.state_dict().items()}}, strict=True)
+    m.train()
+    eng = m.engine
+    x = O.make_images(5, 2, cfg["image_size"])
+    # (1) the norm primitive against the engine's own backward
+    g = torch.randn(2, 3, cfg["image_size"], cfg["image_size"], generator=torch.Generator().manual_seed(1)).cuda()
+    eng.store.zero_grad()
+    xrec, _ = m(x)
+    n_fast = eng.last_layer_grad_norm(g).item()
+    (xrec * g).sum().backward()
+    n_ref = m.decoder.get_last_layer().grad.norm().item()
+    assert abs(n_fast - n_ref) <= 2e-3 * n_ref, (n_fast, n_ref)
+    # (2) the training step logs d_weight = 0.1 * ||d nll|| / (||d g|| + 1e-4), recomputed here from the two upstream gradients
+    l0 = m.training_step({"image": x}, 0, 0)
+    assert torch.isfinite(l0) and "train/d_weight" in m.logged
+    xr, _ = m(x)
+    xd = x.to(xr.device)
+    nll = ((xr - xd) ** 2).mean()
+    g_loss = m.loss.disc_loss(m.loss.discriminator(xr))
+    gn, = torch.autograd.grad(nll, xr, retain_graph=True)
+    gg, = torch.autograd.grad(g_loss, xr, retain_graph=True)
+    want = 0.1 * eng.last_layer_grad_norm(gn) / (eng.last_layer_grad_norm(gg) + 1e-4)
+    print("d_weight logged", m.logged["train/d_weight"].item(), "recomputed", want.item(), "norms", eng.last_layer_grad_norm(gn).item(), eng.last_layer_grad_norm(gg).item())
+    # (two separate forward passes through the discriminator: its split-K f32 atomics make them differ in the last bits, and gate flips amplify that)
+    assert abs(m.logged["train/d_weight"].item() - want.item()) <= 2e-2 * abs(want.item())
