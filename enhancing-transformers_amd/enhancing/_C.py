@@ -259,10 +259,28 @@ def gemm(a, b, M: int, N: int, K: int, trans_a: bool = False, trans_b: bool = Fa
             _p(out_f32, F32, "out_f32"), _p(out_bf16, BF16, "out_bf16"), ldc, _p(ws), ws_bytes if ws is not None else 0, _stream())
     if TIMER is None:
         _check(lib().enh_gemm_bf16_ws(*args), "enh_gemm_bf16")
-    else:  # label with the symbol rocprofv3 will report, e.g. "gemm_bf16_pipe2_kernel<false, true>"
+    else:  # label with the symbol rocprofv3 will report, e.g. "gemm_bf16_pipe2_kernel<false, true>" / "gemm_bf16_w256_kernel<false, false, 1>"
         fam = lib().enh_gemm_bf16_variant(int(trans_a), int(trans_b), M, N, K).decode()
-        TIMER.run(f"{fam}<{'true' if trans_a else 'false'}, {'true' if trans_b else 'false'}>", 2.0 * M * N * K,
-                  lambda: _check(lib().enh_gemm_bf16_ws(*args), "enh_gemm_bf16"))
+        targs = f"{'true' if trans_a else 'false'}, {'true' if trans_b else 'false'}"
+        if fam == "gemm_bf16_w256_kernel":   # its epilogue mode is a template parameter (gemm.hip epi_mode(), mirrored here for the label only)
+            targs += f", {_epi_mode_label(accumulate, ws is not None, out_f32 is not None, out_bf16 is not None, bias is not None, act, res is not None)}"
+        TIMER.run(f"{fam}<{targs}>", 2.0 * M * N * K, lambda: _check(lib().enh_gemm_bf16_ws(*args), "enh_gemm_bf16"))
+
+
+def _epi_mode_label(accumulate, have_ws, f32, bf16, bias, act, res) -> int:
+    """EPI_* enum value gemm.hip's epi_mode() selects (0 generic, 1 bf16, 2 bf16+bias+tanh, 3 bf16+dtanh, 4 f32+bias+res, 5 f32, 6 split-K workspace,
+    7 split-K atomics) — used only to label timings with the symbol name a profiler reports"""
+    if accumulate and f32 and not bf16 and not bias and act == ACT_NONE and not res:
+        return 6 if have_ws else 7    # (only when the shape is actually split; an unsplit accumulate call is generic)
+    if not accumulate:
+        if bf16 and not f32:
+            if not bias and act == ACT_NONE and not res: return 1
+            if bias and act == ACT_TANH and not res: return 2
+            if not bias and act == ACT_DTANH and not res: return 3
+        if f32 and not bf16 and act == ACT_NONE:
+            if bias and res: return 4
+            if not bias and not res: return 5
+    return 0
 
 
 _GEMM_WS = {}

@@ -28,7 +28,7 @@ def stats(db, out):
 
 
 def gemm_key(name: str):
-    m = re.search(r"(gemm_bf16_\w*kernel<\w+, \w+>)", name)
+    m = re.search(r"(gemm_bf16_\w*kernel<[\w, ]+>)", name)
     return None if not m else m.group(1)
 
 
