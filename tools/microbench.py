@@ -51,6 +51,16 @@ gemm_case("dgrad fc1 (NN)", M, DIM, MLP, tb=True, out="f32")
 gemm_case("wgrad qkv (TN, split-K)", 3 * DIM, DIM, M, ta=True, tb=True, out="f32", acc=True)
 gemm_case("wgrad fc1 (TN, split-K)", MLP, DIM, M, ta=True, tb=True, out="f32", acc=True)
 gemm_case("wgrad fc2 (TN, split-K)", DIM, MLP, M, ta=True, tb=True, out="f32", acc=True)
+# the fused-epilogue forms the training step actually launches
+def gemm_epi(name, m, n, k, tb=False, **kw):
+    a = bf(m, k); b = bf(k, n) if tb else bf(n, k)
+    t = timeit(lambda: _C.gemm(a, b, m, n, k, trans_b=tb, **kw))
+    print(f"{name:34s} M={m:7d} N={n:5d} K={k:7d}  {t*1e3:8.3f} ms  {2*m*n*k/t/1e12:7.1f} TFLOP/s", flush=True)
+gemm_epi("fwd fc1 +bias+tanh -> bf16", M, MLP, DIM, bias=torch.randn(MLP, device=dev), act=_C.ACT_TANH, out_bf16=torch.empty(M, MLP, dtype=torch.bfloat16, device=dev))
+_res = torch.randn(M, DIM, device=dev)
+gemm_epi("fwd fc2 +bias+res -> f32", M, DIM, MLP, bias=torch.randn(DIM, device=dev), res=_res, res_rows=M, out_f32=torch.empty(M, DIM, device=dev))
+gemm_epi("fwd out +bias+res -> f32", M, DIM, DIM, bias=torch.randn(DIM, device=dev), res=_res, res_rows=M, out_f32=torch.empty(M, DIM, device=dev))
+gemm_epi("dgrad fc2 * dtanh(aux) -> bf16", M, MLP, DIM, tb=True, act=_C.ACT_DTANH, aux=torch.tanh(bf(M, MLP).float()).to(torch.bfloat16), out_bf16=torch.empty(M, MLP, dtype=torch.bfloat16, device=dev))
 gemm_case("pre_quant (N=32)", M, 32, DIM, out="f32")
 gemm_case("to_pixel  (N=192, NN)", M, 192, DIM, tb=True, out="f32")
 
