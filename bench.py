@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--batch", type=int, default=int(os.environ.get("ENH_BENCH_BATCH", "128")), help="images per GPU per step")
     ap.add_argument("--config", type=str, default="imagenet_vitvq_base")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--grad-bf16", action="store_true", help="all-reduce the gradient buckets as bf16 (half the xGMI bytes); default fp32")
     args = ap.parse_args()
 
     import torch
@@ -129,7 +130,7 @@ def main():
     model = initialize_from_config(cfg.model)
     eng = model.engine
     if world > 1:
-        eng.comm = GradSync(eng.store)
+        eng.comm = GradSync(eng.store, compress="bf16" if args.grad_bf16 else None)
         eng.comm.broadcast_parameters(0)
         eng.store.refresh_shadows()
     B, size = args.batch, cfg.model.params.image_size

@@ -33,15 +33,9 @@ class ParamStore:
         """prefixes: restrict the store to parameters whose name starts with one of them (one store per optimizer)"""
         self.device = device
         self.precision = precision
-        self.names: List[str] = []
-        self.offsets: Dict[str, Tuple[int, int, torch.Size]] = {}
         mine = (lambda n: True) if prefixes is None else (lambda n: n.startswith(prefixes))
         params = [(n, p) for n, p in module.named_parameters() if p.requires_grad and mine(n)]
-        total = 0
-        for n, p in params:
-            self.names.append(n)
-            self.offsets[n] = (total, p.numel(), p.shape)
-            total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.names, self.offsets, total = self.layout(params)
         self.numel = total
         self.p = torch.zeros(total, dtype=F32, device=device)
         self.g = torch.zeros(total, dtype=F32, device=device)
@@ -68,6 +62,26 @@ class ParamStore:
         self.step_count = 0
         self.refresh_shadows()
 
+    @staticmethod
+    def layout(params):
+        """flat layout of [(name, tensor)]: registration order, every parameter padded to _ALIGN elements -> (names, {name: (offset, numel, shape)}, total).
+        Pure host arithmetic, shared with the CPU tests of the data-parallel bucket cover."""
+        names: List[str] = []
+        offsets: Dict[str, Tuple[int, int, torch.Size]] = {}
+        total = 0
+        for n, p in params:
+            names.append(n)
+            offsets[n] = (total, p.numel(), p.shape)
+            total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        return names, offsets, total
+
+    @staticmethod
+    def slice_from(names, offsets, prefix: str) -> Tuple[int, int]:
+        offs = [offsets[n] for n in names if n.startswith(prefix)]
+        begin = min(o for o, _, _ in offs)
+        end = max((o + c + _ALIGN - 1) // _ALIGN * _ALIGN for o, c, _ in offs)
+        return begin, end
+
     def refresh_shadows(self) -> None:
         if self.precision == "bf16":
             _C.cast_bf16(self.p, self.p16)
@@ -77,10 +91,19 @@ class ParamStore:
 
     def slice_of(self, prefix: str) -> Tuple[int, int]:
         """[begin, end) range of the flat buffers covered by parameters whose name starts with prefix."""
-        offs = [self.offsets[n] for n in self.names if n.startswith(prefix)]
-        begin = min(o for o, _, _ in offs)
-        end = max((o + c + _ALIGN - 1) // _ALIGN * _ALIGN for o, c, _ in offs)
-        return begin, end
+        return self.slice_from(self.names, self.offsets, prefix)
+
+
+def backward_unit_order(enc_depth: int, dec_depth: int) -> List[str]:
+    """the parameter-name prefixes Stage1Engine.backward_from announces to the gradient synchroniser, in announce order = the order in which the
+    backward schedule finishes them (pixel head, decoder final norm, decoder layers last -> first, quantizer block, encoder likewise, patch embedding).
+    Each prefix is one contiguous slice of the flat gradient buffer; together they must cover it without gaps (tests/test_ddp_cpu.py at base size)."""
+    order = ["decoder.to_pixel.", "decoder.transformer.norm."]
+    order += [f"decoder.transformer.layers.{i}." for i in range(dec_depth - 1, -1, -1)]
+    order += ["post_quant.", "pre_quant.", "quantizer.", "encoder.transformer.norm."]
+    order += [f"encoder.transformer.layers.{i}." for i in range(enc_depth - 1, -1, -1)]
+    order += ["encoder.to_patch_embedding."]
+    return order
 
 
 class _Tower:

@@ -133,3 +133,65 @@ def test_discriminator_optimizer_gloo_world2():
     O.adamw_step(p_ref, (torch.from_numpy(got[0][2]) + torch.from_numpy(got[1][2])) / 2, m, v, 1, 1e-3, 0.9, 0.99, 1e-8, 1e-4)
     for _, p_new, _ in got:
         assert torch.allclose(torch.from_numpy(p_new), p_ref, atol=1e-7)   # both ranks applied the MEAN gradient
+
+
+def test_bucket_cover_at_base_config():
+    """BASELINE config 3 (base towers, DDP): the prefixes the backward schedule announces are contiguous slices of the flat gradient buffer that
+    (a) arrive in reverse layer order, (b) cover the buffer exactly once (gap_elems == 0 by construction), (c) give ~28 MB fp32 buckets per
+    transformer layer — checked on the REAL base-size module tree (host arithmetic only; no device needed)."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "enhancing-transformers_amd"))
+    from enhancing.engine.stage1 import ParamStore, backward_unit_order
+    from enhancing.modules.stage1.layers import ViTDecoder, ViTEncoder
+    from enhancing.modules.stage1.quantizers import VectorQuantizer
+    kw = dict(image_size=256, patch_size=8, dim=768, depth=12, heads=12, mlp_dim=3072)
+    mods = torch.nn.ModuleDict(dict(encoder=ViTEncoder(**kw), decoder=ViTDecoder(**kw), pre_quant=torch.nn.Linear(768, 32), post_quant=torch.nn.Linear(32, 768),
+                                    quantizer=VectorQuantizer(32, 8192)))
+    names, offsets, total = ParamStore.layout([(n, p) for n, p in mods.named_parameters() if p.requires_grad])
+    assert abs(total - 170.664e6) < 1e5                                   # SURVEY.md §A.3: 170.66 M trainable parameters (+ alignment padding)
+    order = backward_unit_order(12, 12)
+    slices = [ParamStore.slice_from(names, offsets, p) for p in order]
+    dec_layers = [s for p, s in zip(order, slices) if p.startswith("decoder.transformer.layers.")]
+    assert [b for b, _ in dec_layers] == sorted((b for b, _ in dec_layers), reverse=True)      # reverse layer order = descending offsets
+    cover = sorted(slices)
+    assert cover[0][0] == 0 and cover[-1][1] == total
+    assert all(cover[i][1] == cover[i + 1][0] for i in range(len(cover) - 1)), "slices must tile the buffer: no gap, no overlap"
+    per_layer = {e - b for b, e in dec_layers}
+    assert len(per_layer) == 1 and abs(per_layer.pop() * 4 - 28.3e6) < 0.5e6                  # 7.09 M parameters = 28.3 MB fp32 per layer bucket
+
+
+def _bf16_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "enhancing-transformers_amd"))
+    from enhancing.engine.ddp import GradSync
+    store = FakeStore(rank)
+    local = store.g.clone()
+    sync = GradSync(store, min_bucket_elems=2000, compress="bf16")
+    for prefix in ["decoder.b.", "decoder.a.", "quantizer.", "encoder.b.", "encoder.a."]:
+        sync.layer_done(prefix)
+    sync.finish()
+    q.put((rank, store.g.clone(), local, sync.bytes_reduced))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradsync_bf16_buckets_world2():
+    """optional bf16 gradient buckets: half the bytes on the wire, sum accurate to bf16 rounding"""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bf16_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=120) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    total = got[0][2] + got[1][2]
+    for _, reduced, _, nbytes in got:
+        assert nbytes == total.numel() * 2
+        assert ((reduced - total).norm() / total.norm()).item() <= 6e-3
+    assert torch.equal(got[0][1], got[1][1])

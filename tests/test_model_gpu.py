@@ -193,6 +193,8 @@ def _ddp_worker(rank, world, port, q):
     m.training_step({"image": x}, 0, 0)
     eng.comm.finish()
     assert eng.comm.gap_elems == 0, "the backward schedule must announce every parameter slice"
+    from enhancing.engine.stage1 import backward_unit_order
+    assert eng.comm.announced == backward_unit_order(cfg["encoder"]["depth"], cfg["decoder"]["depth"]), eng.comm.announced   # the list the CPU cover test uses
     q.put((rank, (eng.store.g.detach().cpu() / world).numpy(), eng.store.p.detach().cpu().numpy()))  # numpy: pickled by value
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
