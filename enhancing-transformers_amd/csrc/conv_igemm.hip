@@ -1,0 +1,448 @@
+// conv_igemm.hip — implicit-GEMM convolutions on channels-last bf16 activations for gfx950 (CDNA4), wave64.
+//
+// Serves (a) the StyleGAN2 discriminator's equalised-lr convolutions — 3x3 / 1x1, stride 1 / 2, forward, input gradient and weight
+// gradient, each of them also as a term of the R1 penalty's second-order pass (reference enhancing/losses/layers.py:163-185 EqualConv2d,
+// enhancing/losses/op/conv2d_gradfix.py:22-42,81-195) and (b) the 3x3 convolutions of the LPIPS VGG16 trunk (lpips 0.1.4
+// pretrained_networks.vgg16; reference call sites enhancing/losses/vqperceptual.py:29,43,74,115).
+//
+// No `cols` tensor exists.  One geometry description (enh_conv_geom) covers every role:
+//   GEMM row m = (b, y, x) of a logical grid Hm x Wm ; contraction index k = (tap (jy, jx), channel c) ; the A operand element is
+//       src[b, y*gs + oy0 + jy*sty, x*gs + ox0 + jx*stx, c]      (zero outside the source image)
+//   and the result row is written at pixel (y*os + oph, x*os + opw) of the output tensor.
+//     forward, stride s, padding p, k x k :  gs = s, oy0 = -p, sty = +1, nty = k, dense output
+//     input gradient, stride 1            :  src = dy, gs = 1, oy0 = +p, sty = -1 (the taps run backwards), weights transposed
+//     input gradient, stride 2            :  one launch per output parity class (ph, pw): only the taps kh = (ph+p)&1, +2, .. reach
+//                                            rows of that parity, their sources are dy[(y' + (ph+p-kh0)/2 - jy)], and the rows are
+//                                            written with os = 2, oph = ph (a class without taps writes zeros)
+// The operand is GATHERED in the load stage — 8 consecutive channels of one tap per 16-byte load — into the same XOR-swizzled LDS
+// images the dense kernels use (gemm_tiles.h); the weights are a small [N][taps*C] matrix packed by enh_conv_pack_weight.
+// The weight gradient is the transposed problem: dW[co][(tap, ci)] = sum over pixels of dy[pix][co] * src[gathered pix, tap][ci] — both
+// operands contraction-major, staged as they lie and read with the LDS transpose read; the pixel axis is split over the grid and the
+// partial slabs are added in a fixed order (deterministic, no atomics).
+// Register-staged double buffer (the gather needs per-lane predication, which global_load_lds cannot do), 128 x 128 x 64 tile,
+// 4 waves of 64 x 64 (v_mfma_f32_16x16x32_bf16), 2 workgroups per CU.  C and N multiples of 8; any grid size.
+#include "gemm_tiles.h"
+
+struct ConvArgs {
+  const uint16_t* X; const uint16_t* Wt;
+  enh_conv_geom g;
+  int64_t M, K;
+  const float* bias; int mode; const uint16_t* aux; const uint16_t* add; float p0, p1;
+  uint16_t* out;
+  int nbm, nbn;
+};
+
+// Workgroup b runs on XCD b % 8 (private 4 MiB L2 each): hand every XCD a CONTIGUOUS run of the linear tile order, so that the vertical halo of
+// a 3x3 tap grid (image rows y-1, y+1 = tiles +-W/128 away) and the nine taps' re-reads of one pixel range hit the same L2 instead of being
+// fetched from the Infinity Cache once per XCD.
+__device__ __forceinline__ int xcd_contiguous(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, pos = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+}
+
+// output element offset (in pixels) of GEMM row m
+__device__ __forceinline__ int64_t conv_out_pixel(const enh_conv_geom& g, int64_t m) {
+  const int64_t hw = (int64_t)g.Hm * g.Wm;
+  const int64_t b = m / hw, rem = m - b * hw;
+  const int y = (int)(rem / g.Wm), x = (int)(rem - (int64_t)y * g.Wm);
+  return (b * g.HO + (int64_t)y * g.os + g.oph) * g.WO + (int64_t)x * g.os + g.opw;
+}
+
+//   mode 0: out = relu(acc + bias[n])                                   (VGG16 conv + ReLU)
+//   mode 1: out = (acc + add[o,n]) * (aux[o,n] > 0)                     (VGG16 input gradient through a ReLU; add optional)
+//   mode 2: out = acc
+//   mode 3: out = lrelu(acc + bias[n], slope p0) * p1                   (EqualConv2d + FusedLeakyReLU; bias optional)
+//   mode 4: out = acc + p0 * add[o,n]                                   (the residual merge of a StyleBlock folded into its skip convolution)
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs args) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2 stages][A tile | B tile]
+  const enh_conv_geom& g = args.g;
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l16 = lane & 15, lg = lane >> 4;
+  const int bid_ = xcd_contiguous((int)blockIdx.x, args.nbm * args.nbn);
+  const int tile_m = bid_ % args.nbm, tile_n = bid_ / args.nbm;
+  const int64_t m0 = (int64_t)tile_m * G_BM, n0 = (int64_t)tile_n * G_BN;
+  const int nk = (int)((args.K + G_BK - 1) / G_BK);
+
+  // this thread gathers chunk c (8 channels) of rows r0 + 32*i: the pixel of a row does not change along K
+  const int c = t & 7, r0 = t >> 3;
+  int py[4], px[4];
+  int64_t pb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t row = m0 + r0 + 32 * i;
+    if (row < args.M) {
+      const int64_t hw = (int64_t)g.Hm * g.Wm;
+      const int64_t b = row / hw, rem = row - b * hw;
+      const int y = (int)(rem / g.Wm), x = (int)(rem - (int64_t)y * g.Wm);
+      py[i] = y * g.gs; px[i] = x * g.gs;
+      pb[i] = b * g.Hs * g.Ws;
+    } else { py[i] = -(1 << 28); px[i] = -(1 << 28); pb[i] = 0; }   // every tap of an out-of-range row falls outside the image -> zeros
+  }
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  // (a second register set for the gathered operand — loads two K steps ahead — was measured SLOWER: 285-383 vs 405 TF/s; the allocator then
+  //  fills all 256 registers and spills)
+  u32x4 ra[4], rb[4];
+  auto gather = [&](int64_t k0) {
+    const int64_t kk = k0 + c * 8;
+    const int tap = (int)(kk / g.C), ch = (int)(kk - (int64_t)tap * g.C);
+    const int jy = tap / g.ntx, jx = tap - jy * g.ntx;
+    const int dy = g.oy0 + jy * g.sty, dx = g.ox0 + jx * g.stx;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int sy = py[i] + dy, sx = px[i] + dx;
+      const bool ok = kk < args.K && sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws;
+      ra[i] = ok ? *reinterpret_cast<const u32x4*>(args.X + (pb[i] + (int64_t)sy * g.Ws + sx) * g.C + ch) : zero4;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t co = n0 + r0 + 32 * i;
+      rb[i] = (co < g.N && kk < args.K) ? *reinterpret_cast<const u32x4*>(args.Wt + co * args.K + kk) : zero4;
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (nk > 0) {
+    gather(0);
+    tile_sstore<false>(ra, smem, t);
+    tile_sstore<false>(rb, smem + G_TILE_BYTES, t);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int stage = kt & 1;
+    if (kt + 1 < nk) gather((int64_t)(kt + 1) * G_BK);
+    const unsigned char* sa = smem + stage * (2 * G_TILE_BYTES);
+    const unsigned char* sb = sa + G_TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      s16x8 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = tile_frag<false>(sa, wm * 64 + i * 16, ks, lg, l16);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = tile_frag<false>(sb, wn * 64 + j * 16, ks, lg, l16);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[j]), __builtin_bit_cast(bf16x8, fa[i]), acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      unsigned char* na = smem + (stage ^ 1) * (2 * G_TILE_BYTES);
+      tile_sstore<false>(ra, na, t);
+      tile_sstore<false>(rb, na + G_TILE_BYTES, t);
+    }
+    __syncthreads();
+  }
+  // epilogue: lane (lg, l16) holds out[m = m0 + wm*64 + i*16 + l16][n = n0 + wn*64 + j*16 + lg*4 + 0..3]
+  const bool dense = g.os == 1 && g.HO == g.Hm && g.WO == g.Wm && g.oph == 0 && g.opw == 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t m = m0 + wm * 64 + i * 16 + l16;
+    if (m >= args.M) continue;
+    const int64_t orow = (dense ? m : conv_out_pixel(g, m)) * g.N;
+    uint2 ax[4], ad[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t n = n0 + wn * 64 + j * 16 + lg * 4;
+      ax[j] = make_uint2(0u, 0u); ad[j] = make_uint2(0u, 0u);
+      if (n < g.N) {
+        if (args.mode == 1) ax[j] = *reinterpret_cast<const uint2*>(args.aux + orow + n);
+        if ((args.mode == 1 || args.mode == 4) && args.add) ad[j] = *reinterpret_cast<const uint2*>(args.add + orow + n);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t n = n0 + wn * 64 + j * 16 + lg * 4;
+      if (n >= g.N) continue;   // N % 8 == 0: the 4 columns are in or out together
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      const uint32_t d0 = ad[j].x, d1 = ad[j].y;
+      const float e0 = bf16_bits_to_f32((uint16_t)(d0 & 0xffffu)), e1 = bf16_bits_to_f32((uint16_t)(d0 >> 16));
+      const float e2 = bf16_bits_to_f32((uint16_t)(d1 & 0xffffu)), e3 = bf16_bits_to_f32((uint16_t)(d1 >> 16));
+      if (args.mode == 0) {
+        const float4 b4 = *reinterpret_cast<const float4*>(args.bias + n);
+        v[0] = fmaxf(v[0] + b4.x, 0.f); v[1] = fmaxf(v[1] + b4.y, 0.f); v[2] = fmaxf(v[2] + b4.z, 0.f); v[3] = fmaxf(v[3] + b4.w, 0.f);
+      } else if (args.mode == 1) {
+        const uint32_t a0 = ax[j].x, a1 = ax[j].y;
+        v[0] = (a0 & 0x7fffu) && !(a0 & 0x8000u) ? v[0] + e0 : 0.f;
+        v[1] = ((a0 >> 16) & 0x7fffu) && !(a0 >> 31) ? v[1] + e1 : 0.f;
+        v[2] = (a1 & 0x7fffu) && !(a1 & 0x8000u) ? v[2] + e2 : 0.f;
+        v[3] = ((a1 >> 16) & 0x7fffu) && !(a1 >> 31) ? v[3] + e3 : 0.f;
+      } else if (args.mode == 3) {
+        if (args.bias) {
+          const float4 b4 = *reinterpret_cast<const float4*>(args.bias + n);
+          v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (v[r] > 0.f ? v[r] : v[r] * args.p0) * args.p1;
+      } else if (args.mode == 4) {
+        v[0] += args.p0 * e0; v[1] += args.p0 * e1; v[2] += args.p0 * e2; v[3] += args.p0 * e3;
+      }
+      const u32x2 o_ = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+      *reinterpret_cast<u32x2*>(args.out + orow + n) = o_;
+    }
+  }
+}
+
+static int conv_geom_check(const enh_conv_geom* g, const char* who) {
+  ENH_REQUIRE(g, ENH_E_BADARG, "%s: geometry is NULL", who);
+  ENH_REQUIRE(g->B > 0 && g->Hs > 0 && g->Ws > 0 && g->Hm > 0 && g->Wm > 0 && g->HO > 0 && g->WO > 0, ENH_E_BADARG, "%s: non-positive size", who);
+  ENH_REQUIRE(g->C > 0 && g->N > 0 && g->C % 8 == 0 && g->N % 8 == 0, ENH_E_SHAPE, "%s: C and N must be multiples of 8 (C=%d N=%d)", who, g->C, g->N);
+  ENH_REQUIRE(g->nty >= 0 && g->ntx >= 0 && g->nty <= 16 && g->ntx <= 16 && g->gs >= 1 && g->os >= 1, ENH_E_SHAPE, "%s: bad tap grid / stride", who);
+  ENH_REQUIRE((int64_t)(g->Hm - 1) * g->os + g->oph < g->HO && (int64_t)(g->Wm - 1) * g->os + g->opw < g->WO && g->oph >= 0 && g->opw >= 0, ENH_E_SHAPE,
+              "%s: the logical grid %dx%d (stride %d, offset %d,%d) does not fit the output %dx%d", who, g->Hm, g->Wm, g->os, g->oph, g->opw, g->HO, g->WO);
+  return ENH_OK;
+}
+
+static void conv_lds_attr_once() {
+  static const bool attr_set = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G_TILE_BYTES);
+    return true;
+  }();
+  (void)attr_set;
+}
+
+extern "C" int enh_conv_nhwc_bf16(const enh_bf16* src, const enh_bf16* wt, const enh_conv_geom* g, int mode, const float* bias, const enh_bf16* aux,
+                                  const enh_bf16* add, float p0, float p1, enh_bf16* out, void* stream) {
+  ENH_REQUIRE(src && wt && out, ENH_E_BADARG, "enh_conv_nhwc_bf16: bad argument");
+  const int rc = conv_geom_check(g, "enh_conv_nhwc_bf16");
+  if (rc != ENH_OK) return rc;
+  ENH_REQUIRE(mode >= 0 && mode <= 4, ENH_E_BADARG, "enh_conv_nhwc_bf16: mode must be 0..4");
+  ENH_REQUIRE((mode != 0 || bias) && (mode != 1 || aux) && (mode != 4 || add), ENH_E_BADARG, "enh_conv_nhwc_bf16: mode 0 needs bias, mode 1 aux, mode 4 add");
+  ConvArgs a;
+  a.X = src; a.Wt = wt; a.g = *g;
+  a.M = (int64_t)g->B * g->Hm * g->Wm; a.K = (int64_t)g->nty * g->ntx * g->C;
+  a.bias = bias; a.mode = mode; a.aux = aux; a.add = add; a.p0 = p0; a.p1 = p1; a.out = out;
+  a.nbm = (int)((a.M + G_BM - 1) / G_BM); a.nbn = (g->N + G_BN - 1) / G_BN;
+  ENH_REQUIRE((int64_t)a.nbm * a.nbn < (1ll << 30), ENH_E_SHAPE, "enh_conv_nhwc_bf16: grid too large");
+  conv_lds_attr_once();
+  conv_igemm_kernel<<<dim3((unsigned)(a.nbm * a.nbn)), 256, 4 * G_TILE_BYTES, (hipStream_t)stream>>>(a);
+  return enh_check_launch("enh_conv_nhwc_bf16");
+}
+
+// the LPIPS entry point: 3x3, stride 1, padding 1 on the general kernel
+extern "C" int enh_conv3x3_nhwc_bf16(const enh_bf16* x, const enh_bf16* wt, int B, int H, int W, int Cin, int Cout, const float* bias, int mode,
+                                     const enh_bf16* aux, const enh_bf16* add, enh_bf16* out, void* stream) {
+  ENH_REQUIRE(mode >= 0 && mode <= 2, ENH_E_BADARG, "enh_conv3x3_nhwc_bf16: mode must be 0, 1 or 2");
+  enh_conv_geom g;
+  g.B = B; g.Hs = H; g.Ws = W; g.C = Cin; g.Hm = H; g.Wm = W; g.gs = 1; g.oy0 = -1; g.ox0 = -1; g.nty = 3; g.ntx = 3; g.sty = 1; g.stx = 1;
+  g.N = Cout; g.HO = H; g.WO = W; g.os = 1; g.oph = 0; g.opw = 0;
+  return enh_conv_nhwc_bf16(x, wt, &g, mode, bias, aux, add, 0.f, 1.f, out, stream);
+}
+
+// =================================================================================================
+// weight gradient: dW[co][(tap, ci)] = sum over pixels (b, y, x) of dy[b, y, x, co] * src[b, y*gs + oy0 + jy*sty, x*gs + ox0 + jx*stx, ci]
+// =================================================================================================
+struct ConvWgradArgs {
+  const uint16_t* X; const uint16_t* DY;
+  enh_conv_geom g;      // g.N = channels of dy ; (Hm, Wm) = dy's spatial size ; output addressing fields unused
+  GemmArgs e;           // epilogue description: M = g.N, N = taps*C, ws / c_f32 / ldc / accumulate / splits / k_per_split
+};
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad_igemm_kernel(const ConvWgradArgs args) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2 stages][A tile (dy, kmaj) | B tile (gathered src, kmaj)]
+  const enh_conv_geom& g = args.g;
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l16 = lane & 15, lg = lane >> 4;
+  const int nwg = args.e.nbm * args.e.nbn;
+  const int lin = xcd_contiguous((int)blockIdx.x, nwg * args.e.splits);   // all tiles of one pixel slice on one XCD: they re-read the same pixels
+  const int split = lin / nwg, bid = lin - split * nwg;
+  const int tile_m = bid % args.e.nbm, tile_n = bid / args.e.nbm;
+  const int64_t m0 = (int64_t)tile_m * G_BM, n0 = (int64_t)tile_n * G_BN;
+  const int64_t k_begin = (int64_t)split * args.e.k_per_split;
+  int64_t k_end = k_begin + args.e.k_per_split;
+  if (k_end > args.e.K) k_end = args.e.K;
+  const int nk = k_end > k_begin ? (int)((k_end - k_begin + G_BK - 1) / G_BK) : 0;
+
+  // B operand: this thread gathers columns n0 + c*8 .. +7 (one tap, 8 channels) of pixel rows r0 + 16*i of every K step
+  const int c = t & 15, r0 = t >> 4;
+  const int64_t ncol = n0 + c * 8;
+  const bool n_ok = ncol < args.e.N;
+  const int tap = n_ok ? (int)(ncol / g.C) : 0, ch = n_ok ? (int)(ncol - (int64_t)tap * g.C) : 0;
+  const int jy = tap / (g.ntx > 0 ? g.ntx : 1), jx = tap - jy * g.ntx;
+  const int dy_ = g.oy0 + jy * g.sty, dx_ = g.ox0 + jx * g.stx;
+  // pixel state of the 4 rows; all advance by 64 pixels per K step
+  const int64_t hw = (int64_t)g.Hm * g.Wm;
+  const int step_b = (int)(G_BK / hw), step_rem = (int)(G_BK - step_b * hw);
+  const int step_y = step_rem / g.Wm, step_x = step_rem - step_y * g.Wm;
+  int pb[4], py[4], px[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t pix = k_begin + r0 + 16 * i;
+    const int64_t b = pix / hw, rem = pix - b * hw;
+    pb[i] = (int)b; py[i] = (int)(rem / g.Wm); px[i] = (int)(rem - (int64_t)py[i] * g.Wm);
+  }
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  u32x4 ra[4], rb[4];   // one register set (a second one, as conv_igemm_kernel has for its gathered operand, spills here: 12 pixel-state registers)
+  auto gather = [&](int64_t k0) {
+    tile_gload<true>(ra, args.DY, g.N, m0, g.N, k0, k_end, t);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t pix = k0 + r0 + 16 * i;
+      const int sy = py[i] * g.gs + dy_, sx = px[i] * g.gs + dx_;
+      const bool ok = n_ok && pix < k_end && sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws;
+      rb[i] = ok ? *reinterpret_cast<const u32x4*>(args.X + (((int64_t)pb[i] * g.Hs + sy) * g.Ws + sx) * g.C + ch) : zero4;
+      // advance this row to the next K step
+      px[i] += step_x;
+      const int cx = px[i] >= g.Wm;
+      px[i] -= cx ? g.Wm : 0;
+      py[i] += step_y + cx;
+      const int cy = py[i] >= g.Hm;
+      py[i] -= cy ? g.Hm : 0;
+      pb[i] += step_b + cy;
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (nk > 0) {
+    gather(k_begin);
+    tile_sstore<true>(ra, smem, t);
+    tile_sstore<true>(rb, smem + G_TILE_BYTES, t);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int stage = kt & 1;
+    if (kt + 1 < nk) gather(k_begin + (int64_t)(kt + 1) * G_BK);
+    const unsigned char* sa = smem + stage * (2 * G_TILE_BYTES);
+    const unsigned char* sb = sa + G_TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      s16x8 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = tile_frag<true>(sa, wm * 64 + i * 16, ks, lg, l16);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = tile_frag<true>(sb, wn * 64 + j * 16, ks, lg, l16);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[j]), __builtin_bit_cast(bf16x8, fa[i]), acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      unsigned char* na = smem + (stage ^ 1) * (2 * G_TILE_BYTES);
+      tile_sstore<true>(ra, na, t);
+      tile_sstore<true>(rb, na + G_TILE_BYTES, t);
+    }
+    __syncthreads();
+  }
+  gemm_epilogue(args.e, acc, m0, n0, wm, wn, lg, l16, split);
+}
+
+struct WgradPlan { int splits; int64_t k_per_split; };
+static WgradPlan conv_wgrad_plan(int64_t M, int64_t N, int64_t K) {
+  const int64_t tiles = ((M + G_BM - 1) / G_BM) * ((N + G_BN - 1) / G_BN);
+  const int64_t ksteps = (K + G_BK - 1) / G_BK;
+  int64_t splits = (1024 + tiles - 1) / tiles;          // ~4 workgroups per CU in total
+  if (splits > ksteps / 4) splits = ksteps / 4;         // at least 4 K steps per slice
+  if (splits < 1) splits = 1;
+  const int64_t per = ((ksteps + splits - 1) / splits) * G_BK;
+  splits = (K + per - 1) / per;
+  return {(int)splits, per};
+}
+
+extern "C" size_t enh_conv_wgrad_workspace_bytes(const enh_conv_geom* g) {
+  if (!g || g->N <= 0 || g->C <= 0) return 0;
+  const int64_t M = g->N, N = (int64_t)g->nty * g->ntx * g->C, K = (int64_t)g->B * g->Hm * g->Wm;
+  const WgradPlan p = conv_wgrad_plan(M, N, K);
+  return p.splits > 1 ? (size_t)p.splits * M * N * sizeof(float) : 0;
+}
+
+extern "C" int enh_conv_wgrad_nhwc_bf16(const enh_bf16* src, const enh_bf16* dy, const enh_conv_geom* g, float* dw, void* ws, size_t ws_bytes, void* stream) {
+  ENH_REQUIRE(src && dy && dw, ENH_E_BADARG, "enh_conv_wgrad_nhwc_bf16: bad argument");
+  ENH_REQUIRE(g, ENH_E_BADARG, "enh_conv_wgrad_nhwc_bf16: geometry is NULL");
+  enh_conv_geom gg = *g; gg.HO = g->Hm; gg.WO = g->Wm; gg.os = 1; gg.oph = 0; gg.opw = 0;   // the output-addressing fields are not used by this role
+  const int rc = conv_geom_check(&gg, "enh_conv_wgrad_nhwc_bf16");
+  if (rc != ENH_OK) return rc;
+  ENH_REQUIRE(g->nty > 0 && g->ntx > 0, ENH_E_SHAPE, "enh_conv_wgrad_nhwc_bf16: empty tap grid");
+  ENH_REQUIRE((int64_t)g->B * g->Hm * g->Wm < (1ll << 31) && (int64_t)g->B * g->Hs * g->Ws < (1ll << 31), ENH_E_SHAPE, "enh_conv_wgrad_nhwc_bf16: more than 2^31 pixels");
+  ConvWgradArgs a;
+  a.X = src; a.DY = dy; a.g = gg;
+  GemmArgs& e = a.e;
+  e.A = nullptr; e.lda = 0; e.B = nullptr; e.ldb = 0;
+  e.M = g->N; e.N = (int64_t)g->nty * g->ntx * g->C; e.K = (int64_t)g->B * g->Hm * g->Wm;
+  const WgradPlan p = conv_wgrad_plan(e.M, e.N, e.K);
+  e.k_per_split = p.k_per_split; e.splits = p.splits;
+  e.bias = nullptr; e.act = ENH_ACT_NONE; e.aux = nullptr; e.ldaux = 0; e.res = nullptr; e.ldres = 0; e.res_rows = 0;
+  e.c_bf16 = nullptr; e.c_f32 = dw; e.ldc = e.N; e.ws = nullptr; e.accumulate = 0;
+  e.nbm = (int)((e.M + G_BM - 1) / G_BM); e.nbn = (int)((e.N + G_BN - 1) / G_BN);
+  const int64_t MN = e.M * e.N;
+  if (p.splits > 1) {
+    ENH_REQUIRE(ws && ws_bytes >= (size_t)p.splits * MN * sizeof(float), ENH_E_WORKSPACE, "enh_conv_wgrad_nhwc_bf16: workspace too small (%zu < %zu bytes)",
+                ws_bytes, (size_t)p.splits * MN * sizeof(float));
+    e.ws = (float*)ws; e.accumulate = 3;
+  }
+  static const bool attr_set = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_igemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G_TILE_BYTES);
+    return true;
+  }();
+  (void)attr_set;
+  hipStream_t s = (hipStream_t)stream;
+  conv_wgrad_igemm_kernel<<<dim3((unsigned)(e.nbm * e.nbn * p.splits)), 256, 4 * G_TILE_BYTES, s>>>(a);
+  if (p.splits > 1) splitk_reduce_kernel<<<dim3((unsigned)((MN / 4 + 255) / 256)), 256, 0, s>>>(e.ws, p.splits, MN, e.N, dw, e.N, 0);
+  return enh_check_launch("enh_conv_wgrad_nhwc_bf16");
+}
+
+// =================================================================================================
+// weight packing: parameter layout [Cout][Cin][k][k] f32  <->  the [rows][taps * cols] matrices the kernels above read / write
+// =================================================================================================
+// transposed = 0: out[co][(jy*ntx + jx)*Cp + ci] = scale * w[co][ci][kh0 + jy*kstep][kw0 + jx*kstep]   rows co < Rp (Rp >= Cout), ci < Cp (Cp >= Cin)
+// transposed = 1: out[ci][(jy*ntx + jx)*Cp + co] = scale * w[co][ci][kh0 + jy*kstep][kw0 + jx*kstep]   rows ci < Rp (Rp >= Cin),  co < Cp (Cp >= Cout)
+// rows / columns beyond the real channel counts are zero
+__global__ void conv_pack_weight_kernel(const float* __restrict__ w, int Cout, int Cin, int k, float scale, int transposed, int kh0, int kw0, int kstep,
+                                        int nty, int ntx, int Rp, int Cp, uint16_t* __restrict__ out) {
+  const int64_t total = (int64_t)Rp * nty * ntx * Cp;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int col = (int)(i % Cp);
+  const int64_t q = i / Cp;
+  const int tap = (int)(q % (nty * ntx)), row = (int)(q / (nty * ntx));
+  const int jy = tap / ntx, jx = tap - jy * ntx;
+  const int co = transposed ? col : row, ci = transposed ? row : col;
+  float v = 0.f;
+  if (co < Cout && ci < Cin) v = scale * w[(((int64_t)co * Cin + ci) * k + kh0 + jy * kstep) * k + kw0 + jx * kstep];
+  out[i] = f32_to_bf16_bits(v);
+}
+
+extern "C" int enh_conv_pack_weight(const float* w, int Cout, int Cin, int k, float scale, int transposed, int kh0, int kw0, int kstep, int nty, int ntx,
+                                    int rows_padded, int cols_padded, enh_bf16* out, void* stream) {
+  ENH_REQUIRE(w && out && Cout > 0 && Cin > 0 && k > 0 && kstep > 0, ENH_E_BADARG, "enh_conv_pack_weight: bad argument");
+  ENH_REQUIRE(nty >= 0 && ntx >= 0 && kh0 >= 0 && kw0 >= 0 && (nty == 0 || kh0 + (nty - 1) * kstep < k) && (ntx == 0 || kw0 + (ntx - 1) * kstep < k), ENH_E_SHAPE,
+              "enh_conv_pack_weight: tap selection outside the %dx%d kernel", k, k);
+  ENH_REQUIRE(rows_padded >= (transposed ? Cin : Cout) && cols_padded >= (transposed ? Cout : Cin), ENH_E_SHAPE, "enh_conv_pack_weight: padded sizes too small");
+  const int64_t total = (int64_t)rows_padded * nty * ntx * cols_padded;
+  if (total == 0) return ENH_OK;
+  conv_pack_weight_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, (hipStream_t)stream>>>(w, Cout, Cin, k, scale, transposed, kh0, kw0, kstep, nty, ntx,
+                                                                                                  rows_padded, cols_padded, out);
+  return enh_check_launch("enh_conv_pack_weight");
+}
+
+// dw[co][ci][kh][kw] = scale * dwp[co][(kh*k + kw)*Cp + ci]
+__global__ void conv_unpack_wgrad_kernel(const float* __restrict__ dwp, int Cout, int Cin, int Cp, int k, float scale, float* __restrict__ dw) {
+  const int64_t total = (int64_t)Cout * Cin * k * k;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int kw = (int)(i % k);
+  int64_t q = i / k;
+  const int kh = (int)(q % k); q /= k;
+  const int ci = (int)(q % Cin), co = (int)(q / Cin);
+  dw[i] = scale * dwp[((int64_t)co * k * k + kh * k + kw) * Cp + ci];
+}
+
+extern "C" int enh_conv_unpack_wgrad(const float* dwp, int Cout, int Cin, int cin_padded, int k, float scale, float* dw, void* stream) {
+  ENH_REQUIRE(dwp && dw && Cout > 0 && Cin > 0 && k > 0 && cin_padded >= Cin, ENH_E_BADARG, "enh_conv_unpack_wgrad: bad argument");
+  const int64_t total = (int64_t)Cout * Cin * k * k;
+  conv_unpack_wgrad_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, (hipStream_t)stream>>>(dwp, Cout, Cin, cin_padded, k, scale, dw);
+  return enh_check_launch("enh_conv_unpack_wgrad");
+}

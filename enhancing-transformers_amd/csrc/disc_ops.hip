@@ -197,3 +197,266 @@ extern "C" int enh_upfirdn2d(const float* in, const float* kernel, float* out, i
                                                                              down_x, down_y, pad_x0, pad_y0);
   return enh_check_launch("enh_upfirdn2d");
 }
+
+// =================================================================================================
+// Channels-last bf16 element-wise kernels of the implicit-GEMM discriminator path (activations [B,H,W,C] bf16, C % 8 == 0).
+// Each is linear in its data argument and closed under differentiation (the derivative of every one is another launch of
+// the same kernel with other arguments), which is what lets the R1 penalty differentiate through the backward pass.
+// =================================================================================================
+__device__ __forceinline__ void unpack8(const u32x4 v, float (&f)[8]) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { f[2 * k] = __uint_as_float(v[k] << 16); f[2 * k + 1] = __uint_as_float(v[k] & 0xffff0000u); }
+}
+__device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
+  return (u32x4){pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7])};
+}
+
+// FIR filter with unit up / down factors (Blur, reference enhancing/losses/layers.py:140-160 -> upfirdn2d(input, kernel, pad)):
+//   out[b,oy,ox,c] = sum_{i,j} w(i,j) * x[b, oy + i - pad_y0, ox + j - pad_x0, c],  w(i,j) = kernel[kh-1-i][kw-1-j]  (flip = 0: upfirdn2d's convention)
+//                                                                                   or   kernel[i][j]            (flip = 1: its adjoint)
+// one thread = 8 channels x 4 consecutive output columns of one row: (kw + 3) * kh 16-byte loads for 4 outputs
+__global__ __launch_bounds__(256) void blur_nhwc_kernel(const uint16_t* __restrict__ x, const float* __restrict__ kernel, uint16_t* __restrict__ out,
+                                                        int B, int H, int W, int C, int Ho, int Wo, int kh, int kw, int pad_y0, int pad_x0, int flip) {
+  __shared__ float s_k[64];
+  if ((int)threadIdx.x < kh * kw) {
+    const int i = threadIdx.x / kw, j = threadIdx.x % kw;
+    s_k[threadIdx.x] = flip ? kernel[i * kw + j] : kernel[(kh - 1 - i) * kw + (kw - 1 - j)];
+  }
+  __syncthreads();
+  const int c8n = C >> 3, wq = (Wo + 3) >> 2;
+  const int64_t total = (int64_t)B * Ho * wq * c8n;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int c8 = (int)(idx % c8n);
+  int64_t q = idx / c8n;
+  const int xq = (int)(q % wq); q /= wq;
+  const int oy = (int)(q % Ho);
+  const int64_t b = q / Ho;
+  const int ox0 = xq * 4;
+  float acc[4][8];
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[o][k] = 0.f;
+  for (int i = 0; i < kh; ++i) {
+    const int iy = oy + i - pad_y0;
+    if (iy < 0 || iy >= H) continue;
+    const uint16_t* row = x + ((b * H + iy) * (int64_t)W) * C + c8 * 8;
+    for (int jj = 0; jj < kw + 3; ++jj) {
+      const int ix = ox0 + jj - pad_x0;
+      if (ix < 0 || ix >= W) continue;
+      float f[8];
+      unpack8(*reinterpret_cast<const u32x4*>(row + (int64_t)ix * C), f);
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        const int j = jj - o;
+        if (j >= 0 && j < kw) {
+          const float wv = s_k[i * kw + j];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) acc[o][k] += wv * f[k];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+    if (ox0 + o < Wo) *reinterpret_cast<u32x4*>(out + ((b * Ho + oy) * (int64_t)Wo + ox0 + o) * C + c8 * 8) = pack8(acc[o]);
+}
+
+extern "C" int enh_blur_nhwc_bf16(const enh_bf16* x, const float* kernel, int B, int H, int W, int C, int kh, int kw, int pad_y0, int pad_y1, int pad_x0,
+                                  int pad_x1, int flip, enh_bf16* out, void* stream) {
+  ENH_REQUIRE(x && kernel && out && B > 0 && H > 0 && W > 0, ENH_E_BADARG, "enh_blur_nhwc_bf16: bad argument");
+  ENH_REQUIRE(C > 0 && C % 8 == 0 && kh > 0 && kw > 0 && kh * kw <= 64, ENH_E_SHAPE, "enh_blur_nhwc_bf16: C must be a multiple of 8 and the kernel at most 64 taps");
+  const int Ho = H + pad_y0 + pad_y1 - kh + 1, Wo = W + pad_x0 + pad_x1 - kw + 1;
+  ENH_REQUIRE(Ho > 0 && Wo > 0, ENH_E_SHAPE, "enh_blur_nhwc_bf16: empty output");
+  const int64_t total = (int64_t)B * Ho * ((Wo + 3) / 4) * (C / 8);
+  blur_nhwc_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, (hipStream_t)stream>>>(x, kernel, out, B, H, W, C, Ho, Wo, kh, kw, pad_y0, pad_x0, flip);
+  return enh_check_launch("enh_blur_nhwc_bf16");
+}
+
+// y = g * (ref > 0 ? 1 : slope) * scale   (the derivative of FusedLeakyReLU through its saved OUTPUT, fused_act.py:21-45; ref == NULL: y = g * scale)
+__global__ __launch_bounds__(256) void lrelu_gate_bf16_kernel(const uint16_t* __restrict__ g, const uint16_t* __restrict__ ref, uint16_t* __restrict__ y, int64_t n8,
+                                                              float slope, float scale) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  float f[8], r[8];
+  unpack8(*reinterpret_cast<const u32x4*>(g + i * 8), f);
+  if (ref) {
+    unpack8(*reinterpret_cast<const u32x4*>(ref + i * 8), r);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] *= (r[k] > 0.f ? 1.f : slope) * scale;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] *= scale;
+  }
+  *reinterpret_cast<u32x4*>(y + i * 8) = pack8(f);
+}
+
+extern "C" int enh_lrelu_gate_bf16(const enh_bf16* g, const enh_bf16* ref, int64_t n, float slope, float scale, enh_bf16* y, void* stream) {
+  ENH_REQUIRE(g && y && n > 0, ENH_E_BADARG, "enh_lrelu_gate_bf16: bad argument");
+  ENH_REQUIRE(n % 8 == 0, ENH_E_SHAPE, "enh_lrelu_gate_bf16: n must be a multiple of 8");
+  lrelu_gate_bf16_kernel<<<dim3((unsigned)((n / 8 + 255) / 256)), 256, 0, (hipStream_t)stream>>>(g, ref, y, n / 8, slope, scale);
+  return enh_check_launch("enh_lrelu_gate_bf16");
+}
+
+// img [B,C,H,W] f32 (C <= 8) -> [B,H,W,8] bf16 with channels C..7 zero, and its adjoint ([B,H,W,8] bf16 -> [B,C,H,W] f32, the padding channels dropped)
+__global__ __launch_bounds__(256) void img_to_nhwc8_kernel(const float* __restrict__ img, uint16_t* __restrict__ out, int C, int64_t HW, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // pixel index over B*H*W
+  if (i >= total) return;
+  const int64_t b = i / HW, p = i - b * HW;
+  float f[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) f[c] = c < C ? img[(b * C + c) * HW + p] : 0.f;
+  *reinterpret_cast<u32x4*>(out + i * 8) = pack8(f);
+}
+__global__ __launch_bounds__(256) void nhwc8_to_img_kernel(const uint16_t* __restrict__ src, float* __restrict__ img, int C, int64_t HW, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int64_t b = i / HW, p = i - b * HW;
+  float f[8];
+  unpack8(*reinterpret_cast<const u32x4*>(src + i * 8), f);
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+    if (c < C) img[(b * C + c) * HW + p] = f[c];
+}
+
+extern "C" int enh_img_to_nhwc8(const float* img, int B, int C, int H, int W, enh_bf16* out, void* stream) {
+  ENH_REQUIRE(img && out && B > 0 && H > 0 && W > 0 && C > 0 && C <= 8, ENH_E_BADARG, "enh_img_to_nhwc8: bad argument (1 <= C <= 8)");
+  const int64_t total = (int64_t)B * H * W;
+  img_to_nhwc8_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, (hipStream_t)stream>>>(img, out, C, (int64_t)H * W, total);
+  return enh_check_launch("enh_img_to_nhwc8");
+}
+extern "C" int enh_nhwc8_to_img(const enh_bf16* src, int B, int C, int H, int W, float* img, void* stream) {
+  ENH_REQUIRE(img && src && B > 0 && H > 0 && W > 0 && C > 0 && C <= 8, ENH_E_BADARG, "enh_nhwc8_to_img: bad argument (1 <= C <= 8)");
+  const int64_t total = (int64_t)B * H * W;
+  nhwc8_to_img_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, (hipStream_t)stream>>>(src, img, C, (int64_t)H * W, total);
+  return enh_check_launch("enh_nhwc8_to_img");
+}
+
+// Minibatch standard deviation (reference enhancing/losses/layers.py:358-367, stddev_feat = 1) on channels-last bf16, fused with the concatenation and
+// the channel padding of the final convolution's input: sample b belongs to slot b % n (n = B / group); for every position p = (h,w,c) the standard
+// deviation over the `group` samples of the slot, sd_p = sqrt(var_p + 1e-8) (biased variance), is averaged over p into ONE scalar per slot:
+//   out[b,h,w,0..C-1] = x[b,h,w,:] ; out[b,h,w,C] = mean_p sd_p of b's slot ; out[b,h,w,C+1..Cp-1] = 0
+// One workgroup per slot (the tensor is B x 4 x 4 x 512: a few hundred KiB); fixed-order reductions, no atomics.
+__device__ __forceinline__ float block_sum_256(float v, float* s_red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) s_red[wave] = v;
+  __syncthreads();
+  return s_red[0] + s_red[1] + s_red[2] + s_red[3];
+}
+
+__global__ __launch_bounds__(256) void stddev_fwd_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ out, int group, int n, int HW, int C, int Cp) {
+  __shared__ float s_red[4];
+  const int slot = blockIdx.x;
+  const int64_t P = (int64_t)HW * C;
+  float part = 0.f;
+  for (int64_t p8 = threadIdx.x; p8 < P / 8; p8 += 256) {
+    float m[8], q[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { m[k] = 0.f; q[k] = 0.f; }
+    for (int gi = 0; gi < group; ++gi) {
+      float f[8];
+      unpack8(*reinterpret_cast<const u32x4*>(x + ((int64_t)gi * n + slot) * P + p8 * 8), f);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) m[k] += f[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m[k] /= (float)group;
+    for (int gi = 0; gi < group; ++gi) {
+      float f[8];
+      unpack8(*reinterpret_cast<const u32x4*>(x + ((int64_t)gi * n + slot) * P + p8 * 8), f);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) q[k] += (f[k] - m[k]) * (f[k] - m[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) part += sqrtf(q[k] / (float)group + 1e-8f);
+  }
+  const float sd = block_sum_256(part, s_red) / (float)P;
+  // write the group's samples: copy, the statistic, zero padding
+  const int cq = Cp / 8;                       // 16-byte chunks per output pixel
+  for (int gi = 0; gi < group; ++gi) {
+    const int64_t b = (int64_t)gi * n + slot;
+    for (int64_t i = threadIdx.x; i < (int64_t)HW * cq; i += 256) {
+      const int64_t pix = i / cq;
+      const int ch = (int)(i - pix * cq) * 8;
+      u32x4 v;
+      if (ch + 8 <= C) v = *reinterpret_cast<const u32x4*>(x + (b * HW + pix) * C + ch);
+      else {
+        float f[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) f[k] = ch + k < C ? bf16_bits_to_f32(x[(b * HW + pix) * C + ch + k]) : (ch + k == C ? sd : 0.f);
+        v = pack8(f);
+      }
+      *reinterpret_cast<u32x4*>(out + (b * HW + pix) * Cp + ch) = v;
+    }
+  }
+}
+
+// dx[b,p] = g[b,p] + (sum over the slot's samples and pixels of g[.., C]) / P * (x[b,p] - mean_p) / (group * sd_p)
+__global__ __launch_bounds__(256) void stddev_bwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ g, uint16_t* __restrict__ dx, int group, int n,
+                                                         int HW, int C, int Cp) {
+  __shared__ float s_red[4];
+  const int slot = blockIdx.x;
+  const int64_t P = (int64_t)HW * C;
+  float part = 0.f;
+  for (int i = threadIdx.x; i < group * HW; i += 256) {
+    const int64_t b = (int64_t)(i / HW) * n + slot;
+    part += bf16_bits_to_f32(g[(b * HW + i % HW) * Cp + C]);
+  }
+  const float gsd = block_sum_256(part, s_red) / (float)P;
+  const int c8 = C / 8;
+  for (int64_t p8 = threadIdx.x; p8 < P / 8; p8 += 256) {
+    const int64_t pix = p8 / c8;
+    const int ch = (int)(p8 - pix * c8) * 8;
+    float m[8], q[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { m[k] = 0.f; q[k] = 0.f; }
+    for (int gi = 0; gi < group; ++gi) {
+      float f[8];
+      unpack8(*reinterpret_cast<const u32x4*>(x + ((int64_t)gi * n + slot) * P + p8 * 8), f);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) m[k] += f[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m[k] /= (float)group;
+    for (int gi = 0; gi < group; ++gi) {
+      float f[8];
+      unpack8(*reinterpret_cast<const u32x4*>(x + ((int64_t)gi * n + slot) * P + p8 * 8), f);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) q[k] += (f[k] - m[k]) * (f[k] - m[k]);
+    }
+    float coef[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) coef[k] = gsd / ((float)group * sqrtf(q[k] / (float)group + 1e-8f));
+    for (int gi = 0; gi < group; ++gi) {
+      const int64_t b = (int64_t)gi * n + slot;
+      float f[8], gv[8];
+      unpack8(*reinterpret_cast<const u32x4*>(x + b * P + p8 * 8), f);
+      unpack8(*reinterpret_cast<const u32x4*>(g + (b * HW + pix) * Cp + ch), gv);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) f[k] = gv[k] + coef[k] * (f[k] - m[k]);
+      *reinterpret_cast<u32x4*>(dx + b * P + p8 * 8) = pack8(f);
+    }
+  }
+}
+
+static int stddev_check(const void* a, const void* b, int B, int HW, int C, int Cp, int group, const char* who) {
+  ENH_REQUIRE(a && b && B > 0 && HW > 0 && group > 0, ENH_E_BADARG, "%s: bad argument", who);
+  ENH_REQUIRE(B % group == 0 && C % 8 == 0 && Cp % 8 == 0 && Cp > C, ENH_E_SHAPE, "%s: B %% group == 0, C %% 8 == 0 and Cp > C (a multiple of 8) required", who);
+  return ENH_OK;
+}
+extern "C" int enh_minibatch_stddev_nhwc(const enh_bf16* x, int B, int HW, int C, int Cp, int group, enh_bf16* out, void* stream) {
+  const int rc = stddev_check(x, out, B, HW, C, Cp, group, "enh_minibatch_stddev_nhwc");
+  if (rc != ENH_OK) return rc;
+  stddev_fwd_kernel<<<dim3((unsigned)(B / group)), 256, 0, (hipStream_t)stream>>>(x, out, group, B / group, HW, C, Cp);
+  return enh_check_launch("enh_minibatch_stddev_nhwc");
+}
+extern "C" int enh_minibatch_stddev_nhwc_backward(const enh_bf16* x, const enh_bf16* g, int B, int HW, int C, int Cp, int group, enh_bf16* dx, void* stream) {
+  const int rc = stddev_check(x, dx, B, HW, C, Cp, group, "enh_minibatch_stddev_nhwc_backward");
+  if (rc != ENH_OK) return rc;
+  ENH_REQUIRE(g, ENH_E_BADARG, "enh_minibatch_stddev_nhwc_backward: g is NULL");
+  stddev_bwd_kernel<<<dim3((unsigned)(B / group)), 256, 0, (hipStream_t)stream>>>(x, g, dx, group, B / group, HW, C, Cp);
+  return enh_check_launch("enh_minibatch_stddev_nhwc_backward");
+}

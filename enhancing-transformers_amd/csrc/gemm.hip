@@ -23,233 +23,7 @@
 #include <stdlib.h>
 #include "common.h"
 
-#ifndef ENH_NT_EPILOGUE
-#define ENH_NT_EPILOGUE 0  // tried 1 (non-temporal C stores, to keep L2 for the operand slices): 442 -> 407 img/s, because the NEXT kernel
-                           // (LayerNorm, attention, the following GEMM) finds C in L2 / Infinity Cache when it is stored normally
-#endif
-#define G_BM 128
-#define G_BN 128
-#define G_BK 64
-#define G_TILE_BYTES 16384  // one operand tile (either layout)
-
-// ---- LDS layouts -------------------------------------------------------------------------------
-// "row" layout  (operand stored [rows][K]):   128 rows x 128 B ; 16-B chunk c (0..7) of row r lives at
-//     r*128 + ((c ^ ((r>>1)&7)) << 4)
-// "kmaj" layout (operand stored [K][cols]):    64 k-rows x 256 B ; 32-B chunk q (0..7) of k-row k lives at
-//     k*256 + ((q ^ ((k&3) | (((k>>3)&1)<<2))) << 5)      (8-byte pieces inside a chunk stay in order)
-__device__ __forceinline__ int lds_row_off(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
-__device__ __forceinline__ int lds_kmaj_off(int k, int q) { return k * 256 + ((q ^ ((k & 3) | (((k >> 3) & 1) << 2))) << 5); }
-
-struct GemmArgs {
-  const uint16_t* A; int64_t lda;
-  const uint16_t* B; int64_t ldb;
-  int64_t M, N, K;
-  int64_t k_per_split;  // multiple of G_BK
-  const float* bias; int act; const uint16_t* aux; int64_t ldaux;
-  const float* res; int64_t ldres; int64_t res_rows;
-  int accumulate;       // 1: += C_old ; 2: split-K partial -> f32 atomicAdd into c_f32 ; 3: split-K partial -> workspace slab (two-pass, deterministic)
-  float* ws;            // split-K workspace [splits][M][N] f32 (accumulate == 3)
-  float* c_f32; uint16_t* c_bf16; int64_t ldc;
-  int nbm, nbn;
-  int splits;  // number of K-slices (1 = no split-K; otherwise a multiple of 8)
-};
-
-// global -> registers: one 128 x 64 (row layout) or 64 x 128 (kmaj layout) bf16 operand tile, 4 x 16 B per thread
-template <bool TR>
-__device__ __forceinline__ void tile_gload(u32x4 (&r)[4], const uint16_t* __restrict__ P, int64_t ld, int64_t x0,
-                                           int64_t X, int64_t k0, int64_t k_end, int t) {
-  const u32x4 zero4 = {0u, 0u, 0u, 0u};
-  if (!TR) {
-    const int c = t & 7, r0 = t >> 3;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int64_t row = x0 + r0 + 32 * i, kk = k0 + c * 8;
-      r[i] = (row < X && kk < k_end) ? *reinterpret_cast<const u32x4*>(P + row * ld + kk) : zero4;
-    }
-  } else {
-    const int c = t & 15, r0 = t >> 4;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int64_t kk = k0 + r0 + 16 * i, col = x0 + c * 8;
-      r[i] = (kk < k_end && col < X) ? *reinterpret_cast<const u32x4*>(P + kk * ld + col) : zero4;
-    }
-  }
-}
-// registers -> LDS (swizzled image)
-template <bool TR>
-__device__ __forceinline__ void tile_sstore(const u32x4 (&r)[4], unsigned char* tile, int t) {
-  if (!TR) {
-    const int c = t & 7, r0 = t >> 3;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(tile + lds_row_off(r0 + 32 * i, c)) = r[i];
-  } else {
-    const int c = t & 15, r0 = t >> 4;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(tile + lds_kmaj_off(r0 + 16 * i, c >> 1) + ((c & 1) << 4)) = r[i];
-  }
-}
-// MFMA 16x16x32 operand fragment: lane (lg, l16) gets tile index base + l16, k = ks*32 + lg*8 + 0..7
-template <bool TR>
-__device__ __forceinline__ s16x8 tile_frag(const unsigned char* tile, int base, int ks, int lg, int l16) {
-  if (!TR) {
-    return *reinterpret_cast<const s16x8*>(tile + lds_row_off(base + l16, ks * 4 + lg));
-  } else {
-    // loader role of this lane inside its 16-lane group: k-row (l16>>2), 4 columns starting at (l16&3)*4
-    const int kr = ks * 32 + lg * 8 + (l16 >> 2);
-    const int q = base >> 4;  // 32-byte chunk = 16 columns
-    const s16x4 lo = lds_tr_read_b64(tile + lds_kmaj_off(kr, q) + (l16 & 3) * 8);
-    const s16x4 hi = lds_tr_read_b64(tile + lds_kmaj_off(kr + 4, q) + (l16 & 3) * 8);
-    s16x8 o;
-    o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
-    o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
-    return o;
-  }
-}
-
-// ---- epilogue -----------------------------------------------------------------------------------------------
-// One body for every kernel: 4 consecutive output columns of one row.  The fused options (bias / tanh / tanh' / residual / accumulate / f32 and
-// bf16 stores / split-K partials) are RUNTIME arguments of the C ABI, but a kernel whose epilogue tests them per element pays for it: with one
-// wave per SIMD nothing hides the instruction fetch after each (wave-uniform) branch — the 256 x 256 kernel lost 19 us per tile, more than its
-// K loop at K = 768.  So the combinations the training step uses are compile-time MODES selected once per kernel; anything else takes the
-// generic (branchy) mode.
-enum { EPI_GENERIC = 0, EPI_BF16, EPI_BF16_BIAS_TANH, EPI_BF16_DTANH, EPI_F32_BIAS_RES, EPI_F32, EPI_WS, EPI_ATOMIC, EPI_NMODES };
-
-__host__ __device__ __forceinline__ int epi_mode(const GemmArgs& a) {
-  if (a.accumulate == 3) return EPI_WS;
-  if (a.accumulate == 2) return EPI_ATOMIC;
-  if (a.accumulate == 0) {
-    const bool only16 = a.c_bf16 && !a.c_f32, only32 = a.c_f32 && !a.c_bf16;
-    if (only16 && !a.bias && a.act == ENH_ACT_NONE && !a.res) return EPI_BF16;
-    if (only16 && a.bias && a.act == ENH_ACT_TANH && !a.res) return EPI_BF16_BIAS_TANH;
-    if (only16 && !a.bias && a.act == ENH_ACT_DTANH && !a.res) return EPI_BF16_DTANH;
-    if (only32 && a.bias && a.act == ENH_ACT_NONE && a.res) return EPI_F32_BIAS_RES;
-    if (only32 && !a.bias && a.act == ENH_ACT_NONE && !a.res) return EPI_F32;
-  }
-  return EPI_GENERIC;
-}
-
-// The operands an epilogue READS (residual / position row, saved tanh output, previous C) are fetched by epi_load for a whole group of
-// elements BEFORE any of them is consumed: a load issued and awaited per element exposes the full memory latency 64 times per wave.
-struct EpiIn { float4 res; float4 old; uint2 aux; };
-
-template <int MODE>
-__device__ __forceinline__ EpiIn epi_load(const GemmArgs& args, int64_t m, int64_t n) {
-  constexpr bool G = MODE == EPI_GENERIC;
-  EpiIn in;
-  in.res = make_float4(0.f, 0.f, 0.f, 0.f); in.old = in.res; in.aux = make_uint2(0u, 0u);
-  if (MODE == EPI_BF16_DTANH || (G && args.act == ENH_ACT_DTANH)) in.aux = *reinterpret_cast<const uint2*>(args.aux + m * args.ldaux + n);
-  if (MODE == EPI_F32_BIAS_RES || (G && args.res)) {
-    const int64_t mr = args.res_rows == args.M ? m : m % args.res_rows;   // residual stream (res_rows = M) or position table (row mod n_tokens)
-    in.res = *reinterpret_cast<const float4*>(args.res + mr * args.ldres + n);
-  }
-  if (G && args.accumulate == 1 && args.c_f32) in.old = *reinterpret_cast<const float4*>(args.c_f32 + m * args.ldc + n);
-  return in;
-}
-
-template <int MODE>
-__device__ __forceinline__ void epi4(const GemmArgs& args, float (&v)[4], const EpiIn& in, int64_t m, int64_t n, int split) {
-  constexpr bool G = MODE == EPI_GENERIC;
-  if (MODE == EPI_WS || (G && args.accumulate == 3)) {   // split-K partial -> workspace slab [split][M][N] (reduced by splitk_reduce_kernel in a fixed order)
-    const f32x4 o_ = {v[0], v[1], v[2], v[3]};
-    *reinterpret_cast<f32x4*>(args.ws + ((int64_t)split * args.M + m) * args.N + n) = o_;
-    return;
-  }
-  float* cp = (G ? args.c_f32 != nullptr : (MODE == EPI_F32_BIAS_RES || MODE == EPI_F32 || MODE == EPI_ATOMIC)) ? args.c_f32 + m * args.ldc + n : nullptr;
-  if (MODE == EPI_ATOMIC || (G && args.accumulate == 2)) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) atomicAdd(cp + r, v[r]);
-    return;
-  }
-  if (MODE == EPI_BF16_BIAS_TANH || MODE == EPI_F32_BIAS_RES || (G && args.bias)) {
-    const float4 b4 = *reinterpret_cast<const float4*>(args.bias + n);
-    v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-  }
-  if (MODE == EPI_BF16_BIAS_TANH) {
-    // tanh(x) = 1 - 2 / (exp(2x) + 1) on the transcendental unit (v_exp_f32 + v_rcp_f32, ~6 instructions): absolute error ~1e-7, invisible after the
-    // bf16 rounding of this mode's output.  libm's tanhf (~40 instructions) cost 0.55 ms of the 1.41 ms fc1 forward GEMM (402 M elements per launch).
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float t = __builtin_amdgcn_exp2f(v[r] * 2.8853900817779268f);
-      v[r] = 1.f - 2.f * __builtin_amdgcn_rcpf(t + 1.f);
-    }
-  } else if (G && args.act == ENH_ACT_TANH) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
-  } else if (MODE == EPI_BF16_DTANH || (G && args.act == ENH_ACT_DTANH)) {
-    const float h0 = bf16_bits_to_f32((uint16_t)(in.aux.x & 0xffffu)), h1 = bf16_bits_to_f32((uint16_t)(in.aux.x >> 16));
-    const float h2 = bf16_bits_to_f32((uint16_t)(in.aux.y & 0xffffu)), h3 = bf16_bits_to_f32((uint16_t)(in.aux.y >> 16));
-    v[0] *= 1.f - h0 * h0; v[1] *= 1.f - h1 * h1; v[2] *= 1.f - h2 * h2; v[3] *= 1.f - h3 * h3;
-  }
-  if (MODE == EPI_F32_BIAS_RES || (G && args.res)) { v[0] += in.res.x; v[1] += in.res.y; v[2] += in.res.z; v[3] += in.res.w; }
-  if (G && args.accumulate == 1 && cp) { v[0] += in.old.x; v[1] += in.old.y; v[2] += in.old.z; v[3] += in.old.w; }
-  if (cp) { const f32x4 o_ = {v[0], v[1], v[2], v[3]}; if (ENH_NT_EPILOGUE) __builtin_nontemporal_store(o_, reinterpret_cast<f32x4*>(cp)); else *reinterpret_cast<f32x4*>(cp) = o_; }
-  if (MODE == EPI_BF16 || MODE == EPI_BF16_BIAS_TANH || MODE == EPI_BF16_DTANH || (G && args.c_bf16)) {
-    const u32x2 o_ = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-    if (ENH_NT_EPILOGUE) __builtin_nontemporal_store(o_, reinterpret_cast<u32x2*>(args.c_bf16 + m * args.ldc + n)); else *reinterpret_cast<u32x2*>(args.c_bf16 + m * args.ldc + n) = o_;
-  }
-}
-
-// run LOOPS<MODE>(...) with the mode chosen once (wave-uniform switch)
-#define EPI_DISPATCH(CALL)                                                     \
-  do {                                                                         \
-    switch (epi_mode(args)) {                                                  \
-      case EPI_BF16: { constexpr int EM = EPI_BF16; CALL; } break;             \
-      case EPI_BF16_BIAS_TANH: { constexpr int EM = EPI_BF16_BIAS_TANH; CALL; } break; \
-      case EPI_BF16_DTANH: { constexpr int EM = EPI_BF16_DTANH; CALL; } break; \
-      case EPI_F32_BIAS_RES: { constexpr int EM = EPI_F32_BIAS_RES; CALL; } break; \
-      case EPI_F32: { constexpr int EM = EPI_F32; CALL; } break;               \
-      case EPI_WS: { constexpr int EM = EPI_WS; CALL; } break;                 \
-      case EPI_ATOMIC: { constexpr int EM = EPI_ATOMIC; CALL; } break;         \
-      default: { constexpr int EM = EPI_GENERIC; CALL; } break;                \
-    }                                                                          \
-  } while (0)
-
-// 16x16 accumulator layout (pipe2 / fallback): lane (lg, l16) holds C[m = .. + l16][n = .. + lg*4 + 0..3] (MFMA issued with swapped operands)
-template <int MODE>
-__device__ __forceinline__ void gemm_epilogue_loops(const GemmArgs& args, f32x4 (&acc)[4][4], int64_t m0, int64_t n0, int wm, int wn, int lg, int l16, int split) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int64_t m = m0 + wm * 64 + i * 16 + l16;
-    if (m >= args.M) continue;
-    EpiIn in[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int64_t n = n0 + wn * 64 + j * 16 + lg * 4;
-      if (n < args.N) in[j] = epi_load<MODE>(args, m, n);  // N % 4 == 0: the 4 columns are in or out together
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int64_t n = n0 + wn * 64 + j * 16 + lg * 4;
-      if (n >= args.N) continue;
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      epi4<MODE>(args, v, in[j], m, n, split);
-    }
-  }
-}
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& args, f32x4 (&acc)[4][4], int64_t m0, int64_t n0, int wm, int wn, int lg, int l16, int split) {
-  EPI_DISPATCH((gemm_epilogue_loops<EM>(args, acc, m0, n0, wm, wn, lg, l16, split)));
-}
-
-// tile scheduling shared by both kernels
-__device__ __forceinline__ void gemm_tile_coords(const GemmArgs& args, int& split, int& tile_m, int& tile_n) {
-  // (1) XCD-aware: workgroup b runs on XCD b % 8 -> give each XCD a contiguous run of tile slots;
-  // (2) grouped order inside the run: 8 row-panels x all column tiles, row-fastest, so the ~64 tiles an XCD has in
-  //     flight form an ~8 x 8 patch whose A and B panels (8 x 196 KB each at K = 768) both stay in its 4 MiB L2.
-  const int nwg = args.nbm * args.nbn;  // tiles per K-split
-  // (tried: pinning each K-slice of a split-K launch to one XCD halves the fabric traffic PMC reports, but runs 10-15 % slower —
-  //  the duplicated fetches were Infinity-Cache hits, and spreading a slice over all XCDs gives more channel parallelism)
-  split = blockIdx.x / nwg;
-  int bid = blockIdx.x - split * nwg;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, pos = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
-  }
-  const int per_group = 8 * args.nbn;
-  const int grp = bid / per_group, within = bid - grp * per_group;
-  const int rows = (args.nbm - grp * 8) < 8 ? (args.nbm - grp * 8) : 8;
-  tile_m = grp * 8 + within % rows;
-  tile_n = within / rows;
-}
+#include "gemm_tiles.h"
 
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs args) {
@@ -680,179 +454,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   gemm_epilogue32_loops<EPI, 4, false>(args, acc, m0 + wm * 128, n0 + wn * 128, lane, split);
 }
 
-// split-K second pass: C[m][n] (+)= sum over the splits of the partial slabs, in a fixed order (deterministic, no atomics)
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, int64_t MN, int64_t N, float* __restrict__ c, int64_t ldc, int accumulate) {
-  const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-  if (i4 >= MN) return;
-  f32x4 s = *reinterpret_cast<const f32x4*>(ws + i4);
-  for (int k = 1; k < splits; ++k) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(ws + (int64_t)k * MN + i4);
-    s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
-  }
-  const int64_t m = i4 / N, n = i4 - m * N;
-  float* cp = c + m * ldc + n;
-  if (accumulate) {
-    const f32x4 o = *reinterpret_cast<const f32x4*>(cp);
-    s[0] += o[0]; s[1] += o[1]; s[2] += o[2]; s[3] += o[3];
-  }
-  *reinterpret_cast<f32x4*>(cp) = s;
-}
-
-// =================================================================================================
-// Implicit-GEMM 3x3 convolution (stride 1, padding 1) on channels-last bf16 activations — the convolution of the LPIPS VGG16 trunk
-// (lpips 0.1.4 pretrained_networks.vgg16 = torchvision vgg16.features; reference call sites enhancing/losses/vqperceptual.py:29,43,74,115) and of
-// its input gradient.  No `cols` tensor exists: the A operand of the GEMM
-//      out[(b,h,w), co] = sum over (kh, kw, ci) of x[b, h+kh-1, w+kw-1, ci] * wt[co][(kh*3 + kw)*Cin + ci]
-// is GATHERED in the load stage — row (b,h,w), 8 consecutive channels of one tap per 16-byte load, zeros outside the image — into the same
-// swizzled LDS image the dense kernels use; the weights are stored tap-major [Cout][9*Cin] once (they are frozen).  The input gradient is the same
-// kernel on the flipped / transposed weights.  Register-staged double buffer (the gather needs per-lane predication, which global_load_lds cannot
-// do), 128 x 128 x 64 tile, 4 waves of 64 x 64, 2 workgroups per CU.  Cin, Cout multiples of 8; any M = B*H*W.
-//   mode 0: out = relu(acc + bias[co])                  -> bf16      (forward)
-//   mode 1: out = (acc + add[m,co]) * (aux[m,co] > 0)   -> bf16      (input gradient; add = gradient arriving from the LPIPS head at this
-//                                                                     activation (optional), aux = the saved post-ReLU activation)
-//   mode 2: out = acc                                   -> bf16      (input gradient in front of a max-pool: routed / masked by the pool backward)
-// =================================================================================================
-struct ConvArgs {
-  const uint16_t* X; const uint16_t* Wt;
-  int64_t M; int H, W, Cin, Cout; int64_t K;
-  const float* bias; int mode; const uint16_t* aux; const uint16_t* add;
-  uint16_t* out;
-  int nbm, nbn;
-};
-
-__global__ __launch_bounds__(256, 2) void conv3x3_igemm_kernel(const ConvArgs args) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2 stages][A tile | B tile]
-  const int t = threadIdx.x;
-  const int lane = t & 63, wave = t >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int l16 = lane & 15, lg = lane >> 4;
-  const int tile_m = blockIdx.x % args.nbm, tile_n = blockIdx.x / args.nbm;
-  const int64_t m0 = (int64_t)tile_m * G_BM, n0 = (int64_t)tile_n * G_BN;
-  const int nk = (int)((args.K + G_BK - 1) / G_BK);
-
-  // this thread gathers chunk c (8 channels) of rows r0 + 32*i: the pixel of a row does not change along K
-  const int c = t & 7, r0 = t >> 3;
-  int ph[4], pw[4];
-  int64_t pbase[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int64_t row = m0 + r0 + 32 * i;
-    if (row < args.M) {
-      const int64_t hw = (int64_t)args.H * args.W;
-      const int64_t b = row / hw, rem = row - b * hw;
-      ph[i] = (int)(rem / args.W); pw[i] = (int)(rem - (int64_t)ph[i] * args.W);
-      pbase[i] = row * args.Cin;     // element offset of pixel (b,h,w), channel 0
-    } else { ph[i] = -4; pw[i] = -4; pbase[i] = 0; }   // every tap of an out-of-range row falls outside the image -> zeros
-  }
-  const u32x4 zero4 = {0u, 0u, 0u, 0u};
-  u32x4 ra[4], rb[4];
-  auto gather = [&](int64_t k0) {
-    const int64_t kk = k0 + c * 8;
-    const int tap = (int)(kk / args.Cin), ch = (int)(kk - (int64_t)tap * args.Cin);
-    const int dh = tap / 3 - 1, dw = tap - (tap / 3) * 3 - 1;
-    const int64_t doff = ((int64_t)dh * args.W + dw) * args.Cin + ch;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int hh = ph[i] + dh, ww = pw[i] + dw;
-      const bool ok = kk < args.K && hh >= 0 && hh < args.H && ww >= 0 && ww < args.W;
-      ra[i] = ok ? *reinterpret_cast<const u32x4*>(args.X + pbase[i] + doff) : zero4;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int64_t co = n0 + r0 + 32 * i;
-      rb[i] = (co < args.Cout && kk < args.K) ? *reinterpret_cast<const u32x4*>(args.Wt + co * args.K + kk) : zero4;
-    }
-  };
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  gather(0);
-  tile_sstore<false>(ra, smem, t);
-  tile_sstore<false>(rb, smem + G_TILE_BYTES, t);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int stage = kt & 1;
-    if (kt + 1 < nk) gather((int64_t)(kt + 1) * G_BK);
-    const unsigned char* sa = smem + stage * (2 * G_TILE_BYTES);
-    const unsigned char* sb = sa + G_TILE_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      s16x8 fa[4], fb[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = tile_frag<false>(sa, wm * 64 + i * 16, ks, lg, l16);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = tile_frag<false>(sb, wn * 64 + j * 16, ks, lg, l16);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[j]), __builtin_bit_cast(bf16x8, fa[i]), acc[i][j], 0, 0, 0);
-    }
-    if (kt + 1 < nk) {
-      unsigned char* na = smem + (stage ^ 1) * (2 * G_TILE_BYTES);
-      tile_sstore<false>(ra, na, t);
-      tile_sstore<false>(rb, na + G_TILE_BYTES, t);
-    }
-    __syncthreads();
-  }
-  // epilogue: lane (lg, l16) holds out[m = m0 + wm*64 + i*16 + l16][n = n0 + wn*64 + j*16 + lg*4 + 0..3]
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int64_t m = m0 + wm * 64 + i * 16 + l16;
-    if (m >= args.M) continue;
-    uint2 ax[4], ad[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int64_t n = n0 + wn * 64 + j * 16 + lg * 4;
-      ax[j] = make_uint2(0u, 0u); ad[j] = make_uint2(0u, 0u);
-      if (args.mode == 1 && n < args.Cout) {
-        ax[j] = *reinterpret_cast<const uint2*>(args.aux + m * args.Cout + n);
-        if (args.add) ad[j] = *reinterpret_cast<const uint2*>(args.add + m * args.Cout + n);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int64_t n = n0 + wn * 64 + j * 16 + lg * 4;
-      if (n >= args.Cout) continue;   // Cout % 8 == 0: the 4 columns are in or out together
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      if (args.mode == 0) {
-        const float4 b4 = *reinterpret_cast<const float4*>(args.bias + n);
-        v[0] = fmaxf(v[0] + b4.x, 0.f); v[1] = fmaxf(v[1] + b4.y, 0.f); v[2] = fmaxf(v[2] + b4.z, 0.f); v[3] = fmaxf(v[3] + b4.w, 0.f);
-      } else if (args.mode == 1) {
-        const uint32_t a0 = ax[j].x, a1 = ax[j].y, d0 = ad[j].x, d1 = ad[j].y;
-        v[0] = (a0 & 0x7fffu) && !(a0 & 0x8000u) ? v[0] + bf16_bits_to_f32((uint16_t)(d0 & 0xffffu)) : 0.f;
-        v[1] = ((a0 >> 16) & 0x7fffu) && !(a0 >> 31) ? v[1] + bf16_bits_to_f32((uint16_t)(d0 >> 16)) : 0.f;
-        v[2] = (a1 & 0x7fffu) && !(a1 & 0x8000u) ? v[2] + bf16_bits_to_f32((uint16_t)(d1 & 0xffffu)) : 0.f;
-        v[3] = ((a1 >> 16) & 0x7fffu) && !(a1 >> 31) ? v[3] + bf16_bits_to_f32((uint16_t)(d1 >> 16)) : 0.f;
-      }
-      const u32x2 o_ = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-      *reinterpret_cast<u32x2*>(args.out + m * args.Cout + n) = o_;
-    }
-  }
-}
-
-extern "C" int enh_conv3x3_nhwc_bf16(const enh_bf16* x, const enh_bf16* wt, int B, int H, int W, int Cin, int Cout, const float* bias, int mode,
-                                     const enh_bf16* aux, const enh_bf16* add, enh_bf16* out, void* stream) {
-  ENH_REQUIRE(x && wt && out && B > 0 && H > 0 && W > 0, ENH_E_BADARG, "enh_conv3x3_nhwc_bf16: bad argument");
-  ENH_REQUIRE(Cin > 0 && Cout > 0 && Cin % 8 == 0 && Cout % 8 == 0, ENH_E_SHAPE, "enh_conv3x3_nhwc_bf16: Cin and Cout must be multiples of 8 (Cin=%d Cout=%d)", Cin, Cout);
-  ENH_REQUIRE((mode == 0 && bias) || (mode == 1 && aux) || mode == 2, ENH_E_BADARG, "enh_conv3x3_nhwc_bf16: mode 0 needs bias, mode 1 needs aux, mode 2 neither");
-  ConvArgs a;
-  a.X = x; a.Wt = wt; a.M = (int64_t)B * H * W; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.K = 9ll * Cin;
-  a.bias = bias; a.mode = mode; a.aux = aux; a.add = add; a.out = out;
-  a.nbm = (int)((a.M + G_BM - 1) / G_BM); a.nbn = (Cout + G_BN - 1) / G_BN;
-  ENH_REQUIRE((int64_t)a.nbm * a.nbn < (1ll << 30), ENH_E_SHAPE, "enh_conv3x3_nhwc_bf16: grid too large");
-  static const bool attr_set = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_igemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G_TILE_BYTES);
-    return true;
-  }();
-  (void)attr_set;
-  conv3x3_igemm_kernel<<<dim3((unsigned)(a.nbm * a.nbn)), 256, 4 * G_TILE_BYTES, (hipStream_t)stream>>>(a);
-  return enh_check_launch("enh_conv3x3_nhwc_bf16");
-}
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

@@ -1,0 +1,251 @@
+// gemm_tiles.h — building blocks shared by the dense GEMM kernels (gemm.hip) and the implicit-GEMM convolutions (conv_igemm.hip):
+// swizzled LDS tile images, register staging, MFMA fragment reads (plain and transpose-read), the fused epilogue and the split-K second pass.
+#pragma once
+#include "common.h"
+
+#ifndef ENH_NT_EPILOGUE
+#define ENH_NT_EPILOGUE 0  // tried 1 (non-temporal C stores, to keep L2 for the operand slices): 442 -> 407 img/s, because the NEXT kernel
+                           // (LayerNorm, attention, the following GEMM) finds C in L2 / Infinity Cache when it is stored normally
+#endif
+#define G_BM 128
+#define G_BN 128
+#define G_BK 64
+#define G_TILE_BYTES 16384  // one operand tile (either layout)
+
+// ---- LDS layouts -------------------------------------------------------------------------------
+// "row" layout  (operand stored [rows][K]):   128 rows x 128 B ; 16-B chunk c (0..7) of row r lives at
+//     r*128 + ((c ^ ((r>>1)&7)) << 4)
+// "kmaj" layout (operand stored [K][cols]):    64 k-rows x 256 B ; 32-B chunk q (0..7) of k-row k lives at
+//     k*256 + ((q ^ ((k&3) | (((k>>3)&1)<<2))) << 5)      (8-byte pieces inside a chunk stay in order)
+__device__ __forceinline__ int lds_row_off(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
+__device__ __forceinline__ int lds_kmaj_off(int k, int q) { return k * 256 + ((q ^ ((k & 3) | (((k >> 3) & 1) << 2))) << 5); }
+
+struct GemmArgs {
+  const uint16_t* A; int64_t lda;
+  const uint16_t* B; int64_t ldb;
+  int64_t M, N, K;
+  int64_t k_per_split;  // multiple of G_BK
+  const float* bias; int act; const uint16_t* aux; int64_t ldaux;
+  const float* res; int64_t ldres; int64_t res_rows;
+  int accumulate;       // 1: += C_old ; 2: split-K partial -> f32 atomicAdd into c_f32 ; 3: split-K partial -> workspace slab (two-pass, deterministic)
+  float* ws;            // split-K workspace [splits][M][N] f32 (accumulate == 3)
+  float* c_f32; uint16_t* c_bf16; int64_t ldc;
+  int nbm, nbn;
+  int splits;  // number of K-slices (1 = no split-K; otherwise a multiple of 8)
+};
+
+// global -> registers: one 128 x 64 (row layout) or 64 x 128 (kmaj layout) bf16 operand tile, 4 x 16 B per thread
+template <bool TR>
+__device__ __forceinline__ void tile_gload(u32x4 (&r)[4], const uint16_t* __restrict__ P, int64_t ld, int64_t x0,
+                                           int64_t X, int64_t k0, int64_t k_end, int t) {
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  if (!TR) {
+    const int c = t & 7, r0 = t >> 3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t row = x0 + r0 + 32 * i, kk = k0 + c * 8;
+      r[i] = (row < X && kk < k_end) ? *reinterpret_cast<const u32x4*>(P + row * ld + kk) : zero4;
+    }
+  } else {
+    const int c = t & 15, r0 = t >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t kk = k0 + r0 + 16 * i, col = x0 + c * 8;
+      r[i] = (kk < k_end && col < X) ? *reinterpret_cast<const u32x4*>(P + kk * ld + col) : zero4;
+    }
+  }
+}
+// registers -> LDS (swizzled image)
+template <bool TR>
+__device__ __forceinline__ void tile_sstore(const u32x4 (&r)[4], unsigned char* tile, int t) {
+  if (!TR) {
+    const int c = t & 7, r0 = t >> 3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(tile + lds_row_off(r0 + 32 * i, c)) = r[i];
+  } else {
+    const int c = t & 15, r0 = t >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(tile + lds_kmaj_off(r0 + 16 * i, c >> 1) + ((c & 1) << 4)) = r[i];
+  }
+}
+// MFMA 16x16x32 operand fragment: lane (lg, l16) gets tile index base + l16, k = ks*32 + lg*8 + 0..7
+template <bool TR>
+__device__ __forceinline__ s16x8 tile_frag(const unsigned char* tile, int base, int ks, int lg, int l16) {
+  if (!TR) {
+    return *reinterpret_cast<const s16x8*>(tile + lds_row_off(base + l16, ks * 4 + lg));
+  } else {
+    // loader role of this lane inside its 16-lane group: k-row (l16>>2), 4 columns starting at (l16&3)*4
+    const int kr = ks * 32 + lg * 8 + (l16 >> 2);
+    const int q = base >> 4;  // 32-byte chunk = 16 columns
+    const s16x4 lo = lds_tr_read_b64(tile + lds_kmaj_off(kr, q) + (l16 & 3) * 8);
+    const s16x4 hi = lds_tr_read_b64(tile + lds_kmaj_off(kr + 4, q) + (l16 & 3) * 8);
+    s16x8 o;
+    o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
+    o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
+    return o;
+  }
+}
+
+// ---- epilogue -----------------------------------------------------------------------------------------------
+// One body for every kernel: 4 consecutive output columns of one row.  The fused options (bias / tanh / tanh' / residual / accumulate / f32 and
+// bf16 stores / split-K partials) are RUNTIME arguments of the C ABI, but a kernel whose epilogue tests them per element pays for it: with one
+// wave per SIMD nothing hides the instruction fetch after each (wave-uniform) branch — the 256 x 256 kernel lost 19 us per tile, more than its
+// K loop at K = 768.  So the combinations the training step uses are compile-time MODES selected once per kernel; anything else takes the
+// generic (branchy) mode.
+enum { EPI_GENERIC = 0, EPI_BF16, EPI_BF16_BIAS_TANH, EPI_BF16_DTANH, EPI_F32_BIAS_RES, EPI_F32, EPI_WS, EPI_ATOMIC, EPI_NMODES };
+
+__host__ __device__ __forceinline__ int epi_mode(const GemmArgs& a) {
+  if (a.accumulate == 3) return EPI_WS;
+  if (a.accumulate == 2) return EPI_ATOMIC;
+  if (a.accumulate == 0) {
+    const bool only16 = a.c_bf16 && !a.c_f32, only32 = a.c_f32 && !a.c_bf16;
+    if (only16 && !a.bias && a.act == ENH_ACT_NONE && !a.res) return EPI_BF16;
+    if (only16 && a.bias && a.act == ENH_ACT_TANH && !a.res) return EPI_BF16_BIAS_TANH;
+    if (only16 && !a.bias && a.act == ENH_ACT_DTANH && !a.res) return EPI_BF16_DTANH;
+    if (only32 && a.bias && a.act == ENH_ACT_NONE && a.res) return EPI_F32_BIAS_RES;
+    if (only32 && !a.bias && a.act == ENH_ACT_NONE && !a.res) return EPI_F32;
+  }
+  return EPI_GENERIC;
+}
+
+// The operands an epilogue READS (residual / position row, saved tanh output, previous C) are fetched by epi_load for a whole group of
+// elements BEFORE any of them is consumed: a load issued and awaited per element exposes the full memory latency 64 times per wave.
+struct EpiIn { float4 res; float4 old; uint2 aux; };
+
+template <int MODE>
+__device__ __forceinline__ EpiIn epi_load(const GemmArgs& args, int64_t m, int64_t n) {
+  constexpr bool G = MODE == EPI_GENERIC;
+  EpiIn in;
+  in.res = make_float4(0.f, 0.f, 0.f, 0.f); in.old = in.res; in.aux = make_uint2(0u, 0u);
+  if (MODE == EPI_BF16_DTANH || (G && args.act == ENH_ACT_DTANH)) in.aux = *reinterpret_cast<const uint2*>(args.aux + m * args.ldaux + n);
+  if (MODE == EPI_F32_BIAS_RES || (G && args.res)) {
+    const int64_t mr = args.res_rows == args.M ? m : m % args.res_rows;   // residual stream (res_rows = M) or position table (row mod n_tokens)
+    in.res = *reinterpret_cast<const float4*>(args.res + mr * args.ldres + n);
+  }
+  if (G && args.accumulate == 1 && args.c_f32) in.old = *reinterpret_cast<const float4*>(args.c_f32 + m * args.ldc + n);
+  return in;
+}
+
+template <int MODE>
+__device__ __forceinline__ void epi4(const GemmArgs& args, float (&v)[4], const EpiIn& in, int64_t m, int64_t n, int split) {
+  constexpr bool G = MODE == EPI_GENERIC;
+  if (MODE == EPI_WS || (G && args.accumulate == 3)) {   // split-K partial -> workspace slab [split][M][N] (reduced by splitk_reduce_kernel in a fixed order)
+    const f32x4 o_ = {v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(args.ws + ((int64_t)split * args.M + m) * args.N + n) = o_;
+    return;
+  }
+  float* cp = (G ? args.c_f32 != nullptr : (MODE == EPI_F32_BIAS_RES || MODE == EPI_F32 || MODE == EPI_ATOMIC)) ? args.c_f32 + m * args.ldc + n : nullptr;
+  if (MODE == EPI_ATOMIC || (G && args.accumulate == 2)) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) atomicAdd(cp + r, v[r]);
+    return;
+  }
+  if (MODE == EPI_BF16_BIAS_TANH || MODE == EPI_F32_BIAS_RES || (G && args.bias)) {
+    const float4 b4 = *reinterpret_cast<const float4*>(args.bias + n);
+    v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+  }
+  if (MODE == EPI_BF16_BIAS_TANH) {
+    // tanh(x) = 1 - 2 / (exp(2x) + 1) on the transcendental unit (v_exp_f32 + v_rcp_f32, ~6 instructions): absolute error ~1e-7, invisible after the
+    // bf16 rounding of this mode's output.  libm's tanhf (~40 instructions) cost 0.55 ms of the 1.41 ms fc1 forward GEMM (402 M elements per launch).
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float t = __builtin_amdgcn_exp2f(v[r] * 2.8853900817779268f);
+      v[r] = 1.f - 2.f * __builtin_amdgcn_rcpf(t + 1.f);
+    }
+  } else if (G && args.act == ENH_ACT_TANH) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
+  } else if (MODE == EPI_BF16_DTANH || (G && args.act == ENH_ACT_DTANH)) {
+    const float h0 = bf16_bits_to_f32((uint16_t)(in.aux.x & 0xffffu)), h1 = bf16_bits_to_f32((uint16_t)(in.aux.x >> 16));
+    const float h2 = bf16_bits_to_f32((uint16_t)(in.aux.y & 0xffffu)), h3 = bf16_bits_to_f32((uint16_t)(in.aux.y >> 16));
+    v[0] *= 1.f - h0 * h0; v[1] *= 1.f - h1 * h1; v[2] *= 1.f - h2 * h2; v[3] *= 1.f - h3 * h3;
+  }
+  if (MODE == EPI_F32_BIAS_RES || (G && args.res)) { v[0] += in.res.x; v[1] += in.res.y; v[2] += in.res.z; v[3] += in.res.w; }
+  if (G && args.accumulate == 1 && cp) { v[0] += in.old.x; v[1] += in.old.y; v[2] += in.old.z; v[3] += in.old.w; }
+  if (cp) { const f32x4 o_ = {v[0], v[1], v[2], v[3]}; if (ENH_NT_EPILOGUE) __builtin_nontemporal_store(o_, reinterpret_cast<f32x4*>(cp)); else *reinterpret_cast<f32x4*>(cp) = o_; }
+  if (MODE == EPI_BF16 || MODE == EPI_BF16_BIAS_TANH || MODE == EPI_BF16_DTANH || (G && args.c_bf16)) {
+    const u32x2 o_ = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    if (ENH_NT_EPILOGUE) __builtin_nontemporal_store(o_, reinterpret_cast<u32x2*>(args.c_bf16 + m * args.ldc + n)); else *reinterpret_cast<u32x2*>(args.c_bf16 + m * args.ldc + n) = o_;
+  }
+}
+
+// run LOOPS<MODE>(...) with the mode chosen once (wave-uniform switch)
+#define EPI_DISPATCH(CALL)                                                     \
+  do {                                                                         \
+    switch (epi_mode(args)) {                                                  \
+      case EPI_BF16: { constexpr int EM = EPI_BF16; CALL; } break;             \
+      case EPI_BF16_BIAS_TANH: { constexpr int EM = EPI_BF16_BIAS_TANH; CALL; } break; \
+      case EPI_BF16_DTANH: { constexpr int EM = EPI_BF16_DTANH; CALL; } break; \
+      case EPI_F32_BIAS_RES: { constexpr int EM = EPI_F32_BIAS_RES; CALL; } break; \
+      case EPI_F32: { constexpr int EM = EPI_F32; CALL; } break;               \
+      case EPI_WS: { constexpr int EM = EPI_WS; CALL; } break;                 \
+      case EPI_ATOMIC: { constexpr int EM = EPI_ATOMIC; CALL; } break;         \
+      default: { constexpr int EM = EPI_GENERIC; CALL; } break;                \
+    }                                                                          \
+  } while (0)
+
+// 16x16 accumulator layout (pipe2 / fallback): lane (lg, l16) holds C[m = .. + l16][n = .. + lg*4 + 0..3] (MFMA issued with swapped operands)
+template <int MODE>
+__device__ __forceinline__ void gemm_epilogue_loops(const GemmArgs& args, f32x4 (&acc)[4][4], int64_t m0, int64_t n0, int wm, int wn, int lg, int l16, int split) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t m = m0 + wm * 64 + i * 16 + l16;
+    if (m >= args.M) continue;
+    EpiIn in[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t n = n0 + wn * 64 + j * 16 + lg * 4;
+      if (n < args.N) in[j] = epi_load<MODE>(args, m, n);  // N % 4 == 0: the 4 columns are in or out together
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t n = n0 + wn * 64 + j * 16 + lg * 4;
+      if (n >= args.N) continue;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      epi4<MODE>(args, v, in[j], m, n, split);
+    }
+  }
+}
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& args, f32x4 (&acc)[4][4], int64_t m0, int64_t n0, int wm, int wn, int lg, int l16, int split) {
+  EPI_DISPATCH((gemm_epilogue_loops<EM>(args, acc, m0, n0, wm, wn, lg, l16, split)));
+}
+
+// tile scheduling shared by both kernels
+__device__ __forceinline__ void gemm_tile_coords(const GemmArgs& args, int& split, int& tile_m, int& tile_n) {
+  // (1) XCD-aware: workgroup b runs on XCD b % 8 -> give each XCD a contiguous run of tile slots;
+  // (2) grouped order inside the run: 8 row-panels x all column tiles, row-fastest, so the ~64 tiles an XCD has in
+  //     flight form an ~8 x 8 patch whose A and B panels (8 x 196 KB each at K = 768) both stay in its 4 MiB L2.
+  const int nwg = args.nbm * args.nbn;  // tiles per K-split
+  // (tried: pinning each K-slice of a split-K launch to one XCD halves the fabric traffic PMC reports, but runs 10-15 % slower —
+  //  the duplicated fetches were Infinity-Cache hits, and spreading a slice over all XCDs gives more channel parallelism)
+  split = blockIdx.x / nwg;
+  int bid = blockIdx.x - split * nwg;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, pos = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+  }
+  const int per_group = 8 * args.nbn;
+  const int grp = bid / per_group, within = bid - grp * per_group;
+  const int rows = (args.nbm - grp * 8) < 8 ? (args.nbm - grp * 8) : 8;
+  tile_m = grp * 8 + within % rows;
+  tile_n = within / rows;
+}
+
+
+// split-K second pass: C[m][n] (+)= sum over the splits of the partial slabs, in a fixed order (deterministic, no atomics)
+static __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, int64_t MN, int64_t N, float* __restrict__ c, int64_t ldc, int accumulate) {
+  const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 >= MN) return;
+  f32x4 s = *reinterpret_cast<const f32x4*>(ws + i4);
+  for (int k = 1; k < splits; ++k) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(ws + (int64_t)k * MN + i4);
+    s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+  }
+  const int64_t m = i4 / N, n = i4 - m * N;
+  float* cp = c + m * ldc + n;
+  if (accumulate) {
+    const f32x4 o = *reinterpret_cast<const f32x4*>(cp);
+    s[0] += o[0]; s[1] += o[1]; s[2] += o[2]; s[3] += o[3];
+  }
+  *reinterpret_cast<f32x4*>(cp) = s;
+}

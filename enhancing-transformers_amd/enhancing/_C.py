@@ -52,6 +52,17 @@ SIGNATURES = {
     "enh_upfirdn2d": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "enh_im2col_bf16": (_i32, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp]),
     "enh_col2im_f32": (_i32, [_vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _i64, _vp]),
+    "enh_conv_nhwc_bf16": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _f32, _f32, _vp, _vp]),
+    "enh_conv_wgrad_workspace_bytes": (_sz, [_vp]),
+    "enh_conv_wgrad_nhwc_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "enh_conv_pack_weight": (_i32, [_vp, _i32, _i32, _i32, _f32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "enh_conv_unpack_wgrad": (_i32, [_vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),
+    "enh_blur_nhwc_bf16": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "enh_lrelu_gate_bf16": (_i32, [_vp, _vp, _i64, _f32, _f32, _vp, _vp]),
+    "enh_img_to_nhwc8": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "enh_nhwc8_to_img": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "enh_minibatch_stddev_nhwc": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "enh_minibatch_stddev_nhwc_backward": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "enh_gemm_f32": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _i64, _i64, _i64, _vp, _i32, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _i64, _vp]),
     "enh_attention_forward_f32": (_i32, [_vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp]),
     "enh_attention_backward_f32": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp]),
@@ -69,7 +80,7 @@ SIGNATURES = {
 }
 
 _LIB = None
-ABI_VERSION = 4   # ENH_ABI_VERSION of the include/enh_hip.h these signatures were written against
+ABI_VERSION = 5   # ENH_ABI_VERSION of the include/enh_hip.h these signatures were written against
 
 
 def lib():
@@ -399,6 +410,117 @@ def col2im(dcols, B: int, C: int, H: int, W: int, k: int, stride: int, pad: int,
     Ho, Wo = conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad)
     _check(lib().enh_col2im_f32(_p(dcols), dcols.stride(0), B, C, H, W, k, stride, pad, Ho, Wo, _p(out), sb, sc, _stream()), "enh_col2im_f32")
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# implicit-GEMM convolutions and element-wise kernels on channels-last bf16 activations (discriminator, LPIPS trunk)
+# ------------------------------------------------------------------------------------------------
+class ConvGeom(ctypes.Structure):
+    """enh_conv_geom of include/enh_hip.h"""
+    _fields_ = [(n, _c.c_int) for n in "B Hs Ws C Hm Wm gs oy0 ox0 nty ntx sty stx N HO WO os oph opw".split()]
+
+
+def _geom(g) -> ConvGeom:
+    return g if isinstance(g, ConvGeom) else ConvGeom(**{k: int(v) for k, v in g.items()})
+
+
+def conv_nhwc(src, wt, geom, mode: int, bias=None, aux=None, add=None, p0: float = 0.0, p1: float = 1.0, out=None):
+    """src [B,Hs,Ws,C] bf16, wt [N, taps*C] bf16 -> out [B,HO,WO,N] bf16 (allocated unless given); see enh_conv_nhwc_bf16"""
+    g = _geom(geom)
+    if out is None:
+        out = torch.empty(g.B, g.HO, g.WO, g.N, dtype=BF16, device=src.device)
+    work = 2.0 * g.B * g.Hm * g.Wm * g.N * g.nty * g.ntx * g.C
+    _timed("conv_igemm_kernel", work,
+           lambda: _check(lib().enh_conv_nhwc_bf16(_p(src, BF16, "src"), _p(wt, BF16, "wt"), ctypes.byref(g), mode, _p(bias, F32, "bias"), _p(aux, BF16, "aux"),
+                                                   _p(add, BF16, "add"), p0, p1, _p(out, BF16, "out"), _stream()), "enh_conv_nhwc_bf16"))
+    return out
+
+
+def conv_wgrad_nhwc(src, dy, geom):
+    """-> f32 [N, taps*C]: sum over the pixels of dy of dy[pix, n] * gathered src[pix, (tap, c)]"""
+    g = _geom(geom)
+    dw = torch.empty(g.N, g.nty * g.ntx * g.C, dtype=F32, device=src.device)
+    nb = lib().enh_conv_wgrad_workspace_bytes(ctypes.byref(g))
+    ws = _gemm_workspace(src.device, nb) if nb else None
+    work = 2.0 * g.B * g.Hm * g.Wm * g.N * g.nty * g.ntx * g.C
+    _timed("conv_wgrad_igemm_kernel", work,
+           lambda: _check(lib().enh_conv_wgrad_nhwc_bf16(_p(src, BF16, "src"), _p(dy, BF16, "dy"), ctypes.byref(g), _p(dw), _p(ws), nb, _stream()),
+                          "enh_conv_wgrad_nhwc_bf16"))
+    return dw
+
+
+def conv_pack_weight(w, scale: float, transposed: bool, kh0: int, kw0: int, kstep: int, nty: int, ntx: int, rows_padded: int, cols_padded: int):
+    """w [Cout,Cin,k,k] f32 -> bf16 [rows_padded, nty*ntx*cols_padded]"""
+    Cout, Cin, k, _ = w.shape
+    out = torch.empty(rows_padded, max(nty * ntx * cols_padded, 8), dtype=BF16, device=w.device)
+    if nty * ntx:
+        _check(lib().enh_conv_pack_weight(_p(w, F32, "w"), Cout, Cin, k, scale, int(transposed), kh0, kw0, kstep, nty, ntx, rows_padded, cols_padded,
+                                          _p(out), _stream()), "enh_conv_pack_weight")
+    return out
+
+
+def conv_unpack_wgrad(dwp, Cout: int, Cin: int, cin_padded: int, k: int, scale: float):
+    dw = torch.empty(Cout, Cin, k, k, dtype=F32, device=dwp.device)
+    _check(lib().enh_conv_unpack_wgrad(_p(dwp, F32, "dwp"), Cout, Cin, cin_padded, k, scale, _p(dw), _stream()), "enh_conv_unpack_wgrad")
+    return dw
+
+
+def blur_nhwc(x, kernel, pad0: int, pad1: int, flip: bool):
+    """x [B,H,W,C] bf16, kernel [kh,kw] f32 -> [B, H+pad0+pad1-kh+1, W+pad0+pad1-kw+1, C] bf16"""
+    B, H, W, C = x.shape
+    kh, kw = kernel.shape
+    out = torch.empty(B, H + pad0 + pad1 - kh + 1, W + pad0 + pad1 - kw + 1, C, dtype=BF16, device=x.device)
+    _check(lib().enh_blur_nhwc_bf16(_p(x, BF16, "x"), _p(kernel, F32, "kernel"), B, H, W, C, kh, kw, pad0, pad1, pad0, pad1, int(flip), _p(out), _stream()),
+           "enh_blur_nhwc_bf16")
+    return out
+
+
+def lrelu_gate(g, ref, slope: float, scale: float):
+    y = torch.empty_like(g)
+    _check(lib().enh_lrelu_gate_bf16(_p(g, BF16, "g"), _p(ref, BF16, "ref"), g.numel(), slope, scale, _p(y), _stream()), "enh_lrelu_gate_bf16")
+    return y
+
+
+def img_to_nhwc8(img):
+    B, C, H, W = img.shape
+    out = torch.empty(B, H, W, 8, dtype=BF16, device=img.device)
+    _check(lib().enh_img_to_nhwc8(_p(img, F32, "img"), B, C, H, W, _p(out), _stream()), "enh_img_to_nhwc8")
+    return out
+
+
+def nhwc8_to_img(src, C: int):
+    B, H, W, _ = src.shape
+    img = torch.empty(B, C, H, W, dtype=F32, device=src.device)
+    _check(lib().enh_nhwc8_to_img(_p(src, BF16, "src"), B, C, H, W, _p(img), _stream()), "enh_nhwc8_to_img")
+    return img
+
+
+def minibatch_stddev_nhwc(x, group: int, Cp: int):
+    """x [B,H,W,C] bf16 -> [B,H,W,Cp] bf16: x, the slot's mean standard deviation in channel C, zeros above (enh_minibatch_stddev_nhwc)"""
+    B, H, W, C = x.shape
+    out = torch.empty(B, H, W, Cp, dtype=BF16, device=x.device)
+    _check(lib().enh_minibatch_stddev_nhwc(_p(x, BF16, "x"), B, H * W, C, Cp, group, _p(out), _stream()), "enh_minibatch_stddev_nhwc")
+    return out
+
+
+def minibatch_stddev_nhwc_backward(x, g, group: int):
+    B, H, W, C = x.shape
+    dx = torch.empty_like(x)
+    _check(lib().enh_minibatch_stddev_nhwc_backward(_p(x, BF16, "x"), _p(g, BF16, "g"), B, H * W, C, g.shape[3], group, _p(dx), _stream()),
+           "enh_minibatch_stddev_nhwc_backward")
+    return dx
+
+
+def colsum_nhwc(x):
+    """sum over every axis but the last of a channels-last bf16 tensor -> f32 [C]; narrow C is folded so that a row of the kernel covers 512 columns"""
+    C = x.shape[-1]
+    M = x.numel() // C
+    r = 1
+    while C * r < 512 and M % (2 * r) == 0:
+        r *= 2
+    out = torch.empty(C * r, dtype=F32, device=x.device)
+    _check(lib().enh_colsum_bf16(_p(x, BF16, "x"), M // r, C * r, C * r, _p(out), 0, _stream()), "enh_colsum_bf16")
+    return out.view(r, C).sum(0) if r > 1 else out
 
 
 # ------------------------------------------------------------------------------------------------

@@ -2,14 +2,15 @@
 (reference enhancing/losses/layers.py:22-40 d-losses, :140-264 Blur / EqualConv2d / EqualLinear / ConvLayer / StyleBlock, :322-377
 StyleDiscriminator), running on this library's HIP kernels:
 
-  convolutions   im2col -> bf16 MFMA GEMM (f32 accumulate) -> col2im      op/conv2d_gradfix.py
-  blur           enh_upfirdn2d                                             op/upfirdn2d.py
-  bias + lrelu   enh_fused_bias_act                                        op/fused_act.py
-  linears        the same GEMM                                             op/conv2d_gradfix.linear
+  convolutions   implicit GEMM on bf16 MFMA (gather in the load stage, no im2col tensor): forward, input gradient and weight gradient,
+                 bias + leaky-ReLU and the residual merge fused into the epilogue                    op/conv_nhwc.py  (enh_conv_nhwc_bf16, ...)
+  blur           4x4 FIR on channels-last bf16                                                        op/conv_nhwc.py  (enh_blur_nhwc_bf16)
+  linears        enh_gemm_bf16                                                                        op/conv2d_gradfix.linear
 
-Inside the discriminator the activations are channel-major ([C, B, H, W] — the layout the convolution GEMM writes); every layer
-class also keeps the reference's NCHW ``forward`` so it can be used on its own.  The minibatch-stddev feature, the residual merge and
-the three scalar d-losses are a few elementwise torch ops on tensors of at most B x 512 x 4 x 4 elements.
+Inside ``StyleDiscriminator.forward`` the activations are channels-last bf16 ([B, H, W, C], C padded to a multiple of 8 with zero channels:
+the 3-channel image enters as 8, the 513-channel input of the final convolution as 520).  Every layer class also keeps the reference's
+NCHW f32 ``forward`` (used on its own it runs the older explicit lowering im2col -> GEMM -> col2im of op/conv2d_gradfix.py, which
+``StyleDiscriminator(lowering="im2col")`` still selects for A/B comparison).  The three scalar d-losses are torch ops on B logits.
 Not built: PatchDiscriminator / ActNorm (layers.py:50-137, 266-319) — no stage-1 loss of the reference constructs them
 (VQLPIPSWithDiscriminator always builds StyleDiscriminator, vqperceptual.py:81)."""
 from __future__ import annotations
@@ -21,7 +22,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .op import FusedLeakyReLU, conv2d_gradfix, fused_leaky_relu, upfirdn2d
+from .op import FusedLeakyReLU, conv2d_gradfix, conv_nhwc, fused_leaky_relu, upfirdn2d
 
 
 def hinge_d_loss(logits_fake, logits_real=None):
@@ -67,6 +68,9 @@ class Blur(nn.Module):
     def forward(self, input: torch.Tensor) -> torch.Tensor:   # planes are independent: NCHW and channel-major alike
         return upfirdn2d(input, self.kernel, pad=self.pad)
 
+    def forward_nhwc(self, x: torch.Tensor) -> torch.Tensor:
+        return conv_nhwc.blur(x, self.kernel, self.pad)
+
 
 class EqualConv2d(nn.Module):
     def __init__(self, in_channel: int, out_channel: int, kernel_size: int, stride: int = 1, padding: int = 0, bias: bool = True) -> None:
@@ -82,6 +86,20 @@ class EqualConv2d(nn.Module):
         if self.bias is not None:
             out = out + self.bias.view(-1, 1, 1, 1)
         return out
+
+    def forward_nhwc(self, x: torch.Tensor, act: Optional[FusedLeakyReLU] = None, add: Optional[torch.Tensor] = None, alpha: float = 1.0) -> torch.Tensor:
+        """x [B,H,W,Cp] bf16.  act: the FusedLeakyReLU that follows (fused into the kernel's epilogue); add / alpha: returns
+        alpha * (conv(x) + add) — the residual merge of a StyleBlock, with alpha folded into the weights"""
+        if act is not None:
+            if self.bias is not None or add is not None:
+                raise RuntimeError("EqualConv2d.forward_nhwc: an activated convolution carries its bias in the activation and takes no residual")
+            return conv_nhwc.conv_bias_lrelu(x, self.weight, act.bias, self.scale, self.stride, self.padding, act.negative_slope, act.scale)
+        if add is not None:
+            if self.bias is not None:
+                raise RuntimeError("EqualConv2d.forward_nhwc: the residual merge is only fused into a bias-free convolution")
+            return conv_nhwc.conv_add(x, self.weight, add, self.scale * alpha, self.stride, self.padding, alpha)
+        out = conv_nhwc.conv(x, self.weight, self.scale * alpha, self.stride, self.padding)
+        return out if self.bias is None else out + (alpha * self.bias).to(out.dtype)
 
     def forward(self, input: torch.Tensor) -> torch.Tensor:
         return conv2d_gradfix.conv2d(input, self.weight * self.scale, bias=self.bias, stride=self.stride, padding=self.padding)
@@ -123,6 +141,13 @@ class ConvLayer(nn.Sequential):
             layers.append(FusedLeakyReLU(out_channel, bias=bias))
         super().__init__(*layers)
 
+    def forward_nhwc(self, x: torch.Tensor, add: Optional[torch.Tensor] = None, alpha: float = 1.0) -> torch.Tensor:
+        mods = list(self)
+        if isinstance(mods[0], Blur):
+            x, mods = mods[0].forward_nhwc(x), mods[1:]
+        act = mods[1] if len(mods) > 1 else None
+        return mods[0].forward_nhwc(x, act=act, add=add, alpha=alpha)
+
     def forward_cm(self, x: torch.Tensor, layout: str = "cm") -> torch.Tensor:
         for m in self:
             if isinstance(m, EqualConv2d):
@@ -141,6 +166,10 @@ class StyleBlock(nn.Module):
         self.conv2 = ConvLayer(in_channel, out_channel, 3, downsample=True)
         self.skip = ConvLayer(in_channel, out_channel, 1, downsample=True, activate=False, bias=False)
 
+    def forward_nhwc(self, x: torch.Tensor) -> torch.Tensor:
+        out = self.conv2.forward_nhwc(self.conv1.forward_nhwc(x))
+        return self.skip.forward_nhwc(x, add=out, alpha=1 / sqrt(2))      # (out + skip(x)) / sqrt(2) in the skip convolution's epilogue
+
     def forward_cm(self, x: torch.Tensor) -> torch.Tensor:
         out = self.conv2.forward_cm(self.conv1.forward_cm(x))
         return (out + self.skip.forward_cm(x)) / sqrt(2)
@@ -150,8 +179,11 @@ class StyleBlock(nn.Module):
 
 
 class StyleDiscriminator(nn.Module):
-    def __init__(self, size: int = 256, channel_multiplier: int = 2, blur_kernel=(1, 3, 3, 1)) -> None:
+    def __init__(self, size: int = 256, channel_multiplier: int = 2, blur_kernel=(1, 3, 3, 1), lowering: str = "igemm") -> None:
         super().__init__()
+        if lowering not in ("igemm", "im2col"):
+            raise ValueError(f"StyleDiscriminator: lowering must be 'igemm' or 'im2col', got {lowering!r}")
+        self.lowering = lowering
         channels = {4: 512, 8: 512, 16: 512, 32: 512, 64: 256 * channel_multiplier, 128: 128 * channel_multiplier,
                     256: 64 * channel_multiplier, 512: 32 * channel_multiplier, 1024: 16 * channel_multiplier}
         log_size = int(log2(size))
@@ -169,6 +201,22 @@ class StyleDiscriminator(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """x [B,3,size,size] f32 on the ROCm device -> logits [B] (layers.py:354-377)"""
+        return self._forward_nhwc(x) if self.lowering == "igemm" else self._forward_cm(x)
+
+    def _forward_nhwc(self, x: torch.Tensor) -> torch.Tensor:
+        out = conv_nhwc.image_to_nhwc8(x)                             # [B,H,W,8] bf16
+        for blk in self.blocks:
+            out = blk.forward_nhwc(out)
+        B, H, W, C = out.shape
+        # minibatch standard deviation (layers.py:358-367): sample b belongs to slot b % (B/group); one scalar per slot
+        group = min(B, self.stddev_group)
+        group = B // (B // group)
+        out = conv_nhwc.minibatch_stddev(out, group)                     # 513 channels, zero-padded to 520
+        out = self.final_conv.forward_nhwc(out)                          # [B,4,4,512]
+        out = out.permute(0, 3, 1, 2).reshape(B, -1).float()             # per-sample (c, h, w) flattening, as the reference's .view
+        return self.final_linear(out).squeeze()
+
+    def _forward_cm(self, x: torch.Tensor) -> torch.Tensor:
         out = self.blocks[0].forward_cm(x.contiguous(), layout="nchw")
         for blk in list(self.blocks)[1:]:
             out = blk.forward_cm(out)

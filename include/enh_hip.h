@@ -36,7 +36,7 @@ extern "C" {
 typedef uint16_t enh_bf16; /* raw bfloat16 bits */
 
 const char* enh_last_error(void);
-#define ENH_ABI_VERSION 4   /* bumped whenever a signature below changes; the bindings check it at load */
+#define ENH_ABI_VERSION 5   /* bumped whenever a signature below changes; the bindings check it at load */
 int enh_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -197,6 +197,60 @@ int enh_im2col_bf16(const float* x, int64_t stride_b, int64_t stride_c, int B, i
                     int Ho, int Wo, enh_bf16* cols, int64_t ld, void* stream);
 int enh_col2im_f32(const enh_bf16* dcols, int64_t ld, int B, int C, int H, int W, int k, int stride, int pad, int Ho, int Wo,
                    float* dx, int64_t stride_b, int64_t stride_c, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolutions on channels-last bf16 activations [B,H,W,C] (no im2col tensor): EqualConv2d forward, input gradient and
+ * weight gradient of the StyleGAN2 discriminator (enhancing/losses/layers.py:163-185; the three roles conv2d_gradfix differentiates
+ * through, enhancing/losses/op/conv2d_gradfix.py:81-195) and the 3x3 convolutions of the LPIPS VGG16 trunk.
+ * ------------------------------------------------------------------------------------------------ */
+/* One description for every role.  GEMM row m = (b, y, x) of a logical grid Hm x Wm; contraction index = (tap (jy, jx), channel c);
+ * operand element = src[b, y*gs + oy0 + jy*sty, x*gs + ox0 + jx*stx, c] (zero outside the source); the result row goes to pixel
+ * (y*os + oph, x*os + opw) of the output tensor [B,HO,WO,N].
+ *   forward  (stride s, padding p, k x k): src = x,  gs = s, oy0 = ox0 = -p, sty = stx = +1, nty = ntx = k, (Hm,Wm) = (HO,WO) = output size, os = 1
+ *   dgrad, s = 1:  src = dy, gs = 1, oy0 = ox0 = +p, sty = stx = -1, nty = ntx = k, (Hm,Wm) = (HO,WO) = input size, weights packed transposed
+ *   dgrad, s = 2:  one launch per output parity class (ph, pw): taps kh = kh0 + 2 jy with kh0 = (ph + p) & 1, oy0 = (ph + p - kh0) / 2, sty = -1,
+ *                  Hm = (H - ph + 1) / 2, os = 2, oph = ph (same in x); a class without taps (nty*ntx = 0) writes zeros
+ *   wgrad:         src = x, (Hm,Wm) = dy's spatial size, gs / oy0 / sty / nty as in forward, N = channels of dy (output fields unused) */
+typedef struct enh_conv_geom {
+  int B;
+  int Hs, Ws, C;               /* source tensor [B,Hs,Ws,C], C % 8 == 0 */
+  int Hm, Wm;                  /* logical grid enumerated as GEMM rows */
+  int gs, oy0, ox0, nty, ntx, sty, stx;
+  int N;                       /* output channels, N % 8 == 0 */
+  int HO, WO, os, oph, opw;    /* output tensor and the placement of the logical grid in it */
+} enh_conv_geom;
+/* out[o, n] = epilogue( sum_{tap,c} src[...] * wt[n][tap*C + c] ), wt [N][nty*ntx*C] bf16 (enh_conv_pack_weight), o = output pixel of the row
+ *   mode 0: relu(acc + bias[n])                     mode 1: (acc + add[o,n]) * (aux[o,n] > 0)   (add optional)      mode 2: acc
+ *   mode 3: lrelu(acc + bias[n], slope p0) * p1     (EqualConv2d + FusedLeakyReLU, layers.py:220-264 / fused_act.py:48-76; bias optional)
+ *   mode 4: acc + p0 * add[o,n]                     (StyleBlock's (out + skip) / sqrt(2), layers.py:262, folded into the skip convolution) */
+int enh_conv_nhwc_bf16(const enh_bf16* src, const enh_bf16* wt, const enh_conv_geom* g, int mode, const float* bias, const enh_bf16* aux,
+                       const enh_bf16* add, float p0, float p1, enh_bf16* out, void* stream);
+/* dw[n][tap*C + c] = sum over pixels (b,y,x) of dy[b,y,x,n] * src[b, y*gs + oy0 + jy*sty, x*gs + ox0 + jx*stx, c]   (f32, overwritten).
+ * The pixel axis is split over the grid; partial slabs go to `ws` (enh_conv_wgrad_workspace_bytes) and are added in a fixed order. */
+size_t enh_conv_wgrad_workspace_bytes(const enh_conv_geom* g);
+int enh_conv_wgrad_nhwc_bf16(const enh_bf16* src, const enh_bf16* dy, const enh_conv_geom* g, float* dw, void* ws, size_t ws_bytes, void* stream);
+/* parameter layout [Cout][Cin][k][k] f32 (x scale) -> packed bf16 operand, taps (kh0 + jy*kstep, kw0 + jx*kstep):
+ *   transposed = 0: out[co][(jy*ntx+jx)*cols_padded + ci]  (forward)      transposed = 1: out[ci][(jy*ntx+jx)*cols_padded + co]  (input gradient)
+ * rows / columns beyond the real channel counts are zero.  enh_conv_unpack_wgrad: dw[co][ci][kh][kw] = scale * dwp[co][(kh*k+kw)*cin_padded + ci] */
+int enh_conv_pack_weight(const float* w, int Cout, int Cin, int k, float scale, int transposed, int kh0, int kw0, int kstep, int nty, int ntx,
+                         int rows_padded, int cols_padded, enh_bf16* out, void* stream);
+int enh_conv_unpack_wgrad(const float* dwp, int Cout, int Cin, int cin_padded, int k, float scale, float* dw, void* stream);
+/* Blur (layers.py:140-160 -> upfirdn2d with unit up / down): out[b,oy,ox,c] = sum_{i,j} w(i,j) x[b, oy+i-pad_y0, ox+j-pad_x0, c] with
+ * w(i,j) = kernel[kh-1-i][kw-1-j] (flip = 0, upfirdn2d's convention) or kernel[i][j] (flip = 1, the adjoint); out is [B, H+pad_y0+pad_y1-kh+1, W+..., C];
+ * pads may be negative (crop) */
+int enh_blur_nhwc_bf16(const enh_bf16* x, const float* kernel, int B, int H, int W, int C, int kh, int kw, int pad_y0, int pad_y1, int pad_x0,
+                       int pad_x1, int flip, enh_bf16* out, void* stream);
+/* y = g * (ref > 0 ? 1 : slope) * scale — the first / second derivative of FusedLeakyReLU through its saved output (fused_act.py:21-45);
+ * ref == NULL: y = g * scale.  n % 8 == 0 */
+int enh_lrelu_gate_bf16(const enh_bf16* g, const enh_bf16* ref, int64_t n, float slope, float scale, enh_bf16* y, void* stream);
+/* Minibatch standard deviation (layers.py:358-367, stddev_feat = 1) fused with the concatenation and the channel padding of the final convolution's input:
+ * x [B,HW,C] bf16 -> out [B,HW,Cp] bf16 with out[..,0..C-1] = x, out[..,C] = mean over (h,w,c) of sqrt(var over the group + 1e-8) of the sample's slot
+ * (sample b is in slot b % (B/group); biased variance), out[..,C+1..] = 0.  Backward: dx [B,HW,C] from g [B,HW,Cp].  B % group == 0, C % 8 == 0, Cp % 8 == 0, Cp > C. */
+int enh_minibatch_stddev_nhwc(const enh_bf16* x, int B, int HW, int C, int Cp, int group, enh_bf16* out, void* stream);
+int enh_minibatch_stddev_nhwc_backward(const enh_bf16* x, const enh_bf16* g, int B, int HW, int C, int Cp, int group, enh_bf16* dx, void* stream);
+/* img [B,C,H,W] f32, C <= 8  ->  [B,H,W,8] bf16 (channels C..7 zero), and the adjoint (padding channels dropped) */
+int enh_img_to_nhwc8(const float* img, int B, int C, int H, int W, enh_bf16* out, void* stream);
+int enh_nhwc8_to_img(const enh_bf16* src, int B, int C, int H, int W, float* img, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * fp32 "exact mode": the same contractions with fp32 operands and fixed ascending-k fp32 accumulation (no bf16 anywhere), for end-to-end

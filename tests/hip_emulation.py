@@ -63,8 +63,111 @@ def install(monkeypatch, exact: bool = True):
     def upfirdn2d(x, kernel, ux, uy, dx, dy, p0, p1, p2, p3):
         return DO.upfirdn2d(x[None], kernel, (ux, uy), (dx, dy), (p0, p1, p2, p3))[0]
 
+
+    # ---- channels-last implicit-GEMM path (op/conv_nhwc.py): emulated from the GEOMETRY the host code builds, tap by tap ----
+    def _g(geom):
+        return geom if isinstance(geom, dict) else {n: getattr(geom, n) for n, _ in _C.ConvGeom._fields_}
+
+    def _gathered(src, g):
+        """[B, Hm, Wm, taps, C] f32: src[b, y*gs + oy0 + jy*sty, x*gs + ox0 + jx*stx, c], zero outside"""
+        B, Hs, Ws, C = src.shape
+        assert (B, Hs, Ws, C) == (g["B"], g["Hs"], g["Ws"], g["C"]) and C % 8 == 0
+        out = torch.zeros(B, g["Hm"], g["Wm"], g["nty"] * g["ntx"], C)
+        ys, xs = torch.arange(g["Hm"]) * g["gs"], torch.arange(g["Wm"]) * g["gs"]
+        for jy in range(g["nty"]):
+            for jx in range(g["ntx"]):
+                sy, sx = ys + g["oy0"] + jy * g["sty"], xs + g["ox0"] + jx * g["stx"]
+                oky, okx = (sy >= 0) & (sy < Hs), (sx >= 0) & (sx < Ws)
+                v = src.float()[:, sy.clamp(0, Hs - 1)][:, :, sx.clamp(0, Ws - 1)]
+                out[:, :, :, jy * g["ntx"] + jx] = v * (oky[:, None] & okx[None, :])[None, :, :, None]
+        return out
+
+    def conv_nhwc(src, wt, geom, mode, bias=None, aux=None, add=None, p0=0.0, p1=1.0, out=None):
+        g = _g(geom)
+        taps = g["nty"] * g["ntx"]
+        if out is None:
+            out = torch.full((g["B"], g["HO"], g["WO"], g["N"]), float("nan"), dtype=low)
+        A = _gathered(src, g).reshape(g["B"], g["Hm"], g["Wm"], taps * g["C"])
+        acc = A @ wt[:, :taps * g["C"]].float().t() if taps else torch.zeros(g["B"], g["Hm"], g["Wm"], g["N"])
+        assert wt.shape[0] == g["N"]
+        sl = (slice(None), slice(g["oph"], g["oph"] + (g["Hm"] - 1) * g["os"] + 1, g["os"]), slice(g["opw"], g["opw"] + (g["Wm"] - 1) * g["os"] + 1, g["os"]))
+        if mode == 0:
+            acc = torch.relu(acc + bias)
+        elif mode == 1:
+            acc = (acc + (add[sl].float() if add is not None else 0)) * (aux[sl] > 0)
+        elif mode == 3:
+            v = acc + bias if bias is not None else acc
+            acc = torch.where(v > 0, v, v * p0) * p1
+        elif mode == 4:
+            acc = acc + p0 * add[sl].float()
+        out[sl] = acc.to(low)
+        return out
+
+    def conv_wgrad_nhwc(src, dy, geom):
+        g = _g(geom)
+        A = _gathered(src, g).reshape(-1, g["nty"] * g["ntx"] * g["C"])
+        assert dy.shape == (g["B"], g["Hm"], g["Wm"], g["N"])
+        return dy.float().reshape(-1, g["N"]).t() @ A
+
+    def conv_pack_weight(w, scale, transposed, kh0, kw0, kstep, nty, ntx, rows_padded, cols_padded):
+        Cout, Cin, k, _ = w.shape
+        out = torch.zeros(rows_padded, max(nty * ntx * cols_padded, 8))
+        if nty * ntx:
+            sel = (w * scale)[:, :, kh0::kstep, kw0::kstep][:, :, :nty, :ntx]          # [Cout, Cin, nty, ntx]
+            m = sel.permute(1, 2, 3, 0) if transposed else sel.permute(0, 2, 3, 1)    # [rows, nty, ntx, cols]
+            o = torch.zeros(rows_padded, nty, ntx, cols_padded)
+            o[:m.shape[0], :, :, :m.shape[3]] = m
+            out = o.reshape(rows_padded, -1)
+        return out.to(low)
+
+    def conv_unpack_wgrad(dwp, Cout, Cin, cin_padded, k, scale):
+        return scale * dwp.reshape(Cout, k, k, cin_padded)[:, :, :, :Cin].permute(0, 3, 1, 2).contiguous()
+
+    def blur_nhwc(x, kernel, pad0, pad1, flip):
+        assert x.shape[3] % 8 == 0
+        kq = kernel if not flip else torch.flip(kernel, [0, 1])       # DO.upfirdn2d applies the (flipped) kernel of the reference's convention
+        xp = x.float().permute(0, 3, 1, 2)
+        neg0, neg1 = max(-pad0, 0), max(-pad1, 0)
+        if neg0 or neg1:
+            xp = xp[:, :, neg0:xp.shape[2] - neg1, neg0:xp.shape[3] - neg1]
+        y = DO.upfirdn2d(xp, kq, pad=(max(pad0, 0), max(pad1, 0)))
+        return y.permute(0, 2, 3, 1).contiguous().to(low)
+
+    def lrelu_gate(g_, ref, slope, scale):
+        assert g_.numel() % 8 == 0
+        v = g_.float()
+        if ref is not None:
+            v = v * torch.where(ref > 0, torch.ones_like(v), torch.full_like(v, slope))
+        return (v * scale).to(low)
+
+    def img_to_nhwc8(img):
+        B, C, H, W = img.shape
+        out = torch.zeros(B, H, W, 8)
+        out[..., :C] = img.permute(0, 2, 3, 1)
+        return out.to(low)
+
+    def nhwc8_to_img(src, C):
+        return src.float()[..., :C].permute(0, 3, 1, 2).contiguous()
+
+    def colsum_nhwc(x):
+        return x.float().reshape(-1, x.shape[-1]).sum(0)
+
+    def minibatch_stddev_nhwc(x, group, Cp):
+        from enhancing.losses.op.conv_nhwc import _stddev_torch
+        return _stddev_torch(x.float(), group, Cp).to(low)
+
+    def minibatch_stddev_nhwc_backward(x, g, group):
+        from enhancing.losses.op.conv_nhwc import _stddev_torch
+        with torch.enable_grad():
+            x32 = x.detach().float().requires_grad_(True)
+            dx, = torch.autograd.grad(_stddev_torch(x32, group, g.shape[3]), x32, g.float())
+        return dx.to(low)
+
     for name, fn in dict(gemm=gemm, cast_bf16=cast_bf16, im2col=im2col, col2im=col2im, fused_bias_act=fused_bias_act,
-                         channel_sum=channel_sum, upfirdn2d=upfirdn2d).items():
+                         channel_sum=channel_sum, upfirdn2d=upfirdn2d, conv_nhwc=conv_nhwc, conv_wgrad_nhwc=conv_wgrad_nhwc,
+                         conv_pack_weight=conv_pack_weight, conv_unpack_wgrad=conv_unpack_wgrad, blur_nhwc=blur_nhwc, lrelu_gate=lrelu_gate,
+                         img_to_nhwc8=img_to_nhwc8, nhwc8_to_img=nhwc8_to_img, colsum_nhwc=colsum_nhwc,
+                         minibatch_stddev_nhwc=minibatch_stddev_nhwc, minibatch_stddev_nhwc_backward=minibatch_stddev_nhwc_backward).items():
         monkeypatch.setattr(_C, name, fn)
     if exact:
         class _Torch:   # conv2d_gradfix allocates its low-precision containers as torch.bfloat16

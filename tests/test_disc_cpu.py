@@ -32,8 +32,9 @@ def test_disc_oracle_matches_reference_golden(gold):
     assert rel(sd["blocks.0.0.weight"].grad, torch.from_numpy(gold["g_rgb_w"])) <= 1e-4
 
 
+@pytest.mark.parametrize("lowering", ["igemm", "im2col"])
 @pytest.mark.parametrize("B", [8, 6, 2])
-def test_discriminator_wiring_first_and_second_order(monkeypatch, B):
+def test_discriminator_wiring_first_and_second_order(monkeypatch, B, lowering):
     """kernels replaced by exact torch stand-ins: logits, d logits / d image, and the parameter gradients of (R1 penalty + d-loss)
     — which differentiate THROUGH the first backward — must equal the fp32 oracle's to rounding"""
     import disc_oracle as O
@@ -42,7 +43,7 @@ def test_discriminator_wiring_first_and_second_order(monkeypatch, B):
     from enhancing.losses.layers import StyleDiscriminator
     from enhancing.losses.op import conv2d_gradfix
     torch.manual_seed(B)
-    D = StyleDiscriminator(size=16)
+    D = StyleDiscriminator(size=16, lowering=lowering)
     with torch.no_grad():
         for n, p in D.named_parameters():
             if n.endswith("bias"):
