@@ -139,52 +139,60 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs args)
     }
     __syncthreads();
   }
-  // epilogue: lane (lg, l16) holds out[m = m0 + wm*64 + i*16 + l16][n = n0 + wn*64 + j*16 + lg*4 + 0..3]
+  // epilogue: lane (lg, l16) holds out[m = m0 + wm*64 + i*16 + l16][n = n0 + wn*64 + j*16 + lg*4 + 0..3].  Everything the epilogue READS (bias, aux, add)
+  // is requested for all 16 element groups before the first store: CDNA4's vmcnt retires loads and stores in order, so a load issued after a store
+  // can only be waited for together with that store's acknowledgement (gemm_tiles.h epi_bias).
   const bool dense = g.os == 1 && g.HO == g.Hm && g.WO == g.Wm && g.oph == 0 && g.opw == 0;
+  int64_t orow[4];
+  float4 b4[4];
+  uint2 ax[4][4], ad[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int64_t n = n0 + wn * 64 + j * 16 + lg * 4;
+    b4[j] = ((args.mode == 0 || args.mode == 3) && args.bias && n < g.N) ? *reinterpret_cast<const float4*>(args.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int64_t m = m0 + wm * 64 + i * 16 + l16;
-    if (m >= args.M) continue;
-    const int64_t orow = (dense ? m : conv_out_pixel(g, m)) * g.N;
-    uint2 ax[4], ad[4];
+    orow[i] = m < args.M ? (dense ? m : conv_out_pixel(g, m)) * g.N : -1;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int64_t n = n0 + wn * 64 + j * 16 + lg * 4;
-      ax[j] = make_uint2(0u, 0u); ad[j] = make_uint2(0u, 0u);
-      if (n < g.N) {
-        if (args.mode == 1) ax[j] = *reinterpret_cast<const uint2*>(args.aux + orow + n);
-        if ((args.mode == 1 || args.mode == 4) && args.add) ad[j] = *reinterpret_cast<const uint2*>(args.add + orow + n);
+      ax[i][j] = make_uint2(0u, 0u); ad[i][j] = make_uint2(0u, 0u);
+      if (orow[i] >= 0 && n < g.N) {
+        if (args.mode == 1) ax[i][j] = *reinterpret_cast<const uint2*>(args.aux + orow[i] + n);
+        if ((args.mode == 1 || args.mode == 4) && args.add) ad[i][j] = *reinterpret_cast<const uint2*>(args.add + orow[i] + n);
       }
     }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (orow[i] < 0) continue;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int64_t n = n0 + wn * 64 + j * 16 + lg * 4;
       if (n >= g.N) continue;   // N % 8 == 0: the 4 columns are in or out together
       float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      const uint32_t d0 = ad[j].x, d1 = ad[j].y;
+      const uint32_t d0 = ad[i][j].x, d1 = ad[i][j].y;
       const float e0 = bf16_bits_to_f32((uint16_t)(d0 & 0xffffu)), e1 = bf16_bits_to_f32((uint16_t)(d0 >> 16));
       const float e2 = bf16_bits_to_f32((uint16_t)(d1 & 0xffffu)), e3 = bf16_bits_to_f32((uint16_t)(d1 >> 16));
       if (args.mode == 0) {
-        const float4 b4 = *reinterpret_cast<const float4*>(args.bias + n);
-        v[0] = fmaxf(v[0] + b4.x, 0.f); v[1] = fmaxf(v[1] + b4.y, 0.f); v[2] = fmaxf(v[2] + b4.z, 0.f); v[3] = fmaxf(v[3] + b4.w, 0.f);
+        v[0] = fmaxf(v[0] + b4[j].x, 0.f); v[1] = fmaxf(v[1] + b4[j].y, 0.f); v[2] = fmaxf(v[2] + b4[j].z, 0.f); v[3] = fmaxf(v[3] + b4[j].w, 0.f);
       } else if (args.mode == 1) {
-        const uint32_t a0 = ax[j].x, a1 = ax[j].y;
+        const uint32_t a0 = ax[i][j].x, a1 = ax[i][j].y;
         v[0] = (a0 & 0x7fffu) && !(a0 & 0x8000u) ? v[0] + e0 : 0.f;
         v[1] = ((a0 >> 16) & 0x7fffu) && !(a0 >> 31) ? v[1] + e1 : 0.f;
         v[2] = (a1 & 0x7fffu) && !(a1 & 0x8000u) ? v[2] + e2 : 0.f;
         v[3] = ((a1 >> 16) & 0x7fffu) && !(a1 >> 31) ? v[3] + e3 : 0.f;
       } else if (args.mode == 3) {
-        if (args.bias) {
-          const float4 b4 = *reinterpret_cast<const float4*>(args.bias + n);
-          v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-        }
+        v[0] += b4[j].x; v[1] += b4[j].y; v[2] += b4[j].z; v[3] += b4[j].w;
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = (v[r] > 0.f ? v[r] : v[r] * args.p0) * args.p1;
       } else if (args.mode == 4) {
         v[0] += args.p0 * e0; v[1] += args.p0 * e1; v[2] += args.p0 * e2; v[3] += args.p0 * e3;
       }
       const u32x2 o_ = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-      *reinterpret_cast<u32x2*>(args.out + orow + n) = o_;
+      *reinterpret_cast<u32x2*>(args.out + orow[i] + n) = o_;
     }
   }
 }

@@ -279,35 +279,81 @@ __device__ __forceinline__ s16x8 frag32(const unsigned char* tile, int base, int
 
 // epilogue for the swapped 32x32 accumulator layout: acc[i][j][r] = C[mw + i*32 + (lane&31)][nw + j*32 + 8*(r>>2) + 4*(lane>>5) + (r&3)]
 template <int MODE, int NJ, bool BOUNDS>
-__device__ __forceinline__ void gemm_epilogue32_loops(const GemmArgs& args, f32x16 (&acc)[4][NJ], int64_t mw, int64_t nw, int lane, int split) {
+__device__ __forceinline__ void gemm_epilogue32_loops(const GemmArgs& args, f32x16 (&acc)[4][NJ], int64_t mw, int64_t nw, int lane, int split, float* wave_bias) {
   const int l31 = lane & 31, hi = lane >> 5;
+  // Row-blocks whose inputs (saved tanh output / residual / old C) are requested TOGETHER before the first is consumed.  With one wave per SIMD every
+  // group costs one full memory round trip (~2-4 us under load) during which nothing else runs, so the group is made as large as the registers allow:
+  // the accumulators live in AGPRs and the K loop's fragment registers are dead here.  8 bytes per element group: all four row-blocks (128 VGPRs);
+  // 16 bytes (f32 residual): two.
+  constexpr int GI = MODE == EPI_BF16_DTANH ? 4 : (MODE == EPI_F32_BIAS_RES ? 2 : 1);
+  if (MODE == EPI_GENERIC) {   // runtime-flag mode: one row-block at a time, the bias fetched where it is used (the round-1 code shape: no spills)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int64_t m = mw + i * 32 + l31;
-    if (BOUNDS && m >= args.M) continue;
-    EpiIn in[NJ][4];   // one row-block's inputs (residual / aux / old C) are all requested before the first one is used
+    for (int i = 0; i < 4; ++i) {
+      const int64_t m = mw + i * 32 + l31;
+      if (BOUNDS && m >= args.M) continue;
+      EpiIn in[NJ][4];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const int64_t n = nw + j * 32 + 8 * g4 + 4 * hi;
-        if (!BOUNDS || n < args.N) in[j][g4] = epi_load<MODE>(args, m, n);
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int64_t n = nw + j * 32 + 8 * g4 + 4 * hi;
+          if (!BOUNDS || n < args.N) in[j][g4] = epi_load<MODE>(args, m, n);
+        }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int64_t n = nw + j * 32 + 8 * g4 + 4 * hi;
+          if (BOUNDS && n >= args.N) continue;
+          float v[4] = {acc[i][j][g4 * 4 + 0], acc[i][j][g4 * 4 + 1], acc[i][j][g4 * 4 + 2], acc[i][j][g4 * 4 + 3]};
+          epi4<MODE>(args, v, in[j][g4], epi_bias<MODE>(args, n), m, n, split);
+        }
       }
+    }
+    return;
+  }
+  // The bias of the wave's NJ*32 columns goes through a wave-private LDS strip: fetched once and BEFORE any store (see epi_bias), and read back with
+  // ds_read_b128 — LDS traffic is counted by lgkmcnt, so unlike a global load it can be waited for without waiting for the stores in flight, and
+  // it costs no registers across the row-blocks.
+  constexpr bool HAS_BIAS = MODE == EPI_BF16_BIAS_TANH || MODE == EPI_F32_BIAS_RES;
+  if (HAS_BIAS && lane < NJ * 8) {
+    const int64_t n = nw + lane * 4;
+    const float4 bv = (!BOUNDS || n < args.N) ? *reinterpret_cast<const float4*>(args.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(wave_bias + lane * 4) = bv;
+  }
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
+  for (int i0 = 0; i0 < 4; i0 += GI) {
+    EpiIn in[GI][NJ][4];
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const int64_t n = nw + j * 32 + 8 * g4 + 4 * hi;
-        if (BOUNDS && n >= args.N) continue;
-        float v[4] = {acc[i][j][g4 * 4 + 0], acc[i][j][g4 * 4 + 1], acc[i][j][g4 * 4 + 2], acc[i][j][g4 * 4 + 3]};
-        epi4<MODE>(args, v, in[j][g4], m, n, split);
+    for (int ii = 0; ii < GI; ++ii) {
+      const int64_t m = mw + (i0 + ii) * 32 + l31;
+      if (BOUNDS && m >= args.M) continue;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int64_t n = nw + j * 32 + 8 * g4 + 4 * hi;
+          if (!BOUNDS || n < args.N) in[ii][j][g4] = epi_load<MODE>(args, m, n);
+        }
+    }
+#pragma unroll
+    for (int ii = 0; ii < GI; ++ii) {
+      const int i = i0 + ii;
+      const int64_t m = mw + i * 32 + l31;
+      if (BOUNDS && m >= args.M) continue;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int64_t n = nw + j * 32 + 8 * g4 + 4 * hi;
+          if (BOUNDS && n >= args.N) continue;
+          float v[4] = {acc[i][j][g4 * 4 + 0], acc[i][j][g4 * 4 + 1], acc[i][j][g4 * 4 + 2], acc[i][j][g4 * 4 + 3]};
+          const float4 b4 = HAS_BIAS ? *reinterpret_cast<const float4*>(wave_bias + j * 32 + 8 * g4 + 4 * hi) : make_float4(0.f, 0.f, 0.f, 0.f);
+          epi4<MODE>(args, v, in[ii][j][g4], b4, m, n, split);
+        }
       }
     }
   }
-}
-template <int NJ, bool BOUNDS>   // BOUNDS = false: the kernel only runs shapes that are whole tiles (a per-element range check is 64 more branches per wave)
-__device__ __forceinline__ void gemm_epilogue32(const GemmArgs& args, f32x16 (&acc)[4][NJ], int64_t mw, int64_t nw, int lane, int split) {
-  EPI_DISPATCH((gemm_epilogue32_loops<EM, NJ, BOUNDS>(args, acc, mw, nw, lane, split)));
 }
 
 // =================================================================================================
@@ -328,6 +374,7 @@ __device__ __forceinline__ void gemm_epilogue32(const GemmArgs& args, f32x16 (&a
 // Shapes: M, N multiples of 256, every K slice a multiple of 64 with at least two stages; everything else runs pipe2 / the fallback.
 // =================================================================================================
 #define W2_SLOT (4 * G_TILE_BYTES)
+#define W2_BIAS_BYTES 2048   // behind the two slots: 128 f32 bias values per wave for the epilogue (see gemm_epilogue32_loops)
 // staging source of the lane for slab parity p (slabs 2u + p): !TR: 8 rows x 128 B per slab ; TR: 4 k-rows x 256 B per slab
 template <bool TR>
 __device__ __forceinline__ const uint16_t* w256_src(const uint16_t* __restrict__ P, int64_t ld, int64_t x0, int64_t k_begin, int p, int lane) {
@@ -451,7 +498,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #undef W2_MM
 #undef W2_FENCE
 #undef W2_KSTEP
-  gemm_epilogue32_loops<EPI, 4, false>(args, acc, m0 + wm * 128, n0 + wn * 128, lane, split);
+  gemm_epilogue32_loops<EPI, 4, false>(args, acc, m0 + wm * 128, n0 + wn * 128, lane, split,
+                                       reinterpret_cast<float*>(smem + 2 * W2_SLOT) + wave * 128);
 }
 
 
@@ -598,11 +646,11 @@ extern "C" int enh_gemm_bf16_ws(const enh_bf16* A, int64_t lda, int trans_a, con
     static const bool w2_attr = [] {
       for (int l = 0; l < 4; ++l)
         for (int e = 0; e < EPI_NMODES; ++e)
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(table[l][e]), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W2_SLOT);
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(table[l][e]), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W2_SLOT + W2_BIAS_BYTES);
       return true;
     }();
     (void)w2_attr;
-    hipLaunchKernelGGL(table[(trans_a ? 2 : 0) + (trans_b ? 1 : 0)][epi_mode(g)], grid, dim3(256), (size_t)(2 * W2_SLOT), s, g);
+    hipLaunchKernelGGL(table[(trans_a ? 2 : 0) + (trans_b ? 1 : 0)][epi_mode(g)], grid, dim3(256), (size_t)(2 * W2_SLOT + W2_BIAS_BYTES), s, g);
   } else if (family == 3) LAUNCH(gemm_bf16_pipe2_kernel, 256, lds2);
   else LAUNCH(gemm_bf16_kernel, 256, lds2);
 #undef LAUNCH

@@ -126,8 +126,17 @@ __device__ __forceinline__ EpiIn epi_load(const GemmArgs& args, int64_t m, int64
   return in;
 }
 
+// bias[n..n+3] for the modes that add one.  Loaded by the CALLER, once per column group and before the first store of the epilogue: CDNA4's vmcnt
+// counts stores too and retires in order, so a load issued after a store cannot be waited for without also waiting for that store's acknowledgement
+// — a bias load inside the per-element body serialised the whole epilogue on its own stores.
 template <int MODE>
-__device__ __forceinline__ void epi4(const GemmArgs& args, float (&v)[4], const EpiIn& in, int64_t m, int64_t n, int split) {
+__device__ __forceinline__ float4 epi_bias(const GemmArgs& args, int64_t n) {
+  if (MODE == EPI_BF16_BIAS_TANH || MODE == EPI_F32_BIAS_RES) return *reinterpret_cast<const float4*>(args.bias + n);
+  return make_float4(0.f, 0.f, 0.f, 0.f);   // (the generic mode fetches its bias inside epi4, behind its runtime flags)
+}
+
+template <int MODE>
+__device__ __forceinline__ void epi4(const GemmArgs& args, float (&v)[4], const EpiIn& in, const float4& b4, int64_t m, int64_t n, int split) {
   constexpr bool G = MODE == EPI_GENERIC;
   if (MODE == EPI_WS || (G && args.accumulate == 3)) {   // split-K partial -> workspace slab [split][M][N] (reduced by splitk_reduce_kernel in a fixed order)
     const f32x4 o_ = {v[0], v[1], v[2], v[3]};
@@ -140,9 +149,10 @@ __device__ __forceinline__ void epi4(const GemmArgs& args, float (&v)[4], const 
     for (int r = 0; r < 4; ++r) atomicAdd(cp + r, v[r]);
     return;
   }
-  if (MODE == EPI_BF16_BIAS_TANH || MODE == EPI_F32_BIAS_RES || (G && args.bias)) {
-    const float4 b4 = *reinterpret_cast<const float4*>(args.bias + n);
-    v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+  if (MODE == EPI_BF16_BIAS_TANH || MODE == EPI_F32_BIAS_RES) { v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w; }
+  if (G && args.bias) {
+    const float4 bg = *reinterpret_cast<const float4*>(args.bias + n);
+    v[0] += bg.x; v[1] += bg.y; v[2] += bg.z; v[3] += bg.w;
   }
   if (MODE == EPI_BF16_BIAS_TANH) {
     // tanh(x) = 1 - 2 / (exp(2x) + 1) on the transcendental unit (v_exp_f32 + v_rcp_f32, ~6 instructions): absolute error ~1e-7, invisible after the
@@ -187,6 +197,12 @@ __device__ __forceinline__ void epi4(const GemmArgs& args, float (&v)[4], const 
 // 16x16 accumulator layout (pipe2 / fallback): lane (lg, l16) holds C[m = .. + l16][n = .. + lg*4 + 0..3] (MFMA issued with swapped operands)
 template <int MODE>
 __device__ __forceinline__ void gemm_epilogue_loops(const GemmArgs& args, f32x4 (&acc)[4][4], int64_t m0, int64_t n0, int wm, int wn, int lg, int l16, int split) {
+  float4 b4[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int64_t n = n0 + wn * 64 + j * 16 + lg * 4;
+    b4[j] = n < args.N ? epi_bias<MODE>(args, n) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int64_t m = m0 + wm * 64 + i * 16 + l16;
@@ -202,7 +218,7 @@ __device__ __forceinline__ void gemm_epilogue_loops(const GemmArgs& args, f32x4 
       const int64_t n = n0 + wn * 64 + j * 16 + lg * 4;
       if (n >= args.N) continue;
       float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      epi4<MODE>(args, v, in[j], m, n, split);
+      epi4<MODE>(args, v, in[j], b4[j], m, n, split);
     }
   }
 }
