@@ -82,24 +82,49 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
     adx[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   const int64_t stride = (int64_t)gridDim.x * 4;
-  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += stride) {
-    const float mu = mean[row], rs = rstd[row];
+  // Software pipeline over the rows of this wave: the loads of the NEXT row are issued before the stores of the current one.  CDNA4 retires vector
+  // memory operations in order (vmcnt counts stores too), so loads issued after a row's stores could only be waited for together with those stores'
+  // acknowledgements — one exposed HBM round trip per row with only two waves per SIMD to cover it.
+  struct RowIn { float4 xv[NCH]; float4 dv[NCH]; float4 rr[NCH]; float mu, rs; };
+  auto load_row = [&](int64_t row, RowIn& in) {
+    in.mu = mean[row]; in.rs = rstd[row];
     const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * D);
-    float4 xh[NCH], g[NCH], rr[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        in.xv[i] = xr[c];
+        if (DY16) {
+          const uint2 r = reinterpret_cast<const uint2*>(static_cast<const uint16_t*>(dy_any) + (size_t)row * D)[c];
+          in.dv[i] = make_float4(__uint_as_float(r.x), __uint_as_float(r.y), 0.f, 0.f);   // raw bf16 pairs, unpacked where they are used
+        } else {
+          in.dv[i] = reinterpret_cast<const float4*>(static_cast<const float*>(dy_any) + (size_t)row * D)[c];
+        }
+        if (dres) in.rr[i] = reinterpret_cast<const float4*>(dres + (size_t)row * D)[c];
+      }
+    }
+  };
+  RowIn cur, nxt;
+  int64_t row = (int64_t)blockIdx.x * 4 + wave;
+  if (row < M) load_row(row, cur);
+  for (; row < M; row += stride) {
+    const bool more = row + stride < M;
+    if (more) load_row(row + stride, nxt);
+    const float mu = cur.mu, rs = cur.rs;
+    float4 xh[NCH], g[NCH];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int c = lane + 64 * i;
       if (c < nch) {
-        const float4 xv = xr[c];
+        const float4 xv = cur.xv[i];
         float4 dv;
         if (DY16) {
-          const uint2 r = reinterpret_cast<const uint2*>(static_cast<const uint16_t*>(dy_any) + (size_t)row * D)[c];
-          dv = make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u));
+          const uint32_t r0 = __float_as_uint(cur.dv[i].x), r1 = __float_as_uint(cur.dv[i].y);
+          dv = make_float4(__uint_as_float(r0 << 16), __uint_as_float(r0 & 0xffff0000u), __uint_as_float(r1 << 16), __uint_as_float(r1 & 0xffff0000u));
         } else {
-          dv = reinterpret_cast<const float4*>(static_cast<const float*>(dy_any) + (size_t)row * D)[c];
+          dv = cur.dv[i];
         }
-        if (dres) rr[i] = reinterpret_cast<const float4*>(dres + (size_t)row * D)[c];
         xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
         g[i] = make_float4(dv.x * gw[i].x, dv.y * gw[i].y, dv.z * gw[i].z, dv.w * gw[i].w);
         s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
@@ -123,7 +148,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         o.z = rs * (g[i].z - c1 - xh[i].z * c2);
         o.w = rs * (g[i].w - c1 - xh[i].w * c2);
         if (dres) {
-          const float4 r = rr[i];
+          const float4 r = cur.rr[i];
           o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
         }
         reinterpret_cast<float4*>(dx32 + (size_t)row * D)[c] = o;
@@ -131,6 +156,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         adx[i].x += o.x; adx[i].y += o.y; adx[i].z += o.z; adx[i].w += o.w;
       }
     }
+    if (more) cur = nxt;
   }
   // column partials: 4 waves -> 1 through LDS, then one f32 atomic per column per workgroup
   if (wave > 0) {
