@@ -253,3 +253,30 @@ extern "C" int enh_adamw_step(float* p, const float* g, float* m, float* v, enh_
                                                                       grad_scale, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)));
   return enh_check_launch("enh_adamw_step");
 }
+
+// Device-side tail of the input pipeline (reference enhancing/dataloader/imagenet.py:26-54: Resize -> RandomCrop / CenterCrop -> RandomHorizontalFlip ->
+// ToTensor): crop window, flip and ToTensor (uint8 HWC -> float CHW / 255) of a batch of decoded, resized images in one pass.  The images arrive as
+// uint8 [B, Hs, Ws, 3] (each resized image in the top-left corner of its Hs x Ws slot), meta[b] = (y0, x0, flip).  Pure data movement + one division:
+// bit-identical to the host path (numpy crop, [:, ::-1], astype(float32) / 255).
+__global__ __launch_bounds__(256) void crop_flip_u8_kernel(const uint8_t* __restrict__ src, const int* __restrict__ meta, float* __restrict__ out, int B, int Hs,
+                                                           int Ws, int R) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over (b, y, x)
+  const int64_t total = (int64_t)B * R * R;
+  if (idx >= total) return;
+  const int x = (int)(idx % R), y = (int)((idx / R) % R);
+  const int64_t b = idx / ((int64_t)R * R);
+  const int y0 = meta[b * 3 + 0], x0 = meta[b * 3 + 1], flip = meta[b * 3 + 2];
+  const int sx = x0 + (flip ? R - 1 - x : x), sy = y0 + y;
+  const uint8_t* p = src + ((b * Hs + sy) * (int64_t)Ws + sx) * 3;
+  float* o = out + b * 3 * (int64_t)R * R + (int64_t)y * R + x;
+  o[0] = (float)p[0] / 255.0f;
+  o[(int64_t)R * R] = (float)p[1] / 255.0f;
+  o[2 * (int64_t)R * R] = (float)p[2] / 255.0f;
+}
+
+extern "C" int enh_crop_flip_u8(const uint8_t* src, int B, int Hs, int Ws, const int32_t* meta, int R, float* out, void* stream) {
+  ENH_REQUIRE(src && meta && out && B > 0 && R > 0 && Hs >= R && Ws >= R, ENH_E_BADARG, "enh_crop_flip_u8: bad argument (the staging slot must hold an R x R window)");
+  const int64_t total = (int64_t)B * R * R;
+  crop_flip_u8_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, (hipStream_t)stream>>>(src, meta, out, B, Hs, Ws, R);
+  return enh_check_launch("enh_crop_flip_u8");
+}

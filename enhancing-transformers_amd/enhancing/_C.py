@@ -47,6 +47,7 @@ SIGNATURES = {
     "enh_unpatchify_loss": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp]),
     "enh_colsum_bf16": (_i32, [_vp, _i64, _i64, _i64, _vp, _i32, _vp]),
     "enh_cast_f32_bf16": (_i32, [_vp, _vp, _i64, _vp]),
+    "enh_crop_flip_u8": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),
     "enh_fused_bias_act": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _f32, _f32, _vp]),
     "enh_channel_sum_f32": (_i32, [_vp, _i32, _i32, _i64, _vp, _i32, _vp]),
     "enh_upfirdn2d": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
@@ -342,6 +343,14 @@ def colsum(x, M: int, N: int, out, accumulate: bool = False):
 
 def cast_bf16(x, y):
     _check(lib().enh_cast_f32_bf16(_p(x, F32, "x"), _p(y, BF16, "y"), x.numel(), _stream()), "enh_cast_f32_bf16")
+
+
+def crop_flip_u8(src, meta, R: int):
+    """src uint8 [B,Hs,Ws,3], meta int32 [B,3] = (y0, x0, flip) -> f32 [B,3,R,R] in [0,1] (enh_crop_flip_u8)"""
+    B, Hs, Ws, _ = src.shape
+    out = torch.empty(B, 3, R, R, dtype=F32, device=src.device)
+    _check(lib().enh_crop_flip_u8(_p(src, torch.uint8, "src"), B, Hs, Ws, _p(meta, torch.int32, "meta"), R, _p(out), _stream()), "enh_crop_flip_u8")
+    return out
 
 
 def adamw_step(p, g, m, v, p_bf16, step: int, lr: float, beta1: float = 0.9, beta2: float = 0.99, eps: float = 1e-8,

@@ -11,6 +11,27 @@ from torch.utils.data import DataLoader, Dataset
 from ..utils.general import initialize_from_config
 
 
+def _collate_for(ds):
+    if getattr(ds, "device_transform", False):
+        from .imagenet import collate_u8
+        return collate_u8
+    return None
+
+
+class _Mapped:
+    """a DataLoader whose batches go through `fn` (the device-side transform) as they are yielded"""
+
+    def __init__(self, loader, fn) -> None:
+        self.loader, self.fn = loader, fn
+
+    def __len__(self) -> int:
+        return len(self.loader)
+
+    def __iter__(self):
+        for b in self.loader:
+            yield self.fn(b)
+
+
 class DataModuleFromConfig:
     def __init__(self, batch_size: int, train=None, validation=None, test=None, num_workers: Optional[int] = None):
         self.batch_size = batch_size
@@ -50,7 +71,12 @@ class DataModuleFromConfig:
             from torch.utils.data.distributed import DistributedSampler
             sampler = DistributedSampler(ds, num_replicas=self.world, rank=self.rank, shuffle=shuffle)
             self._samplers[key] = sampler
-        return DataLoader(ds, batch_size=self.batch_size, num_workers=workers, shuffle=shuffle and sampler is None, sampler=sampler)
+        loader = DataLoader(ds, batch_size=self.batch_size, num_workers=workers, shuffle=shuffle and sampler is None, sampler=sampler,
+                            collate_fn=_collate_for(ds))
+        if getattr(ds, "device_transform", False):       # crop + flip + ToTensor run on the GPU (imagenet.DeviceTransform)
+            from .imagenet import DeviceTransform
+            return _Mapped(loader, DeviceTransform(ds.resolution))
+        return loader
 
     def set_epoch(self, epoch: int) -> None:
         for s in self._samplers.values():

@@ -3,7 +3,12 @@
 Resize(R) + RandomCrop(R) + RandomHorizontalFlip for train, Resize(R) + CenterCrop(R) for validation, no
 mean/std normalisation.  torchvision is not available here, so the folder walk and the transforms are a small
 PIL / numpy implementation; if ``root`` does not exist the constructor raises (use
-``enhancing.dataloader.synthetic.SyntheticImages`` for synthetic runs — bench.py and the shipped yaml do)."""
+``enhancing.dataloader.synthetic.SyntheticImages`` for synthetic runs — bench.py and the shipped yaml do).
+
+Device-side tail (``device_transform=True``): the worker processes only decode and resize (PIL) and hand over uint8 pixels plus the crop window
+and flip decision they drew; ``DeviceTransform`` then does crop + flip + ToTensor for the whole batch in one HIP kernel (``enh_crop_flip_u8``) and
+yields the same ``{'image', 'class'}`` batch — a quarter of the host-to-device bytes (uint8 instead of float32) and no per-sample float work on the
+host.  The random numbers are drawn in the same order as on the host path, so both paths give bit-identical batches for the same seed."""
 from __future__ import annotations
 
 import os
@@ -30,19 +35,22 @@ def _index(root: str) -> Tuple[List[str], List[int]]:
 class _ImageNetBase(Dataset):
     split = "train"
 
-    def __init__(self, root: str, resolution: int = 256, resize_ratio: float = 0.75) -> None:
+    def __init__(self, root: str, resolution: int = 256, resize_ratio: float = 0.75, device_transform: bool = False) -> None:
         folder = os.path.join(root, self.split)
         if not os.path.isdir(folder):
             raise FileNotFoundError(f"{folder} not found; for synthetic data use enhancing.dataloader.synthetic.SyntheticImages")
         self.resolution = resolution
+        self.device_transform = device_transform
         self.paths, self.labels = _index(folder)
 
     def __len__(self) -> int:
         return len(self.paths)
 
-    def _load(self, path: str, train: bool) -> torch.Tensor:
+    def _decode_resize(self, path: str):
+        """PIL decode + Resize(R) (shorter side -> R, bilinear); then the crop window and flip decision, drawn in the order the host path uses them"""
         from PIL import Image
         r = self.resolution
+        train = self.split == "train"
         im = Image.open(path).convert("RGB")
         w, h = im.size
         s = r / min(w, h)
@@ -52,13 +60,48 @@ class _ImageNetBase(Dataset):
             x0, y0 = np.random.randint(0, w - r + 1), np.random.randint(0, h - r + 1)
         else:
             x0, y0 = (w - r) // 2, (h - r) // 2
-        a = np.asarray(im.crop((x0, y0, x0 + r, y0 + r)), dtype=np.float32) / 255.0
-        if train and np.random.rand() < 0.5:
+        flip = bool(train and np.random.rand() < 0.5)
+        return np.array(im, dtype=np.uint8), y0, x0, flip
+
+    def _load(self, path: str) -> torch.Tensor:
+        r = self.resolution
+        px, y0, x0, flip = self._decode_resize(path)
+        a = px[y0:y0 + r, x0:x0 + r].astype(np.float32) / 255.0
+        if flip:
             a = a[:, ::-1]
         return torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1)))
 
     def __getitem__(self, i: int):
-        return {"image": self._load(self.paths[i], self.split == "train"), "class": torch.tensor([self.labels[i]])}
+        label = torch.tensor([self.labels[i]])
+        if self.device_transform:
+            px, y0, x0, flip = self._decode_resize(self.paths[i])
+            return {"pixels_u8": torch.from_numpy(px), "window": torch.tensor([y0, x0, int(flip)], dtype=torch.int32), "class": label}
+        return {"image": self._load(self.paths[i]), "class": label}
+
+
+def collate_u8(samples):
+    """device_transform samples have different sizes: each goes into the top-left corner of a common [Hmax, Wmax, 3] slot"""
+    H, W = max(s["pixels_u8"].shape[0] for s in samples), max(s["pixels_u8"].shape[1] for s in samples)
+    px = torch.zeros(len(samples), H, W, 3, dtype=torch.uint8)
+    for b, s in enumerate(samples):
+        h, w, _ = s["pixels_u8"].shape
+        px[b, :h, :w] = s["pixels_u8"]
+    return {"pixels_u8": px, "window": torch.stack([s["window"] for s in samples]), "class": torch.stack([s["class"] for s in samples])}
+
+
+class DeviceTransform:
+    """crop + flip + ToTensor on the device for a collate_u8 batch -> the reference's batch contract {'image': float [B,3,R,R] in [0,1], 'class': [B,1]}"""
+
+    def __init__(self, resolution: int, device=None) -> None:
+        self.resolution, self.device = resolution, device
+
+    def __call__(self, batch):
+        if "pixels_u8" not in batch:
+            return batch
+        from .. import _C
+        dev = self.device if self.device is not None else torch.device("cuda", torch.cuda.current_device())
+        img = _C.crop_flip_u8(batch["pixels_u8"].to(dev, non_blocking=True), batch["window"].to(dev, non_blocking=True).contiguous(), self.resolution)
+        return {"image": img, "class": batch["class"]}
 
 
 class ImageNetTrain(_ImageNetBase):

@@ -33,6 +33,14 @@ class Trainer:
         self.val_batches = val_batches
         self.rank, self.local_rank, self.world = 0, 0, 1
         self.global_step = 0
+        self.current_epoch = 0
+        self.callbacks = list(callbacks or [])      # objects with Lightning's hook names (enhancing/utils/callback.py); missing hooks are skipped
+
+    def _hook(self, name: str, *args) -> None:
+        for cb in self.callbacks:
+            fn = getattr(cb, name, None)
+            if callable(fn):
+                fn(self, *args)
 
     def _log(self, rec: dict) -> None:
         if self.rank != 0:
@@ -65,7 +73,9 @@ class Trainer:
             import torch.distributed as dist
             dist.broadcast(opts[1].store.p, 0)
         t0, seen = time.time(), 0
+        self._hook("on_pretrain_routine_start", model)
         for epoch in range(self.max_epochs):
+            self.current_epoch = epoch
             loader = data.train_dataloader()
             if hasattr(data, "set_epoch"):
                 data.set_epoch(epoch)          # DistributedSampler reshuffle (what Lightning does for strategy="ddp")
@@ -85,6 +95,7 @@ class Trainer:
                             o.param_groups[0]["lr"] = base_lr * mult
                         o.step()
                 seen += batch["image"].shape[0] * self.world
+                self._hook("on_train_batch_end", model, None, batch, batch_idx)
                 if last:
                     self.global_step += 1
                     model.global_step = self.global_step
@@ -101,6 +112,7 @@ class Trainer:
                     if vi >= self.val_batches:
                         break
                     model.validation_step(vb, vi)
+                    self._hook("on_validation_batch_end", model, None, vb, 0, vi)
                 self._log({k: float(v) for k, v in model.logged.items() if k.startswith("val/")} | {"epoch": epoch})
             if self.rank == 0:
                 ck = os.path.join(self.root, "ckpt")

@@ -76,3 +76,17 @@ def get_config_from_file(config_file) -> AttrDict:
             raise ValueError(f"unsupported base_config {base!r}")
         cfg = _merge(get_config_from_file(base), cfg)
     return AttrDict.wrap(cfg)
+
+
+def setup_callbacks(exp_config, config):
+    """reference general.py:43-60: [SetupCallback, (checkpointing), ImageLogger] + logger.  Checkpoints are written by the in-repo Trainer itself (one
+    ``{"state_dict": ...}`` file per epoch, what ModelCheckpoint(save_top_k=-1) produces); the wandb logger needs a package that is not installable here,
+    so the logger slot is None and scalar logs go to the Trainer's metrics.jsonl."""
+    import os
+    import pathlib
+    from datetime import datetime
+    from .callback import ImageLogger, SetupCallback
+    now = datetime.now().strftime('%d%m%Y_%H%M%S')
+    basedir = pathlib.Path("experiments", exp_config.name, now)
+    os.makedirs(basedir, exist_ok=True)
+    return [SetupCallback(config, exp_config, basedir), ImageLogger(exp_config.batch_frequency, exp_config.max_images)], None

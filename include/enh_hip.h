@@ -173,6 +173,11 @@ int enh_cast_f32_bf16(const float* x, enh_bf16* y, int64_t n, void* stream);
 int enh_adamw_step(float* p, const float* g, float* m, float* v, enh_bf16* p_bf16, int64_t n, int step, float lr,
                    float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream);
 
+/* Device-side tail of the input pipeline (enhancing/dataloader/imagenet.py:26-54: ... RandomCrop / CenterCrop -> RandomHorizontalFlip -> ToTensor):
+ * src uint8 [B,Hs,Ws,3] (decoded + resized images, each in the top-left corner of its slot), meta int32 [B,3] = (y0, x0, flip) -> out f32 [B,3,R,R] in [0,1].
+ * The window (y0..y0+R, x0..x0+R) must lie inside the image; exact (uint8 / 255.0f). */
+int enh_crop_flip_u8(const uint8_t* src, int B, int Hs, int Ws, const int32_t* meta, int R, float* out, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * StyleGAN2-discriminator native ops ("next" row) — drop-ins for the reference's two pybind ops
  * ------------------------------------------------------------------------------------------------ */

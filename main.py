@@ -37,7 +37,7 @@ if __name__ == '__main__':
         sys.exit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")))
 
     from enhancing.engine.trainer import Trainer
-    from enhancing.utils.general import get_config_from_file, initialize_from_config, set_seed
+    from enhancing.utils.general import AttrDict, get_config_from_file, initialize_from_config, set_seed, setup_callbacks
 
     set_seed(args.seed)
     config = get_config_from_file(Path(ROOT) / "configs" / (args.config + ".yaml"))
@@ -50,7 +50,11 @@ if __name__ == '__main__':
     # exact mode (what the reference runs without --use_amp), and asking for both is an error instead of being silently resolved
     if args.use_amp and args.fp32:
         sys.exit("--use_amp (mixed precision) and --fp32 (no mixed precision) contradict each other")
-    trainer = Trainer(max_epochs=args.epochs, precision=32 if args.fp32 else 16, gpus=args.num_gpus, num_nodes=args.num_nodes,
+    exp_config = AttrDict(vars(args))                 # reference main.py:37: the experiment config is the parsed command line (+ name)
+    exp_config.update(name=args.config, epochs=args.epochs, update_every=args.update_every, base_lr=args.base_lr, use_amp=args.use_amp,
+                      batch_frequency=args.batch_frequency, max_images=args.max_images)
+    callbacks, _logger = setup_callbacks(exp_config, config)      # reference main.py:47
+    trainer = Trainer(callbacks=callbacks, max_epochs=args.epochs, precision=32 if args.fp32 else 16, gpus=args.num_gpus, num_nodes=args.num_nodes,
                       strategy="ddp" if args.num_nodes > 1 or args.num_gpus > 1 else None, accumulate_grad_batches=args.update_every,
                       max_steps=args.max_steps, default_root_dir=os.path.join(ROOT, "experiments", args.config))
     trainer.fit(model, data)

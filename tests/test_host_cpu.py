@@ -268,6 +268,94 @@ def test_imagenet_folder_dataset_contract(tmp_path):
         type(tr)(str(tmp_path / "nope"))
 
 
+def test_device_transform_path_equals_the_host_path(tmp_path, monkeypatch):
+    """device_transform=True: workers hand over uint8 pixels + the crop window / flip they drew; crop + flip + ToTensor then run in ONE kernel
+    (enh_crop_flip_u8, replaced here by its numpy statement).  Same seed -> bit-identical batches on both paths."""
+    import numpy as np
+    from PIL import Image
+    from enhancing import _C
+    from enhancing.dataloader import DataModuleFromConfig
+    rng = np.random.default_rng(1)
+    for ci, wnid in enumerate(("a", "b")):
+        d = tmp_path / "train" / wnid
+        d.mkdir(parents=True)
+        for k in range(3):
+            Image.fromarray(rng.integers(0, 256, (41 + 9 * k, 60 - 11 * ci, 3), dtype=np.uint8)).save(d / f"i{k}.png")
+
+    def crop_flip_u8(src, meta, R):      # the kernel's contract, stated in numpy
+        out = np.zeros((src.shape[0], 3, R, R), np.float32)
+        for b in range(src.shape[0]):
+            y0, x0, flip = (int(v) for v in meta[b])
+            w = src[b, y0:y0 + R, x0:x0 + R].numpy()
+            w = w[:, ::-1] if flip else w
+            out[b] = w.astype(np.float32).transpose(2, 0, 1) / np.float32(255.0)
+        return torch.from_numpy(out)
+    monkeypatch.setattr(_C, "crop_flip_u8", crop_flip_u8)
+    batches = {}
+    for dev in (False, True):
+        node = {"target": "enhancing.dataloader.imagenet.ImageNetTrain", "params": {"root": str(tmp_path), "resolution": 32, "device_transform": dev}}
+        dm = DataModuleFromConfig(batch_size=3, num_workers=0, train=node)
+        dm.setup()
+        loader = dm.train_dataloader()
+        if dev:
+            loader.fn.device = torch.device("cpu")
+        np.random.seed(7)
+        torch.manual_seed(7)
+        batches[dev] = list(loader)
+    assert len(batches[True]) == 2 and set(batches[True][0]) == {"image", "class"}
+    for a, b in zip(batches[False], batches[True]):
+        assert torch.equal(a["image"], b["image"]) and torch.equal(a["class"], b["class"])
+
+
+def test_image_logger_and_setup_callbacks(tmp_path, monkeypatch):
+    """reference utils/callback.py:21-141 + general.py:43-60: frequency rule (every batch_frequency batches and the early 2, 4, ... steps), max_images,
+    clamp, file naming, torchvision's grid geometry; the Trainer calls the Lightning hook names"""
+    import numpy as np
+    from PIL import Image
+    from enhancing.utils.callback import ImageLogger, SetupCallback, make_grid
+    from enhancing.utils.general import AttrDict, setup_callbacks
+    g = make_grid(torch.ones(5, 3, 8, 6), nrow=4)
+    assert g.shape == (3, 2 * 10 + 2, 4 * 8 + 2) and g[:, :2].sum() == 0 and g[:, 2:10, 2:8].min() == 1 and g[:, 12:20, 10:16].sum() == 0
+    assert make_grid(torch.ones(1, 1, 4, 4)).shape == (3, 4, 4)
+
+    class Mod:
+        training, global_step, calls = True, 3, 0
+
+        def eval(self): self.training = False
+        def train(self): self.training = True
+
+        def log_images(self, batch, split="train", pl_module=None):
+            assert not self.training
+            self.calls += 1
+            return {"originals": batch["image"] * 2 - 0.5, "reconstructions": batch["image"]}
+
+    class Tr:
+        rank, root, current_epoch = 0, str(tmp_path), 1
+    lg = ImageLogger(batch_frequency=8, max_images=2)
+    assert lg.log_steps == [1, 2, 4, 8]
+    mod, batch = Mod(), {"image": torch.rand(6, 3, 16, 16)}
+    fired = []
+    for bi in range(20):
+        before = mod.calls
+        lg.on_train_batch_end(Tr(), mod, None, batch, bi)
+        if mod.calls > before:
+            fired.append(bi)
+    assert fired == [0, 2, 4, 8, 16] and mod.training      # the reference's rule: firing at 0 pops the '1' entry (callback.py:117-124)
+    f = tmp_path / "results" / "train" / "originals_gs-000003_e-000001_b-000016.png"
+    assert f.exists() and (tmp_path / "results" / "train" / "reconstructions_gs-000003_e-000001_b-000000.png").exists()
+    im = np.asarray(Image.open(f))
+    assert im.shape == (16 + 4, 2 * 18 + 2, 3)                                  # max_images = 2 -> one row of the nrow=4 grid, 2 px padding
+    Tr.rank = 1
+    lg.on_validation_batch_end(Tr(), mod, None, batch, 0, 0)                   # rank_zero_only
+    assert not (tmp_path / "results" / "val").exists()
+    monkeypatch.chdir(tmp_path)
+    cbs, logger = setup_callbacks(AttrDict(name="exp", batch_frequency=750, max_images=4), AttrDict(model={}))
+    assert isinstance(cbs[0], SetupCallback) and isinstance(cbs[1], ImageLogger) and logger is None
+    Tr.rank = 0
+    cbs[0].on_pretrain_routine_start(Tr(), mod)
+    assert cbs[0].logdir.is_dir() and cbs[0].ckptdir.is_dir()
+
+
 def _build_ours(case, seed):
     """this package's modules in the reference's construction order (vitvqgan.py:34-39)"""
     sys_path_oracle = os.path.join(ROOT, "oracle")

@@ -382,3 +382,21 @@ def test_gemm_suite_under_each_kernel_family(sel, symbol):
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_ops_gpu.py", "-q", "-x", "-m", "gpu", "-k", "gemm and not under_each", "-p", "no:cacheprovider"],
                        env=env, cwd=root, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:]
+
+
+def test_crop_flip_u8_device_transform():
+    """enh_crop_flip_u8 (device-side crop + flip + ToTensor of the input pipeline, reference dataloader/imagenet.py:30-36) is bit-identical to the host path"""
+    import numpy as np
+    from enhancing import _C
+    rs = np.random.RandomState(3)
+    B, Hs, Ws, R = 5, 47, 61, 32
+    src = rs.randint(0, 256, (B, Hs, Ws, 3)).astype(np.uint8)
+    meta = np.stack([rs.randint(0, Hs - R + 1, B), rs.randint(0, Ws - R + 1, B), rs.randint(0, 2, B)], 1).astype(np.int32)
+    out = _C.crop_flip_u8(torch.from_numpy(src).cuda(), torch.from_numpy(meta).cuda(), R).cpu().numpy()
+    for b in range(B):
+        y0, x0, flip = (int(v) for v in meta[b])
+        w = src[b, y0:y0 + R, x0:x0 + R]
+        w = w[:, ::-1] if flip else w
+        assert np.array_equal(out[b], w.astype(np.float32).transpose(2, 0, 1) / np.float32(255.0)), b
+    with pytest.raises(RuntimeError):
+        _C.crop_flip_u8(torch.from_numpy(src).cuda(), torch.from_numpy(meta).cuda(), 64)      # window larger than the staging slot
