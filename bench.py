@@ -111,6 +111,8 @@ def main():
     ap.add_argument("--config", type=str, default="imagenet_vitvq_base")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--grad-bf16", action="store_true", help="all-reduce the gradient buckets as bf16 (half the xGMI bytes); default fp32")
+    ap.add_argument("--grad-algo", choices=["allreduce", "rs_ag"], default="allreduce",
+                    help="per bucket: one RCCL all-reduce (default) or reduce-scatter + all-gather (SURVEY.md 8e's direct exchange); same sums")
     args = ap.parse_args()
 
     import torch
@@ -130,7 +132,7 @@ def main():
     model = initialize_from_config(cfg.model)
     eng = model.engine
     if world > 1:
-        eng.comm = GradSync(eng.store, compress="bf16" if args.grad_bf16 else None)
+        eng.comm = GradSync(eng.store, compress="bf16" if args.grad_bf16 else None, algo=args.grad_algo)
         eng.comm.broadcast_parameters(0)
         eng.store.refresh_shadows()
     B, size = args.batch, cfg.model.params.image_size

@@ -24,8 +24,12 @@ import torch.distributed as dist
 
 
 class GradSync:
-    def __init__(self, store, process_group=None, min_bucket_elems: int = 1 << 20, compress: Optional[str] = None) -> None:
-        """compress = "bf16": buckets travel as bfloat16 (half the xGMI bytes: 341 MB instead of 683 MB per step at base); the sum is
+    def __init__(self, store, process_group=None, min_bucket_elems: int = 1 << 20, compress: Optional[str] = None, algo: str = "allreduce") -> None:
+        """algo = "allreduce": one all-reduce per bucket (RCCL chooses the schedule).  algo = "rs_ag": the bucket is reduce-scattered (each rank sums
+        1/world of it) and all-gathered back — the direct exchange SURVEY.md §8e prefers on a fully connected xGMI node (every rank talks to all 7
+        peers at once, (world-1)/world of the bucket each way, instead of a ring bounded by one link); the elements beyond a multiple of `world`
+        go through a small all-reduce.  Both give the same sums.  Which is faster on 8 x MI355X is a measurement this build has not been able to make.
+        compress = "bf16": buckets travel as bfloat16 (half the xGMI bytes: 341 MB instead of 683 MB per step at base); the sum is
         formed in bf16 by the collective, so this trades ~3 significant digits of the summed gradient for bandwidth — off by default"""
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
@@ -40,11 +44,16 @@ class GradSync:
         self.bytes_reduced = 0
         self.gap_elems = 0                           # elements finish() had to reduce because nobody announced them
         self.announced: List[str] = []               # prefixes in announce order (last step), for the schedule tests
+        if algo not in ("allreduce", "rs_ag"):
+            raise ValueError("algo must be 'allreduce' or 'rs_ag'")
+        self.algo = algo
+        self._ordered = dist.get_backend(process_group) == "nccl"   # RCCL runs a group's collectives in issue order on its own stream; gloo does not promise it
         if compress not in (None, "bf16"):
             raise ValueError("compress must be None or 'bf16'")
         self.compress = compress
         self._g16 = torch.empty_like(store.g, dtype=torch.bfloat16) if compress == "bf16" else None
         self._copyback: List[Tuple[int, int]] = []
+        self._shards: List[torch.Tensor] = []
 
     def broadcast_parameters(self, src: int = 0) -> None:
         """DDP's initial parameter broadcast: every rank starts from rank `src`'s weights."""
@@ -79,8 +88,18 @@ class GradSync:
             view = self._g16[b:e]
             view.copy_(self.store.g[b:e])             # f32 -> bf16 on the compute stream, ordered before the collective
             self._copyback.append((b, e))
-        self._handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
         self.bytes_reduced += view.numel() * view.element_size()
+        main = (view.numel() // self.world) * self.world if self.algo == "rs_ag" and self.world > 1 else 0
+        if main:
+            shard = torch.empty(main // self.world, dtype=view.dtype, device=view.device)
+            rs = dist.reduce_scatter_tensor(shard, view[:main], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            if not self._ordered:
+                rs.wait()
+            self._handles.append(rs)
+            self._handles.append(dist.all_gather_into_tensor(view[:main], shard, group=self.pg, async_op=True))
+            self._shards.append(shard)            # kept alive until finish()
+        if main < view.numel():
+            self._handles.append(dist.all_reduce(view[main:], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
     def finish(self) -> None:
         """Flush what is left, all-reduce any range of the flat gradient nobody announced (safety net: a missed unit must
@@ -103,6 +122,7 @@ class GradSync:
             self.store.g[b:e].copy_(self._g16[b:e])
         self._copyback = []
         self._handles = []
+        self._shards = []
         self._done = []
 
     def begin_step(self) -> None:

@@ -23,7 +23,7 @@ class FakeStore:
         return self.off[prefix]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, algo="allreduce"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import sys
@@ -31,7 +31,7 @@ def _worker(rank, world, port, q):
     from enhancing.engine.ddp import GradSync
     store = FakeStore(rank)
     local = store.g.clone()
-    sync = GradSync(store, min_bucket_elems=2000)
+    sync = GradSync(store, min_bucket_elems=2000, algo=algo)
     sync.broadcast_parameters(0)
     assert torch.all(store.p == 0.0)
     for step in range(2):  # two steps: state must reset between them
@@ -44,21 +44,28 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_gradsync_gloo_world2():
+import pytest
+
+
+@pytest.mark.parametrize("world,algo", [(2, "allreduce"), (2, "rs_ag"), (3, "rs_ag")])
+def test_gradsync_gloo_world2(world, algo):
+    """bucketed gradient sum, as one all-reduce per bucket or as reduce-scatter + all-gather (world 3: bucket sizes are not multiples of the world size,
+    so the remainder path runs too)"""
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, algo)) for r in range(world)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=120) for _ in range(2)]
+    got = [q.get(timeout=120) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     got.sort(key=lambda t: t[0])
-    total = got[0][2] + got[1][2]
+    total = sum(g[2] for g in got)
     for _, reduced, _ in got:
-        assert torch.allclose(reduced, total, atol=1e-6)   # SUM; the 1/world mean is folded into AdamW's grad_scale
+        assert torch.allclose(reduced, total, atol=1e-5)   # SUM; the 1/world mean is folded into AdamW's grad_scale
+        assert torch.equal(reduced, got[0][1])             # every rank ends with the same bits
 
 
 def test_gradsync_reduces_unannounced_slices():
