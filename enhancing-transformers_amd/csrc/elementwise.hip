@@ -71,8 +71,10 @@ __global__ __launch_bounds__(256) void unpatchify_loss_kernel(
 }
 
 // out[n] += sum_m x[m,n] ; x bf16.  Wave = 128 columns (4 B per lane), 4 waves split the rows of a chunk.
+// part_stride == 0: every row chunk adds into out[n] with f32 atomics; part_stride == N: chunk y stores its partial at out[y*N + n] (deterministic
+// form: colsum_reduce_kernel then adds the chunks in a fixed order)
 __global__ __launch_bounds__(256) void colsum_bf16_kernel(const uint16_t* __restrict__ x, int64_t M, int64_t N,
-                                                          int64_t ldx, int64_t rows_per_block, float* __restrict__ out) {
+                                                          int64_t ldx, int64_t rows_per_block, float* __restrict__ out, int64_t part_stride) {
   __shared__ float s_part[3][128];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t n0 = (int64_t)blockIdx.x * 128 + lane * 2;
@@ -91,15 +93,15 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const uint16_t* __rest
   __syncthreads();
   if (wave == 0 && n0 < N) {
     for (int ww = 0; ww < 3; ++ww) { a0 += s_part[ww][lane * 2]; a1 += s_part[ww][lane * 2 + 1]; }
-    atomicAdd(&out[n0], a0);
-    atomicAdd(&out[n0 + 1], a1);
+    { if (part_stride) out[(int64_t)blockIdx.y * part_stride + n0] = a0; else atomicAdd(&out[n0], a0); }
+    { if (part_stride) out[(int64_t)blockIdx.y * part_stride + n0 + 1] = a1; else atomicAdd(&out[n0 + 1], a1); }
   }
 }
 
 // Wide variant (N % 8 == 0, 16-byte aligned rows): a lane owns 8 columns (one 16-byte load per row), a wave covers 512 contiguous
 // columns = 1 KiB of a row, and four rows are in flight per wave.
 __global__ __launch_bounds__(256) void colsum_bf16_wide_kernel(const uint16_t* __restrict__ x, int64_t M, int64_t N, int64_t ldx,
-                                                               int64_t rows_per_block, float* __restrict__ out) {
+                                                               int64_t rows_per_block, float* __restrict__ out, int64_t part_stride) {
   __shared__ float s_part[3][512];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t n0 = (int64_t)blockIdx.x * 512 + lane * 8;
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(256) void colsum_bf16_wide_kernel(const uint16_t* _
     for (int k = 0; k < 8; ++k) {
       float a = acc[k];
       for (int ww = 0; ww < 3; ++ww) a += s_part[ww][lane * 8 + k];
-      atomicAdd(&out[n0 + k], a);
+      { if (part_stride) out[(int64_t)blockIdx.y * part_stride + n0 + k] = a; else atomicAdd(&out[n0 + k], a); }
     }
   }
 }
@@ -215,25 +217,51 @@ extern "C" int enh_unpatchify_loss(const float* pix, const float* target, int B,
   return enh_check_launch("enh_unpatchify_loss");
 }
 
-extern "C" int enh_colsum_bf16(const enh_bf16* x, int64_t M, int64_t N, int64_t ldx, float* out, int accumulate, void* stream) {
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ part, int chunks, int64_t N, float* __restrict__ out, int accumulate) {
+  __shared__ float s_red[256];
+  const int64_t n = (int64_t)blockIdx.x * 16 + (threadIdx.x & 15);
+  const float t = fixed_order_rowsum16(part, chunks, N, n, n < N, s_red);
+  if ((threadIdx.x >> 4) == 0 && n < N) out[n] = accumulate ? out[n] + t : t;
+}
+
+static int64_t colsum_chunks(int64_t M) {
+  const int64_t chunks = (M + 511) / 512;
+  return chunks > 256 ? 256 : chunks;
+}
+
+extern "C" size_t enh_colsum_bf16_workspace_bytes(int64_t M, int64_t N) { return M > 0 && N > 0 ? (size_t)colsum_chunks(M) * N * sizeof(float) : 0; }
+
+static int colsum_bf16_impl(const enh_bf16* x, int64_t M, int64_t N, int64_t ldx, float* out, int accumulate, float* part, void* stream) {
   ENH_REQUIRE(x && out, ENH_E_BADARG, "enh_colsum_bf16: null pointer");
   ENH_REQUIRE(M > 0 && N > 0 && N % 2 == 0 && ldx % 2 == 0, ENH_E_SHAPE, "enh_colsum_bf16: N and ldx must be even");
   hipStream_t s = (hipStream_t)stream;
-  if (!accumulate) {
+  if (!accumulate && !part) {
     hipError_t e = hipMemsetAsync(out, 0, (size_t)N * sizeof(float), s);
     if (e != hipSuccess) { enh_set_error("enh_colsum_bf16: memset failed: %s", hipGetErrorString(e)); return ENH_E_HIP_BASE - (int)e; }
   }
-  int64_t chunks = (M + 511) / 512;
-  if (chunks > 256) chunks = 256;
+  const int64_t chunks = colsum_chunks(M);
   const int64_t rows_per_block = (M + chunks - 1) / chunks;
+  float* dst = part ? part : out;
+  const int64_t stride = part ? N : 0;
   if (N % 8 == 0 && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0) {
     dim3 grid((unsigned)((N + 511) / 512), (unsigned)chunks);
-    colsum_bf16_wide_kernel<<<grid, 256, 0, s>>>(x, M, N, ldx, rows_per_block, out);
+    colsum_bf16_wide_kernel<<<grid, 256, 0, s>>>(x, M, N, ldx, rows_per_block, dst, stride);
   } else {
     dim3 grid((unsigned)((N + 127) / 128), (unsigned)chunks);
-    colsum_bf16_kernel<<<grid, 256, 0, s>>>(x, M, N, ldx, rows_per_block, out);
+    colsum_bf16_kernel<<<grid, 256, 0, s>>>(x, M, N, ldx, rows_per_block, dst, stride);
   }
+  if (part) colsum_reduce_kernel<<<dim3((unsigned)((N + 15) / 16)), 256, 0, s>>>(part, (int)chunks, N, out, accumulate);
   return enh_check_launch("enh_colsum_bf16");
+}
+
+extern "C" int enh_colsum_bf16(const enh_bf16* x, int64_t M, int64_t N, int64_t ldx, float* out, int accumulate, void* stream) {
+  return colsum_bf16_impl(x, M, N, ldx, out, accumulate, nullptr, stream);
+}
+
+// deterministic form: per-chunk partial rows in `ws` (enh_colsum_bf16_workspace_bytes), added in a fixed order
+extern "C" int enh_colsum_bf16_ws(const enh_bf16* x, int64_t M, int64_t N, int64_t ldx, float* out, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+  ENH_REQUIRE(ws && ws_bytes >= enh_colsum_bf16_workspace_bytes(M, N), ENH_E_WORKSPACE, "enh_colsum_bf16_ws: workspace too small (%zu bytes)", ws_bytes);
+  return colsum_bf16_impl(x, M, N, ldx, out, accumulate, (float*)ws, stream);
 }
 
 extern "C" int enh_cast_f32_bf16(const float* x, enh_bf16* y, int64_t n, void* stream) {

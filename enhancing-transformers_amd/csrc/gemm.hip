@@ -608,7 +608,7 @@ extern "C" int enh_gemm_bf16_ws(const enh_bf16* A, int64_t lda, int trans_a, con
     // with a workspace: partial slabs + a fixed-order second pass (deterministic); without: f32 atomics into C (N % 4 == 0 and a dense slab need ldc == N
     // only for the workspace form)
     const size_t need = (size_t)pl.splits * (size_t)M * (size_t)N * sizeof(float);
-    if (workspace && family == 7) {
+    if (workspace) {   // every kernel family shares the epilogue, so the two-pass form is not tied to the 256 x 256 kernel
       ENH_REQUIRE(workspace_bytes >= need, ENH_E_WORKSPACE, "enh_gemm_bf16: workspace of %zu bytes needed, %zu given", need, workspace_bytes);
       g.accumulate = 3; g.ws = (float*)workspace; two_pass = true;
     } else {

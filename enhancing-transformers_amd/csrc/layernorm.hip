@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
                                                      const float* __restrict__ rstd, const float* __restrict__ dres,
                                                      int64_t M, int D, float* __restrict__ dx32,
                                                      uint16_t* __restrict__ dx16, float* __restrict__ dw,
-                                                     float* __restrict__ db, float* __restrict__ dxsum) {
+                                                     float* __restrict__ db, float* __restrict__ dxsum, float* __restrict__ part) {
   __shared__ float s_dw[3][NCH * 256];  // waves 1..3 park their column partials here
   __shared__ float s_db[3][NCH * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -179,8 +179,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           for (int ww = 0; ww < 3; ++ww) { aw[k] += s_dw[ww][c * 4 + k]; ab[k] += s_db[ww][c * 4 + k]; }
-          atomicAdd(&dw[c * 4 + k], aw[k]);
-          atomicAdd(&db[c * 4 + k], ab[k]);
+          if (part) {   // deterministic form: this workgroup's partial row; ln_bwd_reduce_kernel adds the rows in a fixed order
+            part[((size_t)blockIdx.x * 3 + 0) * D + c * 4 + k] = aw[k];
+            part[((size_t)blockIdx.x * 3 + 1) * D + c * 4 + k] = ab[k];
+          } else {
+            atomicAdd(&dw[c * 4 + k], aw[k]);
+            atomicAdd(&db[c * 4 + k], ab[k]);
+          }
         }
       }
     }
@@ -205,7 +210,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             for (int ww = 0; ww < 3; ++ww) ax[k] += s_dw[ww][c * 4 + k];
-            atomicAdd(&dxsum[c * 4 + k], ax[k]);
+            if (part) part[((size_t)blockIdx.x * 3 + 2) * D + c * 4 + k] = ax[k];
+            else atomicAdd(&dxsum[c * 4 + k], ax[k]);
           }
         }
       }
@@ -232,29 +238,62 @@ extern "C" int enh_layernorm_forward(const float* x, const float* w, const float
 
 template <bool DY16>
 static void ln_bwd_launch(int grid, hipStream_t s, const void* dy, const float* x, const float* w, const float* mean, const float* rstd,
-                          const float* dres, int64_t M, int D, float* dx_f32, enh_bf16* dx_bf16, float* dw, float* db, float* dx_colsum) {
+                          const float* dres, int64_t M, int D, float* dx_f32, enh_bf16* dx_bf16, float* dw, float* db, float* dx_colsum, float* part) {
   switch ((D + 255) / 256) {
-    case 1: ln_bwd_kernel<1, DY16><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum); break;
-    case 2: ln_bwd_kernel<2, DY16><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum); break;
-    case 3: ln_bwd_kernel<3, DY16><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum); break;
-    case 4: ln_bwd_kernel<4, DY16><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum); break;
-    case 5: ln_bwd_kernel<5, DY16><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum); break;
-    default: ln_bwd_kernel<8, DY16><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum); break;
+    case 1: ln_bwd_kernel<1, DY16><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum, part); break;
+    case 2: ln_bwd_kernel<2, DY16><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum, part); break;
+    case 3: ln_bwd_kernel<3, DY16><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum, part); break;
+    case 4: ln_bwd_kernel<4, DY16><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum, part); break;
+    case 5: ln_bwd_kernel<5, DY16><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum, part); break;
+    default: ln_bwd_kernel<8, DY16><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum, part); break;
   }
+}
+
+// second pass of the deterministic form: out[j] += sum over the workgroups of part[wg][which][j], in a fixed order (common.h fixed_order_rowsum16)
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ part, int nwg, int D, float* __restrict__ dw, float* __restrict__ db,
+                                                            float* __restrict__ dxsum) {
+  __shared__ float s_red[256];
+  const int which = blockIdx.y;
+  float* out = which == 0 ? dw : (which == 1 ? db : dxsum);
+  if (!out) return;   // (uniform per workgroup)
+  const int j = blockIdx.x * 16 + (threadIdx.x & 15);
+  const float t = fixed_order_rowsum16(part + (size_t)which * D, nwg, (int64_t)3 * D, j, j < D, s_red);
+  if ((threadIdx.x >> 4) == 0 && j < D) out[j] += t;
+}
+
+static int ln_bwd_grid(int64_t M) {
+  // Persistent grid: every workgroup ends with 3*D column partials (dw, db, dx_colsum), so their number is kept at two workgroups per CU —
+  // measured 328 / 337 / 355 / 395 / 528 us at 512 / 768 / 1024 / 1280 / 4096 workgroups (M = 131072, D = 768, atomic form).
+  const int64_t want = (M + 3) / 4;
+  return (int)(want < 512 ? want : 512);
+}
+
+extern "C" size_t enh_layernorm_backward_workspace_bytes(int64_t M, int D) {
+  return M > 0 && D > 0 ? (size_t)ln_bwd_grid(M) * 3 * D * sizeof(float) : 0;
+}
+
+static int ln_bwd_impl(const float* dy, const enh_bf16* dy_bf16, const float* x, const float* w, const float* mean, const float* rstd, const float* dres,
+                       int64_t M, int D, float* dx_f32, enh_bf16* dx_bf16, float* dw, float* db, float* dx_colsum, float* part, void* stream) {
+  ENH_REQUIRE((dy != nullptr) != (dy_bf16 != nullptr), ENH_E_BADARG, "enh_layernorm_backward: pass exactly one of dy (f32) / dy_bf16");
+  ENH_REQUIRE(x && w && mean && rstd && dx_f32 && dw && db, ENH_E_BADARG, "enh_layernorm_backward: null pointer");
+  ENH_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 2048, ENH_E_SHAPE, "enh_layernorm_backward: need D %% 4 == 0 and D <= 2048, got M=%lld D=%d", (long long)M, D);
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = ln_bwd_grid(M);
+  if (dy_bf16) ln_bwd_launch<true>(grid, s, dy_bf16, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum, part);
+  else ln_bwd_launch<false>(grid, s, dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum, part);
+  if (part) ln_bwd_reduce_kernel<<<dim3((unsigned)((D + 15) / 16), 3), 256, 0, s>>>(part, grid, D, dw, db, dx_colsum);
+  return enh_check_launch("enh_layernorm_backward");
 }
 
 extern "C" int enh_layernorm_backward(const float* dy, const enh_bf16* dy_bf16, const float* x, const float* w, const float* mean,
                                       const float* rstd, const float* dres, int64_t M, int D, float* dx_f32,
                                       enh_bf16* dx_bf16, float* dw, float* db, float* dx_colsum, void* stream) {
-  ENH_REQUIRE((dy != nullptr) != (dy_bf16 != nullptr), ENH_E_BADARG, "enh_layernorm_backward: pass exactly one of dy (f32) / dy_bf16");
-  ENH_REQUIRE(x && w && mean && rstd && dx_f32 && dw && db, ENH_E_BADARG, "enh_layernorm_backward: null pointer");
-  ENH_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 2048, ENH_E_SHAPE, "enh_layernorm_backward: need D %% 4 == 0 and D <= 2048, got M=%lld D=%d", (long long)M, D);
-  hipStream_t s = (hipStream_t)stream;
-  // Persistent grid: every workgroup ends with 3*D f32 atomics (dw, db, dx_colsum), so their number is kept at two workgroups per CU —
-  // measured 328 / 337 / 355 / 395 / 528 us at 512 / 768 / 1024 / 1280 / 4096 workgroups (M = 131072, D = 768).
-  const int64_t want = (M + 3) / 4;
-  const int grid = (int)(want < 512 ? want : 512);
-  if (dy_bf16) ln_bwd_launch<true>(grid, s, dy_bf16, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum);
-  else ln_bwd_launch<false>(grid, s, dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum);
-  return enh_check_launch("enh_layernorm_backward");
+  return ln_bwd_impl(dy, dy_bf16, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum, nullptr, stream);
+}
+
+extern "C" int enh_layernorm_backward_ws(const float* dy, const enh_bf16* dy_bf16, const float* x, const float* w, const float* mean,
+                                         const float* rstd, const float* dres, int64_t M, int D, float* dx_f32,
+                                         enh_bf16* dx_bf16, float* dw, float* db, float* dx_colsum, void* ws, size_t ws_bytes, void* stream) {
+  ENH_REQUIRE(ws && ws_bytes >= enh_layernorm_backward_workspace_bytes(M, D), ENH_E_WORKSPACE, "enh_layernorm_backward_ws: workspace too small (%zu bytes)", ws_bytes);
+  return ln_bwd_impl(dy, dy_bf16, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum, (float*)ws, stream);
 }

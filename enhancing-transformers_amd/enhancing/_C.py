@@ -20,6 +20,10 @@ _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("ENH_HIP_LIB", os.path.join(_PKG_ROOT, "lib", "libenh_hip.so"))
 
 ACT_NONE, ACT_TANH, ACT_DTANH = 0, 1, 2
+# Reductions across workgroups (LayerNorm dgamma / dbeta / fused bias sums, bias column sums, split-K weight gradients) run in their two-pass,
+# fixed-order form by default: gradients are bit-reproducible from run to run (tests/test_parity_base_gpu.py).  ENH_DETERMINISTIC=0 selects the
+# f32-atomic forms for A/B timing.
+DETERMINISTIC = os.environ.get("ENH_DETERMINISTIC", "1") != "0"
 
 _c = ctypes
 _vp, _i64, _i32, _f32, _sz = _c.c_void_p, _c.c_int64, _c.c_int, _c.c_float, _c.c_size_t
@@ -34,6 +38,8 @@ SIGNATURES = {
     "enh_vq_lookup": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "enh_layernorm_forward": (_i32, [_vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "enh_layernorm_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "enh_layernorm_backward_ws": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "enh_layernorm_backward_workspace_bytes": (_sz, [_i64, _i32]),
     "enh_gemm_bf16": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _i64, _i64, _i64, _vp, _i32, _vp, _i64, _vp, _i64, _i64,
                              _i32, _vp, _vp, _i64, _vp]),
     "enh_gemm_bf16_ws": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _i64, _i64, _i64, _vp, _i32, _vp, _i64, _vp, _i64, _i64,
@@ -46,6 +52,8 @@ SIGNATURES = {
     "enh_patchify": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "enh_unpatchify_loss": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp]),
     "enh_colsum_bf16": (_i32, [_vp, _i64, _i64, _i64, _vp, _i32, _vp]),
+    "enh_colsum_bf16_ws": (_i32, [_vp, _i64, _i64, _i64, _vp, _i32, _vp, _sz, _vp]),
+    "enh_colsum_bf16_workspace_bytes": (_sz, [_i64, _i64]),
     "enh_cast_f32_bf16": (_i32, [_vp, _vp, _i64, _vp]),
     "enh_crop_flip_u8": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),
     "enh_fused_bias_act": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _f32, _f32, _vp]),
@@ -242,10 +250,19 @@ def layernorm_forward(x, w, b, eps: float = 1e-5, y_bf16=None, y_f32=None, mean=
 def layernorm_backward(dy, x, w, mean, rstd, dres, dx_f32, dx_bf16, dw, db, dx_colsum=None):
     M, D = x.shape
     dy32, dy16 = (None, dy) if dy.dtype == BF16 else (dy, None)   # upstream gradient: f32, or the dgrad GEMM's bf16 output
-    _check(lib().enh_layernorm_backward(_p(dy32, F32, "dy"), _p(dy16, BF16, "dy_bf16"), _p(x, F32, "x"), _p(w, F32, "w"), _p(mean, F32, "mean"),
-                                        _p(rstd, F32, "rstd"), _p(dres, F32, "dres"), M, D, _p(dx_f32, F32, "dx_f32"),
-                                        _p(dx_bf16, BF16, "dx_bf16"), _p(dw, F32, "dw"), _p(db, F32, "db"), _p(dx_colsum, F32, "dx_colsum"),
-                                        _stream()), "enh_layernorm_backward")
+    if not DETERMINISTIC:
+        _check(lib().enh_layernorm_backward(_p(dy32, F32, "dy"), _p(dy16, BF16, "dy_bf16"), _p(x, F32, "x"), _p(w, F32, "w"), _p(mean, F32, "mean"),
+                                            _p(rstd, F32, "rstd"), _p(dres, F32, "dres"), M, D, _p(dx_f32, F32, "dx_f32"),
+                                            _p(dx_bf16, BF16, "dx_bf16"), _p(dw, F32, "dw"), _p(db, F32, "db"), _p(dx_colsum, F32, "dx_colsum"),
+                                            _stream()), "enh_layernorm_backward")
+        return
+    # deterministic form: per-workgroup column partials in a caller-owned workspace + a fixed-order second pass (no f32 atomics)
+    nb = lib().enh_layernorm_backward_workspace_bytes(M, D)
+    ws = _workspace(nb, x.device)
+    _check(lib().enh_layernorm_backward_ws(_p(dy32, F32, "dy"), _p(dy16, BF16, "dy_bf16"), _p(x, F32, "x"), _p(w, F32, "w"), _p(mean, F32, "mean"),
+                                           _p(rstd, F32, "rstd"), _p(dres, F32, "dres"), M, D, _p(dx_f32, F32, "dx_f32"),
+                                           _p(dx_bf16, BF16, "dx_bf16"), _p(dw, F32, "dw"), _p(db, F32, "db"), _p(dx_colsum, F32, "dx_colsum"),
+                                           _p(ws), ws.numel(), _stream()), "enh_layernorm_backward_ws")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -338,7 +355,13 @@ def unpatchify_loss(pix, target, B: int, C: int, H: int, W: int, p: int, w_l1: f
 
 
 def colsum(x, M: int, N: int, out, accumulate: bool = False):
-    _check(lib().enh_colsum_bf16(_p(x, BF16, "x"), M, N, x.stride(0), _p(out, F32, "out"), int(accumulate), _stream()), "enh_colsum_bf16")
+    """out[n] (+)= sum_m x[m, n]; deterministic two-pass form (per-chunk partials in a workspace, fixed-order second pass)"""
+    if not DETERMINISTIC:
+        _check(lib().enh_colsum_bf16(_p(x, BF16, "x"), M, N, x.stride(0), _p(out, F32, "out"), int(accumulate), _stream()), "enh_colsum_bf16")
+        return
+    nb = lib().enh_colsum_bf16_workspace_bytes(M, N)
+    ws = _workspace(nb, x.device)
+    _check(lib().enh_colsum_bf16_ws(_p(x, BF16, "x"), M, N, x.stride(0), _p(out, F32, "out"), int(accumulate), _p(ws), ws.numel(), _stream()), "enh_colsum_bf16_ws")
 
 
 def cast_bf16(x, y):
@@ -528,7 +551,7 @@ def colsum_nhwc(x):
     while C * r < 512 and M % (2 * r) == 0:
         r *= 2
     out = torch.empty(C * r, dtype=F32, device=x.device)
-    _check(lib().enh_colsum_bf16(_p(x, BF16, "x"), M // r, C * r, C * r, _p(out), 0, _stream()), "enh_colsum_bf16")
+    colsum(x.view(M // r, C * r), M // r, C * r, out)
     return out.view(r, C).sum(0) if r > 1 else out
 
 

@@ -98,6 +98,12 @@ int enh_layernorm_forward(const float* x, const float* w, const float* b, int64_
 int enh_layernorm_backward(const float* dy, const enh_bf16* dy_bf16, const float* x, const float* w, const float* mean,
                            const float* rstd, const float* dres, int64_t M, int D, float* dx_f32,
                            enh_bf16* dx_bf16, float* dw, float* db, float* dx_colsum, void* stream);
+/* Deterministic form: the per-workgroup column partials of dw / db / dx_colsum go to `ws` (enh_layernorm_backward_workspace_bytes) and a second pass
+ * adds them in a fixed order — bit-reproducible from run to run; enh_layernorm_backward uses f32 atomics instead. */
+size_t enh_layernorm_backward_workspace_bytes(int64_t M, int D);
+int enh_layernorm_backward_ws(const float* dy, const enh_bf16* dy_bf16, const float* x, const float* w, const float* mean,
+                              const float* rstd, const float* dres, int64_t M, int D, float* dx_f32, enh_bf16* dx_bf16, float* dw,
+                              float* db, float* dx_colsum, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * bf16 MFMA GEMM with fused epilogue — every nn.Linear / patch conv on the path
@@ -166,6 +172,9 @@ int enh_unpatchify_loss(const float* pix, const float* target, int B, int C, int
                         float w_l2, float* xrec, double* sums, enh_bf16* dpix_bf16, void* stream);
 /* out[n] (+)= sum_m x[m,n] (bias gradients); x bf16 [M,N] */
 int enh_colsum_bf16(const enh_bf16* x, int64_t M, int64_t N, int64_t ldx, float* out, int accumulate, void* stream);
+/* deterministic form: per-row-chunk partials in `ws` (enh_colsum_bf16_workspace_bytes), added in a fixed order; enh_colsum_bf16 uses f32 atomics */
+size_t enh_colsum_bf16_workspace_bytes(int64_t M, int64_t N);
+int enh_colsum_bf16_ws(const enh_bf16* x, int64_t M, int64_t N, int64_t ldx, float* out, int accumulate, void* ws, size_t ws_bytes, void* stream);
 /* f32 -> bf16 cast (weight shadows) */
 int enh_cast_f32_bf16(const float* x, enh_bf16* y, int64_t n, void* stream);
 /* torch.optim.AdamW(lr, betas=(0.9,0.99), weight_decay=1e-4) step over one flat buffer (vitvqgan.py:160),
