@@ -49,6 +49,8 @@ class FlatAdamW:
             scale /= dist.get_world_size()
         s.step_count += 1
         _C.adamw_step(s.p, s.g, s.m, s.v, None, s.step_count, g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], scale)
+        from ..losses.op.conv_nhwc import invalidate_packed_weights
+        invalidate_packed_weights()          # the kernel wrote the weights through raw pointers: cached operand images are stale
 
     def state_dict(self) -> dict:
         s = self.store

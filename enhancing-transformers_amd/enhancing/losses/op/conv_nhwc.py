@@ -15,6 +15,8 @@ conv2d_gradfix applies here too.  The element-wise pieces (``_Gate`` = derivativ
 ``_ToNHWC8`` / ``_FromNHWC8``) are linear in their data argument and their own adjoints up to arguments.  No CPU branch exists."""
 from __future__ import annotations
 
+import weakref
+
 import torch
 from torch.autograd import Function
 
@@ -35,13 +37,34 @@ def _out_size(n: int, k: int, stride: int, pad: int) -> int:
 
 
 # ---- kernel-level helpers (not differentiable by themselves) ----------------------------------------------------------------------
+# Packed bf16 operand images of the PARAMETERS are cached between optimizer steps: one adversarial step runs the discriminator forward three times
+# and its input-gradient twice with unchanged weights.  A cache entry is keyed on the parameter object, its storage, its autograd version (in-place torch
+# writes bump it) and the packing arguments; the fused AdamW kernel writes through raw pointers, so FlatAdamW.step() calls
+# invalidate_packed_weights().  Anything that is not an nn.Parameter (the weight-shaped gradient of a second-order pass) is packed every time.
+_PACKED = {}
+
+
+def invalidate_packed_weights() -> None:
+    _PACKED.clear()
+
+
+def _pack(w, scale, transposed, kh0, kw0, kstep, nty, ntx, rows, cols):
+    if not isinstance(w, torch.nn.Parameter):
+        return _C.conv_pack_weight(w.contiguous(), scale, transposed, kh0, kw0, kstep, nty, ntx, rows, cols)
+    key = (id(w), w.data_ptr(), w._version, float(scale), transposed, kh0, kw0, kstep, nty, ntx, rows, cols)
+    hit = _PACKED.get(key)
+    if hit is None or hit[0]() is not w:          # (the weak reference guards against a recycled id / address of a freed parameter)
+        hit = _PACKED[key] = (weakref.ref(w), _C.conv_pack_weight(w.detach().contiguous(), scale, transposed, kh0, kw0, kstep, nty, ntx, rows, cols))
+    return hit[1]
+
+
 def _fwd(x, w, scale, stride, pad, mode=2, bias=None, add=None, p0=0.0, p1=1.0):
     B, H, W, Cp = x.shape
     Cout, Cin, k, _ = w.shape
     if Cp % 8 or Cp < Cin or Cout % 8:
         raise RuntimeError(f"conv_nhwc: x has {Cp} channels for a weight {tuple(w.shape)}; channels must be padded to a multiple of 8 and Cout % 8 == 0")
     Ho, Wo = _out_size(H, k, stride, pad), _out_size(W, k, stride, pad)
-    wt = _C.conv_pack_weight(w.contiguous(), scale, False, 0, 0, 1, k, k, Cout, Cp)
+    wt = _pack(w, scale, False, 0, 0, 1, k, k, Cout, Cp)
     geom = dict(B=B, Hs=H, Ws=W, C=Cp, Hm=Ho, Wm=Wo, gs=stride, oy0=-pad, ox0=-pad, nty=k, ntx=k, sty=1, stx=1, N=Cout, HO=Ho, WO=Wo, os=1, oph=0, opw=0)
     return _C.conv_nhwc(x, wt, geom, mode, bias=bias, add=add, p0=p0, p1=p1)
 
@@ -49,9 +72,8 @@ def _fwd(x, w, scale, stride, pad, mode=2, bias=None, add=None, p0=0.0, p1=1.0):
 def _dgrad(dy, w, scale, stride, pad, H, W, Cp):
     B, Ho, Wo, Cout = dy.shape
     k = w.shape[2]
-    w = w.contiguous()
     if stride == 1:
-        wt = _C.conv_pack_weight(w, scale, True, 0, 0, 1, k, k, Cp, Cout)
+        wt = _pack(w, scale, True, 0, 0, 1, k, k, Cp, Cout)
         geom = dict(B=B, Hs=Ho, Ws=Wo, C=Cout, Hm=H, Wm=W, gs=1, oy0=pad, ox0=pad, nty=k, ntx=k, sty=-1, stx=-1, N=Cp, HO=H, WO=W, os=1, oph=0, opw=0)
         return _C.conv_nhwc(dy, wt, geom, 2)
     out = None
@@ -63,7 +85,7 @@ def _dgrad(dy, w, scale, stride, pad, H, W, Cp):
             ntx, ox0, Wm = len(range(kw0, k, stride)), (pw + pad - kw0) // stride, (W - pw + stride - 1) // stride
             if Hm <= 0 or Wm <= 0:
                 continue
-            wt = _C.conv_pack_weight(w, scale, True, kh0, kw0, stride, nty, ntx, Cp, Cout)
+            wt = _pack(w, scale, True, kh0, kw0, stride, nty, ntx, Cp, Cout)
             geom = dict(B=B, Hs=Ho, Ws=Wo, C=Cout, Hm=Hm, Wm=Wm, gs=1, oy0=oy0, ox0=ox0, nty=nty, ntx=ntx, sty=-1, stx=-1, N=Cp, HO=H, WO=W,
                         os=stride, oph=ph, opw=pw)
             out = _C.conv_nhwc(dy, wt, geom, 2, out=out)
