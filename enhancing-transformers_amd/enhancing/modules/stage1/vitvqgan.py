@@ -173,7 +173,7 @@ class ViTVQ(nn.Module):
             return aeloss.detach()
         if optimizer_idx == 0:
             w1, w2, cw = self._loss_weights()
-            out = self.engine.forward_backward(x, w_l1=w1, w_l2=w2, codebook_weight=cw, zero_grad=zero_grad)
+            out = self.engine.forward_backward_graphed(x, w_l1=w1, w_l2=w2, codebook_weight=cw, zero_grad=zero_grad)   # eager unless engine.use_graphs
             log = {"train/total_loss": out["loss"], "train/quant_loss": out["quant_loss"], "train/rec_loss": out["rec_loss"],
                    "train/loglaplace_loss": out["loglaplace_loss"], "train/loggaussian_loss": out["loggaussian_loss"],
                    "train/perceptual_loss": torch.zeros((), device=out["loss"].device)}
