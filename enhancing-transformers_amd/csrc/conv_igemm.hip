@@ -48,6 +48,66 @@ __device__ __forceinline__ int64_t conv_out_pixel(const enh_conv_geom& g, int64_
   return (b * g.HO + (int64_t)y * g.os + g.oph) * g.WO + (int64_t)x * g.os + g.opw;
 }
 
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& args, f32x4 (&acc)[4][4], int64_t m0, int64_t n0, int wm, int wn, int lg, int l16) {
+  const enh_conv_geom& g = args.g;
+  // epilogue: lane (lg, l16) holds out[m = m0 + wm*64 + i*16 + l16][n = n0 + wn*64 + j*16 + lg*4 + 0..3].  Everything the epilogue READS (bias, aux, add)
+  // is requested for all 16 element groups before the first store: CDNA4's vmcnt retires loads and stores in order, so a load issued after a store
+  // can only be waited for together with that store's acknowledgement (gemm_tiles.h epi_bias).
+  const bool dense = g.os == 1 && g.HO == g.Hm && g.WO == g.Wm && g.oph == 0 && g.opw == 0;
+  int64_t orow[4];
+  float4 b4[4];
+  uint2 ax[4][4], ad[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int64_t n = n0 + wn * 64 + j * 16 + lg * 4;
+    b4[j] = ((args.mode == 0 || args.mode == 3) && args.bias && n < g.N) ? *reinterpret_cast<const float4*>(args.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t m = m0 + wm * 64 + i * 16 + l16;
+    orow[i] = m < args.M ? (dense ? m : conv_out_pixel(g, m)) * g.N : -1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t n = n0 + wn * 64 + j * 16 + lg * 4;
+      ax[i][j] = make_uint2(0u, 0u); ad[i][j] = make_uint2(0u, 0u);
+      if (orow[i] >= 0 && n < g.N) {
+        if (args.mode == 1) ax[i][j] = *reinterpret_cast<const uint2*>(args.aux + orow[i] + n);
+        if ((args.mode == 1 || args.mode == 4) && args.add) ad[i][j] = *reinterpret_cast<const uint2*>(args.add + orow[i] + n);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (orow[i] < 0) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t n = n0 + wn * 64 + j * 16 + lg * 4;
+      if (n >= g.N) continue;   // N % 8 == 0: the 4 columns are in or out together
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      const uint32_t d0 = ad[i][j].x, d1 = ad[i][j].y;
+      const float e0 = bf16_bits_to_f32((uint16_t)(d0 & 0xffffu)), e1 = bf16_bits_to_f32((uint16_t)(d0 >> 16));
+      const float e2 = bf16_bits_to_f32((uint16_t)(d1 & 0xffffu)), e3 = bf16_bits_to_f32((uint16_t)(d1 >> 16));
+      if (args.mode == 0) {
+        v[0] = fmaxf(v[0] + b4[j].x, 0.f); v[1] = fmaxf(v[1] + b4[j].y, 0.f); v[2] = fmaxf(v[2] + b4[j].z, 0.f); v[3] = fmaxf(v[3] + b4[j].w, 0.f);
+      } else if (args.mode == 1) {
+        const uint32_t a0 = ax[i][j].x, a1 = ax[i][j].y;
+        v[0] = (a0 & 0x7fffu) && !(a0 & 0x8000u) ? v[0] + e0 : 0.f;
+        v[1] = ((a0 >> 16) & 0x7fffu) && !(a0 >> 31) ? v[1] + e1 : 0.f;
+        v[2] = (a1 & 0x7fffu) && !(a1 & 0x8000u) ? v[2] + e2 : 0.f;
+        v[3] = ((a1 >> 16) & 0x7fffu) && !(a1 >> 31) ? v[3] + e3 : 0.f;
+      } else if (args.mode == 3) {
+        v[0] += b4[j].x; v[1] += b4[j].y; v[2] += b4[j].z; v[3] += b4[j].w;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (v[r] > 0.f ? v[r] : v[r] * args.p0) * args.p1;
+      } else if (args.mode == 4) {
+        v[0] += args.p0 * e0; v[1] += args.p0 * e1; v[2] += args.p0 * e2; v[3] += args.p0 * e3;
+      }
+      const u32x2 o_ = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+      *reinterpret_cast<u32x2*>(args.out + orow[i] + n) = o_;
+    }
+  }
+}
+
 //   mode 0: out = relu(acc + bias[n])                                   (VGG16 conv + ReLU)
 //   mode 1: out = (acc + add[o,n]) * (aux[o,n] > 0)                     (VGG16 input gradient through a ReLU; add optional)
 //   mode 2: out = acc
@@ -139,62 +199,136 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs args)
     }
     __syncthreads();
   }
-  // epilogue: lane (lg, l16) holds out[m = m0 + wm*64 + i*16 + l16][n = n0 + wn*64 + j*16 + lg*4 + 0..3].  Everything the epilogue READS (bias, aux, add)
-  // is requested for all 16 element groups before the first store: CDNA4's vmcnt retires loads and stores in order, so a load issued after a store
-  // can only be waited for together with that store's acknowledgement (gemm_tiles.h epi_bias).
-  const bool dense = g.os == 1 && g.HO == g.Hm && g.WO == g.Wm && g.oph == 0 && g.opw == 0;
-  int64_t orow[4];
-  float4 b4[4];
-  uint2 ax[4][4], ad[4][4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int64_t n = n0 + wn * 64 + j * 16 + lg * 4;
-    b4[j] = ((args.mode == 0 || args.mode == 3) && args.bias && n < g.N) ? *reinterpret_cast<const float4*>(args.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
+  conv_epilogue(args, acc, m0, n0, wm, wn, lg, l16);
+}
+
+// =================================================================================================
+// LDS-DMA form of the same convolution for C % 64 == 0 (every 3x3 / 1x1 layer of the discriminator past the first, the VGG16 trunk): a 64-deep K step
+// then lies inside ONE tap, so the gather is "row pointer + a tap offset that is uniform for the workgroup", and global_load_lds (16 B per lane straight
+// into the swizzled LDS image, no staging registers, no ds_write pass) can fetch it — the zero padding by pointing the lanes whose tap falls outside
+// the image at a zero page instead of predicating them.  K loop = gemm_bf16_pipe2_kernel's (gemm.hip): one mid-iteration barrier, the loads of stage
+// kt+2 spread one per two MFMAs, fragments of the next half-step read under the MFMAs of the current one.
+// =================================================================================================
+__device__ __attribute__((aligned(16))) uint32_t g_conv_zero_page[4] = {0u, 0u, 0u, 0u};
+
+__global__ __launch_bounds__(256, 2) void conv_igemm_glds_kernel(const ConvArgs args) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2 stages][A tile | B tile]
+  const enh_conv_geom& g = args.g;
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l16 = lane & 15, lg = lane >> 4;
+  const int bid_ = xcd_contiguous((int)blockIdx.x, args.nbm * args.nbn);
+  const int tile_m = bid_ % args.nbm, tile_n = bid_ / args.nbm;
+  const int64_t m0 = (int64_t)tile_m * G_BM, n0 = (int64_t)tile_n * G_BN;
+  const int nk = (int)(args.K / G_BK);
+
+  // A operand: slab i of this wave = rows (wave*4 + i)*8 + (lane>>3), physical chunk lane&7 holding logical chunk c = pc ^ ((r>>1)&7) (gemm_tiles.h row image)
+  int py[4], px[4], coff[4];
+  int64_t pb[4];
+  const uint16_t* bsrc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int64_t m = m0 + wm * 64 + i * 16 + l16;
-    orow[i] = m < args.M ? (dense ? m : conv_out_pixel(g, m)) * g.N : -1;
+    const int r = (wave * 4 + i) * 8 + (lane >> 3), pc = lane & 7;
+    const int c = pc ^ ((r >> 1) & 7);
+    coff[i] = c * 8;
+    const int64_t row = m0 + r;
+    if (row < args.M) {
+      const int64_t hw = (int64_t)g.Hm * g.Wm;
+      const int64_t b = row / hw, rem = row - b * hw;
+      const int y = (int)(rem / g.Wm), x = (int)(rem - (int64_t)y * g.Wm);
+      py[i] = y * g.gs; px[i] = x * g.gs; pb[i] = b * g.Hs * g.Ws;
+    } else { py[i] = -(1 << 28); px[i] = -(1 << 28); pb[i] = 0; }
+    int64_t co = n0 + r;                       // B operand (weights [N][K]): rows beyond N are clamped, their products land in columns that are never stored
+    if (co > g.N - 1) co = g.N - 1;
+    bsrc[i] = args.Wt + co * args.K + c * 8;
+  }
+  const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_conv_zero_page);
+  // source pointers of K step `ks` (uniform tap) for the four A slabs
+  auto a_ptrs = [&](int ks, const uint16_t* (&ap)[4]) {
+    const int k0 = ks * G_BK;
+    const int tap = k0 / g.C, ch0 = k0 - tap * g.C;
+    const int jy = tap / g.ntx, jx = tap - jy * g.ntx;
+    const int dy = g.oy0 + jy * g.sty, dx = g.ox0 + jx * g.stx;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int64_t n = n0 + wn * 64 + j * 16 + lg * 4;
-      ax[i][j] = make_uint2(0u, 0u); ad[i][j] = make_uint2(0u, 0u);
-      if (orow[i] >= 0 && n < g.N) {
-        if (args.mode == 1) ax[i][j] = *reinterpret_cast<const uint2*>(args.aux + orow[i] + n);
-        if ((args.mode == 1 || args.mode == 4) && args.add) ad[i][j] = *reinterpret_cast<const uint2*>(args.add + orow[i] + n);
+    for (int i = 0; i < 4; ++i) {
+      const int sy = py[i] + dy, sx = px[i] + dx;
+      const bool ok = sy >= 0 && sy < g.Hs && sx >= 0 && sx < g.Ws;
+      ap[i] = ok ? args.X + (pb[i] + (int64_t)sy * g.Ws + sx) * g.C + ch0 + coff[i] : zero;
+    }
+  };
+#define CG_LOAD(PTR, BUF, WHICH, I)                                                                                                          \
+  __builtin_amdgcn_global_load_lds((const GLB_AS void*)(PTR), (LDS_AS void*)(smem + (BUF) * (2 * G_TILE_BYTES) + (WHICH) * G_TILE_BYTES + (wave * 4 + (I)) * 1024), 16, 0, 0)
+#define CG_READ(FA, FB, BUF, KS)                                                                                         \
+  do {                                                                                                                   \
+    const unsigned char* sa_ = smem + (BUF) * (2 * G_TILE_BYTES);                                                        \
+    const unsigned char* sb_ = sa_ + G_TILE_BYTES;                                                                       \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) FA[i_] = tile_frag<false>(sa_, wm * 64 + i_ * 16, KS, lg, l16);     \
+    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) FB[j_] = tile_frag<false>(sb_, wn * 64 + j_ * 16, KS, lg, l16);     \
+  } while (0)
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  s16x8 fa0[4], fb0[4], fa1[4], fb1[4];
+  const uint16_t* ap[4];
+
+  if (nk > 0) {
+    a_ptrs(0, ap);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { CG_LOAD(ap[i], 0, 0, i); CG_LOAD(bsrc[i], 0, 1, i); bsrc[i] += G_BK; }
+    if (nk > 1) {
+      a_ptrs(1, ap);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { CG_LOAD(ap[i], 1, 0, i); CG_LOAD(bsrc[i], 1, 1, i); bsrc[i] += G_BK; }
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // stage 0 landed (stage 1's 8 loads may be outstanding)
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    CG_READ(fa0, fb0, 0, 0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+  }
+  int buf = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    CG_READ(fa1, fb1, buf, 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb0[j]), __builtin_bit_cast(bf16x8, fa0[i]), acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0): F1 in registers, my share of stage kt+1 landed
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 1 < nk) CG_READ(fa0, fb0, buf ^ 1, 0);
+    const bool more = kt + 2 < nk;
+    if (more) a_ptrs(kt + 2, ap);
+    __builtin_amdgcn_sched_barrier(0);
+    // second half: the 8 loads of stage kt+2 (into the buffer stage kt just vacated) one per two MFMAs
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        acc[i][jj * 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb1[jj * 2]), __builtin_bit_cast(bf16x8, fa1[i]), acc[i][jj * 2], 0, 0, 0);
+        acc[i][jj * 2 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb1[jj * 2 + 1]), __builtin_bit_cast(bf16x8, fa1[i]), acc[i][jj * 2 + 1], 0, 0, 0);
+        if (more) {
+          if (jj == 0) CG_LOAD(ap[i], buf, 0, i);
+          else { CG_LOAD(bsrc[i], buf, 1, i); bsrc[i] += G_BK; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): next F0 has arrived under the MFMAs above
+    buf ^= 1;
   }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (orow[i] < 0) continue;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int64_t n = n0 + wn * 64 + j * 16 + lg * 4;
-      if (n >= g.N) continue;   // N % 8 == 0: the 4 columns are in or out together
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      const uint32_t d0 = ad[i][j].x, d1 = ad[i][j].y;
-      const float e0 = bf16_bits_to_f32((uint16_t)(d0 & 0xffffu)), e1 = bf16_bits_to_f32((uint16_t)(d0 >> 16));
-      const float e2 = bf16_bits_to_f32((uint16_t)(d1 & 0xffffu)), e3 = bf16_bits_to_f32((uint16_t)(d1 >> 16));
-      if (args.mode == 0) {
-        v[0] = fmaxf(v[0] + b4[j].x, 0.f); v[1] = fmaxf(v[1] + b4[j].y, 0.f); v[2] = fmaxf(v[2] + b4[j].z, 0.f); v[3] = fmaxf(v[3] + b4[j].w, 0.f);
-      } else if (args.mode == 1) {
-        const uint32_t a0 = ax[i][j].x, a1 = ax[i][j].y;
-        v[0] = (a0 & 0x7fffu) && !(a0 & 0x8000u) ? v[0] + e0 : 0.f;
-        v[1] = ((a0 >> 16) & 0x7fffu) && !(a0 >> 31) ? v[1] + e1 : 0.f;
-        v[2] = (a1 & 0x7fffu) && !(a1 & 0x8000u) ? v[2] + e2 : 0.f;
-        v[3] = ((a1 >> 16) & 0x7fffu) && !(a1 >> 31) ? v[3] + e3 : 0.f;
-      } else if (args.mode == 3) {
-        v[0] += b4[j].x; v[1] += b4[j].y; v[2] += b4[j].z; v[3] += b4[j].w;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = (v[r] > 0.f ? v[r] : v[r] * args.p0) * args.p1;
-      } else if (args.mode == 4) {
-        v[0] += args.p0 * e0; v[1] += args.p0 * e1; v[2] += args.p0 * e2; v[3] += args.p0 * e3;
-      }
-      const u32x2 o_ = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-      *reinterpret_cast<u32x2*>(args.out + orow[i] + n) = o_;
-    }
-  }
+#undef CG_LOAD
+#undef CG_READ
+  conv_epilogue(args, acc, m0, n0, wm, wn, lg, l16);
 }
 
 static int conv_geom_check(const enh_conv_geom* g, const char* who) {
@@ -207,8 +341,16 @@ static int conv_geom_check(const enh_conv_geom* g, const char* who) {
   return ENH_OK;
 }
 
+static int g_conv_variant = 0;   // 0 = per-shape choice, 1 = register-staged kernel everywhere (A/B measurements; explicit state like enh_gemm_set_kernel)
+extern "C" int enh_conv_set_kernel(int variant) {
+  ENH_REQUIRE(variant == 0 || variant == 1, ENH_E_BADARG, "enh_conv_set_kernel: variant must be 0 (auto) or 1 (register-staged)");
+  g_conv_variant = variant;
+  return ENH_OK;
+}
+
 static void conv_lds_attr_once() {
   static const bool attr_set = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_glds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G_TILE_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G_TILE_BYTES);
     return true;
   }();
@@ -229,7 +371,10 @@ extern "C" int enh_conv_nhwc_bf16(const enh_bf16* src, const enh_bf16* wt, const
   a.nbm = (int)((a.M + G_BM - 1) / G_BM); a.nbn = (g->N + G_BN - 1) / G_BN;
   ENH_REQUIRE((int64_t)a.nbm * a.nbn < (1ll << 30), ENH_E_SHAPE, "enh_conv_nhwc_bf16: grid too large");
   conv_lds_attr_once();
-  conv_igemm_kernel<<<dim3((unsigned)(a.nbm * a.nbn)), 256, 4 * G_TILE_BYTES, (hipStream_t)stream>>>(a);
+  if (g->C % G_BK == 0 && a.K >= 2 * G_BK && g_conv_variant != 1)
+    conv_igemm_glds_kernel<<<dim3((unsigned)(a.nbm * a.nbn)), 256, 4 * G_TILE_BYTES, (hipStream_t)stream>>>(a);
+  else
+    conv_igemm_kernel<<<dim3((unsigned)(a.nbm * a.nbn)), 256, 4 * G_TILE_BYTES, (hipStream_t)stream>>>(a);
   return enh_check_launch("enh_conv_nhwc_bf16");
 }
 

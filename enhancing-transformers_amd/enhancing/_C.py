@@ -62,6 +62,7 @@ SIGNATURES = {
     "enh_im2col_bf16": (_i32, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp]),
     "enh_col2im_f32": (_i32, [_vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _i64, _vp]),
     "enh_conv_nhwc_bf16": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _f32, _f32, _vp, _vp]),
+    "enh_conv_set_kernel": (_i32, [_i32]),
     "enh_conv_wgrad_workspace_bytes": (_sz, [_vp]),
     "enh_conv_wgrad_nhwc_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "enh_conv_pack_weight": (_i32, [_vp, _i32, _i32, _i32, _f32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
@@ -116,6 +117,8 @@ def lib():
             _check_rc = L.enh_gemm_set_kernel(fam)
             if _check_rc != 0:
                 raise RuntimeError(L.enh_last_error().decode())
+        if os.environ.get("ENH_CONV_KERNEL") == "reg" and L.enh_conv_set_kernel(1) != 0:      # A/B: register-staged convolution kernel everywhere
+            raise RuntimeError(L.enh_last_error().decode())
     return _LIB
 
 
