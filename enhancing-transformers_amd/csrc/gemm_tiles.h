@@ -135,20 +135,10 @@ __device__ __forceinline__ float4 epi_bias(const GemmArgs& args, int64_t n) {
   return make_float4(0.f, 0.f, 0.f, 0.f);   // (the generic mode fetches its bias inside epi4, behind its runtime flags)
 }
 
+// the arithmetic of an epilogue on one group of 4 columns (bias, activation, residual, accumulate) — everything but the stores
 template <int MODE>
-__device__ __forceinline__ void epi4(const GemmArgs& args, float (&v)[4], const EpiIn& in, const float4& b4, int64_t m, int64_t n, int split) {
+__device__ __forceinline__ void epi_value(const GemmArgs& args, float (&v)[4], const EpiIn& in, const float4& b4, int64_t n) {
   constexpr bool G = MODE == EPI_GENERIC;
-  if (MODE == EPI_WS || (G && args.accumulate == 3)) {   // split-K partial -> workspace slab [split][M][N] (reduced by splitk_reduce_kernel in a fixed order)
-    const f32x4 o_ = {v[0], v[1], v[2], v[3]};
-    *reinterpret_cast<f32x4*>(args.ws + ((int64_t)split * args.M + m) * args.N + n) = o_;
-    return;
-  }
-  float* cp = (G ? args.c_f32 != nullptr : (MODE == EPI_F32_BIAS_RES || MODE == EPI_F32 || MODE == EPI_ATOMIC)) ? args.c_f32 + m * args.ldc + n : nullptr;
-  if (MODE == EPI_ATOMIC || (G && args.accumulate == 2)) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) atomicAdd(cp + r, v[r]);
-    return;
-  }
   if (MODE == EPI_BF16_BIAS_TANH || MODE == EPI_F32_BIAS_RES) { v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w; }
   if (G && args.bias) {
     const float4 bg = *reinterpret_cast<const float4*>(args.bias + n);
@@ -171,7 +161,24 @@ __device__ __forceinline__ void epi4(const GemmArgs& args, float (&v)[4], const 
     v[0] *= 1.f - h0 * h0; v[1] *= 1.f - h1 * h1; v[2] *= 1.f - h2 * h2; v[3] *= 1.f - h3 * h3;
   }
   if (MODE == EPI_F32_BIAS_RES || (G && args.res)) { v[0] += in.res.x; v[1] += in.res.y; v[2] += in.res.z; v[3] += in.res.w; }
-  if (G && args.accumulate == 1 && cp) { v[0] += in.old.x; v[1] += in.old.y; v[2] += in.old.z; v[3] += in.old.w; }
+  if (G && args.accumulate == 1 && args.c_f32) { v[0] += in.old.x; v[1] += in.old.y; v[2] += in.old.z; v[3] += in.old.w; }
+}
+
+template <int MODE>
+__device__ __forceinline__ void epi4(const GemmArgs& args, float (&v)[4], const EpiIn& in, const float4& b4, int64_t m, int64_t n, int split) {
+  constexpr bool G = MODE == EPI_GENERIC;
+  if (MODE == EPI_WS || (G && args.accumulate == 3)) {   // split-K partial -> workspace slab [split][M][N] (reduced by splitk_reduce_kernel in a fixed order)
+    const f32x4 o_ = {v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(args.ws + ((int64_t)split * args.M + m) * args.N + n) = o_;
+    return;
+  }
+  float* cp = (G ? args.c_f32 != nullptr : (MODE == EPI_F32_BIAS_RES || MODE == EPI_F32 || MODE == EPI_ATOMIC)) ? args.c_f32 + m * args.ldc + n : nullptr;
+  if (MODE == EPI_ATOMIC || (G && args.accumulate == 2)) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) atomicAdd(cp + r, v[r]);
+    return;
+  }
+  epi_value<MODE>(args, v, in, b4, n);
   if (cp) { const f32x4 o_ = {v[0], v[1], v[2], v[3]}; if (ENH_NT_EPILOGUE) __builtin_nontemporal_store(o_, reinterpret_cast<f32x4*>(cp)); else *reinterpret_cast<f32x4*>(cp) = o_; }
   if (MODE == EPI_BF16 || MODE == EPI_BF16_BIAS_TANH || MODE == EPI_BF16_DTANH || (G && args.c_bf16)) {
     const u32x2 o_ = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
