@@ -48,12 +48,16 @@ __device__ __forceinline__ int64_t conv_out_pixel(const enh_conv_geom& g, int64_
   return (b * g.HO + (int64_t)y * g.os + g.oph) * g.WO + (int64_t)x * g.os + g.opw;
 }
 
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& args, f32x4 (&acc)[4][4], int64_t m0, int64_t n0, int wm, int wn, int lg, int l16) {
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& args, f32x4 (&acc)[4][4], int64_t m0, int64_t n0, int wm, int wn, int lg, int l16,
+                                              unsigned char* stage) {
   const enh_conv_geom& g = args.g;
+  const bool dense = g.os == 1 && g.HO == g.Hm && g.WO == g.Wm && g.oph == 0 && g.opw == 0;
+  // wave-uniform: the wave's 64 columns all exist and the rows are consecutive output pixels -> its 64 x 64 block leaves through LDS (see below; the
+  // strided rows of a stride-2 input gradient gain nothing from whole-row stores and pay for eight pixel decompositions per lane: 377 -> 412 us)
+  const bool staged = dense && n0 + wn * 64 + 64 <= g.N;
   // epilogue: lane (lg, l16) holds out[m = m0 + wm*64 + i*16 + l16][n = n0 + wn*64 + j*16 + lg*4 + 0..3].  Everything the epilogue READS (bias, aux, add)
   // is requested for all 16 element groups before the first store: CDNA4's vmcnt retires loads and stores in order, so a load issued after a store
   // can only be waited for together with that store's acknowledgement (gemm_tiles.h epi_bias).
-  const bool dense = g.os == 1 && g.HO == g.Hm && g.WO == g.Wm && g.oph == 0 && g.opw == 0;
   int64_t orow[4];
   float4 b4[4];
   uint2 ax[4][4], ad[4][4];
@@ -103,7 +107,25 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& args, f32x4 (&acc)
         v[0] += args.p0 * e0; v[1] += args.p0 * e1; v[2] += args.p0 * e2; v[3] += args.p0 * e3;
       }
       const u32x2 o_ = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-      *reinterpret_cast<u32x2*>(args.out + orow[i] + n) = o_;
+      if (staged) {
+        const int row = i * 16 + l16;
+        *reinterpret_cast<u32x2*>(stage + row * 128 + (((j * 2 + (lg >> 1)) ^ (row & 7)) << 4) + (lg & 1) * 8) = o_;
+      } else {
+        *reinterpret_cast<u32x2*>(args.out + orow[i] + n) = o_;
+      }
+    }
+  }
+  if (staged) {
+    // The accumulator layout offers 8 bytes per lane, 16 rows x 32 B per store instruction; through a wave-private XOR-swizzled 8-KiB LDS tile the block
+    // leaves as 16 bytes per lane, whole 128-byte row segments (gemm.hip gemm_epilogue32_loops has the measurements: 3.1-3.9 -> ~5 TB/s of stores).
+    // Rows that do not exist (orow < 0 above) were skipped by their writer lanes and are skipped by their reader lanes.
+    const int lane = lg * 16 + l16;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int row = p * 8 + (lane >> 3), c = lane & 7;
+      const int64_t m = m0 + wm * 64 + row;
+      const u32x4 w = *reinterpret_cast<const u32x4*>(stage + row * 128 + ((c ^ (row & 7)) << 4));
+      if (m < args.M) *reinterpret_cast<u32x4*>(args.out + m * g.N + n0 + wn * 64 + c * 8) = w;
     }
   }
 }
@@ -199,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs args)
     }
     __syncthreads();
   }
-  conv_epilogue(args, acc, m0, n0, wm, wn, lg, l16);
+  conv_epilogue(args, acc, m0, n0, wm, wn, lg, l16, smem + wave * 8192);   // the stages are free: no LDS read follows the loop's last barrier
 }
 
 // =================================================================================================
@@ -328,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_glds_kernel(const ConvArgs 
   }
 #undef CG_LOAD
 #undef CG_READ
-  conv_epilogue(args, acc, m0, n0, wm, wn, lg, l16);
+  conv_epilogue(args, acc, m0, n0, wm, wn, lg, l16, smem + wave * 8192);   // the stages are free: no LDS read follows the loop's last barrier
 }
 
 static int conv_geom_check(const enh_conv_geom* g, const char* who) {
