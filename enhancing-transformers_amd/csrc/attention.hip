@@ -180,35 +180,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
 }
 
 // =================================================================================================
-// backward: delta[b,h,q] = sum_d dO * O
-// =================================================================================================
-__global__ void attn_delta_kernel(const uint16_t* __restrict__ o, const uint16_t* __restrict__ d_o, int64_t BN, int N, int H,
-                                  float* __restrict__ delta) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (b*N + q) * H + h
-  if (i >= BN * H) return;
-  const int h = (int)(i % H);
-  const int64_t bq = i / H;
-  const int64_t bb = bq / N, q = bq % N;
-  const u32x4* po = reinterpret_cast<const u32x4*>(o + i * ATT_D);
-  const u32x4* pd = reinterpret_cast<const u32x4*>(d_o + i * ATT_D);
-  float acc = 0.f;
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    const u32x4 a = po[c], g = pd[c];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      acc += bf16_bits_to_f32((uint16_t)(a[k] & 0xffffu)) * bf16_bits_to_f32((uint16_t)(g[k] & 0xffffu));
-      acc += bf16_bits_to_f32((uint16_t)(a[k] >> 16)) * bf16_bits_to_f32((uint16_t)(g[k] >> 16));
-    }
-  }
-  delta[(bb * H + h) * N + q] = acc;
-}
-
-// =================================================================================================
 // backward: dQ  (same skeleton as forward; K tile is read both as rows and transposed)
 // =================================================================================================
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ d_o,
-                                                             const float* __restrict__ lse, const float* __restrict__ delta, int B, int N,
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ o, const uint16_t* __restrict__ d_o,
+                                                             const float* __restrict__ lse, float* __restrict__ delta, int B, int N,
                                                              int H, float scale, float scale_log2, uint16_t* __restrict__ dqkv) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][ATT_TILE_BYTES];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -232,7 +207,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
     dof[ds] = *reinterpret_cast<const s16x8*>(dOp + (int64_t)qrow * (H * ATT_D) + ds * 16 + hi * 8);
   }
   const float lse_q = lse[((int64_t)b * H + h) * N + qrow] * 1.4426950408889634f;
-  const float del_q = delta[((int64_t)b * H + h) * N + qrow];
+  // delta[q] = sum_d dO[q][d] * O[q][d]: a lane already holds half of its query's dO row as MFMA fragments, so the row dot product is 32 products per
+  // lane and one cross-half exchange here — and is WRITTEN for the dK/dV kernel that runs next (this replaced a separate pass over O and dO per layer)
+  float dpart = 0.f;
+#pragma unroll
+  for (int ds = 0; ds < 4; ++ds) {
+    const s16x8 of = *reinterpret_cast<const s16x8*>(o + ((int64_t)b * N + qrow) * (H * ATT_D) + h * ATT_D + ds * 16 + hi * 8);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dpart += bf16_bits_to_f32((uint16_t)of[k]) * bf16_bits_to_f32((uint16_t)dof[ds][k]);
+  }
+  const float del_q = dpart + __shfl_xor(dpart, 32, 64);
+  if (active && hi == 0) delta[((int64_t)b * H + h) * N + qrow] = del_q;
 
   f32x16 dq[2];
 #pragma unroll
@@ -428,12 +413,10 @@ extern "C" int enh_attention_backward(const enh_bf16* qkv, const enh_bf16* out, 
   ENH_REQUIRE(B > 0 && H > 0 && N > 0 && N % 64 == 0, ENH_E_SHAPE, "enh_attention_backward: need N %% 64 == 0 (B=%d N=%d H=%d)", B, N, H);
   ENH_REQUIRE(scale > 0.f, ENH_E_BADARG, "enh_attention_backward: scale must be positive");
   hipStream_t s = (hipStream_t)stream;
-  const int64_t BN = (int64_t)B * N;
-  attn_delta_kernel<<<(int)((BN * H + 255) / 256), 256, 0, s>>>(out, dout, BN, N, H, delta_ws);
   const int64_t nblk = (N + 127) / 128, heads = (int64_t)B * H;
   const dim3 grid((unsigned)(((heads + 7) / 8) * 8 * nblk));
   const float sl2 = scale * 1.4426950408889634f;
-  attn_bwd_dq_kernel<<<grid, 256, 0, s>>>(qkv, dout, lse, delta_ws, B, N, H, scale, sl2, dqkv);
+  attn_bwd_dq_kernel<<<grid, 256, 0, s>>>(qkv, out, dout, lse, delta_ws, B, N, H, scale, sl2, dqkv);   // also writes delta_ws = rowsum(dO * O) for the next kernel
   attn_bwd_dkv_kernel<<<grid, 256, 0, s>>>(qkv, dout, lse, delta_ws, B, N, H, scale, sl2, dqkv);
   return enh_check_launch("enh_attention_backward");
 }

@@ -338,7 +338,7 @@ def attention_forward(qkv, B: int, N: int, H: int, scale: float, out, lse):
 
 
 def attention_backward(qkv, out, dout, lse, B: int, N: int, H: int, scale: float, dqkv, delta_ws):
-    _timed("attn_bwd (delta+dq+dkv kernels)", 10.0 * B * H * N * N * 64,
+    _timed("attn_bwd (dq+dkv kernels)", 10.0 * B * H * N * N * 64,
            lambda: _check(lib().enh_attention_backward(_p(qkv, BF16, "qkv"), _p(out, BF16, "out"), _p(dout, BF16, "dout"), _p(lse, F32, "lse"), B, N, H,
                                                        scale, _p(dqkv, BF16, "dqkv"), _p(delta_ws, F32, "delta_ws"), _stream()),
                           "enh_attention_backward"))
