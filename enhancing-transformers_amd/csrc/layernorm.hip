@@ -262,10 +262,11 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
 }
 
 static int ln_bwd_grid(int64_t M) {
-  // Persistent grid: every workgroup ends with 3*D column partials (dw, db, dx_colsum), so their number is kept at two workgroups per CU —
-  // measured 328 / 337 / 355 / 395 / 528 us at 512 / 768 / 1024 / 1280 / 4096 workgroups (M = 131072, D = 768, atomic form).
+  // Persistent grid, ONE workgroup per CU: with the row loop software-pipelined a workgroup keeps its CU's memory pipe busy by itself, and whole
+  // multiples of the 256 CUs matter more than occupancy — measured 294 / 343 / 317 / 340 / 345 / 373 us at 256 / 384 / 512 / 768 / 1024 / 2048
+  // workgroups (M = 131072, D = 768, bf16 dy; the atomic form of round 1 was best at 512).
   const int64_t want = (M + 3) / 4;
-  return (int)(want < 512 ? want : 512);
+  return (int)(want < 256 ? want : 256);
 }
 
 extern "C" size_t enh_layernorm_backward_workspace_bytes(int64_t M, int D) {
