@@ -39,7 +39,7 @@ def _worker(rank, world, port, q, algo="allreduce"):
         for prefix in ["decoder.b.", "decoder.a.", "quantizer.", "encoder.b.", "encoder.a."]:  # backward order
             sync.layer_done(prefix)
         sync.finish()
-    q.put((rank, store.g.clone(), local))
+    q.put((rank, store.g.numpy().copy(), local.numpy().copy()))   # numpy, not tensors: a tensor travels as a shared-memory handle that dies with this process
     dist.barrier()
     dist.destroy_process_group()
 
@@ -57,7 +57,7 @@ def test_gradsync_gloo_world2(world, algo):
     procs = [ctx.Process(target=_worker, args=(r, world, port, q, algo)) for r in range(world)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=120) for _ in range(world)]
+    got = [(r, torch.from_numpy(a), torch.from_numpy(b)) for r, a, b in (q.get(timeout=120) for _ in range(world))]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -180,7 +180,7 @@ def _bf16_worker(rank, world, port, q):
     for prefix in ["decoder.b.", "decoder.a.", "quantizer.", "encoder.b.", "encoder.a."]:
         sync.layer_done(prefix)
     sync.finish()
-    q.put((rank, store.g.clone(), local, sync.bytes_reduced))
+    q.put((rank, store.g.numpy().copy(), local.numpy().copy(), sync.bytes_reduced))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -193,7 +193,7 @@ def test_gradsync_bf16_buckets_world2():
     procs = [ctx.Process(target=_bf16_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = sorted((q.get(timeout=120) for _ in range(2)), key=lambda t: t[0])
+    got = sorted(((r, torch.from_numpy(a), torch.from_numpy(b), n) for r, a, b, n in (q.get(timeout=120) for _ in range(2))), key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
