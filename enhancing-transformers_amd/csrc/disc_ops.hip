@@ -1,9 +1,9 @@
 // disc_ops.hip — gfx950 versions of the reference's ONLY native code: the two StyleGAN2-discriminator ops
 //   fused_bias_act  (reference enhancing/losses/op/fused_bias_act_kernel.cu:18-65, bound at fused_bias_act.cpp:17-31)
 //   upfirdn2d       (reference enhancing/losses/op/upfirdn2d_kernel.cu:49-207, bound at upfirdn2d.cpp:17-30)
-// Both are HBM-bound streaming kernels: 16-byte accesses along the contiguous (W) axis, one pass over the data.
-// SURVEY.md §8f rank 1 ("next" row): the discriminator itself (equalised-lr convolutions on MFMA, minibatch-stddev, R1)
-// is not built yet; these two ops are what its activation / blur layers call.
+// Both are HBM-bound streaming kernels: 16-byte accesses along the contiguous (W) axis, one pass over the data.  They serve the layer classes' own
+// NCHW f32 API; the discriminator's forward runs on the channels-last bf16 kernels further down (blur, gate, layout change, minibatch standard
+// deviation) and on the implicit-GEMM convolutions of conv_igemm.hip.
 #include "common.h"
 #include <stdlib.h>
 

@@ -476,6 +476,8 @@ class Stage1Engine:
             return self.forward_backward(img, w_l1, w_l2, codebook_weight, zero_grad)
         key = (tuple(img.shape), float(w_l1), float(w_l2), float(codebook_weight), bool(zero_grad))
         entry = self._graphs.get(key)
+        if entry is None and len(self._graphs) >= 8:      # ragged batch sizes: do not hoard one graph (and its private memory pool) per shape
+            return self.forward_backward(img, w_l1, w_l2, codebook_weight, zero_grad)
         if entry is None:
             static_img = torch.empty(img.shape, dtype=F32, device=self.device)
             static_img.copy_(img)

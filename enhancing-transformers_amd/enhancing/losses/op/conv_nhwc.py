@@ -53,6 +53,8 @@ def _pack(w, scale, transposed, kh0, kw0, kstep, nty, ntx, rows, cols):
         return _C.conv_pack_weight(w.contiguous(), scale, transposed, kh0, kw0, kstep, nty, ntx, rows, cols)
     key = (id(w), w.data_ptr(), w._version, float(scale), transposed, kh0, kw0, kstep, nty, ntx, rows, cols)
     hit = _PACKED.get(key)
+    if hit is None and len(_PACKED) >= 512:        # an optimizer that never calls invalidate_packed_weights() (in-place torch updates bump the version
+        _PACKED.clear()                            # every step) must not grow the cache without bound
     if hit is None or hit[0]() is not w:          # (the weak reference guards against a recycled id / address of a freed parameter)
         hit = _PACKED[key] = (weakref.ref(w), _C.conv_pack_weight(w.detach().contiguous(), scale, transposed, kh0, kw0, kstep, nty, ntx, rows, cols))
     return hit[1]
