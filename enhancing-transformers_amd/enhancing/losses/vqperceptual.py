@@ -109,10 +109,15 @@ class VQLPIPSWithDiscriminator(VQLPIPS):
             if optimizer_idx == 0:
                 return super().forward(codebook_loss, inputs, reconstructions, optimizer_idx, global_step, batch_idx, last_layer, split)
             return None, {}
-        from .op import conv2d_gradfix
+        from .op import conv2d_gradfix, conv_nhwc
         inputs = inputs.contiguous()
         reconstructions = reconstructions.contiguous()
         self.disc_store(reconstructions.device)
+        if optimizer_idx == 0:
+            # packed operand images of the discriminator's weights are reused for every pass of ONE training step (the weights only change in the
+            # discriminator's optimizer step, which invalidates them itself); dropping them here as well covers writers that bypass both the
+            # autograd version counter and that optimizer (a broadcast into the flat buffer, `param.data` assignments)
+            conv_nhwc.invalidate_packed_weights()
         disc_factor = 1 if global_step >= self.discriminator_iter_start else 0
 
         if optimizer_idx == 0:   # generator update (vqperceptual.py:111-146)

@@ -117,3 +117,34 @@ def test_loss_module_generator_and_discriminator_sides(monkeypatch):
     L.eval()
     _, log = L(q, x, r, 1, 7, 0, split="val")
     assert "val/r1_reg" not in log and set(log) == {"val/disc_loss", "val/logits_real", "val/logits_fake"}
+
+
+def test_packed_weight_cache_follows_the_weights(monkeypatch):
+    """op/conv_nhwc.py caches the packed bf16 operand images of nn.Parameters between optimizer steps: reused while the weights are unchanged, rebuilt
+    after an in-place torch update (autograd version), after invalidate_packed_weights() (what the fused AdamW calls: it writes through raw pointers) and
+    for a different parameter that happens to get a recycled address; plain tensors (second-order weight-shaped gradients) are never cached"""
+    import hip_emulation
+    hip_emulation.install(monkeypatch, exact=True)
+    from enhancing import _C
+    from enhancing.losses.op import conv_nhwc
+    calls = []
+    real = _C.conv_pack_weight
+    monkeypatch.setattr(_C, "conv_pack_weight", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    conv_nhwc.invalidate_packed_weights()
+    torch.manual_seed(0)
+    w = torch.nn.Parameter(torch.randn(16, 8, 3, 3))
+    x = torch.randn(2, 6, 6, 8)
+    y0 = conv_nhwc.conv(x, w, 0.5, 1, 1)
+    y1 = conv_nhwc.conv(x, w, 0.5, 1, 1)
+    assert len(calls) == 1 and torch.equal(y0, y1)
+    with torch.no_grad():
+        w.mul_(2.0)                                       # in-place torch write: the version counter moves
+    y2 = conv_nhwc.conv(x, w, 0.5, 1, 1)
+    assert len(calls) == 2 and rel(y2, 2 * y0) <= 1e-6
+    w.data.mul_(0.5)                                      # a writer the version counter does not see ...
+    assert torch.equal(conv_nhwc.conv(x, w, 0.5, 1, 1), y2) and len(calls) == 2      # ... is served the stale image, which is why
+    conv_nhwc.invalidate_packed_weights()                                            # raw-pointer writers must invalidate
+    assert rel(conv_nhwc.conv(x, w, 0.5, 1, 1), y0) <= 1e-6 and len(calls) == 3
+    conv_nhwc.conv(x, w.detach() * 1.0, 0.5, 1, 1)        # not a Parameter: packed every time
+    conv_nhwc.conv(x, w.detach() * 1.0, 0.5, 1, 1)
+    assert len(calls) == 5
