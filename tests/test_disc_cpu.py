@@ -148,3 +148,55 @@ def test_packed_weight_cache_follows_the_weights(monkeypatch):
     conv_nhwc.conv(x, w.detach() * 1.0, 0.5, 1, 1)        # not a Parameter: packed every time
     conv_nhwc.conv(x, w.detach() * 1.0, 0.5, 1, 1)
     assert len(calls) == 5
+
+
+@pytest.mark.parametrize("H,W,k,s,p", [(9, 11, 3, 1, 1), (9, 11, 3, 2, 0), (10, 8, 3, 2, 1), (7, 7, 1, 2, 0), (8, 9, 1, 1, 0), (11, 10, 3, 3, 1), (6, 6, 5, 2, 2),
+                                       (5, 4, 3, 1, 0), (4, 4, 3, 2, 1)])
+def test_conv_geometry_of_every_role_against_torch(monkeypatch, H, W, k, s, p):
+    """the enh_conv_geom structs op/conv_nhwc.py builds for the forward, the input gradient (one launch per output parity class when stride > 1, classes
+    without taps writing zeros) and the weight gradient, interpreted tap by tap by the test-only stand-in, against F.conv2d and its autograd — including
+    strides, paddings and ragged sizes the discriminator itself never uses"""
+    import hip_emulation
+    hip_emulation.install(monkeypatch, exact=True)
+    from enhancing.losses.op import conv_nhwc
+    g = torch.Generator().manual_seed(H * 100 + W * 10 + k + s + p)
+    B, Cin, Cout = 2, 5, 16
+    Cp = conv_nhwc.pad8(Cin)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.conv2d(xr, 0.3 * wr, stride=s, padding=p)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    xp = torch.zeros(B, H, W, Cp)
+    xp[..., :Cin] = x.permute(0, 2, 3, 1)
+    xd, wd = xp.requires_grad_(True), w.clone().requires_grad_(True)
+    y = conv_nhwc.conv(xd, wd, 0.3, s, p)
+    assert rel(y.permute(0, 3, 1, 2), yr) <= 1e-6
+    y.backward(dy.permute(0, 2, 3, 1).contiguous())
+    assert rel(xd.grad[..., :Cin].permute(0, 3, 1, 2), xr.grad) <= 1e-6 and not xd.grad[..., Cin:].abs().sum().item()
+    assert rel(wd.grad, wr.grad) <= 1e-6
+
+
+@pytest.mark.parametrize("pad", [(2, 2), (1, 1), (2, 1), (0, 3), (-1, 2)])
+def test_nhwc_blur_and_its_adjoint_against_the_ops_oracle(monkeypatch, pad):
+    """conv_nhwc.blur = upfirdn2d(x, k, pad) with unit factors; its backward is the same kernel with the taps in the other order and pads kh-1-pad
+    (negative pads = cropping included), checked against autograd through the oracle's upfirdn2d"""
+    import disc_ops_oracle as DO
+    import hip_emulation
+    hip_emulation.install(monkeypatch, exact=True)
+    from enhancing.losses.op import conv_nhwc
+    g = torch.Generator().manual_seed(7)
+    kern = torch.rand(4, 4, generator=g)
+    x = torch.randn(2, 9, 10, 8, generator=g)
+    xr = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    crop0, crop1 = max(-pad[0], 0), max(-pad[1], 0)
+    xc = xr[:, :, crop0:xr.shape[2] - crop1, crop0:xr.shape[3] - crop1]
+    yr = DO.upfirdn2d(xc, kern, pad=(max(pad[0], 0), max(pad[1], 0)))
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xd = x.clone().requires_grad_(True)
+    y = conv_nhwc.blur(xd, kern, pad)
+    assert rel(y.permute(0, 3, 1, 2), yr) <= 1e-6
+    y.backward(gy.permute(0, 2, 3, 1).contiguous())
+    assert rel(xd.grad.permute(0, 3, 1, 2), xr.grad) <= 1e-6
