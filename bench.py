@@ -197,6 +197,7 @@ def main():
     if rank != 0:
         if world > 1:
             dist.barrier()
+            dist.destroy_process_group()
         return
     img_per_s = args.steps * B * world / elapsed
     ks = timer.summary()
@@ -244,6 +245,7 @@ def main():
     print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
