@@ -210,7 +210,7 @@ class StyleDiscriminator(nn.Module):
         B, H, W, C = out.shape
         # minibatch standard deviation (layers.py:358-367): sample b belongs to slot b % (B/group); one scalar per slot
         group = min(B, self.stddev_group)
-        group = B // (B // group)
+        group = B // (B // group)                                      # the reference's own adjustment for B % group != 0 (layers.py:361-362), kept verbatim in meaning: B = 6 -> one group of 6
         out = conv_nhwc.minibatch_stddev(out, group)                     # 513 channels, zero-padded to 520
         out = self.final_conv.forward_nhwc(out)                          # [B,4,4,512]
         out = out.permute(0, 3, 1, 2).reshape(B, -1).float()             # per-sample (c, h, w) flattening, as the reference's .view
@@ -223,7 +223,7 @@ class StyleDiscriminator(nn.Module):
         C, B, H, W = out.shape
         # minibatch standard deviation (layers.py:358-367): sample b belongs to slot b % (B/group); one scalar per slot
         group = min(B, self.stddev_group)
-        group = B // (B // group)
+        group = B // (B // group)                                      # the reference's own adjustment for B % group != 0 (layers.py:361-362), kept verbatim in meaning: B = 6 -> one group of 6
         n = B // group
         sd = torch.sqrt(out.view(C, group, n, H, W).var(1, unbiased=False) + 1e-8).mean(dim=(0, 2, 3))      # [n]
         sd_map = sd.repeat(group).view(1, B, 1, 1).expand(1, B, H, W)

@@ -11,9 +11,13 @@ returned as [B, 1, 1, 1].  The module tree and state-dict keys are those of lpip
 
 WEIGHTS.  lpips loads an ImageNet-pretrained torchvision VGG16 and its own learned lin layers; neither can be obtained in this environment (no
 network, no lpips / torchvision wheel).  ``LPIPS(model_path=...)`` or the environment variable ``ENH_LPIPS_WEIGHTS`` names a ``torch.save``d state dict
-in the lpips key layout; without it the trunk gets torchvision's own initialiser (kaiming-normal fan_out, zero bias) and the lin layers uniform [0, 1)
-weights (the learned ones are non-negative too) from a PRIVATE generator (the global RNG is not consumed), and a warning says so once: the term is then
-structurally right, differentiable and timed on the real topology, but its VALUES are not the published metric — "parity unpinned" (SURVEY.md §8c).
+in the lpips key layout; a checkpoint of the whole model that carries ``loss.perceptual_loss.*`` (as the reference's do) supplies them through the
+parent's ``load_state_dict`` as well.  Without weights the module can be CONSTRUCTED (so that such a checkpoint can be loaded into it) but its forward
+RAISES — the reference's ``lpips.LPIPS(net='vgg')`` fails offline too, and a silently random perceptual term would be logged as if it were the metric.
+Random initialisation is an explicit opt-in (``pretrained=False`` or ``ENH_LPIPS_RANDOM_INIT=1``; used by tests and bench configurations): the trunk then
+gets torchvision's own initialiser (kaiming-normal fan_out, zero bias) and the lin layers uniform [0, 1) weights (the learned ones are non-negative
+too) from a PRIVATE generator (the global RNG is not consumed) — structurally right, differentiable and timed on the real topology, but its VALUES
+are not the published metric: "parity unpinned" (SURVEY.md §8c).  ``weights_loaded`` says which of the two is running.
 
 Execution: both images go through the trunk as one batch of 2B in channels-last bf16; the first convolution is fused with the scaling layer
 (``enh_vgg_conv1``), the other twelve are implicit GEMMs on MFMA (``enh_conv3x3_nhwc_bf16``: bias + ReLU fused; the input gradient is the same kernel on
@@ -91,8 +95,9 @@ class _LPIPSFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout):
+        # ctx.saved is NOT dropped here: calculate_adaptive_factor (vqperceptual.py:94-103) differentiates nll_loss — which contains this term — with
+        # retain_graph=True before the real backward runs through the same node a second time; the activations are freed with the graph
         d_in1 = ctx.module._run_backward(ctx.saved, gout.reshape(-1).float().contiguous(), ctx.normalize, ctx.shape)
-        ctx.saved = None
         return None, None, d_in1, None
 
 
@@ -108,13 +113,18 @@ class LPIPS(nn.Module):
             setattr(self, f"lin{k}", NetLinLayer(c))
         self.lins = nn.ModuleList([getattr(self, f"lin{k}") for k in range(self.L)])   # lpips registers them twice: both key families exist
         self._dev: Dict[str, object] = {}
-        self.weights_loaded = False
+        self.weights_loaded = False       # True once an lpips-format state dict went in (directly or through a parent's load_state_dict)
+        self.random_init = False          # True only on the explicit opt-in below
         path = model_path or os.environ.get("ENH_LPIPS_WEIGHTS")
         if path:
             sd = torch.load(path, map_location="cpu")
             self.load_state_dict(sd.get("state_dict", sd), strict=True)
-        else:
+        elif not pretrained or os.environ.get("ENH_LPIPS_RANDOM_INIT", "0") not in ("", "0"):
             self._random_init()
+        else:                              # constructed empty: forward raises until weights arrive (see the module docstring)
+            with torch.no_grad():
+                for p in self.parameters():
+                    p.zero_()
         self.eval()
 
     # ---- parameters ----------------------------------------------------------------------------------------
@@ -129,9 +139,10 @@ class LPIPS(nn.Module):
                     p.bias.zero_()
             for k in range(self.L):
                 getattr(self, f"lin{k}").model[1].weight.uniform_(0.0, 1.0, generator=g)
+        self.random_init = True
         if not _warned:
-            warnings.warn("LPIPS: no pretrained weights available (set ENH_LPIPS_WEIGHTS or model_path to an lpips-format state dict): the perceptual term "
-                          "runs on a randomly initialised VGG16 — right topology and cost, values NOT the published metric (parity unpinned)")
+            warnings.warn("LPIPS: random initialisation requested (pretrained=False / ENH_LPIPS_RANDOM_INIT=1): the perceptual term runs on a randomly "
+                          "initialised VGG16 — right topology and cost, values NOT the published metric (parity unpinned)")
             _warned = True
 
     def _conv(self, idx: int) -> _ConvParams:
@@ -141,22 +152,29 @@ class LPIPS(nn.Module):
                     return getattr(getattr(self.net, f"slice{k + 1}"), str(idx))
         raise KeyError(idx)
 
-    def load_state_dict(self, state_dict, strict: bool = True, **kw):
-        out = super().load_state_dict(state_dict, strict=strict, **kw)
+    def _load_from_state_dict(self, state_dict, prefix, *a, **k):
+        # reached both by self.load_state_dict and by a PARENT's (ViTVQ.init_from_ckpt loading a reference checkpoint that carries
+        # loss.perceptual_loss.*), which never calls a child's load_state_dict override
+        if any(key.startswith(prefix + "net.") for key in state_dict) and any(key.startswith(prefix + "lin") for key in state_dict):
+            self.weights_loaded = True
         self._dev.clear()
-        self.weights_loaded = True
-        return out
+        return super()._load_from_state_dict(state_dict, prefix, *a, **k)
 
     def _apply(self, fn, *a, **k):
         self._dev.clear()
         return super()._apply(fn, *a, **k)
 
+    def _weights_fingerprint(self):
+        # (storage address, in-place version) of every parameter: any load / copy_ / optimizer-style write invalidates the packed operand cache
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
     def _device_weights(self, device: torch.device) -> dict:
-        """kernel operand forms of the frozen weights, built once per device: tap-major bf16 [Cout][9*Cin] for the forward implicit GEMM and the
-        flipped / transposed [Cin][9*Cout] for the input gradient"""
-        if self._dev.get("device") == device:
+        """kernel operand forms of the frozen weights, built once per device and parameter version: tap-major bf16 [Cout][9*Cin] for the forward
+        implicit GEMM and the flipped / transposed [Cin][9*Cout] for the input gradient"""
+        fp = self._weights_fingerprint()
+        if self._dev.get("device") == device and self._dev.get("fingerprint") == fp:
             return self._dev
-        d: Dict[str, object] = {"device": device, "fwd": {}, "bwd": {}, "bias": {}, "lin": []}
+        d: Dict[str, object] = {"device": device, "fingerprint": fp, "fwd": {}, "bwd": {}, "bias": {}, "lin": []}
         for convs in _SLICES:
             for idx, cin, cout in convs:
                 p = self._conv(idx)
@@ -179,6 +197,10 @@ class LPIPS(nn.Module):
         """d(in0, in1) as [B,1,1,1]; images in [-1,1], or in [0,1] with normalize=True (lpips' own flag).  Differentiable w.r.t. in1."""
         if retPerLayer:
             raise NotImplementedError("retPerLayer is not used by the reference")
+        if not (self.weights_loaded or self.random_init):
+            raise RuntimeError("LPIPS has no weights: pass model_path / set ENH_LPIPS_WEIGHTS to an lpips-format state dict (lpips 0.1.4, net='vgg'), load a "
+                               "checkpoint that carries loss.perceptual_loss.*, set perceptual_weight: 0, or opt in to a randomly initialised trunk with "
+                               "pretrained=False / ENH_LPIPS_RANDOM_INIT=1 (values then are NOT the published metric)")
         if not in1.is_cuda:
             raise RuntimeError("LPIPS runs only on a ROCm device: the HIP path has no CPU fallback")
         in0 = in0.detach().to(device=in1.device, dtype=torch.float32).contiguous()

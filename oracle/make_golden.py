@@ -140,6 +140,6 @@ if __name__ == "__main__":
     print("golden vectors written to", GOLD)
 
 
-# NOTE: tests/golden/disc_ops.npz (discriminator native ops) is produced by the AST-extraction snippet documented in
-# oracle/disc_ops_oracle.py: the reference's op/*.py cannot be imported (they JIT-compile CUDA sources at import), so its pure-Python
-# fallbacks `upfirdn2d_native` and the CPU branch of `fused_leaky_relu` are extracted with `ast` and executed as they are.
+# NOTE: tests/golden/disc_ops.npz (discriminator native ops) is produced by oracle/make_golden_disc_ops.py: the reference's op/*.py cannot be
+# imported (they JIT-compile CUDA sources at import), so its pure-Python fallbacks `upfirdn2d_native` and the CPU branch of
+# `fused_leaky_relu` are extracted with `ast` and executed as they are.

@@ -16,3 +16,9 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture
+def lpips_random_init(monkeypatch):
+    """explicit opt-in to a randomly initialised LPIPS trunk (no lpips weights can be obtained offline; enhancing/losses/lpips.py raises without it)"""
+    monkeypatch.setenv("ENH_LPIPS_RANDOM_INIT", "1")

@@ -186,3 +186,33 @@ def test_adaptive_adversarial_weight(C):
     print("d_weight logged", m.logged["train/d_weight"].item(), "recomputed", want.item(), "norms", eng.last_layer_grad_norm(gn).item(), eng.last_layer_grad_norm(gg).item())
     # (two separate forward passes through the discriminator: its split-K f32 atomics make them differ in the last bits, and gate flips amplify that)
     assert abs(m.logged["train/d_weight"].item() - want.item()) <= 2e-2 * abs(want.item())
+
+
+def test_adaptive_adversarial_weight_with_the_perceptual_term(C, lpips_random_init):
+    """use_adaptive_adv with the reference's DEFAULT perceptual_weight (1.0).  calculate_adaptive_factor differentiates nll_loss —
+    which contains the LPIPS term — with retain_graph=True (vqperceptual.py:94-103) and the real backward then runs through the same autograd node a
+    second time: both optimizers' training steps must complete, log a finite d_weight, and give gradients to the autoencoder."""
+    import vitvq_oracle as O
+    from enhancing.modules.stage1.vitvqgan import ViTVQ
+    from enhancing.utils.general import AttrDict
+    cfg = O.TINY_CFG
+    loss = {"target": "enhancing.losses.vqperceptual.VQLPIPSWithDiscriminator",
+            "params": dict(loglaplace_weight=0.0, loggaussian_weight=1.0, perceptual_weight=1.0, adversarial_weight=0.1, use_adaptive_adv=True,
+                           disc_params={"size": cfg["image_size"]})}
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = ViTVQ("image", cfg["image_size"], cfg["patch_size"], AttrDict.wrap(cfg["encoder"]), AttrDict.wrap(cfg["decoder"]),
+                  AttrDict.wrap(cfg["quantizer"]), AttrDict.wrap(loss))
+    assert m.loss.perceptual_loss.random_init and not m.loss.perceptual_loss.weights_loaded
+    m.load_state_dict({**O.make_params(cfg, seed=11), **{"loss." + k: v for k, v in m.loss.state_dict().items()}}, strict=True)
+    m.train()
+    x = O.make_images(5, 2, cfg["image_size"])
+    m.engine.store.zero_grad()
+    l0 = m.training_step({"image": x}, 0, 0)
+    assert torch.isfinite(l0) and torch.isfinite(m.logged["train/d_weight"]) and m.logged["train/d_weight"].item() > 0
+    assert m.logged["train/perceptual_loss"].item() > 0
+    gn = float(m.engine.store.g.float().norm())
+    assert gn > 0 and gn == gn
+    l1 = m.training_step({"image": x}, 0, 1)
+    assert torch.isfinite(l1)

@@ -82,6 +82,39 @@ def test_loss_modules_construct_every_term():
     assert abs(loss.item() - (((r - x) ** 2).mean().item() + 0.5)) < 1e-6
 
 
+def test_lpips_without_weights_raises_and_parent_load_supplies_them(monkeypatch):
+    """(1) no silent random perceptual term — without weights the module constructs (so a checkpoint can be loaded into it) but its forward
+    raises unless random init was an explicit opt-in; (2) a PARENT's load_state_dict (a reference checkpoint carrying loss.perceptual_loss.*) marks
+    the weights as loaded and invalidates the packed operand cache, and so does an in-place write to a parameter."""
+    from enhancing.losses.lpips import LPIPS
+    from enhancing.losses.vqperceptual import VQLPIPS
+    monkeypatch.delenv("ENH_LPIPS_RANDOM_INIT", raising=False)
+    monkeypatch.delenv("ENH_LPIPS_WEIGHTS", raising=False)
+    P = VQLPIPS(perceptual_weight=0.1)
+    m = P.perceptual_loss
+    assert not m.weights_loaded and not m.random_init
+    with pytest.raises(RuntimeError, match="LPIPS has no weights"):
+        m(torch.zeros(1, 3, 16, 16), torch.zeros(1, 3, 16, 16))
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        src = LPIPS(net="vgg", pretrained=False)                     # explicit opt-in
+    assert src.random_init and not src.weights_loaded
+    cpu = torch.device("cpu")
+    before = m._device_weights(cpu)["fwd"][2].clone()
+    P.load_state_dict({"perceptual_loss." + k: v for k, v in src.state_dict().items()}, strict=True)      # parent load: child override never runs
+    assert m.weights_loaded
+    after = m._device_weights(cpu)["fwd"][2]
+    assert before.abs().max() == 0 and after.abs().max() > 0       # stale (zero) operands were not re-used
+    with torch.no_grad():
+        m._conv(2).weight.mul_(2.0)                             # in-place write: version bump -> cache rebuilt
+    assert torch.equal(m._device_weights(cpu)["fwd"][2].float(), (after.float() * 2).to(torch.bfloat16).float())
+    monkeypatch.setenv("ENH_LPIPS_RANDOM_INIT", "1")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert LPIPS(net="vgg").random_init
+
+
 def test_reference_yaml_files_load_unchanged():
     """the reference's OWN configs/imagenet_vitvq_{small,base,large}.yaml (not this repo's edited copies) resolve through the
     reflection factory byte for byte — ViTVQ with VQLPIPSWithDiscriminator (LPIPS 0.1 + StyleGAN discriminator 0.1) and the ImageNet data module."""

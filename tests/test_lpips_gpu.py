@@ -103,7 +103,7 @@ def test_lpips_head_forward_backward(C, Cc):
     assert rel(_nchw(df), f1.grad) <= 4e-3
 
 
-def test_lpips_distance_and_gradient_vs_oracle():
+def test_lpips_distance_and_gradient_vs_oracle(lpips_random_init):
     """the whole term: d(in0, in1) [B,1,1,1] and d/d in1, identical random weights on both sides (state-dict keys of lpips 0.1.4)"""
     import lpips_oracle as LO
     from enhancing.losses.lpips import LPIPS

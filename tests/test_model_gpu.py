@@ -378,7 +378,7 @@ def test_inference_between_forward_and_backward_is_refused(tiny):
         xrec.sum().backward()
 
 
-def test_training_step_with_the_lpips_term_vs_oracle():
+def test_training_step_with_the_lpips_term_vs_oracle(lpips_random_init):
     """optimizer_idx 0 with VQLPIPS(perceptual_weight=0.1): forward -> loss module (pixel + LPIPS + codebook) -> autograd through the HIP LPIPS and the
     engine's backward (reference vitvqgan.py:103-115, vqperceptual.py:41-46), against the fp32 oracle with the same (random) LPIPS weights"""
     import warnings
