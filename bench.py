@@ -23,6 +23,19 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 FWD_GFLOP_PER_IMG_BASE = 426.44      # SURVEY.md §8(d) / BASELINE.md
 STEP_TFLOP_PER_IMG_BASE = 1.279      # 1 fwd + 1 bwd = 3x forward
 MFMA_BF16_PEAK_TFLOPS = 2500.0       # dense, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_F32_PEAK_TFLOPS = 157.3         # exact-f32 MFMA = the vector rate (same guide, "Matrix cores")
+HBM_PEAK_GBS = 8000.0                # spec; ~6300 achievable (same guide, "HBM")
+# A mismatch between two fp32 evaluations of quantizers.py:78-80 is a legitimate near-tie iff the EXACT (fp64) distance gap of the two codes is below
+# this bound.  Derivation (n = 32, u = 2^-24; unit vectors, so every partial sum has magnitude <= 1 and d <= 4): an implementation computes
+# fl(fl(A + B_j) - 2 C_j) with A = |zn|^2, B_j = |en_j|^2, C_j = zn.en_j, each an n-term fp32 sum whose error is <= n u in ANY summation order
+# (the reference's torch.sum / einsum blocking is not specified, the kernel's is include/enh_hip.h's contract); A's error is common to every j and
+# cancels in the argmin; the two outer operations round by <= 2u and <= 4u.  So each computed d_j is within (n + 2n + 6) u of (exact + constant), two
+# codes can swap order in one implementation only if their exact gap is <= 2 (3n + 6) u, and two implementations can disagree only if one of them
+# swapped: gap <= (6n + 12) u = 204 u = 1.22e-5 = 51 ulp of the intermediate sum A + B ~ 2.  That is the worst case; the random-walk expectation for
+# the largest gap seen over ~1e9 comparisons is ~1e-6 (4-6 ulp), which is what the runs show.  Anything above the bound is a kernel bug -> FAIL.
+VQ_N = 32
+VQ_NEAR_TIE_BOUND = (6 * VQ_N + 12) * 2.0 ** -24
+ULP_OF_2 = 2.0 ** -22
 
 
 def cpu_baseline(max_seconds: float = 40.0):
@@ -76,30 +89,64 @@ def cpu_baseline(max_seconds: float = 40.0):
 
 
 def vq_match_rate(h_dev, idx_dev, codebook_dev, depth: int, use_residual: bool):
-    """Second half of BASELINE.json's metric: the VQ argmin match-rate at the OP BOUNDARY — the quantizer input h the timed step just
-    produced on the GPU (M = per-GPU batch x 1024 tokens), quantized by the reference's formula on the host (oracle, the checker) vs the
-    indices the HIP kernel produced for the same h.  Any mismatch is audited as an fp32 near-tie (top-2 distance gap < 1e-6 in fp64),
-    SURVEY.md §8(d) metric 2."""
+    """Second half of BASELINE.json's metric: the VQ argmin match-rate at the OP BOUNDARY — a quantizer input h produced on the GPU by the measured path
+    (M = per-GPU batch x 1024 tokens), quantized by the reference's formula on the host (oracle, the checker) vs the indices the HIP kernel produced for
+    the SAME h and the SAME codebook (both snapshotted from one forward pass with no optimizer step in between).  Every mismatch is audited in fp64:
+    which side (if any) holds the exact argmin, and the exact distance gap between the two picks in ulps of the intermediate sum |zn|^2 + |en|^2 ~ 2.
+    status = "FAIL" if any gap exceeds VQ_NEAR_TIE_BOUND (see its derivation above): main() then exits non-zero.  SURVEY.md §8(d) metric 2."""
     import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import vitvq_oracle as O
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
     h, idx, E = h_dev.detach().float().cpu(), idx_dev.detach().cpu().view(h_dev.shape[0], -1), codebook_dev.detach().float().cpu()
-    M, mism, worst_gap = h.shape[0], 0, 0.0
+    M, mism, audits = h.shape[0], 0, []
+    en64 = torch.nn.functional.normalize(E.double(), dim=-1)
     for s in range(0, M, 16384):
         zz = h[s:s + 16384]
         _, _, it = O.quantizer_forward(zz, E, 0.25, True, use_residual, depth if use_residual else None)
         it = it.view(zz.shape[0], -1)
         bad = (it != idx[s:s + 16384]).any(dim=1).nonzero().view(-1)
         mism += len(bad)
-        if not use_residual:
-            en = torch.nn.functional.normalize(E.double(), dim=-1)
-            for j in bad.tolist()[:64]:
-                zn = torch.nn.functional.normalize(zz[j:j + 1].double(), dim=-1)
-                d = ((zn ** 2).sum(1, keepdim=True) + (en ** 2).sum(1) - 2 * zn @ en.t()).view(-1)
-                worst_gap = max(worst_gap, (d[it[j, 0]] - d[idx[s + j, 0]]).abs().item())
-    return {"value": 1.0 - mism / M, "tokens": M, "mismatches": mism, "worst_mismatch_gap_fp64": worst_gap,
-            "boundary": "identical quantizer input h (from the timed step's last batch); HIP indices vs the reference formula on the host"}
+        if use_residual:
+            continue       # (the audit below is for the single-stage quantizer the headline config uses)
+        for j in bad.tolist()[:256]:
+            zn = torch.nn.functional.normalize(zz[j:j + 1].double(), dim=-1)
+            d = ((zn ** 2).sum(1, keepdim=True) + (en64 ** 2).sum(1) - 2 * zn @ en64.t()).view(-1)
+            ref_i, hip_i, best = int(it[j, 0]), int(idx[s + j, 0]), int(torch.argmin(d))
+            gap = abs(float(d[ref_i] - d[hip_i]))
+            audits.append({"token": s + j, "reference_pick": ref_i, "hip_pick": hip_i, "fp64_argmin": best,
+                           "fp64_argmin_side": "hip" if best == hip_i else ("reference" if best == ref_i else "neither"),
+                           "gap_fp64": gap, "gap_ulps_of_2": round(gap / ULP_OF_2, 2)})
+    worst = max((a_["gap_fp64"] for a_ in audits), default=0.0)
+    sides = {k: sum(1 for a_ in audits if a_["fp64_argmin_side"] == k) for k in ("hip", "reference", "neither")}
+    ok = worst <= VQ_NEAR_TIE_BOUND
+    return {"value": 1.0 - mism / M, "tokens": M, "mismatches": mism, "distinct_codes": int(idx.unique().numel()), "codebook_size": int(E.shape[0]),
+            "worst_mismatch_gap_fp64": worst, "worst_mismatch_gap_ulps_of_2": round(worst / ULP_OF_2, 2),
+            "near_tie_bound_fp64": VQ_NEAR_TIE_BOUND, "near_tie_bound_ulps_of_2": round(VQ_NEAR_TIE_BOUND / ULP_OF_2, 1),
+            "fp64_argmin_held_by": sides, "audited": audits[:16], "status": "ok" if ok else "FAIL",
+            "boundary": "identical quantizer input h and codebook (one extra forward pass after the timed region, no optimizer step in between); "
+                        "HIP indices vs the reference formula (fp32, torch CPU) on the host"}
+
+
+def kernel_rooflines(ks: dict, steps_timed: int, ms_per_step: float, pmc: dict):
+    """every timed kernel with a work model, priced against ITS roofline: bf16 MFMA 2.5 PF, exact-f32 MFMA 157.3 TF, HBM 8 TB/s.  `traffic` comes from
+    a committed PMC pass of the SAME config and batch (profiles/pmc_step.json, written by tools/rocpd_summary.py pmc) and is null otherwise."""
+    peak = {"flop": (MFMA_BF16_PEAK_TFLOPS, "TFLOP/s", "mfma", 1e12), "flop_f32": (MFMA_F32_PEAK_TFLOPS, "TFLOP/s", "mfma_f32", 1e12),
+            "byte": (HBM_PEAK_GBS, "GB/s", "hbm", 1e9)}
+    out = {}
+    for k, v in ks.items():
+        pk, unit, bound, div = peak[v["unit"]]
+        ach = v["work"] / (v["total_ms"] * 1e-3) / div
+        sym = k.split(" (")[0]
+        tr = None
+        for name, rec in (pmc or {}).items():
+            if name == sym or name.startswith(sym + "<") or (k.startswith("vq_forward") and name == "vq_nn_kernel") or \
+                    (k.startswith("attn_bwd") and name.startswith("attn_bwd")):
+                tr = (tr or 0.0) + rec.get("hbm_bytes_per_launch", 0.0)
+        out[k] = {"kernel": k, "bound": bound, "achieved": round(ach, 1), "peak": pk, "unit": unit, "frac": round(ach / pk, 4), "traffic": tr,
+                  "launches_timed": v["launches"], "avg_launch_ms": round(v["avg_ms"], 4),
+                  "share_of_step": round((v["total_ms"] / steps_timed) / ms_per_step, 4)}
+    return out
 
 
 def main():
@@ -131,7 +178,14 @@ def main():
     dev = torch.device(f"cuda:{local_rank}")
     set_seed(0)  # identical init on every rank (then broadcast anyway, as DDP does)
     cfg = get_config_from_file(os.path.join(ROOT, "configs", args.config + ".yaml"))
+    pw = float(cfg.model.params.loss.get("params", {}).get("perceptual_weight", 1.0))      # VQLPIPS' default is 1.0 (vqperceptual.py:25)
+    lpips_info = None
+    if pw != 0.0 and not os.environ.get("ENH_LPIPS_WEIGHTS"):
+        os.environ["ENH_LPIPS_RANDOM_INIT"] = "1"      # explicit opt-in (enhancing/losses/lpips.py): timing the real topology on random weights; reported below
     model = initialize_from_config(cfg.model)
+    if pw != 0.0:
+        pl = model.loss.perceptual_loss
+        lpips_info = {"perceptual_weight": pw, "weights_loaded": bool(pl.weights_loaded), "random_init": bool(pl.random_init)}
     eng = model.engine
     if world > 1:
         eng.comm = GradSync(eng.store, compress="bf16" if args.grad_bf16 else None, algo=args.grad_algo)
@@ -194,51 +248,78 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    comm_info = None
+    if world > 1:
+        # per-rank exposed communication (so that the first real multi-GPU run explains itself) + the bucket accounting the DDP tests insist on
+        mine = eng.comm.comm_wait_ms(last=args.steps)
+        mine.update(rank=rank, bytes_reduced_per_step=eng.comm.bytes_reduced / max(len(eng.comm.host_wait_ms), 1), gap_elems=eng.comm.gap_elems)
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        comm_info = {"backend": dist.get_backend(), "algo": args.grad_algo, "bucket_dtype": "bf16" if args.grad_bf16 else "fp32",
+                     "n_params": int(eng.store.g.numel()), "per_rank": allr,
+                     "note": "stream_ms = time the compute stream waited for the collectives after backward (HIP events), host_ms = host time in wait()"}
     if rank != 0:
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
         return
     img_per_s = args.steps * B * world / elapsed
+    ms_per_step = elapsed / args.steps * 1e3
     ks = timer.summary()
-    gemms = {k: v for k, v in ks.items() if k.startswith("gemm_bf16_")}
-    dom = max(gemms, key=lambda k: gemms[k]["total_ms"])
-    d = gemms[dom]
-    achieved = d["work"] / d["launches"] / (d["avg_ms"] * 1e-3) / 1e12
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_gemm.json")
-    traffic = None
+    steps_timed = 2 if use_graphs else args.steps
+    # PMC traffic only from a pass over the SAME config and batch (profiles/pmc_step.json: {"config":, "batch":, "kernels": {symbol: {...}}})
+    pmc, pmc_path = None, os.path.join(ROOT, "profiles", "pmc_step.json")
     if os.path.exists(pmc_path):
         try:
-            traffic = json.load(open(pmc_path)).get(dom, {}).get("hbm_bytes_per_launch")
+            rec = json.load(open(pmc_path))
+            if rec.get("config") == args.config and int(rec.get("batch", -1)) == B:
+                pmc = rec.get("kernels", {})
         except Exception:
-            traffic = None
+            pmc = None
+    roofs = kernel_rooflines(ks, steps_timed, ms_per_step, pmc)
+    dom = max(roofs, key=lambda k: roofs[k]["share_of_step"])          # dominant kernel over ALL timed kernels (GEMM, attention, conv, VQ, LN, AdamW)
     is_base = args.config == "imagenet_vitvq_base"
     res = {
         "metric": "images/sec ViT-VQGAN-base 256px stage-1 train; VQ argmin match-rate" if is_base else f"images/sec {args.config} 256px stage-1 train",
         "value": round(img_per_s, 2), "unit": "images/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": (f"{args.config}.yaml two-optimizer step exactly as the reference drives it: autoencoder fwd + bwd through the StyleGAN2 "
                                 f"discriminator (L2 + codebook + 0.1*vanilla GAN) + AdamW, then forward again + discriminator fwd/bwd on real and fake "
-                                f"(lazy R1 every 16 batches) + AdamW; LPIPS weight 0" if adversarial else
+                                f"(lazy R1 every 16 batches) + AdamW" + (f"; LPIPS weight {pw}" if pw else "; LPIPS weight 0") if adversarial else
                                 f"{args.config}.yaml AE training step (1 fwd + 1 bwd + grad all-reduce + AdamW), loss = 1.0*L2 + 1.0*codebook "
                                 f"(LPIPS/GAN weights 0)") + ", K=8192 x 32 l2-normalised codes, fp32 master weights, bf16 MFMA operands / fp32 accumulate",
                    "per_gpu_batch": B, "global_batch": B * world, "image": f"{size}x{size}", "parallelism": f"dp{world}",
                    "hip_graph_replay": bool(use_graphs)},
         "final_loss": loss,
         "step_mfma_frac": round(img_per_s / world * STEP_TFLOP_PER_IMG_BASE / MFMA_BF16_PEAK_TFLOPS, 4) if is_base else None,
-        "roofline": {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
-                     "launches_timed": d["launches"], "avg_launch_ms": round(d["avg_ms"], 4),
-                     "share_of_step": round((d["total_ms"] / (2 if use_graphs else args.steps)) / (elapsed * 1e3 / args.steps), 3)},
-        "kernels": {k: {"launches": v["launches"], "total_ms": round(v["total_ms"], 2), "tflops": round(v["work"] / (v["total_ms"] * 1e-3) / 1e12, 1)}
+        "roofline": roofs[dom],
+        "kernels": {k: {"launches": v["launches"], "total_ms": round(v["total_ms"], 2), "bound": roofs[k]["bound"], "achieved": roofs[k]["achieved"],
+                        "unit": roofs[k]["unit"], "frac": roofs[k]["frac"], "share_of_step": roofs[k]["share_of_step"], "traffic": roofs[k]["traffic"]}
                     for k, v in sorted(ks.items())},
     }
+    if lpips_info is not None:
+        res["config"]["lpips"] = lpips_info
+    vqk = next((k for k in roofs if k.startswith("vq_forward")), None)
+    if vqk is not None:      # north_star: "wavefront-reduced nearest-neighbour HIP kernel evidenced by rocprof HBM GB/s vs peak"; SURVEY §8(d): fraction of 157.3 TF
+        r, v = roofs[vqk], ks[vqk]
+        tokens = B * (size // cfg.model.params.patch_size) ** 2
+        vq = {"tokens_per_launch": tokens, "tokens_per_s": round(tokens / (v["avg_ms"] * 1e-3), 0), "f32_tflops": r["achieved"],
+              "frac_of_f32_mfma_peak": r["frac"], "avg_launch_ms": r["avg_launch_ms"],
+              "algorithmic_bytes_per_launch": tokens * 264 + 8192 * 32 * 4, "hbm_bytes_per_launch_pmc": r["traffic"],
+              "hbm_gbs_pmc": round(r["traffic"] / (v["avg_ms"] * 1e-3) / 1e9, 1) if r["traffic"] else None, "hbm_peak_gbs": HBM_PEAK_GBS,
+              "note": "compute-bound by design (1986 FLOP/B): the [M, 8192] distance matrix never touches HBM, so GB/s is a small fraction of peak"}
+        res["vq"] = vq
+    if comm_info is not None:
+        res["comm"] = comm_info
     if world == 1 and not args.no_cpu_baseline:
-        # checker legs (oracle on the host cores): the argmin match-rate on the h of the last timed step, then the CPU baseline
-        if "h" in out and "indices" in out:
+        # checker legs (oracle on the host cores): the argmin match-rate on ONE extra forward pass (no optimizer step between the kernel's argmin and the
+        # snapshot of its inputs), then the CPU baseline
+        if not adversarial:
+            chk = eng.forward_backward(batches[0], w_l1=0.0, w_l2=1.0, codebook_weight=1.0)
+            torch.cuda.synchronize()
             q = model.quantizer
-            mr = vq_match_rate(out["h"], out["indices"], eng.store.w["quantizer.embedding.weight"], q.depth, bool(q.use_residual))
+            mr = vq_match_rate(chk["h"].clone(), chk["indices"].clone(), eng.store.w["quantizer.embedding.weight"].clone(), q.depth, bool(q.use_residual))
             res["vq_match_rate"] = mr["value"]
             res["vq_match"] = mr
         res["cpu_baseline"] = cpu_baseline()
@@ -246,6 +327,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if res.get("vq_match", {}).get("status") == "FAIL":
+        sys.exit(3)      # an index mismatch that is NOT an fp32 near-tie: the line above says which token
 
 
 if __name__ == "__main__":

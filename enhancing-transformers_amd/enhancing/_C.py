@@ -152,31 +152,33 @@ class KernelTimer:
 
     def __init__(self) -> None:
         self.records = {}
+        self.units = {}      # name -> "flop" (bf16 MFMA work), "flop_f32" (exact-f32 MFMA work) or "byte" (algorithmic HBM bytes)
 
-    def run(self, name: str, work: float, fn) -> None:
+    def run(self, name: str, work: float, fn, unit: str = "flop") -> None:
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         fn()
         e.record()
         self.records.setdefault(name, []).append((s, e, work))
+        self.units[name] = unit
 
     def summary(self) -> dict:
         torch.cuda.synchronize()
         out = {}
         for name, recs in self.records.items():
             ms = [s.elapsed_time(e) for s, e, _ in recs]
-            out[name] = dict(launches=len(recs), total_ms=sum(ms), avg_ms=sum(ms) / len(ms), work=sum(w for _, _, w in recs))
+            out[name] = dict(launches=len(recs), total_ms=sum(ms), avg_ms=sum(ms) / len(ms), work=sum(w for _, _, w in recs), unit=self.units[name])
         return out
 
 
 TIMER: Optional[KernelTimer] = None
 
 
-def _timed(name: str, work: float, fn) -> None:
+def _timed(name: str, work: float, fn, unit: str = "flop") -> None:
     if TIMER is None:
         fn()
     else:
-        TIMER.run(name, work, fn)
+        TIMER.run(name, work, fn, unit)
 
 # ------------------------------------------------------------------------------------------------
 # quantizer
@@ -205,8 +207,10 @@ def vq_forward(z: torch.Tensor, codebook: torch.Tensor, beta: float, depth: int,
     L = lib()
     nb = L.enh_vq_workspace_bytes(M, K, depth)
     ws = _workspace(nb, z.device)
-    _check(L.enh_vq_forward(_p(z, F32, "z"), _p(codebook, F32, "codebook"), M, K, d, beta, depth, int(use_norm), _p(zq), _p(zq16),
-                            _p(idx), _p(loss), _p(ws), ws.numel(), _stream()), "enh_vq_forward")
+    # work model: 2*K*d FLOP per token per depth on the exact-f32 MFMA (157.3 TF peak); the call = vq_prep + vq_nn + vq_loss_finalize
+    _timed("vq_forward (vq_prep + vq_nn_kernel + vq_loss_finalize)", 2.0 * M * K * d * depth,
+           lambda: _check(L.enh_vq_forward(_p(z, F32, "z"), _p(codebook, F32, "codebook"), M, K, d, beta, depth, int(use_norm), _p(zq), _p(zq16),
+                                           _p(idx), _p(loss), _p(ws), ws.numel(), _stream()), "enh_vq_forward"), unit="flop_f32")
     return zq, zq16, idx, loss
 
 
@@ -262,10 +266,12 @@ def layernorm_backward(dy, x, w, mean, rstd, dres, dx_f32, dx_bf16, dw, db, dx_c
     # deterministic form: per-workgroup column partials in a caller-owned workspace + a fixed-order second pass (no f32 atomics)
     nb = lib().enh_layernorm_backward_workspace_bytes(M, D)
     ws = _workspace(nb, x.device)
-    _check(lib().enh_layernorm_backward_ws(_p(dy32, F32, "dy"), _p(dy16, BF16, "dy_bf16"), _p(x, F32, "x"), _p(w, F32, "w"), _p(mean, F32, "mean"),
+    # algorithmic HBM bytes per element: dy (2 or 4) + x 4 + dres 4 in, dx f32 4 + dx bf16 2 out  (16 B/elem with bf16 dy)
+    bpe = (2 if dy16 is not None else 4) + 4 + (4 if dres is not None else 0) + (4 if dx_f32 is not None else 0) + (2 if dx_bf16 is not None else 0)
+    _timed("ln_bwd_kernel", float(bpe) * M * D, lambda: _check(lib().enh_layernorm_backward_ws(_p(dy32, F32, "dy"), _p(dy16, BF16, "dy_bf16"), _p(x, F32, "x"), _p(w, F32, "w"), _p(mean, F32, "mean"),
                                            _p(rstd, F32, "rstd"), _p(dres, F32, "dres"), M, D, _p(dx_f32, F32, "dx_f32"),
                                            _p(dx_bf16, BF16, "dx_bf16"), _p(dw, F32, "dw"), _p(db, F32, "db"), _p(dx_colsum, F32, "dx_colsum"),
-                                           _p(ws), ws.numel(), _stream()), "enh_layernorm_backward_ws")
+                                           _p(ws), ws.numel(), _stream()), "enh_layernorm_backward_ws"), unit="byte")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -381,8 +387,10 @@ def crop_flip_u8(src, meta, R: int):
 
 def adamw_step(p, g, m, v, p_bf16, step: int, lr: float, beta1: float = 0.9, beta2: float = 0.99, eps: float = 1e-8,
                weight_decay: float = 1e-4, grad_scale: float = 1.0):
-    _check(lib().enh_adamw_step(_p(p, F32, "p"), _p(g, F32, "g"), _p(m, F32, "m"), _p(v, F32, "v"), _p(p_bf16, BF16, "p_bf16"),
-                                p.numel(), step, lr, beta1, beta2, eps, weight_decay, grad_scale, _stream()), "enh_adamw_step")
+    # 30 B per parameter: p, g, m, v read (16) + p, m, v written (12) + the bf16 operand shadow written (2)
+    _timed("adamw_kernel", (28.0 + (2.0 if p_bf16 is not None else 0.0)) * p.numel(),
+           lambda: _check(lib().enh_adamw_step(_p(p, F32, "p"), _p(g, F32, "g"), _p(m, F32, "m"), _p(v, F32, "v"), _p(p_bf16, BF16, "p_bf16"),
+                                               p.numel(), step, lr, beta1, beta2, eps, weight_decay, grad_scale, _stream()), "enh_adamw_step"), unit="byte")
 
 
 # ------------------------------------------------------------------------------------------------

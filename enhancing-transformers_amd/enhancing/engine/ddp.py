@@ -17,6 +17,7 @@ so it is exercised on CPU with the gloo backend in tests/test_ddp_cpu.py.
 """
 from __future__ import annotations
 
+import time
 from typing import List, Optional, Tuple
 
 import torch
@@ -54,6 +55,11 @@ class GradSync:
         self._g16 = torch.empty_like(store.g, dtype=torch.bfloat16) if compress == "bf16" else None
         self._copyback: List[Tuple[int, int]] = []
         self._shards: List[torch.Tensor] = []
+        # exposed communication per step: time finish() blocked the host (gloo waits on the host) and time the COMPUTE STREAM stood waiting for the
+        # collectives' stream (RCCL: wait() is a stream dependency, the host does not block) — HIP events around the waits, read by comm_wait_ms()
+        self.host_wait_ms: List[float] = []
+        self._wait_events: List[Tuple[torch.cuda.Event, torch.cuda.Event]] = []
+        self.buckets_last_step = 0
 
     def broadcast_parameters(self, src: int = 0) -> None:
         """DDP's initial parameter broadcast: every rank starts from rank `src`'s weights."""
@@ -116,8 +122,18 @@ class GradSync:
         for b, e in gaps:
             self.gap_elems += e - b
             self._reduce(b, e)
+        on_gpu = self.store.g.is_cuda
+        if on_gpu:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        t0 = time.perf_counter()
         for h in self._handles:
             h.wait()
+        self.host_wait_ms.append((time.perf_counter() - t0) * 1e3)
+        if on_gpu:
+            ev[1].record()
+            self._wait_events.append(ev)
+        self.buckets_last_step = len(self._handles)
         for b, e in self._copyback:
             self.store.g[b:e].copy_(self._g16[b:e])
         self._copyback = []
@@ -127,6 +143,19 @@ class GradSync:
 
     def begin_step(self) -> None:
         self.announced = []
+
+    def comm_wait_ms(self, last: Optional[int] = None) -> dict:
+        """per-step exposed communication of the last `last` steps (all if None): `stream_ms` = how long the compute stream stood still between the end
+        of backward and the last collective's completion (HIP events; what the step actually pays for the all-reduce under RCCL), `host_ms` = host
+        time inside the waits (the whole cost under gloo).  Synchronises the device."""
+        host = self.host_wait_ms[-last:] if last else list(self.host_wait_ms)
+        stream = []
+        if self._wait_events:
+            torch.cuda.synchronize()
+            evs = self._wait_events[-last:] if last else self._wait_events
+            stream = [a.elapsed_time(b) for a, b in evs]
+        mean = lambda v: sum(v) / len(v) if v else None
+        return {"host_ms": mean(host), "stream_ms": mean(stream), "steps": len(host), "buckets_per_step": self.buckets_last_step}
 
 
 def init_process_group_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:

@@ -18,7 +18,7 @@ from .ddp import GradSync, init_process_group_from_env
 class Trainer:
     def __init__(self, max_epochs: int = 100, precision: int = 32, gpus: int = 1, num_nodes: int = 1, strategy: Optional[str] = None,
                  accumulate_grad_batches: int = 1, callbacks=None, logger=None, max_steps: Optional[int] = None,
-                 default_root_dir: str = "experiments", log_every_n_steps: int = 10, val_batches: int = 4) -> None:
+                 default_root_dir: str = "experiments", log_every_n_steps: int = 10, limit_val_batches: Optional[int] = None) -> None:
         self.max_epochs, self.max_steps = max_epochs, max_steps
         # Lightning's `precision` (reference main.py:52): 16 = --use_amp = mixed precision.  On MI355X the mixed-precision dtype is bf16 (fp32 master
         # weights / accumulation; bf16 keeps fp32's exponent range, so Lightning's fp16 GradScaler has nothing to do and its semantics are the
@@ -30,7 +30,7 @@ class Trainer:
         self.strategy = strategy
         self.root = default_root_dir
         self.log_every = log_every_n_steps
-        self.val_batches = val_batches
+        self.val_batches = limit_val_batches      # Lightning's limit_val_batches as a batch count; None = the whole validation set (Lightning's default)
         self.rank, self.local_rank, self.world = 0, 0, 1
         self.global_step = 0
         self.current_epoch = 0
@@ -48,6 +48,26 @@ class Trainer:
         os.makedirs(self.root, exist_ok=True)
         with open(os.path.join(self.root, "metrics.jsonl"), "a") as f:
             f.write(json.dumps(rec) + "\n")
+
+    def validate(self, model, data) -> dict:
+        """One pass over the validation loader.  Lightning's on_epoch=True aggregation (reference vitvqgan.py:137-148): every logged val/* scalar is
+        averaged over the batches, weighted by batch size; the two keys logged with sync_dist=True are already cross-rank means per batch (ViTVQ.log),
+        so with the DistributedSampler's equal shards their epoch value is the mean over the WHOLE validation set on every rank; the others stay
+        rank-local and rank 0's are written, as Lightning does for sync_dist=False."""
+        sums, weight = {}, 0
+        for vi, vb in enumerate(data.val_dataloader()):
+            if self.val_batches is not None and vi >= self.val_batches:
+                break
+            model.validation_step(vb, vi)
+            self._hook("on_validation_batch_end", model, None, vb, 0, vi)
+            n = int(vb["image"].shape[0]) if isinstance(vb, dict) and "image" in vb else 1
+            weight += n
+            for k, v in model.logged.items():
+                if k.startswith("val/"):
+                    sums[k] = sums.get(k, 0.0) + float(v) * n
+        out = {k: v / max(weight, 1) for k, v in sums.items()}
+        out["val_images_per_rank"] = weight
+        return out
 
     def fit(self, model, data) -> None:
         self.rank, self.local_rank, self.world = init_process_group_from_env()
@@ -108,12 +128,7 @@ class Trainer:
                     if self.max_steps is not None and self.global_step >= self.max_steps:
                         break
             if "validation" in data.dataset_configs:
-                for vi, vb in enumerate(data.val_dataloader()):
-                    if vi >= self.val_batches:
-                        break
-                    model.validation_step(vb, vi)
-                    self._hook("on_validation_batch_end", model, None, vb, 0, vi)
-                self._log({k: float(v) for k, v in model.logged.items() if k.startswith("val/")} | {"epoch": epoch})
+                self._log(self.validate(model, data) | {"epoch": epoch})
             if self.rank == 0:
                 ck = os.path.join(self.root, "ckpt")
                 os.makedirs(ck, exist_ok=True)

@@ -133,7 +133,15 @@ class ViTVQ(nn.Module):
         return x.contiguous()
 
     # ---- Lightning protocol ------------------------------------------------------------------
-    def log(self, name: str, value, **_) -> None:
+    def log(self, name: str, value, sync_dist: bool = False, **_) -> None:
+        """Lightning's ``self.log``.  ``sync_dist=True`` (reference vitvqgan.py:137-138, the only collective outside DDP's gradient all-reduce,
+        SURVEY.md §8e): the value is replaced by its MEAN over the ranks of the default process group before it is recorded."""
+        if sync_dist and torch.is_tensor(value):
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                value = value.detach().clone().float()
+                dist.all_reduce(value, op=dist.ReduceOp.SUM)
+                value /= dist.get_world_size()
         self.logged[name] = value
 
     def log_dict(self, d: Dict[str, Any], **_) -> None:
@@ -201,8 +209,8 @@ class ViTVQ(nn.Module):
         x = self.get_input(batch, self.image_key)
         xrec, qloss = self(x)
         aeloss, log = self.loss(qloss, x.to(xrec.device), xrec, 0, self.global_step, batch_idx, last_layer=self.decoder.get_last_layer(), split="val")
-        self.log("val/rec_loss", log["val/rec_loss"])
-        self.log("val/total_loss", aeloss)
+        self.log("val/rec_loss", log["val/rec_loss"], sync_dist=True)     # vitvqgan.py:137-138: on_step + on_epoch, sync_dist=True
+        self.log("val/total_loss", aeloss, sync_dist=True)
         self.log_dict({k: v for k, v in log.items() if k not in ("val/rec_loss", "val/total_loss")})
         if hasattr(self.loss, "discriminator"):   # vitvqgan.py:144-148
             _, log_disc = self.loss(qloss, x.to(xrec.device), xrec, 1, self.global_step, batch_idx, last_layer=self.decoder.get_last_layer(), split="val")

@@ -256,7 +256,7 @@ def test_trainer_drives_the_lightning_protocol_in_order(monkeypatch, tmp_path):
 
     monkeypatch.setattr(T, "init_process_group_from_env", lambda *a, **k: (0, 0, 1))
     monkeypatch.setattr(torch.cuda, "set_device", lambda *_: None)
-    tr = T.Trainer(max_epochs=1, accumulate_grad_batches=2, default_root_dir=str(tmp_path), log_every_n_steps=1, val_batches=2)
+    tr = T.Trainer(max_epochs=1, accumulate_grad_batches=2, default_root_dir=str(tmp_path), log_every_n_steps=1, limit_val_batches=2)
     tr.fit(Model(), Data())
     train = [c for c in calls if c[0] in ("ts", "ae.step", "disc.step")]
     assert train == [

@@ -2,7 +2,9 @@
 profiles/:  kernel-trace --stats summary (per-kernel calls / total / average / share) and, for --pmc passes, the
 per-launch HBM traffic of the GEMM instantiations (profiles/pmc_gemm.json).
 Usage: python tools/rocpd_summary.py stats <results.db> <out.csv>
-       python tools/rocpd_summary.py pmc <fetch.db> <write.db> <out.json>"""
+       python tools/rocpd_summary.py pmc <fetch.db> <write.db> <out.json> [<config> <batch>]
+The pmc mode keys EVERY kernel by its symbol (template arguments kept, parameter list dropped) and records the config / per-GPU batch of the profiled
+command, so that bench.py attaches `traffic` only to a run of the same workload (profiles/pmc_step.json)."""
 import csv
 import json
 import re
@@ -27,18 +29,27 @@ def stats(db, out):
         print(f"{pct:6.2f}%  {calls:6d} x {avg:10.2f} us   {short(n)[:90]}")
 
 
-def gemm_key(name: str):
-    m = re.search(r"(gemm_bf16_\w*kernel<[\w, ]+>)", name)
-    return None if not m else m.group(1)
+def kernel_key(name: str):
+    """'void gemm_bf16_w256_kernel<true, true, 6>(Args...)' -> 'gemm_bf16_w256_kernel<true, true, 6>';  'attn_fwd_kernel(...)' -> 'attn_fwd_kernel'"""
+    name = re.sub(r"^void ", "", name)
+    depth = 0
+    for i, ch in enumerate(name):
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            return name[:i]
+    return name
 
 
-def pmc(fetch_db, write_db, out):
+def pmc(fetch_db, write_db, out, config=None, batch=None):
     res = {}
     for db, cname in ((fetch_db, "FETCH_SIZE"), (write_db, "WRITE_SIZE")):
         c = sqlite3.connect(db)
         for name, val in c.execute("select kernel_name, value from counters_collection where counter_name = ?", (cname,)):
-            k = gemm_key(name)
-            if k:
+            k = kernel_key(name)
+            if k and not k.startswith(("at::", "void at::")) and "elementwise_kernel" not in k:
                 res.setdefault(k, {}).setdefault(cname, []).append(val)
     outd = {}
     for k, d in res.items():
@@ -48,12 +59,14 @@ def pmc(fetch_db, write_db, out):
                    "launches": len(d.get("FETCH_SIZE", [])),
                    "note": "per-launch average over one bench.py step; reads doubled (gfx950 FETCH_SIZE reports half of a wide "
                            "coalesced stream, MI355X_MICROARCH.md §HBM); WRITE_SIZE uncalibrated"}
-    json.dump(outd, open(out, "w"), indent=1)
-    print(json.dumps(outd, indent=1))
+    doc = {"config": config, "batch": int(batch) if batch is not None else None, "kernels": outd} if config is not None else outd
+    json.dump(doc, open(out, "w"), indent=1)
+    for k, v in sorted(outd.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:12]:
+        print(f"{v['hbm_bytes_per_launch'] / 1e6:10.1f} MB/launch x {v['launches']:5d}   {k}")
 
 
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
     else:
-        pmc(sys.argv[2], sys.argv[3], sys.argv[4])
+        pmc(sys.argv[2], sys.argv[3], sys.argv[4], *(sys.argv[5:7] if len(sys.argv) >= 7 else ()))
