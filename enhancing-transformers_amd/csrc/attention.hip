@@ -58,6 +58,18 @@ __device__ __forceinline__ s16x8 pack8_bf16(const float* p) {
   u32x4 u = {pack_bf16x2(p[0], p[1]), pack_bf16x2(p[2], p[3]), pack_bf16x2(p[4], p[5]), pack_bf16x2(p[6], p[7])};
   return __builtin_bit_cast(s16x8, u);
 }
+// Every global load of a kernel's prologue (Q / dO / K / V fragments, statistics) is waited for HERE, before the tile loop: the compiler's wait-count
+// pass merges the loop-entry state into the loop body, so a fragment load still pending at entry made it wait, in EVERY iteration, for the oldest of
+// the tile prefetch loads issued a few instructions earlier (s_waitcnt vmcnt(3) .. vmcnt(0) in front of the first MFMAs: the whole L2 latency exposed
+// once per key tile — found in round 3 by reading the ISA).
+#define ATT_LOOP_ENTRY() do { __builtin_amdgcn_s_waitcnt(0x0070); __builtin_amdgcn_sched_barrier(0); } while (0)
+// pins a fragment loaded in the prologue: the value must be IN its registers at this point (IR-level sinking otherwise moves the load into the loop
+// preheader, behind ATT_LOOP_ENTRY, and the pending-at-entry state is back)
+__device__ __forceinline__ void att_pin(s16x8& f) {
+  u32x4 u = __builtin_bit_cast(u32x4, f);
+  asm volatile("" : "+v"(u));
+  f = __builtin_bit_cast(s16x8, u);
+}
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
 
 // Workgroup -> (block-within-head, head) mapping.  Hardware places workgroup L on XCD L % 8 (each XCD has a private L2), and the nblk
@@ -107,6 +119,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
   att_gload(rv, Vp, RS, 0, t);
   att_sstore(rk, smem[0][0], t);
   att_sstore(rv, smem[0][1], t);
+#pragma unroll
+  for (int ds = 0; ds < 4; ++ds) att_pin(qf[ds]);
+  ATT_LOOP_ENTRY();
   __syncthreads();
   for (int kt = 0; kt < nt; ++kt) {
     const int st = kt & 1;
@@ -231,6 +246,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
   att_gload(rv, Vp, RS, 0, t);
   att_sstore(rk, smem[0][0], t);
   att_sstore(rv, smem[0][1], t);
+#pragma unroll
+  for (int ds = 0; ds < 4; ++ds) { att_pin(qf[ds]); att_pin(dof[ds]); }
+  ATT_LOOP_ENTRY();
   __syncthreads();
   for (int kt = 0; kt < nt; ++kt) {
     const int st = kt & 1;
@@ -323,17 +341,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
   float rstat = 0.f;
   att_gload(rq, Qp, RS, 0, t);
   att_gload(rd, dOp, OS, 0, t);
-  if (t < 64) rstat = lsep[t] * 1.4426950408889634f; else if (t < 128) rstat = delp[t - 64];
+  // statistics of the 64 queries of a tile: threads 0-63 fetch lse (kept in the log2 domain), 64-127 delta — through ONE select-addressed load in the
+  // straight-line code.  The former `if (t < 64) .. else if (t < 128) ..` put each load in its own divergent block, and the wait-count pass closed
+  // that block with s_waitcnt vmcnt(0): every iteration waited for the Q / dO prefetch issued just before it (found in the ISA, round 3).
+  const float* statp = ((t & 64) ? delp : lsep) + (t & 63);
+  const float stat_mul = (t & 64) ? 1.0f : 1.4426950408889634f;
+  rstat = statp[0];
   att_sstore(rq, smem[0][0], t);
   att_sstore(rd, smem[0][1], t);
-  if (t < 128) s_stat[0][t >> 6][t & 63] = rstat;
+  if (t < 128) s_stat[0][t >> 6][t & 63] = rstat * stat_mul;
+#pragma unroll
+  for (int ds = 0; ds < 4; ++ds) { att_pin(kf[ds]); att_pin(vf[ds]); }
+  ATT_LOOP_ENTRY();
   __syncthreads();
   for (int qt = 0; qt < nt; ++qt) {
     const int st = qt & 1;
     if (qt + 1 < nt) {
       att_gload(rq, Qp, RS, (qt + 1) * 64, t);
       att_gload(rd, dOp, OS, (qt + 1) * 64, t);
-      if (t < 64) rstat = lsep[(qt + 1) * 64 + t] * 1.4426950408889634f; else if (t < 128) rstat = delp[(qt + 1) * 64 + t - 64];
+      rstat = statp[(qt + 1) * 64];                 // (scaled when it is stored, after the tile's arithmetic: nothing here waits for the load)
     }
     const unsigned char* qt_ = smem[st][0];
     const unsigned char* dot_ = smem[st][1];
@@ -374,7 +400,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
     if (qt + 1 < nt) {
       att_sstore(rq, smem[st ^ 1][0], t);
       att_sstore(rd, smem[st ^ 1][1], t);
-      if (t < 128) s_stat[st ^ 1][t >> 6][t & 63] = rstat;
+      if (t < 128) s_stat[st ^ 1][t >> 6][t & 63] = rstat * stat_mul;
     }
     __syncthreads();
   }
