@@ -1,0 +1,267 @@
+// attention_v2.hip — round-3 attention kernels: the data layout, MFMA shapes and LDS images of attention.hip (helpers shared through attention_common.h),
+// re-scheduled as SOFTWARE-PIPELINED, MFMA-PACED instruction streams.  Reference semantics: enhancing/modules/stage1/layers.py:123-130.
+//
+// Why (profiles/r02_attention_lab.txt, profiles/r03_attention_lab.txt): the round-1/2 kernels ran at the SUM of their MFMA and vector time (forward: 512 + 940
+// cycles per 64-key tile and wave, measured 1390) because inside one wave every product waited for the softmax that waited for the previous product.  Here
+// each loop iteration carries INDEPENDENT strands that belong to different tiles, e.g. forward iteration t:
+//     S(t+1) = K(t+1) Q^T  [8 MFMA]   |   numerators of tile t  [vector]   |   O += V(t-1)^T P(t-1),  l += 1^T P(t-1)  [8 + 4 MFMA]
+// and the source is written as slices of { one MFMA ; ~5 vector ops ; at most two LDS reads } separated by scheduling fences
+// (__builtin_amdgcn_sched_barrier(0)), as the w256 GEMM (gemm.hip) is, so that the compiler keeps the interleave.  The vector work was cut to what the
+// exponentials need:
+//   * the running maximum is only a REFERENCE m_ref: tile t is exponentiated against the m_ref of the tiles before it, and O / l (and the numerators still
+//     waiting for their product) are rescaled only when a row's tile maximum exceeds m_ref by more than 2^ATT_THR — a wave-uniform branch taken on the first
+//     tile and then almost never.  Numerators stay below 2^ATT_THR, bf16's RELATIVE precision does not depend on that scale, and lse = m_ref + log2(l) is
+//     exact either way (cdna_hip_programming.md T13; the ordering hazard it describes is handled by rescaling the pending numerators too);
+//   * the row sum l comes from the matrix pipe, l^T[.][q] += ones[.][k] P^T[k][q]: four more MFMAs per tile instead of 32 dependent vector adds, and the
+//     normaliser is then the sum of exactly the bf16 numerators that entered P V;
+//   * no per-tile multiply of the O accumulator, no serial max / sum chains on the critical path (the maximum of tile t+1 is taken under tile t-1's P V).
+// K runs two tiles ahead in a 2-slot LDS ring, V one tile ahead in a 3-slot ring; one barrier per tile; tiles are staged through registers, the global
+// loads issued at the top of an iteration and written to LDS at its end.
+#include "attention_common.h"
+
+#define A2_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define ATT_THR 7.0f
+// Pure vector arithmetic has no chain to the scheduling fences: instruction selection emits it where its RESULT is first needed (the numerators of a
+// slice all sank below the last MFMA of the iteration).  An empty asm that "modifies" the value pins its computation to this point of the stream.
+#define A2_PIN1(a) asm volatile("" : "+v"(a))
+#define A2_PIN2(a, b) asm volatile("" : "+v"(a), "+v"(b))
+
+__device__ __forceinline__ f32x16 f32x16_zero() {
+  const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  return z;
+}
+__device__ __forceinline__ float max4(float a, float b, float c, float d) { return __builtin_fmaxf(__builtin_fmaxf(a, b), __builtin_fmaxf(c, d)); }
+// combine a per-lane value with the other half-wave's (lane ^ 32) through one v_permlane32_swap (no LDS round trip).  Verified semantics
+// (profiles/hw_probe_r01.txt P4): with both operands = v, every lane receives (v[lane & 31], v[(lane & 31) + 32]).
+__device__ __forceinline__ float xhalf_max(float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __builtin_fmaxf(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+}
+__device__ __forceinline__ float xhalf_sum(float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+
+// =================================================================================================
+// forward
+// =================================================================================================
+// One pipelined iteration (see the file header).  SC: scores of the current tile (consumed), SN: scores of the next tile (produced), PC: packed numerators
+// of the current tile (produced), PP: those of the previous tile (consumed by the P V products).  PV: whether a previous tile exists (compile time).
+template <bool PV, bool ONES>
+__device__ __forceinline__ void fwd2_body(const unsigned char* kbuf, const unsigned char* vbuf, const int lane, const float c, const float m_ref,
+                                          const f32x16 (&SC)[2], f32x16 (&SN)[2], s16x8 (&PC)[4], const s16x8 (&PP)[4], f32x16 (&o)[2], f32x16& lacc,
+                                          float (&lsum)[2], const s16x8 (&qf)[4], const s16x8& ones, float& mx_next) {
+  const int l31 = lane & 31, hi = lane >> 5;
+  s16x8 kf[3];
+  s16x8 vf[2][2];
+  float e[8];
+  float mx = -__builtin_inff();
+  kf[0] = att_frag_row(kbuf, 0, 0, l31, hi);
+  kf[1] = att_frag_row(kbuf, 0, 1, l31, hi);
+  A2_FENCE();
+#pragma unroll
+  for (int k = 0; k < 20; ++k) {
+    // ---- the MFMA of this slice: 0-7 the next tile's scores, 8-19 the previous tile's P V (+ row sums) ----
+    if (k < 8) {
+      const int kb = k >> 2, ds = k & 3;
+      SN[kb] = (ds == 0) ? MFMA32(kf[k % 3], qf[ds], f32x16_zero()) : MFMA32(kf[k % 3], qf[ds], SN[kb]);
+      if (k + 2 < 8) kf[(k + 2) % 3] = att_frag_row(kbuf, ((k + 2) >> 2) * 32, (k + 2) & 3, l31, hi);
+    } else if (PV) {
+      const int i = (k - 8) / 3, part = (k - 8) % 3;       // P slice i (16 keys); part 0 / 1: d-block 0 / 1, part 2: the row sum
+      if (part < 2) o[part] = MFMA32(vf[i & 1][part], PP[i], o[part]);
+      else if (ONES) lacc = MFMA32(ones, PP[i], lacc);
+    }
+    // ---- V^T fragments of P slice j, three slices before its first product ----
+    if (PV && k >= 5 && (k - 5) / 3 < 4 && (k - 5) % 3 < 2) {
+      const int j = (k - 5) / 3, db = (k - 5) % 3;
+      vf[j & 1][db] = att_frag_tr(vbuf, (j >> 1) * 32 + 16 * (j & 1), db, lane);
+    }
+    // ---- vector work: numerators of the current tile — P slice k / 5, parts 0-3 two exponentials each, part 4 the packing ----
+    {
+      const int i = k / 5, part = k % 5, kb = i >> 1, r0 = (i & 1) * 8 + 2 * part;
+      if (part < 4) {
+        e[2 * part] = __builtin_amdgcn_exp2f(__builtin_fmaf(SC[kb][r0], c, -m_ref));
+        e[2 * part + 1] = __builtin_amdgcn_exp2f(__builtin_fmaf(SC[kb][r0 + 1], c, -m_ref));
+        if (!ONES) { lsum[0] += e[2 * part]; lsum[1] += e[2 * part + 1]; A2_PIN2(lsum[0], lsum[1]); }
+        A2_PIN2(e[2 * part], e[2 * part + 1]);
+      } else {
+        u32x4 u = {pack_bf16x2(e[0], e[1]), pack_bf16x2(e[2], e[3]), pack_bf16x2(e[4], e[5]), pack_bf16x2(e[6], e[7])};
+        A2_PIN1(u);
+        PC[i] = __builtin_bit_cast(s16x8, u);
+      }
+    }
+    // ---- maximum of the NEXT tile's scores (complete once the product of slice 7 has retired) ----
+    if (k >= 12) {
+      const int g = k - 12, kb = g >> 2, r0 = (g & 3) * 4;
+      mx = __builtin_fmaxf(mx, max4(SN[kb][r0], SN[kb][r0 + 1], SN[kb][r0 + 2], SN[kb][r0 + 3]));
+      A2_PIN1(mx);
+    }
+    A2_FENCE();
+  }
+  mx_next = mx;
+}
+
+// the last tile's P V (nothing left to overlap it with)
+template <bool ONES>
+__device__ __forceinline__ void fwd2_tail(const unsigned char* vbuf, const int lane, const s16x8 (&PP)[4], f32x16 (&o)[2], f32x16& lacc, const s16x8& ones) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const s16x8 v0 = att_frag_tr(vbuf, (i >> 1) * 32 + 16 * (i & 1), 0, lane);
+    const s16x8 v1 = att_frag_tr(vbuf, (i >> 1) * 32 + 16 * (i & 1), 1, lane);
+    o[0] = MFMA32(v0, PP[i], o[0]);
+    o[1] = MFMA32(v1, PP[i], o[1]);
+    if (ONES) lacc = MFMA32(ones, PP[i], lacc);
+  }
+}
+
+// rare path: a row's next-tile maximum exceeds the reference by more than 2^ATT_THR.  Everything still at the old scale is multiplied by
+// alpha = 2^(m_old - m_new) exactly once: O, l, and the numerators of the previous tile that have not entered O yet (bf16, re-rounded).
+template <bool ONES>
+__device__ __forceinline__ void fwd2_rescale(float& m_ref, const float t_next, f32x16 (&o)[2], f32x16& lacc, float (&lsum)[2], s16x8 (&PP)[4]) {
+  const float m_new = __builtin_fmaxf(m_ref, t_next);
+  const float alpha = __builtin_amdgcn_exp2f(m_ref - m_new);
+  m_ref = m_new;
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+  if (ONES) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lacc[r] *= alpha;
+  } else {
+    lsum[0] *= alpha; lsum[1] *= alpha;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    u32x4 u = __builtin_bit_cast(u32x4, PP[i]);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float lo = __builtin_bit_cast(float, u[w] << 16) * alpha, up = __builtin_bit_cast(float, u[w] & 0xffff0000u) * alpha;
+      u[w] = pack_bf16x2(lo, up);
+    }
+    PP[i] = __builtin_bit_cast(s16x8, u);
+  }
+}
+
+template <bool ONES>
+__global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const uint16_t* __restrict__ qkv, int B, int N, int H, float scale_log2,
+                                                           uint16_t* __restrict__ out, float* __restrict__ lse) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[5][ATT_TILE_BYTES];   // K ring: slots 0, 1 ; V ring: slots 2, 3, 4
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  int blk, head;
+  if (!att_block_coords((N + 127) / 128, B * H, blk, head)) return;
+  const int b = head / H, h = head - b * H;
+  const int q0 = blk * 128 + wave * 32;
+  const int64_t RS = (int64_t)3 * H * ATT_D;
+  const uint16_t* Qp = qkv + (int64_t)b * N * RS + h * ATT_D;
+  const uint16_t* Kp = Qp + H * ATT_D;
+  const uint16_t* Vp = Kp + H * ATT_D;
+  const bool active = q0 < N;   // N % 64 == 0: a wave's 32 queries are all in or all out
+  const int qrow = active ? q0 + l31 : l31;
+  s16x8 qf[4];
+#pragma unroll
+  for (int ds = 0; ds < 4; ++ds) qf[ds] = *reinterpret_cast<const s16x8*>(Qp + (int64_t)qrow * RS + ds * 16 + hi * 8);
+  const u32x4 ones_u = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+  const s16x8 ones = __builtin_bit_cast(s16x8, ones_u);
+
+  f32x16 o[2] = {f32x16_zero(), f32x16_zero()};
+  f32x16 lacc = f32x16_zero();
+  float lsum[2] = {0.f, 0.f};
+  f32x16 sA[2], sB[2];
+  s16x8 pA[4], pB[4];
+  const int nt = N / 64;
+
+  // prologue: K(0), V(0), K(1) -> LDS ; S(0) ; m_ref = the first tile's exact maximum
+  u32x4 rk[2], rv[2];
+  att_gload(rk, Kp, RS, 0, t);
+  att_gload(rv, Vp, RS, 0, t);
+  att_sstore(rk, smem[0], t);
+  att_sstore(rv, smem[2], t);
+  if (nt > 1) {
+    att_gload(rk, Kp, RS, 64, t);
+    att_sstore(rk, smem[1], t);
+  }
+#pragma unroll
+  for (int ds = 0; ds < 4; ++ds) att_pin(qf[ds]);
+  ATT_LOOP_ENTRY();
+  __syncthreads();
+  float m_ref;
+  {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int ds = 0; ds < 4; ++ds)
+        sA[kb] = (ds == 0) ? MFMA32(att_frag_row(smem[0], kb * 32, ds, l31, hi), qf[ds], f32x16_zero()) : MFMA32(att_frag_row(smem[0], kb * 32, ds, l31, hi), qf[ds], sA[kb]);
+    float mx = sA[0][0];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = __builtin_fmaxf(mx, sA[kb][r]);
+    m_ref = xhalf_max(mx) * scale_log2;
+  }
+
+  // iteration kt: global loads of K(kt+2) and V(kt+1) at the top, their LDS stores at the bottom (slots free since the barrier that closed kt-1:
+  // K(kt) was last read by the S products of iteration kt-1, V(kt-2) by its P V products)
+  int vslot = 0;   // slot of V(kt) in the 3-ring (index into smem[2..4])
+#define FWD2_ITER(SC_, SN_, PC_, PP_, FIRST_)                                                                                      \
+  do {                                                                                                                             \
+    const bool ldk = kt + 2 < nt, ldv = kt + 1 < nt;                                                                               \
+    const int vnext = vslot == 2 ? 0 : vslot + 1, vprev = vslot == 0 ? 2 : vslot - 1;                                              \
+    if (ldk) att_gload(rk, Kp, RS, (kt + 2) * 64, t);                                                                              \
+    if (ldv) att_gload(rv, Vp, RS, (kt + 1) * 64, t);                                                                              \
+    A2_FENCE();                                                                                                                    \
+    float mxn;                                                                                                                     \
+    if (FIRST_) fwd2_body<false, ONES>(smem[(kt + 1) & 1], smem[2 + vprev], lane, scale_log2, m_ref, SC_, SN_, PC_, PP_, o, lacc, lsum, qf, ones, mxn); \
+    else fwd2_body<true, ONES>(smem[(kt + 1) & 1], smem[2 + vprev], lane, scale_log2, m_ref, SC_, SN_, PC_, PP_, o, lacc, lsum, qf, ones, mxn);         \
+    A2_FENCE();                                                                                                                    \
+    if (ldk) att_sstore(rk, smem[kt & 1], t);                                                                                      \
+    if (ldv) att_sstore(rv, smem[2 + vnext], t);                                                                                   \
+    vslot = vnext;                                                                                                                 \
+    if (ldv) {   /* reference check for tile kt+1 (its scores are in SN_): rescale O, l and the pending numerators PC_ when it grew too much */ \
+      const float tn = xhalf_max(mxn) * scale_log2;                                                                                \
+      if (__builtin_amdgcn_ballot_w64(tn > m_ref + ATT_THR) != 0ull) fwd2_rescale<ONES>(m_ref, tn, o, lacc, lsum, PC_);            \
+    }                                                                                                                              \
+    __syncthreads();                                                                                                               \
+  } while (0)
+
+  int kt = 0;
+  FWD2_ITER(sA, sB, pA, pB, true);
+  for (kt = 1; kt + 1 < nt; kt += 2) {
+    FWD2_ITER(sB, sA, pB, pA, false);
+    ++kt;
+    FWD2_ITER(sA, sB, pA, pB, false);
+    --kt;
+  }
+  if (kt < nt) {            // nt even: one more iteration (an odd tile index: buffers B)
+    FWD2_ITER(sB, sA, pB, pA, false);
+    fwd2_tail<ONES>(smem[2 + (vslot == 0 ? 2 : vslot - 1)], lane, pB, o, lacc, ones);
+  } else {
+    fwd2_tail<ONES>(smem[2 + (vslot == 0 ? 2 : vslot - 1)], lane, pA, o, lacc, ones);
+  }
+#undef FWD2_ITER
+
+  float l;
+  if (ONES) l = lacc[0];
+  else l = xhalf_sum(lsum[0] + lsum[1]);
+  const float inv = 1.0f / l;
+  if (!active) return;
+  uint16_t* op = out + ((int64_t)b * N + q0 + l31) * (H * ATT_D) + h * ATT_D;
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int d0 = db * 32 + 8 * g4 + 4 * hi;
+      u32x2 w = {pack_bf16x2(o[db][g4 * 4 + 0] * inv, o[db][g4 * 4 + 1] * inv), pack_bf16x2(o[db][g4 * 4 + 2] * inv, o[db][g4 * 4 + 3] * inv)};
+      *reinterpret_cast<u32x2*>(op + d0) = w;
+    }
+  if (hi == 0) lse[((int64_t)b * H + h) * N + q0 + l31] = (m_ref + __builtin_amdgcn_logf(l)) * 0.6931471805599453f;
+}
+
+// instantiations + launchers used by attention.hip's C ABI (enh_attention_set_kernel selects the family)
+void attn_fwd2_launch(const uint16_t* qkv, int B, int N, int H, float scale_log2, uint16_t* out, float* lse, bool ones, dim3 grid, hipStream_t s) {
+  if (ones) attn_fwd2_kernel<true><<<grid, 256, 0, s>>>(qkv, B, N, H, scale_log2, out, lse);
+  else attn_fwd2_kernel<false><<<grid, 256, 0, s>>>(qkv, B, N, H, scale_log2, out, lse);
+}
