@@ -357,13 +357,33 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
 // =================================================================================================
 // C ABI
 // =================================================================================================
+// round-3 software-pipelined kernels (attention_v2.hip)
+void attn_fwd2_launch(const uint16_t* qkv, int B, int N, int H, float scale_log2, uint16_t* out, float* lse, bool ones, dim3 grid, hipStream_t s);
+void attn_bwd_dq2_launch(const uint16_t* qkv, const uint16_t* o, const uint16_t* d_o, const float* lse, float* delta, int B, int N, int H, float scale,
+                         float scale_log2, uint16_t* dqkv, dim3 grid, hipStream_t s);
+
+// kernel family per pass: 0 = the library's choice, 1 = the round-1/2 kernels of this file, 2 = the pipelined kernels of attention_v2.hip,
+// 3 = (forward only) pipelined with vector-ALU row sums instead of the ones-MFMA.  Explicit state behind an explicit call, as enh_gemm_set_kernel.
+static int g_att_fwd = 0, g_att_dq = 0, g_att_dkv = 0;
+#define ATT_DEFAULT_FWD 1
+#define ATT_DEFAULT_DQ 1
+#define ATT_DEFAULT_DKV 1
+
+extern "C" int enh_attention_set_kernel(int fwd, int dq, int dkv) {
+  ENH_REQUIRE(fwd >= 0 && fwd <= 3 && dq >= 0 && dq <= 2 && dkv >= 0 && dkv <= 1, ENH_E_BADARG, "enh_attention_set_kernel: fwd in 0..3, dq in 0..2, dkv in 0..1");
+  g_att_fwd = fwd; g_att_dq = dq; g_att_dkv = dkv;
+  return ENH_OK;
+}
+
 extern "C" int enh_attention_forward(const enh_bf16* qkv, int B, int N, int H, float scale, enh_bf16* out, float* lse, void* stream) {
   ENH_REQUIRE(qkv && out && lse, ENH_E_BADARG, "enh_attention_forward: null pointer");
   ENH_REQUIRE(B > 0 && H > 0 && N > 0 && N % 64 == 0, ENH_E_SHAPE, "enh_attention_forward: need N %% 64 == 0 (B=%d N=%d H=%d)", B, N, H);
   ENH_REQUIRE(scale > 0.f, ENH_E_BADARG, "enh_attention_forward: scale must be positive");
   const int64_t nblk = (N + 127) / 128, heads = (int64_t)B * H;
   const dim3 grid((unsigned)(((heads + 7) / 8) * 8 * nblk));  // 1-D: see att_block_coords
-  attn_fwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(qkv, B, N, H, scale * 1.4426950408889634f, out, lse);
+  const int fam = g_att_fwd ? g_att_fwd : ATT_DEFAULT_FWD;
+  if (fam == 1) attn_fwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(qkv, B, N, H, scale * 1.4426950408889634f, out, lse);
+  else attn_fwd2_launch(qkv, B, N, H, scale * 1.4426950408889634f, out, lse, fam == 2, grid, (hipStream_t)stream);
   return enh_check_launch("enh_attention_forward");
 }
 
@@ -376,7 +396,9 @@ extern "C" int enh_attention_backward(const enh_bf16* qkv, const enh_bf16* out, 
   const int64_t nblk = (N + 127) / 128, heads = (int64_t)B * H;
   const dim3 grid((unsigned)(((heads + 7) / 8) * 8 * nblk));
   const float sl2 = scale * 1.4426950408889634f;
-  attn_bwd_dq_kernel<<<grid, 256, 0, s>>>(qkv, out, dout, lse, delta_ws, B, N, H, scale, sl2, dqkv);   // also writes delta_ws = rowsum(dO * O) for the next kernel
+  // (either dQ kernel also writes delta_ws = rowsum(dO * O) for the dK/dV kernel that follows)
+  if ((g_att_dq ? g_att_dq : ATT_DEFAULT_DQ) == 1) attn_bwd_dq_kernel<<<grid, 256, 0, s>>>(qkv, out, dout, lse, delta_ws, B, N, H, scale, sl2, dqkv);
+  else attn_bwd_dq2_launch(qkv, out, dout, lse, delta_ws, B, N, H, scale, sl2, dqkv, grid, s);
   attn_bwd_dkv_kernel<<<grid, 256, 0, s>>>(qkv, dout, lse, delta_ws, B, N, H, scale, sl2, dqkv);
   return enh_check_launch("enh_attention_backward");
 }

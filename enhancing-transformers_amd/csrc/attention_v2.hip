@@ -30,7 +30,13 @@ __device__ __forceinline__ f32x16 f32x16_zero() {
   const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   return z;
 }
-__device__ __forceinline__ float max4(float a, float b, float c, float d) { return __builtin_fmaxf(__builtin_fmaxf(a, b), __builtin_fmaxf(c, d)); }
+// max(a, b, c) in ONE instruction.  fmaxf on MFMA results makes the compiler canonicalise every operand first (v_max_f32 x, x, x: seven instructions
+// for a 4-way maximum, cdna_hip_programming.md "Fused attention" pitfalls); scores are finite products, nothing to canonicalise.
+__device__ __forceinline__ float max3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
 // combine a per-lane value with the other half-wave's (lane ^ 32) through one v_permlane32_swap (no LDS round trip).  Verified semantics
 // (profiles/hw_probe_r01.txt P4): with both operands = v, every lane receives (v[lane & 31], v[(lane & 31) + 32]).
 __device__ __forceinline__ float xhalf_max(float v) {
@@ -59,15 +65,15 @@ __device__ __forceinline__ void fwd2_body(const unsigned char* kbuf, const unsig
   float e[8];
   float mx = -__builtin_inff();
   kf[0] = att_frag_row(kbuf, 0, 0, l31, hi);
-  kf[1] = att_frag_row(kbuf, 0, 1, l31, hi);
+  kf[1] = att_frag_row(kbuf, 32, 0, l31, hi);
   A2_FENCE();
 #pragma unroll
   for (int k = 0; k < 20; ++k) {
     // ---- the MFMA of this slice: 0-7 the next tile's scores, 8-19 the previous tile's P V (+ row sums) ----
     if (k < 8) {
-      const int kb = k >> 2, ds = k & 3;
+      const int kb = k & 1, ds = k >> 1;                  // the two 32-key accumulators alternate: no MFMA waits for the one issued just before it
       SN[kb] = (ds == 0) ? MFMA32(kf[k % 3], qf[ds], f32x16_zero()) : MFMA32(kf[k % 3], qf[ds], SN[kb]);
-      if (k + 2 < 8) kf[(k + 2) % 3] = att_frag_row(kbuf, ((k + 2) >> 2) * 32, (k + 2) & 3, l31, hi);
+      if (k + 2 < 8) kf[(k + 2) % 3] = att_frag_row(kbuf, ((k + 2) & 1) * 32, (k + 2) >> 1, l31, hi);
     } else if (PV) {
       const int i = (k - 8) / 3, part = (k - 8) % 3;       // P slice i (16 keys); part 0 / 1: d-block 0 / 1, part 2: the row sum
       if (part < 2) o[part] = MFMA32(vf[i & 1][part], PP[i], o[part]);
@@ -95,7 +101,7 @@ __device__ __forceinline__ void fwd2_body(const unsigned char* kbuf, const unsig
     // ---- maximum of the NEXT tile's scores (complete once the product of slice 7 has retired) ----
     if (k >= 12) {
       const int g = k - 12, kb = g >> 2, r0 = (g & 3) * 4;
-      mx = __builtin_fmaxf(mx, max4(SN[kb][r0], SN[kb][r0 + 1], SN[kb][r0 + 2], SN[kb][r0 + 3]));
+      mx = max3(max3(mx, SN[kb][r0], SN[kb][r0 + 1]), SN[kb][r0 + 2], SN[kb][r0 + 3]);
       A2_PIN1(mx);
     }
     A2_FENCE();
@@ -199,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const uint16_t* __res
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) mx = __builtin_fmaxf(mx, sA[kb][r]);
+      for (int r = 0; r < 16; r += 2) mx = max3(mx, sA[kb][r], sA[kb][r + 1]);
     m_ref = xhalf_max(mx) * scale_log2;
   }
 
@@ -260,8 +266,162 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const uint16_t* __res
   if (hi == 0) lse[((int64_t)b * H + h) * N + q0 + l31] = (m_ref + __builtin_amdgcn_logf(l)) * 0.6931471805599453f;
 }
 
-// instantiations + launchers used by attention.hip's C ABI (enh_attention_set_kernel selects the family)
+// =================================================================================================
+// backward: dQ  — pipelined over 32-KEY BLOCKS (half tiles): iteration j carries
+//     S(j+1) = K Q^T, dP'(j+1) = V dO^T - delta  [8 MFMA]   |   dS(j) = P(j) o dP'(j), packed  [vector]   |   dQ += K(j-1)^T dS(j-1)  [4 MFMA]
+// delta enters as the C operand of the first dP product (a lane owns one query column, so -delta_q is a per-lane constant held in one 16-register block:
+// D = A B + C with D != C), which removes the per-element subtraction; the softmax scale of dS is applied once to the finished dQ (exact for d = 64).
+// K tiles live in a 3-slot ring (tile t-1 is still read transposed while tile t+1 is read by rows), V in a 2-slot ring; a tile is fetched into registers
+// one tile ahead and written to LDS under the next tile's first block; one barrier per tile.
+// =================================================================================================
+template <bool PREV>
+__device__ __forceinline__ void dq2_block(const unsigned char* krow, const unsigned char* vrow, const int rb_next, const unsigned char* kprev, const int rb_prev,
+                                          const int lane, const float c, const float lse2, const f32x16& negd, const f32x16& SC, const f32x16& DC,
+                                          f32x16& SN, f32x16& DN, s16x8 (&dsC)[2], const s16x8 (&dsP)[2], f32x16 (&dq)[2], const s16x8 (&qf)[4],
+                                          const s16x8 (&dof)[4]) {
+  const int l31 = lane & 31, hi = lane >> 5;
+  s16x8 fr[3];          // row fragments, rolling: slot k uses fr[k % 3]
+  s16x8 kt[4];          // K^T fragments of the previous block: (c2, db) = (f >> 1, f & 1)
+  unsigned dsw[8];
+  fr[0] = att_frag_row(krow, rb_next, 0, l31, hi);
+  fr[1] = att_frag_row(vrow, rb_next, 0, l31, hi);
+  A2_FENCE();
+#pragma unroll
+  for (int k = 0; k < 12; ++k) {
+    if (k < 8) {
+      const int ds = k >> 1;
+      if ((k & 1) == 0) SN = (ds == 0) ? MFMA32(fr[k % 3], qf[ds], f32x16_zero()) : MFMA32(fr[k % 3], qf[ds], SN);     // S^T[key][q]
+      else DN = (ds == 0) ? MFMA32(fr[k % 3], dof[ds], negd) : MFMA32(fr[k % 3], dof[ds], DN);                       // dP^T[key][q] - delta[q]
+      if (k + 2 < 8) fr[(k + 2) % 3] = att_frag_row(((k + 2) & 1) ? vrow : krow, rb_next, (k + 2) >> 1, l31, hi);
+    } else if (PREV) {
+      const int f = k - 8;
+      dq[f & 1] = MFMA32(kt[f], dsP[f >> 1], dq[f & 1]);                                                             // dQ^T[d][q] += K^T dS^T
+    }
+    if (PREV && k >= 4 && k < 8) kt[k - 4] = att_frag_tr(kprev, rb_prev + 16 * ((k - 4) >> 1), (k - 4) & 1, lane);
+    // vector work: pair g of the current block at slices 0, 1, 3, 4, 6, 7, 9, 10
+    if (k % 3 != 2) {
+      const int g = (k / 3) * 2 + (k % 3), r = 2 * g;
+      const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(SC[r], c, -lse2)), p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(SC[r + 1], c, -lse2));
+      dsw[g] = pack_bf16x2(p0 * DC[r], p1 * DC[r + 1]);
+      A2_PIN1(dsw[g]);
+    }
+    A2_FENCE();
+  }
+  const u32x4 u0 = {dsw[0], dsw[1], dsw[2], dsw[3]}, u1 = {dsw[4], dsw[5], dsw[6], dsw[7]};
+  dsC[0] = __builtin_bit_cast(s16x8, u0);
+  dsC[1] = __builtin_bit_cast(s16x8, u1);
+}
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ o, const uint16_t* __restrict__ d_o,
+                                                              const float* __restrict__ lse, float* __restrict__ delta, int B, int N,
+                                                              int H, float scale, float scale_log2, uint16_t* __restrict__ dqkv) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[5][ATT_TILE_BYTES];   // K ring: slots 0-2 ; V ring: slots 3, 4
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  int blk, head;
+  if (!att_block_coords((N + 127) / 128, B * H, blk, head)) return;
+  const int b = head / H, h = head - b * H;
+  const int q0 = blk * 128 + wave * 32;
+  const int64_t RS = (int64_t)3 * H * ATT_D;
+  const uint16_t* Qp = qkv + (int64_t)b * N * RS + h * ATT_D;
+  const uint16_t* Kp = Qp + H * ATT_D;
+  const uint16_t* Vp = Kp + H * ATT_D;
+  const uint16_t* dOp = d_o + (int64_t)b * N * (H * ATT_D) + h * ATT_D;
+  const bool active = q0 < N;
+  const int qrow = active ? q0 + l31 : l31;
+  s16x8 qf[4], dof[4];
+#pragma unroll
+  for (int ds = 0; ds < 4; ++ds) {
+    qf[ds] = *reinterpret_cast<const s16x8*>(Qp + (int64_t)qrow * RS + ds * 16 + hi * 8);
+    dof[ds] = *reinterpret_cast<const s16x8*>(dOp + (int64_t)qrow * (H * ATT_D) + ds * 16 + hi * 8);
+  }
+  const float lse2 = lse[((int64_t)b * H + h) * N + qrow] * 1.4426950408889634f;
+  // delta[q] = sum_d dO[q][d] O[q][d] from the dO fragments already held (written for the dK/dV kernel)
+  float dpart = 0.f;
+#pragma unroll
+  for (int ds = 0; ds < 4; ++ds) {
+    const s16x8 of = *reinterpret_cast<const s16x8*>(o + ((int64_t)b * N + qrow) * (H * ATT_D) + h * ATT_D + ds * 16 + hi * 8);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dpart += bf16_bits_to_f32((uint16_t)of[k]) * bf16_bits_to_f32((uint16_t)dof[ds][k]);
+  }
+  const float del_q = xhalf_sum(dpart);
+  if (active && hi == 0) delta[((int64_t)b * H + h) * N + qrow] = del_q;
+  f32x16 negd;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) negd[r] = -del_q;
+
+  f32x16 dq[2] = {f32x16_zero(), f32x16_zero()};
+  f32x16 sA, dA, sB, dB;
+  s16x8 dsA[2], dsB[2];
+  const int nt = N / 64;
+  u32x4 rk[2], rv[2];
+  att_gload(rk, Kp, RS, 0, t);
+  att_gload(rv, Vp, RS, 0, t);
+  att_sstore(rk, smem[0], t);
+  att_sstore(rv, smem[3], t);
+  if (nt > 1) {
+    att_gload(rk, Kp, RS, 64, t);
+    att_gload(rv, Vp, RS, 64, t);
+    att_sstore(rk, smem[1], t);
+    att_sstore(rv, smem[4], t);
+  }
+#pragma unroll
+  for (int ds = 0; ds < 4; ++ds) { att_pin(qf[ds]); att_pin(dof[ds]); }
+  ATT_LOOP_ENTRY();
+  __syncthreads();
+  // block (0, 0)
+#pragma unroll
+  for (int ds = 0; ds < 4; ++ds) {
+    sA = (ds == 0) ? MFMA32(att_frag_row(smem[0], 0, ds, l31, hi), qf[ds], f32x16_zero()) : MFMA32(att_frag_row(smem[0], 0, ds, l31, hi), qf[ds], sA);
+    dA = (ds == 0) ? MFMA32(att_frag_row(smem[3], 0, ds, l31, hi), dof[ds], negd) : MFMA32(att_frag_row(smem[3], 0, ds, l31, hi), dof[ds], dA);
+  }
+  int ks = 0;   // K ring slot of tile kt ; the V slot is kt & 1
+  for (int kt = 0; kt < nt; ++kt) {
+    const int ksn = ks == 2 ? 0 : ks + 1, ksp = ks == 0 ? 2 : ks - 1;
+    const unsigned char* kcur = smem[ks];
+    const unsigned char* vcur = smem[3 + (kt & 1)];
+    // X: current block (kt, 0) in A ; produces (kt, 1) into B ; dQ of the previous tile's second block (its dS is in dsB)
+    if (kt == 0) dq2_block<false>(kcur, vcur, 32, smem[ksp], 32, lane, scale_log2, lse2, negd, sA, dA, sB, dB, dsA, dsB, dq, qf, dof);
+    else dq2_block<true>(kcur, vcur, 32, smem[ksp], 32, lane, scale_log2, lse2, negd, sA, dA, sB, dB, dsA, dsB, dq, qf, dof);
+    A2_FENCE();
+    if (kt >= 1 && kt + 1 < nt) {          // tile kt+1 (fetched during the previous tile's second block) -> LDS ; slots free since the last barrier
+      att_sstore(rk, smem[ksn], t);
+      att_sstore(rv, smem[3 + ((kt + 1) & 1)], t);
+    }
+    __syncthreads();
+    if (kt + 2 < nt) {
+      att_gload(rk, Kp, RS, (kt + 2) * 64, t);
+      att_gload(rv, Vp, RS, (kt + 2) * 64, t);
+    }
+    A2_FENCE();
+    // Y: current block (kt, 1) in B ; produces (kt+1, 0) into A (stale data after the last tile: never used) ; dQ of block (kt, 0) (dS in dsA)
+    dq2_block<true>(smem[ksn], smem[3 + ((kt + 1) & 1)], 0, kcur, 0, lane, scale_log2, lse2, negd, sB, dB, sA, dA, dsB, dsA, dq, qf, dof);
+    A2_FENCE();
+    ks = ksn;
+  }
+  {   // dQ of the last block (nt-1, 1): its tile sits in the slot before ks
+    const unsigned char* klast = smem[ks == 0 ? 2 : ks - 1];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) dq[f & 1] = MFMA32(att_frag_tr(klast, 32 + 16 * (f >> 1), f & 1, lane), dsB[f >> 1], dq[f & 1]);
+  }
+  if (!active) return;
+  uint16_t* op = dqkv + ((int64_t)b * N + q0 + l31) * RS + h * ATT_D;
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int d0 = db * 32 + 8 * g4 + 4 * hi;
+      u32x2 w = {pack_bf16x2(dq[db][g4 * 4 + 0] * scale, dq[db][g4 * 4 + 1] * scale), pack_bf16x2(dq[db][g4 * 4 + 2] * scale, dq[db][g4 * 4 + 3] * scale)};
+      *reinterpret_cast<u32x2*>(op + d0) = w;
+    }
+}
+
+// launchers used by attention.hip's C ABI (enh_attention_set_kernel selects the family)
 void attn_fwd2_launch(const uint16_t* qkv, int B, int N, int H, float scale_log2, uint16_t* out, float* lse, bool ones, dim3 grid, hipStream_t s) {
   if (ones) attn_fwd2_kernel<true><<<grid, 256, 0, s>>>(qkv, B, N, H, scale_log2, out, lse);
   else attn_fwd2_kernel<false><<<grid, 256, 0, s>>>(qkv, B, N, H, scale_log2, out, lse);
+}
+void attn_bwd_dq2_launch(const uint16_t* qkv, const uint16_t* o, const uint16_t* d_o, const float* lse, float* delta, int B, int N, int H, float scale,
+                         float scale_log2, uint16_t* dqkv, dim3 grid, hipStream_t s) {
+  attn_bwd_dq2_kernel<<<grid, 256, 0, s>>>(qkv, o, d_o, lse, delta, B, N, H, scale, scale_log2, dqkv);
 }

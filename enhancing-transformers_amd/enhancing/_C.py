@@ -47,6 +47,7 @@ SIGNATURES = {
     "enh_gemm_bf16_workspace_bytes": (_sz, [_i32, _i32, _i64, _i64, _i64]),
     "enh_gemm_set_kernel": (_i32, [_i32]),
     "enh_gemm_bf16_variant": (_c.c_char_p, [_i32, _i32, _i64, _i64, _i64]),
+    "enh_attention_set_kernel": (_i32, [_i32, _i32, _i32]),
     "enh_attention_forward": (_i32, [_vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp]),
     "enh_attention_backward": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp]),
     "enh_patchify": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
@@ -90,7 +91,7 @@ SIGNATURES = {
 }
 
 _LIB = None
-ABI_VERSION = 5   # ENH_ABI_VERSION of the include/enh_hip.h these signatures were written against
+ABI_VERSION = 6   # ENH_ABI_VERSION of the include/enh_hip.h these signatures were written against
 
 
 def lib():
@@ -116,6 +117,11 @@ def lib():
                 raise RuntimeError(f"ENH_GEMM_KERNEL={sel!r}: expected reg | pipe2 | w256")
             _check_rc = L.enh_gemm_set_kernel(fam)
             if _check_rc != 0:
+                raise RuntimeError(L.enh_last_error().decode())
+        att = os.environ.get("ENH_ATTN_KERNEL")       # "fwd,dq,dkv" families, e.g. "2,2,1" (0 = library default, 1 = round-2 kernels, 2 = pipelined)
+        if att:
+            f, q, k = (int(x) for x in att.split(","))
+            if L.enh_attention_set_kernel(f, q, k) != 0:
                 raise RuntimeError(L.enh_last_error().decode())
         if os.environ.get("ENH_CONV_KERNEL") == "reg" and L.enh_conv_set_kernel(1) != 0:      # A/B: register-staged convolution kernel everywhere
             raise RuntimeError(L.enh_last_error().decode())
@@ -337,6 +343,11 @@ def _gemm_workspace(device, nbytes: int):
 # ------------------------------------------------------------------------------------------------
 # attention
 # ------------------------------------------------------------------------------------------------
+def attention_set_kernel(fwd: int = 0, dq: int = 0, dkv: int = 0) -> None:
+    """A/B aid: kernel family per pass (include/enh_hip.h enh_attention_set_kernel)"""
+    _check(lib().enh_attention_set_kernel(fwd, dq, dkv), "enh_attention_set_kernel")
+
+
 def attention_forward(qkv, B: int, N: int, H: int, scale: float, out, lse):
     _timed("attn_fwd_kernel", 4.0 * B * H * N * N * 64,
            lambda: _check(lib().enh_attention_forward(_p(qkv, BF16, "qkv"), B, N, H, scale, _p(out, BF16, "out"), _p(lse, F32, "lse"), _stream()),

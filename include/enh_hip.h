@@ -36,7 +36,7 @@ extern "C" {
 typedef uint16_t enh_bf16; /* raw bfloat16 bits */
 
 const char* enh_last_error(void);
-#define ENH_ABI_VERSION 5   /* bumped whenever a signature below changes; the bindings check it at load */
+#define ENH_ABI_VERSION 6   /* bumped whenever a signature below changes; the bindings check it at load */
 int enh_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -154,6 +154,10 @@ int enh_gemm_set_kernel(int family);
  */
 int enh_attention_forward(const enh_bf16* qkv, int B, int N, int H, float scale, enh_bf16* out, float* lse,
                           void* stream);
+/* kernel family per pass for A/B measurements (explicit library state, like enh_gemm_set_kernel): 0 = the library's choice, 1 = the round-1/2
+ * kernels, 2 = the software-pipelined round-3 kernels (csrc/attention_v2.hip), 3 = (forward only) pipelined with vector row sums.  Same results up to
+ * rounding: every family passes the same parity tests. */
+int enh_attention_set_kernel(int fwd, int dq, int dkv);
 /* dqkv [B,N,3*H*64] bf16 ; delta_ws [B,H,N] f32 scratch */
 int enh_attention_backward(const enh_bf16* qkv, const enh_bf16* out, const enh_bf16* dout, const float* lse,
                            int B, int N, int H, float scale, enh_bf16* dqkv, float* delta_ws, void* stream);

@@ -267,8 +267,20 @@ def _attn_ref(qkv, B, N, H, scale):
     return (p @ v).permute(0, 2, 1, 3).reshape(B, N, H * 64), torch.logsumexp(s, dim=-1)
 
 
-@pytest.mark.parametrize("B,N,H", [(2, 1024, 3), (3, 64, 2), (1, 256, 12), (2, 192, 1)])
-def test_attention_forward_backward(C, B, N, H):
+# kernel families per pass (include/enh_hip.h enh_attention_set_kernel): the library's default choice, the round-2 kernels, the software-pipelined
+# round-3 kernels (forward with the ones-MFMA row sum, and with vector row sums)
+ATT_FAMILIES = [(0, 0, 0), (1, 1, 1), (2, 2, 1), (3, 2, 1)]
+
+
+@pytest.fixture(params=ATT_FAMILIES, ids=lambda f: "fam%d%d%d" % f)
+def att_family(request, C):
+    C.attention_set_kernel(*request.param)
+    yield request.param
+    C.attention_set_kernel(0, 0, 0)
+
+
+@pytest.mark.parametrize("B,N,H", [(2, 1024, 3), (3, 64, 2), (1, 256, 12), (2, 192, 1), (1, 128, 2), (1, 320, 1)])
+def test_attention_forward_backward(C, att_family, B, N, H):
     g = torch.Generator().manual_seed(B * 100 + N + H)
     qkv = bf16r(torch.randn(B, N, 3 * H * 64, generator=g) * 1.5)
     do = bf16r(torch.randn(B, N, H * 64, generator=g))
@@ -290,20 +302,39 @@ def test_attention_forward_backward(C, B, N, H):
     assert rel(dq, gq) <= 2 * ATT_TOL and rel(dk, gk) <= 2 * ATT_TOL and rel(dv, gv) <= 2 * ATT_TOL, (rel(dq, gq), rel(dk, gk), rel(dv, gv))
 
 
-def test_attention_spiked_scores(C):
-    """one key dominating a row (forces the running max to jump mid-sweep): online-softmax rescale path."""
+def test_attention_spiked_scores(C, att_family):
+    """keys dominating a row (force the running maximum / the pipelined kernels' reference maximum to jump mid-sweep, several times and in adjacent
+    tiles, incl. the last one): the rescale path, checked row by row against fp64 (cdna_hip_programming.md T13: a wrong rescale order is silent on
+    bounded random data and shows only in the rows that took the branch)."""
     B, N, H = 1, 512, 2
     g = torch.Generator().manual_seed(0)
     qkv = torch.randn(B, N, 3 * H * 64, generator=g)
     qkv[0, 5, :64] *= 6.0
     qkv[0, 300, H * 64:H * 64 + 64] = qkv[0, 5, :64] * 1.5   # key 300 of head 0 aligned with query 5
+    # a staircase for query 70 of head 1: keys in tiles 1, 2, 3 and the last tile, each beating everything before it by a wide margin
+    qv = qkv[0, 70, 64:128].clone()
+    for key, gain in ((100, 2.0), (130, 4.0), (200, 7.0), (505, 11.0)):
+        qkv[0, key, H * 64 + 64:H * 64 + 128] = qv * gain
     qkv = bf16r(qkv)
-    ref, _ = _attn_ref(qkv, B, N, H, 0.125)
+    ref, lse_ref = _attn_ref(qkv, B, N, H, 0.125)
     out = torch.empty(B, N, H * 64, dtype=torch.bfloat16, device="cuda")
     lse = torch.empty(B, H, N, device="cuda")
     C.attention_forward(qkv.to(torch.bfloat16).cuda(), B, N, H, 0.125, out, lse)
     assert torch.isfinite(out.float()).all()
     assert rel(out.float(), ref) <= ATT_TOL
+    assert rel(lse, lse_ref) <= 1e-5
+    for q, h in ((5, 0), (70, 1)):          # the rows that took the branch, individually
+        assert rel(out.float().cpu()[0, q, h * 64:(h + 1) * 64], ref[0, q, h * 64:(h + 1) * 64]) <= 2 * ATT_TOL, (q, h)
+    # backward through the same spiked rows (lse comes from the kernel above)
+    do = bf16r(torch.randn(B, N, H * 64, generator=g))
+    qt = qkv.clone().requires_grad_(True)
+    r2, _ = _attn_ref(qt, B, N, H, 0.125)
+    r2.backward(do.double())
+    dqkv = torch.full((B, N, 3 * H * 64), float("nan"), dtype=torch.bfloat16, device="cuda")
+    delta = torch.empty(B, H, N, device="cuda")
+    C.attention_backward(qkv.to(torch.bfloat16).cuda(), out, do.to(torch.bfloat16).cuda(), lse, B, N, H, 0.125, dqkv, delta)
+    assert torch.isfinite(dqkv.float()).all()
+    assert rel(dqkv.float(), qt.grad) <= 3 * ATT_TOL, rel(dqkv.float(), qt.grad)
 
 
 # ---------------------------------------------------------------------------------------------
