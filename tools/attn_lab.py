@@ -15,7 +15,7 @@ dqkv = torch.empty_like(qkv); delta = torch.empty(B, H, N, device=dev)
 fl = 4 * B * H * N * N * 64
 
 
-def timeit(fn, iters=10, warm=2):
+def timeit(fn, iters=int(os.environ.get("ITERS", "10")), warm=2):
     for _ in range(warm): fn()
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
