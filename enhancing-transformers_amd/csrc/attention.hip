@@ -23,114 +23,19 @@
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, int B, int N, int H, float scale_log2,
                                                           uint16_t* __restrict__ out, float* __restrict__ lse) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][ATT_TILE_BYTES];  // [stage][K | V]
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int l31 = lane & 31, hi = lane >> 5;
   int blk, head;
   if (!att_block_coords((N + 127) / 128, B * H, blk, head)) return;
-  const int b = head / H, h = head - b * H;
-  const int q0 = blk * 128 + wave * 32;
-  const int64_t RS = (int64_t)3 * H * ATT_D;
-  const uint16_t* Qp = qkv + (int64_t)b * N * RS + h * ATT_D;
-  const uint16_t* Kp = Qp + H * ATT_D;
-  const uint16_t* Vp = Kp + H * ATT_D;
-
-  const bool active = q0 < N;  // N % 64 == 0: a wave's 32 queries are all in or all out
-  const int qrow = active ? q0 + l31 : l31;
-  s16x8 qf[4];
-#pragma unroll
-  for (int ds = 0; ds < 4; ++ds) qf[ds] = *reinterpret_cast<const s16x8*>(Qp + (int64_t)qrow * RS + ds * 16 + hi * 8);
-
-  f32x16 o[2];
-#pragma unroll
-  for (int db = 0; db < 2; ++db)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
-  float m_run = -__builtin_inff(), l_part = 0.f;
-
-  const int nt = N / 64;
-  u32x4 rk[2], rv[2];
-  att_gload(rk, Kp, RS, 0, t);
-  att_gload(rv, Vp, RS, 0, t);
-  att_sstore(rk, smem[0][0], t);
-  att_sstore(rv, smem[0][1], t);
-#pragma unroll
-  for (int ds = 0; ds < 4; ++ds) att_pin(qf[ds]);
-  ATT_LOOP_ENTRY();
-  __syncthreads();
-  for (int kt = 0; kt < nt; ++kt) {
-    const int st = kt & 1;
-    if (kt + 1 < nt) {
-      att_gload(rk, Kp, RS, (kt + 1) * 64, t);
-      att_gload(rv, Vp, RS, (kt + 1) * 64, t);
-    }
-    const unsigned char* kt_ = smem[st][0];
-    const unsigned char* vt_ = smem[st][1];
-    // ---- S^T[key][q] = K Q^T ----
-    f32x16 s[2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
-#pragma unroll
-      for (int ds = 0; ds < 4; ++ds) s[kb] = MFMA32(att_frag_row(kt_, kb * 32, ds, l31, hi), qf[ds], s[kb]);
-    }
-    // ---- online softmax for this lane's query column ----
-    float mx = s[0][0];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx * scale_log2);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
-    float p[2][16];
-    float psum = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        p[kb][r] = __builtin_amdgcn_exp2f(s[kb][r] * scale_log2 - m_new);
-        psum += p[kb][r];
-      }
-    l_part = l_part * alpha + psum;
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
-    // ---- O^T[d][q] += V^T P^T ----
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int c2 = 0; c2 < 2; ++c2) {
-        const s16x8 pb = pack8_bf16(&p[kb][c2 * 8]);
-#pragma unroll
-        for (int db = 0; db < 2; ++db) o[db] = MFMA32(att_frag_tr(vt_, kb * 32 + 16 * c2, db, lane), pb, o[db]);
-      }
-    if (kt + 1 < nt) {
-      att_sstore(rk, smem[st ^ 1][0], t);
-      att_sstore(rv, smem[st ^ 1][1], t);
-    }
-    __syncthreads();
-  }
-  const float l = l_part + __shfl_xor(l_part, 32, 64);
-  const float inv = 1.0f / l;
-  if (!active) return;
-  uint16_t* op = out + ((int64_t)b * N + q0 + l31) * (H * ATT_D) + h * ATT_D;
-#pragma unroll
-  for (int db = 0; db < 2; ++db)
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      const int d0 = db * 32 + 8 * g4 + 4 * hi;
-      u32x2 w = {pack_bf16x2(o[db][g4 * 4 + 0] * inv, o[db][g4 * 4 + 1] * inv), pack_bf16x2(o[db][g4 * 4 + 2] * inv, o[db][g4 * 4 + 3] * inv)};
-      *reinterpret_cast<u32x2*>(op + d0) = w;
-    }
-  if (hi == 0) lse[((int64_t)b * H + h) * N + q0 + l31] = (m_run + __builtin_amdgcn_logf(l)) * 0.6931471805599453f;
+  attn_fwd_exact(qkv, B, N, H, scale_log2, out, lse, smem, blk, head);
 }
 
 // =================================================================================================
 // backward: dQ  (same skeleton as forward; K tile is read both as rows and transposed)
 // =================================================================================================
+// MODE 0: the round-2 arithmetic.  MODE 1: -delta enters as the C operand of the first dP product (a lane owns ONE query column, so -delta_q is a
+// per-lane constant kept in a 16-register block; D = A B + C with D != C): 32 subtractions per tile gone.  MODE 2 (q pre-scaled by scale*log2e, i.e.
+// the products are already log2-domain scores): -lse enters the S product the same way and the exponential reads the accumulator directly — no
+// vector arithmetic left but exp, the P o dP' multiply and the bf16 packing.  The kernels are vector-ISSUE bound (profiles/r03_attention_lab.txt).
+template <int MODE>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ o, const uint16_t* __restrict__ d_o,
                                                              const float* __restrict__ lse, float* __restrict__ delta, int B, int N,
                                                              int H, float scale, float scale_log2, uint16_t* __restrict__ dqkv) {
@@ -167,6 +72,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
   }
   const float del_q = dpart + __shfl_xor(dpart, 32, 64);
   if (active && hi == 0) delta[((int64_t)b * H + h) * N + qrow] = del_q;
+  f32x16 negd, negl;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { negd[r] = MODE >= 1 ? -del_q : 0.f; negl[r] = MODE == 2 ? -lse_q : 0.f; }
 
   f32x16 dq[2];
 #pragma unroll
@@ -196,17 +104,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
     for (int kb = 0; kb < 2; ++kb) {
       f32x16 s, dp;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-#pragma unroll
       for (int ds = 0; ds < 4; ++ds) {
-        s = MFMA32(att_frag_row(kt_, kb * 32, ds, l31, hi), qf[ds], s);     // S^T[key][q]
-        dp = MFMA32(att_frag_row(vt_, kb * 32, ds, l31, hi), dof[ds], dp);  // dP^T[key][q] = V dO^T
+        s = MFMA32(att_frag_row(kt_, kb * 32, ds, l31, hi), qf[ds], ds == 0 ? negl : s);     // S^T[key][q]  (- lse[q] in MODE 2)
+        dp = MFMA32(att_frag_row(vt_, kb * 32, ds, l31, hi), dof[ds], ds == 0 ? negd : dp);  // dP^T[key][q] = V dO^T  (- delta[q] in MODE >= 1)
       }
       float dsv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pr = __builtin_amdgcn_exp2f(s[r] * scale_log2 - lse_q);
-        dsv[r] = pr * (dp[r] - del_q);     // (the factor `scale` of dS is applied once to the finished dQ: 32 multiplies instead of 32 per key tile)
+        const float pr = MODE == 2 ? __builtin_amdgcn_exp2f(s[r]) : __builtin_amdgcn_exp2f(s[r] * scale_log2 - lse_q);
+        dsv[r] = MODE >= 1 ? pr * dp[r] : pr * (dp[r] - del_q);     // (the factor `scale` of dS is applied once to the finished dQ)
       }
 #pragma unroll
       for (int c2 = 0; c2 < 2; ++c2) {
@@ -236,6 +142,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
 // =================================================================================================
 // backward: dK, dV  (workgroup owns 128 keys; Q / dO tiles stream through LDS)
 // =================================================================================================
+// CINIT: -delta (and, with PRE — q pre-scaled by scale*log2e — also -lse) enter as the C operands of the first dP / S products: the statistics are
+// loaded from LDS straight into the accumulator registers (the same four 16-byte reads per block as before, no extra registers), which removes the
+// per-element subtraction (and the scale-and-subtract before the exponential).  kscale: the factor of the finished dK (scale, or ln 2 with PRE).
+template <bool CINIT, bool PRE>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ d_o,
                                                               const float* __restrict__ lse, const float* __restrict__ delta, int B, int N,
                                                               int H, float scale, float scale_log2, uint16_t* __restrict__ dqkv) {
@@ -279,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
   // straight-line code.  The former `if (t < 64) .. else if (t < 128) ..` put each load in its own divergent block, and the wait-count pass closed
   // that block with s_waitcnt vmcnt(0): every iteration waited for the Q / dO prefetch issued just before it (found in the ISA, round 3).
   const float* statp = ((t & 64) ? delp : lsep) + (t & 63);
-  const float stat_mul = (t & 64) ? 1.0f : 1.4426950408889634f;
+  const float stat_mul = (t & 64) ? (CINIT ? -1.0f : 1.0f) : ((CINIT && PRE) ? -1.4426950408889634f : 1.4426950408889634f);   // stored negated where they are C operands
   rstat = statp[0];
   att_sstore(rq, smem[0][0], t);
   att_sstore(rd, smem[0][1], t);
@@ -299,26 +209,36 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
     const unsigned char* dot_ = smem[st][1];
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
-      f32x16 s, dp;
+      f32x16 s, dp, lrow;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-#pragma unroll
-      for (int ds = 0; ds < 4; ++ds) {
-        s = MFMA32(att_frag_row(qt_, qb * 32, ds, l31, hi), kf[ds], s);      // S[q][key]
-        dp = MFMA32(att_frag_row(dot_, qb * 32, ds, l31, hi), vf[ds], dp);   // dP[q][key] = dO V^T
-      }
-      float pv[16], dsv[16];
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
+      for (int g4 = 0; g4 < 4; ++g4) {           // the statistics of the 16 query rows this lane holds (rows 8 g4 + 4 hi + 0..3 of the block)
         const int row0 = qb * 32 + 8 * g4 + 4 * hi;
         const f32x4 l4 = *reinterpret_cast<const f32x4*>(&s_stat[st][0][row0]);
         const f32x4 d4 = *reinterpret_cast<const f32x4*>(&s_stat[st][1][row0]);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int r = g4 * 4 + k;
-          pv[r] = __builtin_amdgcn_exp2f(s[r] * scale_log2 - l4[k]);
-          dsv[r] = pv[r] * (dp[r] - d4[k]);      // `scale` is applied once to the finished dK
-        }
+        for (int k = 0; k < 4; ++k) { lrow[g4 * 4 + k] = l4[k]; dp[g4 * 4 + k] = d4[k]; }
+      }
+      const f32x16 drow = dp;
+      if (!(CINIT && PRE)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+      } else {
+        s = lrow;                               // -lse (log2 domain) as the C operand
+      }
+      if (!CINIT) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dp[r] = 0.f;
+      }
+#pragma unroll
+      for (int ds = 0; ds < 4; ++ds) {
+        s = MFMA32(att_frag_row(qt_, qb * 32, ds, l31, hi), kf[ds], s);      // S[q][key]  (- lse[q])
+        dp = MFMA32(att_frag_row(dot_, qb * 32, ds, l31, hi), vf[ds], dp);   // dP[q][key] = dO V^T  (- delta[q])
+      }
+      float pv[16], dsv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        pv[r] = (CINIT && PRE) ? __builtin_amdgcn_exp2f(s[r]) : __builtin_amdgcn_exp2f(s[r] * scale_log2 - lrow[r]);
+        dsv[r] = CINIT ? pv[r] * dp[r] : pv[r] * (dp[r] - drow[r]);      // the factor of dS is applied once to the finished dK
       }
 #pragma unroll
       for (int c2 = 0; c2 < 2; ++c2) {
@@ -358,47 +278,62 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
 // C ABI
 // =================================================================================================
 // round-3 software-pipelined kernels (attention_v2.hip)
-void attn_fwd2_launch(const uint16_t* qkv, int B, int N, int H, float scale_log2, uint16_t* out, float* lse, bool ones, dim3 grid, hipStream_t s);
+void attn_fwd2_launch(const uint16_t* qkv, int B, int N, int H, float scale_log2, uint16_t* out, float* lse, bool ones, bool pre, dim3 grid, hipStream_t s);
 void attn_bwd_dq2_launch(const uint16_t* qkv, const uint16_t* o, const uint16_t* d_o, const float* lse, float* delta, int B, int N, int H, float scale,
-                         float scale_log2, uint16_t* dqkv, dim3 grid, hipStream_t s);
+                         float scale_log2, uint16_t* dqkv, bool pre, dim3 grid, hipStream_t s);
 
-// kernel family per pass: 0 = the library's choice, 1 = the round-1/2 kernels of this file, 2 = the pipelined kernels of attention_v2.hip,
-// 3 = (forward only) pipelined with vector-ALU row sums instead of the ones-MFMA.  Explicit state behind an explicit call, as enh_gemm_set_kernel.
+// kernel family per pass (explicit state behind an explicit call, as enh_gemm_set_kernel); 0 = the library's choice:
+//   forward: 1 round-2 kernel | 2 pipelined, row sums on the matrix pipe | 3 pipelined, vector row sums
+//   dQ     : 1 round-2 kernel | 2 pipelined (attention_v2.hip)           | 3 round-2 skeleton with -delta (and, pre-scaled q, -lse) as MFMA C operands
+//   dK/dV  : 1 round-2 kernel | 2 round-2 skeleton with -delta (and, pre-scaled q, -lse) as MFMA C operands
 static int g_att_fwd = 0, g_att_dq = 0, g_att_dkv = 0;
 #define ATT_DEFAULT_FWD 1
 #define ATT_DEFAULT_DQ 1
 #define ATT_DEFAULT_DKV 1
 
 extern "C" int enh_attention_set_kernel(int fwd, int dq, int dkv) {
-  ENH_REQUIRE(fwd >= 0 && fwd <= 3 && dq >= 0 && dq <= 2 && dkv >= 0 && dkv <= 1, ENH_E_BADARG, "enh_attention_set_kernel: fwd in 0..3, dq in 0..2, dkv in 0..1");
+  ENH_REQUIRE(fwd >= 0 && fwd <= 3 && dq >= 0 && dq <= 3 && dkv >= 0 && dkv <= 2, ENH_E_BADARG, "enh_attention_set_kernel: fwd in 0..3, dq in 0..3, dkv in 0..2");
   g_att_fwd = fwd; g_att_dq = dq; g_att_dkv = dkv;
   return ENH_OK;
 }
 
-extern "C" int enh_attention_forward(const enh_bf16* qkv, int B, int N, int H, float scale, enh_bf16* out, float* lse, void* stream) {
+#define ATT_LOG2E 1.4426950408889634f
+#define ATT_LN2 0.6931471805599453f
+
+extern "C" int enh_attention_forward(const enh_bf16* qkv, int B, int N, int H, float scale, int q_prescaled, enh_bf16* out, float* lse, void* stream) {
   ENH_REQUIRE(qkv && out && lse, ENH_E_BADARG, "enh_attention_forward: null pointer");
   ENH_REQUIRE(B > 0 && H > 0 && N > 0 && N % 64 == 0, ENH_E_SHAPE, "enh_attention_forward: need N %% 64 == 0 (B=%d N=%d H=%d)", B, N, H);
   ENH_REQUIRE(scale > 0.f, ENH_E_BADARG, "enh_attention_forward: scale must be positive");
   const int64_t nblk = (N + 127) / 128, heads = (int64_t)B * H;
   const dim3 grid((unsigned)(((heads + 7) / 8) * 8 * nblk));  // 1-D: see att_block_coords
   const int fam = g_att_fwd ? g_att_fwd : ATT_DEFAULT_FWD;
-  if (fam == 1) attn_fwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(qkv, B, N, H, scale * 1.4426950408889634f, out, lse);
-  else attn_fwd2_launch(qkv, B, N, H, scale * 1.4426950408889634f, out, lse, fam == 2, grid, (hipStream_t)stream);
+  const float sl2 = q_prescaled ? 1.0f : scale * ATT_LOG2E;       // pre-scaled q: the products are log2-domain scores already
+  if (fam == 1) attn_fwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(qkv, B, N, H, sl2, out, lse);
+  else attn_fwd2_launch(qkv, B, N, H, sl2, out, lse, fam == 2, q_prescaled != 0, grid, (hipStream_t)stream);
   return enh_check_launch("enh_attention_forward");
 }
 
 extern "C" int enh_attention_backward(const enh_bf16* qkv, const enh_bf16* out, const enh_bf16* dout, const float* lse, int B, int N,
-                                      int H, float scale, enh_bf16* dqkv, float* delta_ws, void* stream) {
+                                      int H, float scale, int q_prescaled, enh_bf16* dqkv, float* delta_ws, void* stream) {
   ENH_REQUIRE(qkv && out && dout && lse && dqkv && delta_ws, ENH_E_BADARG, "enh_attention_backward: null pointer");
   ENH_REQUIRE(B > 0 && H > 0 && N > 0 && N % 64 == 0, ENH_E_SHAPE, "enh_attention_backward: need N %% 64 == 0 (B=%d N=%d H=%d)", B, N, H);
   ENH_REQUIRE(scale > 0.f, ENH_E_BADARG, "enh_attention_backward: scale must be positive");
   hipStream_t s = (hipStream_t)stream;
   const int64_t nblk = (N + 127) / 128, heads = (int64_t)B * H;
   const dim3 grid((unsigned)(((heads + 7) / 8) * 8 * nblk));
-  const float sl2 = scale * 1.4426950408889634f;
+  const bool pre = q_prescaled != 0;
+  const float sl2 = pre ? 1.0f : scale * ATT_LOG2E;
+  // dQ is the gradient with respect to the UNSCALED q in both conventions (what the projection's weight / input gradients need): factor `scale`.
+  // dK is formed from the q tile as stored: with pre-scaled q' = q * scale * log2e the factor is scale / (scale * log2e) = ln 2.
+  const float kscale = pre ? ATT_LN2 : scale;
   // (either dQ kernel also writes delta_ws = rowsum(dO * O) for the dK/dV kernel that follows)
-  if ((g_att_dq ? g_att_dq : ATT_DEFAULT_DQ) == 1) attn_bwd_dq_kernel<<<grid, 256, 0, s>>>(qkv, out, dout, lse, delta_ws, B, N, H, scale, sl2, dqkv);
-  else attn_bwd_dq2_launch(qkv, out, dout, lse, delta_ws, B, N, H, scale, sl2, dqkv, grid, s);
-  attn_bwd_dkv_kernel<<<grid, 256, 0, s>>>(qkv, dout, lse, delta_ws, B, N, H, scale, sl2, dqkv);
+  const int fq = g_att_dq ? g_att_dq : ATT_DEFAULT_DQ, fk = g_att_dkv ? g_att_dkv : ATT_DEFAULT_DKV;
+  if (fq == 1) attn_bwd_dq_kernel<0><<<grid, 256, 0, s>>>(qkv, out, dout, lse, delta_ws, B, N, H, scale, sl2, dqkv);
+  else if (fq == 2) attn_bwd_dq2_launch(qkv, out, dout, lse, delta_ws, B, N, H, scale, sl2, dqkv, pre, grid, s);
+  else if (pre) attn_bwd_dq_kernel<2><<<grid, 256, 0, s>>>(qkv, out, dout, lse, delta_ws, B, N, H, scale, sl2, dqkv);
+  else attn_bwd_dq_kernel<1><<<grid, 256, 0, s>>>(qkv, out, dout, lse, delta_ws, B, N, H, scale, sl2, dqkv);
+  if (fk == 1) attn_bwd_dkv_kernel<false, false><<<grid, 256, 0, s>>>(qkv, dout, lse, delta_ws, B, N, H, kscale, sl2, dqkv);
+  else if (pre) attn_bwd_dkv_kernel<true, true><<<grid, 256, 0, s>>>(qkv, dout, lse, delta_ws, B, N, H, kscale, sl2, dqkv);
+  else attn_bwd_dkv_kernel<true, false><<<grid, 256, 0, s>>>(qkv, dout, lse, delta_ws, B, N, H, kscale, sl2, dqkv);
   return enh_check_launch("enh_attention_backward");
 }

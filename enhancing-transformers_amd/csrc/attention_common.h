@@ -69,3 +69,111 @@ __device__ __forceinline__ bool att_block_coords(int nblk, int n_heads_total, in
   return head < n_heads_total;
 }
 
+
+// The round-1/2 forward pass of one 128-query block (exact running maximum, O rescaled every tile): the body of attn_fwd_kernel, and the FALLBACK of the
+// pipelined kernel of attention_v2.hip for a workgroup whose scores outgrow its fixed reference.  smem: [2][2][ATT_TILE_BYTES] ([stage][K | V]).
+__device__ __forceinline__ void attn_fwd_exact(const uint16_t* __restrict__ qkv, int B, int N, int H, float scale_log2, uint16_t* __restrict__ out,
+                                               float* __restrict__ lse, unsigned char (*smem)[2][ATT_TILE_BYTES], int blk, int head) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int b = head / H, h = head - b * H;
+  const int q0 = blk * 128 + wave * 32;
+  const int64_t RS = (int64_t)3 * H * ATT_D;
+  const uint16_t* Qp = qkv + (int64_t)b * N * RS + h * ATT_D;
+  const uint16_t* Kp = Qp + H * ATT_D;
+  const uint16_t* Vp = Kp + H * ATT_D;
+
+  const bool active = q0 < N;  // N % 64 == 0: a wave's 32 queries are all in or all out
+  const int qrow = active ? q0 + l31 : l31;
+  s16x8 qf[4];
+#pragma unroll
+  for (int ds = 0; ds < 4; ++ds) qf[ds] = *reinterpret_cast<const s16x8*>(Qp + (int64_t)qrow * RS + ds * 16 + hi * 8);
+
+  f32x16 o[2];
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+  float m_run = -__builtin_inff(), l_part = 0.f;
+
+  const int nt = N / 64;
+  u32x4 rk[2], rv[2];
+  att_gload(rk, Kp, RS, 0, t);
+  att_gload(rv, Vp, RS, 0, t);
+  att_sstore(rk, smem[0][0], t);
+  att_sstore(rv, smem[0][1], t);
+#pragma unroll
+  for (int ds = 0; ds < 4; ++ds) att_pin(qf[ds]);
+  ATT_LOOP_ENTRY();
+  __syncthreads();
+  for (int kt = 0; kt < nt; ++kt) {
+    const int st = kt & 1;
+    if (kt + 1 < nt) {
+      att_gload(rk, Kp, RS, (kt + 1) * 64, t);
+      att_gload(rv, Vp, RS, (kt + 1) * 64, t);
+    }
+    const unsigned char* kt_ = smem[st][0];
+    const unsigned char* vt_ = smem[st][1];
+    // ---- S^T[key][q] = K Q^T ----
+    f32x16 s[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+      for (int ds = 0; ds < 4; ++ds) s[kb] = MFMA32(att_frag_row(kt_, kb * 32, ds, l31, hi), qf[ds], s[kb]);
+    }
+    // ---- online softmax for this lane's query column ----
+    float mx = s[0][0];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx * scale_log2);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float p[2][16];
+    float psum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        p[kb][r] = __builtin_amdgcn_exp2f(s[kb][r] * scale_log2 - m_new);
+        psum += p[kb][r];
+      }
+    l_part = l_part * alpha + psum;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+    // ---- O^T[d][q] += V^T P^T ----
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int c2 = 0; c2 < 2; ++c2) {
+        const s16x8 pb = pack8_bf16(&p[kb][c2 * 8]);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) o[db] = MFMA32(att_frag_tr(vt_, kb * 32 + 16 * c2, db, lane), pb, o[db]);
+      }
+    if (kt + 1 < nt) {
+      att_sstore(rk, smem[st ^ 1][0], t);
+      att_sstore(rv, smem[st ^ 1][1], t);
+    }
+    __syncthreads();
+  }
+  const float l = l_part + __shfl_xor(l_part, 32, 64);
+  const float inv = 1.0f / l;
+  if (!active) return;
+  uint16_t* op = out + ((int64_t)b * N + q0 + l31) * (H * ATT_D) + h * ATT_D;
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int d0 = db * 32 + 8 * g4 + 4 * hi;
+      u32x2 w = {pack_bf16x2(o[db][g4 * 4 + 0] * inv, o[db][g4 * 4 + 1] * inv), pack_bf16x2(o[db][g4 * 4 + 2] * inv, o[db][g4 * 4 + 3] * inv)};
+      *reinterpret_cast<u32x2*>(op + d0) = w;
+    }
+  if (hi == 0) lse[((int64_t)b * H + h) * N + q0 + l31] = (m_run + __builtin_amdgcn_logf(l)) * 0.6931471805599453f;
+}
+

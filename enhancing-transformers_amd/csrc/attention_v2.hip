@@ -20,7 +20,7 @@
 #include "attention_common.h"
 
 #define A2_FENCE() __builtin_amdgcn_sched_barrier(0)
-#define ATT_THR 7.0f
+#define ATT_THR 64.0f
 // Pure vector arithmetic has no chain to the scheduling fences: instruction selection emits it where its RESULT is first needed (the numerators of a
 // slice all sank below the last MFMA of the iteration).  An empty asm that "modifies" the value pins its computation to this point of the stream.
 #define A2_PIN1(a) asm volatile("" : "+v"(a))
@@ -55,10 +55,12 @@ __device__ __forceinline__ float xhalf_sum(float v) {
 // =================================================================================================
 // One pipelined iteration (see the file header).  SC: scores of the current tile (consumed), SN: scores of the next tile (produced), PC: packed numerators
 // of the current tile (produced), PP: those of the previous tile (consumed by the P V products).  PV: whether a previous tile exists (compile time).
-template <bool PV, bool ONES>
+// PRE: q arrives pre-scaled by scale * log2(e) (the products ARE log2-domain scores) and -m_ref enters as the C operand of each tile's first S product
+// (a lane owns one query column: a 16-register block holding -m_ref), so the exponential reads the accumulator directly — no multiply-add per score.
+template <bool PV, bool ONES, bool PRE>
 __device__ __forceinline__ void fwd2_body(const unsigned char* kbuf, const unsigned char* vbuf, const int lane, const float c, const float m_ref,
-                                          const f32x16 (&SC)[2], f32x16 (&SN)[2], s16x8 (&PC)[4], const s16x8 (&PP)[4], f32x16 (&o)[2], f32x16& lacc,
-                                          float (&lsum)[2], const s16x8 (&qf)[4], const s16x8& ones, float& mx_next) {
+                                          const f32x16& negm, const f32x16 (&SC)[2], f32x16 (&SN)[2], s16x8 (&PC)[4], const s16x8 (&PP)[4], f32x16 (&o)[2],
+                                          f32x16& lacc, float (&lsum)[2], const s16x8 (&qf)[4], const s16x8& ones, float& mx_next) {
   const int l31 = lane & 31, hi = lane >> 5;
   s16x8 kf[3];
   s16x8 vf[2][2];
@@ -72,7 +74,7 @@ __device__ __forceinline__ void fwd2_body(const unsigned char* kbuf, const unsig
     // ---- the MFMA of this slice: 0-7 the next tile's scores, 8-19 the previous tile's P V (+ row sums) ----
     if (k < 8) {
       const int kb = k & 1, ds = k >> 1;                  // the two 32-key accumulators alternate: no MFMA waits for the one issued just before it
-      SN[kb] = (ds == 0) ? MFMA32(kf[k % 3], qf[ds], f32x16_zero()) : MFMA32(kf[k % 3], qf[ds], SN[kb]);
+      SN[kb] = (ds == 0) ? (PRE ? MFMA32(kf[k % 3], qf[ds], negm) : MFMA32(kf[k % 3], qf[ds], f32x16_zero())) : MFMA32(kf[k % 3], qf[ds], SN[kb]);
       if (k + 2 < 8) kf[(k + 2) % 3] = att_frag_row(kbuf, ((k + 2) & 1) * 32, (k + 2) >> 1, l31, hi);
     } else if (PV) {
       const int i = (k - 8) / 3, part = (k - 8) % 3;       // P slice i (16 keys); part 0 / 1: d-block 0 / 1, part 2: the row sum
@@ -88,8 +90,8 @@ __device__ __forceinline__ void fwd2_body(const unsigned char* kbuf, const unsig
     {
       const int i = k / 5, part = k % 5, kb = i >> 1, r0 = (i & 1) * 8 + 2 * part;
       if (part < 4) {
-        e[2 * part] = __builtin_amdgcn_exp2f(__builtin_fmaf(SC[kb][r0], c, -m_ref));
-        e[2 * part + 1] = __builtin_amdgcn_exp2f(__builtin_fmaf(SC[kb][r0 + 1], c, -m_ref));
+        e[2 * part] = PRE ? __builtin_amdgcn_exp2f(SC[kb][r0]) : __builtin_amdgcn_exp2f(__builtin_fmaf(SC[kb][r0], c, -m_ref));
+        e[2 * part + 1] = PRE ? __builtin_amdgcn_exp2f(SC[kb][r0 + 1]) : __builtin_amdgcn_exp2f(__builtin_fmaf(SC[kb][r0 + 1], c, -m_ref));
         if (!ONES) { lsum[0] += e[2 * part]; lsum[1] += e[2 * part + 1]; A2_PIN2(lsum[0], lsum[1]); }
         A2_PIN2(e[2 * part], e[2 * part + 1]);
       } else {
@@ -122,39 +124,16 @@ __device__ __forceinline__ void fwd2_tail(const unsigned char* vbuf, const int l
   }
 }
 
-// rare path: a row's next-tile maximum exceeds the reference by more than 2^ATT_THR.  Everything still at the old scale is multiplied by
-// alpha = 2^(m_old - m_new) exactly once: O, l, and the numerators of the previous tile that have not entered O yet (bf16, re-rounded).
-template <bool ONES>
-__device__ __forceinline__ void fwd2_rescale(float& m_ref, const float t_next, f32x16 (&o)[2], f32x16& lacc, float (&lsum)[2], s16x8 (&PP)[4]) {
-  const float m_new = __builtin_fmaxf(m_ref, t_next);
-  const float alpha = __builtin_amdgcn_exp2f(m_ref - m_new);
-  m_ref = m_new;
-#pragma unroll
-  for (int db = 0; db < 2; ++db)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
-  if (ONES) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) lacc[r] *= alpha;
-  } else {
-    lsum[0] *= alpha; lsum[1] *= alpha;
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    u32x4 u = __builtin_bit_cast(u32x4, PP[i]);
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const float lo = __builtin_bit_cast(float, u[w] << 16) * alpha, up = __builtin_bit_cast(float, u[w] & 0xffff0000u) * alpha;
-      u[w] = pack_bf16x2(lo, up);
-    }
-    PP[i] = __builtin_bit_cast(s16x8, u);
-  }
-}
-
-template <bool ONES>
+// The pipelined kernel never rescales: the reference m_ref is the exact maximum of the FIRST tile, and a later tile may exceed it by up to 2^ATT_THR
+// (fp32 / bf16 share an 8-bit exponent: numerators up to 2^64, row sums up to 2^74 are far from overflow, and the relative precision of every term is
+// what it would be against the true maximum).  A workgroup in which some row grows beyond that — logits spanning more than 64 octaves, never seen
+// outside the spiked-score tests — raises a flag in LDS, leaves the fast loop at the next barrier and recomputes its 128 queries with the exact
+// round-2 loop (attn_fwd_exact).  So the hot loop carries no rescale code at all (in-branch writes to O / the score tiles cost 75 spilled registers).
+template <bool ONES, bool PRE>
 __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const uint16_t* __restrict__ qkv, int B, int N, int H, float scale_log2,
                                                            uint16_t* __restrict__ out, float* __restrict__ lse) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[5][ATT_TILE_BYTES];   // K ring: slots 0, 1 ; V ring: slots 2, 3, 4
+  __shared__ int s_bad;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
   int blk, head;
@@ -179,6 +158,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const uint16_t* __res
   f32x16 sA[2], sB[2];
   s16x8 pA[4], pB[4];
   const int nt = N / 64;
+  if (t == 0) s_bad = 0;
 
   // prologue: K(0), V(0), K(1) -> LDS ; S(0) ; m_ref = the first tile's exact maximum
   u32x4 rk[2], rv[2];
@@ -206,48 +186,67 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const uint16_t* __res
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; r += 2) mx = max3(mx, sA[kb][r], sA[kb][r + 1]);
-    m_ref = xhalf_max(mx) * scale_log2;
+    m_ref = PRE ? xhalf_max(mx) : xhalf_max(mx) * scale_log2;
+    if (PRE) {         // the loop's tiles get -m_ref through the C operand; this first one is shifted here
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sA[0][r] -= m_ref; sA[1][r] -= m_ref; }
+    }
   }
+  f32x16 negm;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) negm[r] = PRE ? -m_ref : 0.f;
 
   // iteration kt: global loads of K(kt+2) and V(kt+1) at the top, their LDS stores at the bottom (slots free since the barrier that closed kt-1:
   // K(kt) was last read by the S products of iteration kt-1, V(kt-2) by its P V products)
   int vslot = 0;   // slot of V(kt) in the 3-ring (index into smem[2..4])
+  int bad = 0;     // the flag as read after the previous barrier (tested one iteration late: the read never stalls the loop)
 #define FWD2_ITER(SC_, SN_, PC_, PP_, FIRST_)                                                                                      \
   do {                                                                                                                             \
     const bool ldk = kt + 2 < nt, ldv = kt + 1 < nt;                                                                               \
     const int vnext = vslot == 2 ? 0 : vslot + 1, vprev = vslot == 0 ? 2 : vslot - 1;                                              \
     if (ldk) att_gload(rk, Kp, RS, (kt + 2) * 64, t);                                                                              \
     if (ldv) att_gload(rv, Vp, RS, (kt + 1) * 64, t);                                                                              \
+    const int bad_now = *reinterpret_cast<volatile int*>(&s_bad);                                                                  \
     A2_FENCE();                                                                                                                    \
     float mxn;                                                                                                                     \
-    if (FIRST_) fwd2_body<false, ONES>(smem[(kt + 1) & 1], smem[2 + vprev], lane, scale_log2, m_ref, SC_, SN_, PC_, PP_, o, lacc, lsum, qf, ones, mxn); \
-    else fwd2_body<true, ONES>(smem[(kt + 1) & 1], smem[2 + vprev], lane, scale_log2, m_ref, SC_, SN_, PC_, PP_, o, lacc, lsum, qf, ones, mxn);         \
+    if (FIRST_) fwd2_body<false, ONES, PRE>(smem[(kt + 1) & 1], smem[2 + vprev], lane, scale_log2, m_ref, negm, SC_, SN_, PC_, PP_, o, lacc, lsum, qf, ones, mxn); \
+    else fwd2_body<true, ONES, PRE>(smem[(kt + 1) & 1], smem[2 + vprev], lane, scale_log2, m_ref, negm, SC_, SN_, PC_, PP_, o, lacc, lsum, qf, ones, mxn);         \
     A2_FENCE();                                                                                                                    \
     if (ldk) att_sstore(rk, smem[kt & 1], t);                                                                                      \
     if (ldv) att_sstore(rv, smem[2 + vnext], t);                                                                                   \
     vslot = vnext;                                                                                                                 \
-    if (ldv) {   /* reference check for tile kt+1 (its scores are in SN_): rescale O, l and the pending numerators PC_ when it grew too much */ \
-      const float tn = xhalf_max(mxn) * scale_log2;                                                                                \
-      if (__builtin_amdgcn_ballot_w64(tn > m_ref + ATT_THR) != 0ull) fwd2_rescale<ONES>(m_ref, tn, o, lacc, lsum, PC_);            \
+    if (ldv) {   /* reference check for tile kt+1 (its scores are in SN_) */                                                       \
+      const float tn = xhalf_max(mxn);                                                                                             \
+      const float grow = PRE ? tn : tn * scale_log2 - m_ref;                        /* PRE: SN_ is already relative to m_ref */    \
+      if (__builtin_amdgcn_ballot_w64(grow > ATT_THR) != 0ull && lane == 0) *reinterpret_cast<volatile int*>(&s_bad) = 1;          \
     }                                                                                                                              \
+    bad |= bad_now;                                                                                                                \
     __syncthreads();                                                                                                               \
   } while (0)
 
   int kt = 0;
   FWD2_ITER(sA, sB, pA, pB, true);
-  for (kt = 1; kt + 1 < nt; kt += 2) {
+  for (kt = 1; kt + 1 < nt && !bad; kt += 2) {
     FWD2_ITER(sB, sA, pB, pA, false);
     ++kt;
     FWD2_ITER(sA, sB, pA, pB, false);
     --kt;
   }
-  if (kt < nt) {            // nt even: one more iteration (an odd tile index: buffers B)
-    FWD2_ITER(sB, sA, pB, pA, false);
-    fwd2_tail<ONES>(smem[2 + (vslot == 0 ? 2 : vslot - 1)], lane, pB, o, lacc, ones);
-  } else {
-    fwd2_tail<ONES>(smem[2 + (vslot == 0 ? 2 : vslot - 1)], lane, pA, o, lacc, ones);
+  if (!bad) {
+    if (kt < nt) {            // nt even: one more iteration (an odd tile index: buffers B)
+      FWD2_ITER(sB, sA, pB, pA, false);
+      fwd2_tail<ONES>(smem[2 + (vslot == 0 ? 2 : vslot - 1)], lane, pB, o, lacc, ones);
+    } else {
+      fwd2_tail<ONES>(smem[2 + (vslot == 0 ? 2 : vslot - 1)], lane, pA, o, lacc, ones);
+    }
   }
 #undef FWD2_ITER
+  // every wave reads the flag after the same barrier: the decision is workgroup-uniform (flags raised in the last iterations included)
+  if (bad | *reinterpret_cast<volatile int*>(&s_bad)) {
+    __syncthreads();
+    attn_fwd_exact(qkv, B, N, H, scale_log2, out, lse, reinterpret_cast<unsigned char (*)[2][ATT_TILE_BYTES]>(&smem[0][0]), blk, head);
+    return;
+  }
 
   float l;
   if (ONES) l = lacc[0];
@@ -274,9 +273,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const uint16_t* __res
 // K tiles live in a 3-slot ring (tile t-1 is still read transposed while tile t+1 is read by rows), V in a 2-slot ring; a tile is fetched into registers
 // one tile ahead and written to LDS under the next tile's first block; one barrier per tile.
 // =================================================================================================
-template <bool PREV>
+template <bool PREV, bool PRE>
 __device__ __forceinline__ void dq2_block(const unsigned char* krow, const unsigned char* vrow, const int rb_next, const unsigned char* kprev, const int rb_prev,
-                                          const int lane, const float c, const float lse2, const f32x16& negd, const f32x16& SC, const f32x16& DC,
+                                          const int lane, const float c, const float lse2, const f32x16& negl, const f32x16& negd, const f32x16& SC, const f32x16& DC,
                                           f32x16& SN, f32x16& DN, s16x8 (&dsC)[2], const s16x8 (&dsP)[2], f32x16 (&dq)[2], const s16x8 (&qf)[4],
                                           const s16x8 (&dof)[4]) {
   const int l31 = lane & 31, hi = lane >> 5;
@@ -290,7 +289,7 @@ __device__ __forceinline__ void dq2_block(const unsigned char* krow, const unsig
   for (int k = 0; k < 12; ++k) {
     if (k < 8) {
       const int ds = k >> 1;
-      if ((k & 1) == 0) SN = (ds == 0) ? MFMA32(fr[k % 3], qf[ds], f32x16_zero()) : MFMA32(fr[k % 3], qf[ds], SN);     // S^T[key][q]
+      if ((k & 1) == 0) SN = (ds == 0) ? (PRE ? MFMA32(fr[k % 3], qf[ds], negl) : MFMA32(fr[k % 3], qf[ds], f32x16_zero())) : MFMA32(fr[k % 3], qf[ds], SN);     // S^T[key][q] (- lse[q])
       else DN = (ds == 0) ? MFMA32(fr[k % 3], dof[ds], negd) : MFMA32(fr[k % 3], dof[ds], DN);                       // dP^T[key][q] - delta[q]
       if (k + 2 < 8) fr[(k + 2) % 3] = att_frag_row(((k + 2) & 1) ? vrow : krow, rb_next, (k + 2) >> 1, l31, hi);
     } else if (PREV) {
@@ -301,7 +300,8 @@ __device__ __forceinline__ void dq2_block(const unsigned char* krow, const unsig
     // vector work: pair g of the current block at slices 0, 1, 3, 4, 6, 7, 9, 10
     if (k % 3 != 2) {
       const int g = (k / 3) * 2 + (k % 3), r = 2 * g;
-      const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(SC[r], c, -lse2)), p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(SC[r + 1], c, -lse2));
+      const float p0 = PRE ? __builtin_amdgcn_exp2f(SC[r]) : __builtin_amdgcn_exp2f(__builtin_fmaf(SC[r], c, -lse2));
+      const float p1 = PRE ? __builtin_amdgcn_exp2f(SC[r + 1]) : __builtin_amdgcn_exp2f(__builtin_fmaf(SC[r + 1], c, -lse2));
       dsw[g] = pack_bf16x2(p0 * DC[r], p1 * DC[r + 1]);
       A2_PIN1(dsw[g]);
     }
@@ -312,6 +312,7 @@ __device__ __forceinline__ void dq2_block(const unsigned char* krow, const unsig
   dsC[1] = __builtin_bit_cast(s16x8, u1);
 }
 
+template <bool PRE>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ o, const uint16_t* __restrict__ d_o,
                                                               const float* __restrict__ lse, float* __restrict__ delta, int B, int N,
                                                               int H, float scale, float scale_log2, uint16_t* __restrict__ dqkv) {
@@ -346,9 +347,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const uint16_t* __
   }
   const float del_q = xhalf_sum(dpart);
   if (active && hi == 0) delta[((int64_t)b * H + h) * N + qrow] = del_q;
-  f32x16 negd;
+  f32x16 negd, negl;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) negd[r] = -del_q;
+  for (int r = 0; r < 16; ++r) { negd[r] = -del_q; negl[r] = PRE ? -lse2 : 0.f; }
 
   f32x16 dq[2] = {f32x16_zero(), f32x16_zero()};
   f32x16 sA, dA, sB, dB;
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const uint16_t* __
   // block (0, 0)
 #pragma unroll
   for (int ds = 0; ds < 4; ++ds) {
-    sA = (ds == 0) ? MFMA32(att_frag_row(smem[0], 0, ds, l31, hi), qf[ds], f32x16_zero()) : MFMA32(att_frag_row(smem[0], 0, ds, l31, hi), qf[ds], sA);
+    sA = (ds == 0) ? MFMA32(att_frag_row(smem[0], 0, ds, l31, hi), qf[ds], negl) : MFMA32(att_frag_row(smem[0], 0, ds, l31, hi), qf[ds], sA);
     dA = (ds == 0) ? MFMA32(att_frag_row(smem[3], 0, ds, l31, hi), dof[ds], negd) : MFMA32(att_frag_row(smem[3], 0, ds, l31, hi), dof[ds], dA);
   }
   int ks = 0;   // K ring slot of tile kt ; the V slot is kt & 1
@@ -381,8 +382,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const uint16_t* __
     const unsigned char* kcur = smem[ks];
     const unsigned char* vcur = smem[3 + (kt & 1)];
     // X: current block (kt, 0) in A ; produces (kt, 1) into B ; dQ of the previous tile's second block (its dS is in dsB)
-    if (kt == 0) dq2_block<false>(kcur, vcur, 32, smem[ksp], 32, lane, scale_log2, lse2, negd, sA, dA, sB, dB, dsA, dsB, dq, qf, dof);
-    else dq2_block<true>(kcur, vcur, 32, smem[ksp], 32, lane, scale_log2, lse2, negd, sA, dA, sB, dB, dsA, dsB, dq, qf, dof);
+    if (kt == 0) dq2_block<false, PRE>(kcur, vcur, 32, smem[ksp], 32, lane, scale_log2, lse2, negl, negd, sA, dA, sB, dB, dsA, dsB, dq, qf, dof);
+    else dq2_block<true, PRE>(kcur, vcur, 32, smem[ksp], 32, lane, scale_log2, lse2, negl, negd, sA, dA, sB, dB, dsA, dsB, dq, qf, dof);
     A2_FENCE();
     if (kt >= 1 && kt + 1 < nt) {          // tile kt+1 (fetched during the previous tile's second block) -> LDS ; slots free since the last barrier
       att_sstore(rk, smem[ksn], t);
@@ -395,7 +396,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const uint16_t* __
     }
     A2_FENCE();
     // Y: current block (kt, 1) in B ; produces (kt+1, 0) into A (stale data after the last tile: never used) ; dQ of block (kt, 0) (dS in dsA)
-    dq2_block<true>(smem[ksn], smem[3 + ((kt + 1) & 1)], 0, kcur, 0, lane, scale_log2, lse2, negd, sB, dB, sA, dA, dsB, dsA, dq, qf, dof);
+    dq2_block<true, PRE>(smem[ksn], smem[3 + ((kt + 1) & 1)], 0, kcur, 0, lane, scale_log2, lse2, negl, negd, sB, dB, sA, dA, dsB, dsA, dq, qf, dof);
     A2_FENCE();
     ks = ksn;
   }
@@ -577,13 +578,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_kernel(const uint16_t* _
 }
 
 // launchers used by attention.hip's C ABI (enh_attention_set_kernel selects the family)
-void attn_fwd2_launch(const uint16_t* qkv, int B, int N, int H, float scale_log2, uint16_t* out, float* lse, bool ones, dim3 grid, hipStream_t s) {
-  if (ones) attn_fwd2_kernel<true><<<grid, 256, 0, s>>>(qkv, B, N, H, scale_log2, out, lse);
-  else attn_fwd2_kernel<false><<<grid, 256, 0, s>>>(qkv, B, N, H, scale_log2, out, lse);
+void attn_fwd2_launch(const uint16_t* qkv, int B, int N, int H, float scale_log2, uint16_t* out, float* lse, bool ones, bool pre, dim3 grid, hipStream_t s) {
+  if (ones) {
+    if (pre) attn_fwd2_kernel<true, true><<<grid, 256, 0, s>>>(qkv, B, N, H, scale_log2, out, lse);
+    else attn_fwd2_kernel<true, false><<<grid, 256, 0, s>>>(qkv, B, N, H, scale_log2, out, lse);
+  } else {
+    if (pre) attn_fwd2_kernel<false, true><<<grid, 256, 0, s>>>(qkv, B, N, H, scale_log2, out, lse);
+    else attn_fwd2_kernel<false, false><<<grid, 256, 0, s>>>(qkv, B, N, H, scale_log2, out, lse);
+  }
 }
 void attn_bwd_dq2_launch(const uint16_t* qkv, const uint16_t* o, const uint16_t* d_o, const float* lse, float* delta, int B, int N, int H, float scale,
-                         float scale_log2, uint16_t* dqkv, dim3 grid, hipStream_t s) {
-  attn_bwd_dq2_kernel<<<grid, 256, 0, s>>>(qkv, o, d_o, lse, delta, B, N, H, scale, scale_log2, dqkv);
+                         float scale_log2, uint16_t* dqkv, bool pre, dim3 grid, hipStream_t s) {
+  if (pre) attn_bwd_dq2_kernel<true><<<grid, 256, 0, s>>>(qkv, o, d_o, lse, delta, B, N, H, scale, scale_log2, dqkv);
+  else attn_bwd_dq2_kernel<false><<<grid, 256, 0, s>>>(qkv, o, d_o, lse, delta, B, N, H, scale, scale_log2, dqkv);
 }
 void attn_bwd_dkv2_launch(const uint16_t* qkv, const uint16_t* d_o, const float* lse, const float* delta, int B, int N, int H, float scale,
                           float scale_log2, uint16_t* dqkv, dim3 grid, hipStream_t s) {

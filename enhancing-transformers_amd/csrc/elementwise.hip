@@ -264,6 +264,27 @@ extern "C" int enh_colsum_bf16_ws(const enh_bf16* x, int64_t M, int64_t N, int64
   return colsum_bf16_impl(x, M, N, ldx, out, accumulate, (float*)ws, stream);
 }
 
+// y[i] = bf16(x[i] * (i < n_scaled ? alpha : 1)): the forward operand of a packed q | k | v projection whose q rows carry the softmax scale (one rounding,
+// from the fp32 master) — include/enh_hip.h enh_attention_forward, q_prescaled
+__global__ void cast_f32_bf16_head_scaled_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, int64_t n, int64_t n_scaled, float alpha) {
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n) return;
+  if (i + 3 < n) {
+    float4 v = *reinterpret_cast<const float4*>(x + i);
+    if (i < n_scaled) { v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha; }     // n_scaled % 4 == 0 (checked by the launcher)
+    *reinterpret_cast<uint2*>(y + i) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+  } else {
+    for (int64_t k = i; k < n; ++k) y[k] = f32_to_bf16_bits(x[k] * (k < n_scaled ? alpha : 1.0f));
+  }
+}
+
+extern "C" int enh_cast_f32_bf16_head_scaled(const float* x, enh_bf16* y, int64_t n, int64_t n_scaled, float alpha, void* stream) {
+  ENH_REQUIRE(x && y && n > 0 && n_scaled >= 0 && n_scaled <= n && n_scaled % 4 == 0, ENH_E_BADARG, "enh_cast_f32_bf16_head_scaled: bad argument");
+  const int64_t n4 = (n + 3) / 4;
+  cast_f32_bf16_head_scaled_kernel<<<(int)((n4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, y, n, n_scaled, alpha);
+  return enh_check_launch("enh_cast_f32_bf16_head_scaled");
+}
+
 extern "C" int enh_cast_f32_bf16(const float* x, enh_bf16* y, int64_t n, void* stream) {
   ENH_REQUIRE(x && y && n > 0, ENH_E_BADARG, "enh_cast_f32_bf16: bad argument");
   const int64_t n4 = (n + 3) / 4;

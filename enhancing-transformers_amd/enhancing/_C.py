@@ -48,14 +48,15 @@ SIGNATURES = {
     "enh_gemm_set_kernel": (_i32, [_i32]),
     "enh_gemm_bf16_variant": (_c.c_char_p, [_i32, _i32, _i64, _i64, _i64]),
     "enh_attention_set_kernel": (_i32, [_i32, _i32, _i32]),
-    "enh_attention_forward": (_i32, [_vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp]),
-    "enh_attention_backward": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp]),
+    "enh_attention_forward": (_i32, [_vp, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp]),
+    "enh_attention_backward": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp]),
     "enh_patchify": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "enh_unpatchify_loss": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp]),
     "enh_colsum_bf16": (_i32, [_vp, _i64, _i64, _i64, _vp, _i32, _vp]),
     "enh_colsum_bf16_ws": (_i32, [_vp, _i64, _i64, _i64, _vp, _i32, _vp, _sz, _vp]),
     "enh_colsum_bf16_workspace_bytes": (_sz, [_i64, _i64]),
     "enh_cast_f32_bf16": (_i32, [_vp, _vp, _i64, _vp]),
+    "enh_cast_f32_bf16_head_scaled": (_i32, [_vp, _vp, _i64, _i64, _f32, _vp]),
     "enh_crop_flip_u8": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),
     "enh_fused_bias_act": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _f32, _f32, _vp]),
     "enh_channel_sum_f32": (_i32, [_vp, _i32, _i32, _i64, _vp, _i32, _vp]),
@@ -348,16 +349,17 @@ def attention_set_kernel(fwd: int = 0, dq: int = 0, dkv: int = 0) -> None:
     _check(lib().enh_attention_set_kernel(fwd, dq, dkv), "enh_attention_set_kernel")
 
 
-def attention_forward(qkv, B: int, N: int, H: int, scale: float, out, lse):
+def attention_forward(qkv, B: int, N: int, H: int, scale: float, out, lse, q_prescaled: bool = False):
+    """q_prescaled: the q third of qkv holds q * scale * log2(e) (include/enh_hip.h)"""
     _timed("attn_fwd_kernel", 4.0 * B * H * N * N * 64,
-           lambda: _check(lib().enh_attention_forward(_p(qkv, BF16, "qkv"), B, N, H, scale, _p(out, BF16, "out"), _p(lse, F32, "lse"), _stream()),
-                          "enh_attention_forward"))
+           lambda: _check(lib().enh_attention_forward(_p(qkv, BF16, "qkv"), B, N, H, scale, int(q_prescaled), _p(out, BF16, "out"), _p(lse, F32, "lse"),
+                                                      _stream()), "enh_attention_forward"))
 
 
-def attention_backward(qkv, out, dout, lse, B: int, N: int, H: int, scale: float, dqkv, delta_ws):
+def attention_backward(qkv, out, dout, lse, B: int, N: int, H: int, scale: float, dqkv, delta_ws, q_prescaled: bool = False):
     _timed("attn_bwd (dq+dkv kernels)", 10.0 * B * H * N * N * 64,
            lambda: _check(lib().enh_attention_backward(_p(qkv, BF16, "qkv"), _p(out, BF16, "out"), _p(dout, BF16, "dout"), _p(lse, F32, "lse"), B, N, H,
-                                                       scale, _p(dqkv, BF16, "dqkv"), _p(delta_ws, F32, "delta_ws"), _stream()),
+                                                       scale, int(q_prescaled), _p(dqkv, BF16, "dqkv"), _p(delta_ws, F32, "delta_ws"), _stream()),
                           "enh_attention_backward"))
 
 
@@ -382,6 +384,11 @@ def colsum(x, M: int, N: int, out, accumulate: bool = False):
     nb = lib().enh_colsum_bf16_workspace_bytes(M, N)
     ws = _workspace(nb, x.device)
     _check(lib().enh_colsum_bf16_ws(_p(x, BF16, "x"), M, N, x.stride(0), _p(out, F32, "out"), int(accumulate), _p(ws), ws.numel(), _stream()), "enh_colsum_bf16_ws")
+
+
+def cast_bf16_head_scaled(x, y, n_scaled: int, alpha: float):
+    """y = bf16(x * alpha) for the first n_scaled elements, bf16(x) for the rest"""
+    _check(lib().enh_cast_f32_bf16_head_scaled(_p(x, F32, "x"), _p(y, BF16, "y"), x.numel(), n_scaled, alpha, _stream()), "enh_cast_f32_bf16_head_scaled")
 
 
 def cast_bf16(x, y):
@@ -606,16 +613,16 @@ def ln_bwd(dy, x, w, mean, rstd, dres, dx, dx_operand, dw, db, dx_colsum=None):
     layernorm_backward(dy, x, w, mean, rstd, dres, dx, dx_operand if dx_operand.dtype == BF16 else None, dw, db, dx_colsum)
 
 
-def attn_fwd(qkv, B, N, H, scale, out, lse):
+def attn_fwd(qkv, B, N, H, scale, out, lse, q_prescaled: bool = False):
     if qkv.dtype == BF16:
-        attention_forward(qkv, B, N, H, scale, out, lse)
+        attention_forward(qkv, B, N, H, scale, out, lse, q_prescaled)
     else:
         _check(lib().enh_attention_forward_f32(_p(qkv, F32, "qkv"), B, N, H, scale, _p(out, F32, "out"), _p(lse, F32, "lse"), _stream()), "enh_attention_forward_f32")
 
 
-def attn_bwd(qkv, out, dout, lse, B, N, H, scale, dqkv, delta_ws):
+def attn_bwd(qkv, out, dout, lse, B, N, H, scale, dqkv, delta_ws, q_prescaled: bool = False):
     if qkv.dtype == BF16:
-        attention_backward(qkv, out, dout, lse, B, N, H, scale, dqkv, delta_ws)
+        attention_backward(qkv, out, dout, lse, B, N, H, scale, dqkv, delta_ws, q_prescaled)
     else:
         _check(lib().enh_attention_backward_f32(_p(qkv, F32, "qkv"), _p(out, F32, "out"), _p(dout, F32, "dout"), _p(lse, F32, "lse"), B, N, H, scale,
                                                 _p(dqkv, F32, "dqkv"), _p(delta_ws, F32, "delta_ws"), _stream()), "enh_attention_backward_f32")

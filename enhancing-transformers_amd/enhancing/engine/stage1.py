@@ -15,6 +15,7 @@ PyTorch is used for device memory, streams and ``torch.distributed`` only.
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -60,6 +61,7 @@ class ParamStore:
         # GEMM operand view of every weight: the bf16 shadow (product path) or the fp32 master itself (exact mode)
         self.wa = self.w16 if precision == "bf16" else self.w
         self.step_count = 0
+        self.operand_hooks: List = []      # callables that rebuild derived GEMM operands (e.g. the towers' pre-scaled q | k | v weights) from the masters
         self.refresh_shadows()
 
     @staticmethod
@@ -83,8 +85,14 @@ class ParamStore:
         return begin, end
 
     def refresh_shadows(self) -> None:
+        """to be called after ANY write to the fp32 masters that did not go through Stage1Engine.optimizer_step (initial broadcast, weight loading)"""
         if self.precision == "bf16":
             _C.cast_bf16(self.p, self.p16)
+        self.refresh_operands()
+
+    def refresh_operands(self) -> None:
+        for hook in self.operand_hooks:
+            hook()
 
     def zero_grad(self) -> None:
         self.g.zero_()
@@ -126,6 +134,21 @@ class _Tower:
                 w2=q + "1.fn.net.2.weight", b2=q + "1.fn.net.2.bias"))
         self.lnf_w, self.lnf_b = t + "norm.weight", t + "norm.bias"
         self.first_bias_grad = None  # set by the engine: grad buffer of the bias that feeds layer 0's input (patch-embed / post_quant)
+        # FORWARD operand of to_qkv in the product path: the bf16 image of the fp32 master whose q rows are multiplied by scale * log2(e) before the (single)
+        # rounding, so that the attention kernels see log2-domain logits and feed -max / -lse through the MFMA C operand (include/enh_hip.h
+        # enh_attention_forward, q_prescaled).  The BACKWARD GEMMs keep the plain shadow: the attention backward returns the gradient with respect to the
+        # unscaled q, so neither the input gradient nor the weight gradient needs a correction.  Rebuilt whenever the masters change (store hook).
+        self.q_prescaled = store.precision == "bf16" and os.environ.get("ENH_ATTN_PRESCALE", "1") != "0"
+        self.wqkv_fwd: List[torch.Tensor] = []
+        if self.q_prescaled:
+            self.wqkv_fwd = [torch.empty(3 * self.inner, dim, dtype=torch.bfloat16, device=store.device) for _ in range(depth)]
+            store.operand_hooks.append(self.refresh_qkv_operands)
+            self.refresh_qkv_operands()
+
+    def refresh_qkv_operands(self) -> None:
+        alpha = self.scale * 1.4426950408889634
+        for P, dst in zip(self.L, self.wqkv_fwd):
+            _C.cast_bf16_head_scaled(self.s.w[P["wqkv"]], dst, self.inner * self.dim, alpha)
 
     # ---- activation arena --------------------------------------------------------------------
     def bufs(self, B: int, save: bool) -> dict:
@@ -164,8 +187,8 @@ class _Tower:
         for i, P in enumerate(self.L):
             A = b["layers"][i if save else 0]
             _C.ln_fwd(x, s.w[P["ln1_w"]], s.w[P["ln1_b"]], A["a1"], A["mean1"], A["rstd1"])
-            _C.mm(A["a1"], s.wa[P["wqkv"]], M, 3 * inner, dim, A["qkv"])
-            _C.attn_fwd(A["qkv"], B, self.n_tok, self.heads, self.scale, A["o"], A["lse"])
+            _C.mm(A["a1"], self.wqkv_fwd[i] if self.q_prescaled else s.wa[P["wqkv"]], M, 3 * inner, dim, A["qkv"])
+            _C.attn_fwd(A["qkv"], B, self.n_tok, self.heads, self.scale, A["o"], A["lse"], self.q_prescaled)
             _C.mm(A["o"], s.wa[P["wout"]], M, dim, inner, A["x_mid"], bias=s.w[P["bout"]], res=x, res_rows=M)
             _C.ln_fwd(A["x_mid"], s.w[P["ln2_w"]], s.w[P["ln2_b"]], A["a2"], A["mean2"], A["rstd2"])
             _C.mm(A["a2"], s.wa[P["w1"]], M, mlp, dim, A["hid"], bias=s.w[P["b1"]], act=_C.ACT_TANH)
@@ -204,7 +227,7 @@ class _Tower:
             # ---- attention: x_mid = to_out(attn(to_qkv(a1))) + x_in ----
             _C.mm(gB16, A["o"], dim, inner, M, g[P["wout"]], trans_a=True, trans_b=True, accumulate=True)
             _C.mm(gB16, s.wa[P["wout"]], M, inner, dim, b["do16"], trans_b=True)
-            _C.attn_bwd(A["qkv"], A["o"], b["do16"], A["lse"], B, self.n_tok, self.heads, self.scale, b["dqkv16"], b["delta"])
+            _C.attn_bwd(A["qkv"], A["o"], b["do16"], A["lse"], B, self.n_tok, self.heads, self.scale, b["dqkv16"], b["delta"], self.q_prescaled)
             _C.mm(b["dqkv16"], A["a1"], 3 * inner, dim, M, g[P["wqkv"]], trans_a=True, trans_b=True, accumulate=True)
             _C.mm(b["dqkv16"], s.wa[P["wqkv"]], M, dim, 3 * inner, dA, trans_b=True)
             _C.ln_bwd(dA, b["x"][i], s.w[P["ln1_w"]], A["mean1"], A["rstd1"], gB, gA, gA16, g[P["ln1_w"]], g[P["ln1_b"]],
@@ -536,6 +559,7 @@ class Stage1Engine:
         s.step_count += 1
         _C.adamw_step(s.p, s.g, s.m, s.v, s.p16 if self.precision == "bf16" else None, s.step_count, lr, betas[0], betas[1], eps, weight_decay,
                       grad_scale)
+        s.refresh_operands()      # operands derived from the masters (the towers' pre-scaled q | k | v weights): 24 small launches at base
 
     def train_step(self, img: torch.Tensor, lr: float, **loss_kw) -> dict:
         out = self.forward_backward(img, **loss_kw)

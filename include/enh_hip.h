@@ -151,16 +151,22 @@ int enh_gemm_set_kernel(int family);
  * qkv [B,N,3*H*64] bf16 packed exactly as to_qkv emits it (q | k | v thirds, head-major, layers.py:123-124);
  * out [B,N,H*64] bf16 in the 'b n (h d)' layout to_out consumes (layers.py:130); lse [B,H,N] f32 =
  * row log-sum-exp of the scaled scores (saved for backward).  dim_head = 64, N % 64 == 0.
+ * q_prescaled = 1: the q third already holds q * scale * log2(e) (the caller folded the softmax scale into the projection's q rows, once, in
+ * fp32 before the bf16 rounding).  The score products are then log2-domain logits and the kernels feed -max / -lse / -delta through the MFMA C
+ * operand instead of spending vector instructions on them (the kernels are vector-issue bound, profiles/r03_attention_lab.txt).  Semantics are
+ * unchanged: out / lse are those of softmax(q k^T scale) v for the UNSCALED q, dqkv's q third is the gradient with respect to the unscaled q.
  */
-int enh_attention_forward(const enh_bf16* qkv, int B, int N, int H, float scale, enh_bf16* out, float* lse,
+int enh_attention_forward(const enh_bf16* qkv, int B, int N, int H, float scale, int q_prescaled, enh_bf16* out, float* lse,
                           void* stream);
-/* kernel family per pass for A/B measurements (explicit library state, like enh_gemm_set_kernel): 0 = the library's choice, 1 = the round-1/2
- * kernels, 2 = the software-pipelined round-3 kernels (csrc/attention_v2.hip), 3 = (forward only) pipelined with vector row sums.  Same results up to
- * rounding: every family passes the same parity tests. */
+/* kernel family per pass for A/B measurements (explicit library state, like enh_gemm_set_kernel), 0 = the library's choice:
+ *   fwd: 1 round-2 kernel, 2 software-pipelined with row sums on the matrix pipe, 3 software-pipelined with vector row sums (csrc/attention_v2.hip)
+ *   dq : 1 round-2 kernel, 2 software-pipelined, 3 round-2 skeleton with -delta (-lse too when q is pre-scaled) as MFMA C operands
+ *   dkv: 1 round-2 kernel, 2 round-2 skeleton with -delta (-lse too when q is pre-scaled) as MFMA C operands
+ * Same results up to rounding: every family passes the same parity tests. */
 int enh_attention_set_kernel(int fwd, int dq, int dkv);
 /* dqkv [B,N,3*H*64] bf16 ; delta_ws [B,H,N] f32 scratch */
 int enh_attention_backward(const enh_bf16* qkv, const enh_bf16* out, const enh_bf16* dout, const float* lse,
-                           int B, int N, int H, float scale, enh_bf16* dqkv, float* delta_ws, void* stream);
+                           int B, int N, int H, float scale, int q_prescaled, enh_bf16* dqkv, float* delta_ws, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Patch (un)embedding data movement, pixel loss, reductions, optimizer
@@ -181,6 +187,9 @@ size_t enh_colsum_bf16_workspace_bytes(int64_t M, int64_t N);
 int enh_colsum_bf16_ws(const enh_bf16* x, int64_t M, int64_t N, int64_t ldx, float* out, int accumulate, void* ws, size_t ws_bytes, void* stream);
 /* f32 -> bf16 cast (weight shadows) */
 int enh_cast_f32_bf16(const float* x, enh_bf16* y, int64_t n, void* stream);
+/* y[i] = bf16(x[i] * (i < n_scaled ? alpha : 1)), n_scaled % 4 == 0: forward operand of a packed q | k | v projection weight whose leading q rows carry
+ * the softmax scale * log2(e) (one rounding from the fp32 master; see enh_attention_forward, q_prescaled) */
+int enh_cast_f32_bf16_head_scaled(const float* x, enh_bf16* y, int64_t n, int64_t n_scaled, float alpha, void* stream);
 /* torch.optim.AdamW(lr, betas=(0.9,0.99), weight_decay=1e-4) step over one flat buffer (vitvqgan.py:160),
  * also refreshes the bf16 shadow used by the GEMMs.  grad_scale multiplies g first (DDP mean / accumulation). */
 int enh_adamw_step(float* p, const float* g, float* m, float* v, enh_bf16* p_bf16, int64_t n, int step, float lr,

@@ -268,8 +268,9 @@ def _attn_ref(qkv, B, N, H, scale):
 
 
 # kernel families per pass (include/enh_hip.h enh_attention_set_kernel): the library's default choice, the round-2 kernels, the software-pipelined
-# round-3 kernels (forward with the ones-MFMA row sum, and with vector row sums)
-ATT_FAMILIES = [(0, 0, 0), (1, 1, 1), (2, 2, 1), (3, 2, 1)]
+# round-3 kernels, and the round-2 skeletons with the statistics fed through the MFMA C operand
+ATT_FAMILIES = [(0, 0, 0), (1, 1, 1), (2, 2, 2), (3, 3, 2)]
+LOG2E = 1.4426950408889634
 
 
 @pytest.fixture(params=ATT_FAMILIES, ids=lambda f: "fam%d%d%d" % f)
@@ -279,30 +280,45 @@ def att_family(request, C):
     C.attention_set_kernel(0, 0, 0)
 
 
+def _prescale_q(qkv, H, scale):
+    """the q_prescaled convention of include/enh_hip.h: the q third holds bf16(q * scale * log2e).  Returns (the tensor the kernels get, the UNSCALED
+    fp64 qkv those bits represent — what the reference attention and its gradients are taken on)."""
+    inner = H * 64
+    dev = qkv.clone()
+    dev[..., :inner] = bf16r(qkv[..., :inner] * (scale * LOG2E))
+    ref = dev.double().clone()
+    ref[..., :inner] /= (scale * LOG2E)
+    return dev, ref
+
+
+@pytest.mark.parametrize("pre", [False, True], ids=["plain", "prescaled"])
 @pytest.mark.parametrize("B,N,H", [(2, 1024, 3), (3, 64, 2), (1, 256, 12), (2, 192, 1), (1, 128, 2), (1, 320, 1)])
-def test_attention_forward_backward(C, att_family, B, N, H):
+def test_attention_forward_backward(C, att_family, B, N, H, pre):
     g = torch.Generator().manual_seed(B * 100 + N + H)
     qkv = bf16r(torch.randn(B, N, 3 * H * 64, generator=g) * 1.5)
     do = bf16r(torch.randn(B, N, H * 64, generator=g))
     scale = 64 ** -0.5
-    qt = qkv.clone().requires_grad_(True)
+    qdev, qref = _prescale_q(qkv, H, scale) if pre else (qkv, qkv.double())
+    qt = qref.clone().requires_grad_(True)
     ref, lse_ref = _attn_ref(qt, B, N, H, scale)
     ref.backward(do.double())
-    qd = qkv.to(torch.bfloat16).cuda()
+    qd = qdev.to(torch.bfloat16).cuda()
     out = torch.empty(B, N, H * 64, dtype=torch.bfloat16, device="cuda")
     lse = torch.empty(B, H, N, device="cuda")
-    C.attention_forward(qd, B, N, H, scale, out, lse)
+    C.attention_forward(qd, B, N, H, scale, out, lse, q_prescaled=pre)
     assert rel(out.float(), ref) <= 1.5 * bf16_floor(ref)
-    assert rel(lse, lse_ref) <= 1e-5
+    # lse: 1e-5 when the row sum is taken in fp32; family 2 sums the bf16 numerators on the matrix pipe (the normaliser of exactly what entered P V)
+    assert rel(lse, lse_ref) <= (1e-4 if att_family[0] == 2 else 1e-5)
     dqkv = torch.full((B, N, 3 * H * 64), float("nan"), dtype=torch.bfloat16, device="cuda")
     delta = torch.empty(B, H, N, device="cuda")
-    C.attention_backward(qd, out, do.to(torch.bfloat16).cuda(), lse, B, N, H, scale, dqkv, delta)
+    C.attention_backward(qd, out, do.to(torch.bfloat16).cuda(), lse, B, N, H, scale, dqkv, delta, q_prescaled=pre)
     gq, gk, gv = qt.grad.view(B, N, 3, H * 64).unbind(2)
     dq, dk, dv = dqkv.float().view(B, N, 3, H * 64).unbind(2)
     assert rel(dq, gq) <= 2 * ATT_TOL and rel(dk, gk) <= 2 * ATT_TOL and rel(dv, gv) <= 2 * ATT_TOL, (rel(dq, gq), rel(dk, gk), rel(dv, gv))
 
 
-def test_attention_spiked_scores(C, att_family):
+@pytest.mark.parametrize("pre", [False, True], ids=["plain", "prescaled"])
+def test_attention_spiked_scores(C, att_family, pre):
     """keys dominating a row (force the running maximum / the pipelined kernels' reference maximum to jump mid-sweep, several times and in adjacent
     tiles, incl. the last one): the rescale path, checked row by row against fp64 (cdna_hip_programming.md T13: a wrong rescale order is silent on
     bounded random data and shows only in the rows that took the branch)."""
@@ -316,23 +332,24 @@ def test_attention_spiked_scores(C, att_family):
     for key, gain in ((100, 2.0), (130, 4.0), (200, 7.0), (505, 11.0)):
         qkv[0, key, H * 64 + 64:H * 64 + 128] = qv * gain
     qkv = bf16r(qkv)
-    ref, lse_ref = _attn_ref(qkv, B, N, H, 0.125)
+    qdev, qref = _prescale_q(qkv, H, 0.125) if pre else (qkv, qkv.double())
+    ref, lse_ref = _attn_ref(qref, B, N, H, 0.125)
     out = torch.empty(B, N, H * 64, dtype=torch.bfloat16, device="cuda")
     lse = torch.empty(B, H, N, device="cuda")
-    C.attention_forward(qkv.to(torch.bfloat16).cuda(), B, N, H, 0.125, out, lse)
+    C.attention_forward(qdev.to(torch.bfloat16).cuda(), B, N, H, 0.125, out, lse, q_prescaled=pre)
     assert torch.isfinite(out.float()).all()
     assert rel(out.float(), ref) <= ATT_TOL
-    assert rel(lse, lse_ref) <= 1e-5
+    assert rel(lse, lse_ref) <= (1e-4 if att_family[0] == 2 else 1e-5)
     for q, h in ((5, 0), (70, 1)):          # the rows that took the branch, individually
         assert rel(out.float().cpu()[0, q, h * 64:(h + 1) * 64], ref[0, q, h * 64:(h + 1) * 64]) <= 2 * ATT_TOL, (q, h)
     # backward through the same spiked rows (lse comes from the kernel above)
     do = bf16r(torch.randn(B, N, H * 64, generator=g))
-    qt = qkv.clone().requires_grad_(True)
+    qt = qref.clone().requires_grad_(True)
     r2, _ = _attn_ref(qt, B, N, H, 0.125)
     r2.backward(do.double())
     dqkv = torch.full((B, N, 3 * H * 64), float("nan"), dtype=torch.bfloat16, device="cuda")
     delta = torch.empty(B, H, N, device="cuda")
-    C.attention_backward(qkv.to(torch.bfloat16).cuda(), out, do.to(torch.bfloat16).cuda(), lse, B, N, H, 0.125, dqkv, delta)
+    C.attention_backward(qdev.to(torch.bfloat16).cuda(), out, do.to(torch.bfloat16).cuda(), lse, B, N, H, 0.125, dqkv, delta, q_prescaled=pre)
     assert torch.isfinite(dqkv.float()).all()
     assert rel(dqkv.float(), qt.grad) <= 3 * ATT_TOL, rel(dqkv.float(), qt.grad)
 

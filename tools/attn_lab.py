@@ -30,7 +30,10 @@ def rel(a, b):
 
 
 def check(b, h):
-    x = qkv[b].view(N, 3, H, 64)[:, :, h].double().clone().requires_grad_(True)
+    x = qkv[b].view(N, 3, H, 64)[:, :, h].double().clone()
+    if PRE:
+        x[:, 0] /= CP
+    x.requires_grad_(True)
     q, k, v = x.unbind(1)
     s = (q @ k.t()) * 0.125
     o_ref = torch.softmax(s, -1) @ v
@@ -40,17 +43,21 @@ def check(b, h):
     return dict(out=rel(o, o_ref), lse=rel(lse[b, h], torch.logsumexp(s, -1)), dq=rel(d[:, 0], x.grad[:, 0]), dk=rel(d[:, 1], x.grad[:, 1]), dv=rel(d[:, 2], x.grad[:, 2]))
 
 
+PRE = os.environ.get("PRE", "0") == "1"          # q_prescaled convention: the q third holds bf16(q * scale * log2e)
+CP = 0.125 * 1.4426950408889634
+if PRE:
+    qkv.view(B, N, 3, H * 64)[:, :, 0] = (qkv.view(B, N, 3, H * 64)[:, :, 0].float() * CP).to(torch.bfloat16)
 fams = [tuple(int(x) for x in a.split(",")) for a in sys.argv[1:]] or [(1, 1, 1), (2, 2, 1), (3, 2, 1)]
 for fam in fams:
     _C.attention_set_kernel(*fam)
     out.fill_(float("nan")); dqkv.fill_(float("nan"))
-    _C.attention_forward(qkv, B, N, H, 0.125, out, lse)
-    _C.attention_backward(qkv, out, do, lse, B, N, H, 0.125, dqkv, delta)
+    _C.attention_forward(qkv, B, N, H, 0.125, out, lse, q_prescaled=PRE)
+    _C.attention_backward(qkv, out, do, lse, B, N, H, 0.125, dqkv, delta, q_prescaled=PRE)
     torch.cuda.synchronize()
     errs = [check(b, h) for b, h in ((0, 0), (B - 1, H - 1), (B // 2, 5))]
     worst = {k: max(e[k] for e in errs) for k in errs[0]}
-    tf = timeit(lambda: _C.attention_forward(qkv, B, N, H, 0.125, out, lse))
-    tb = timeit(lambda: _C.attention_backward(qkv, out, do, lse, B, N, H, 0.125, dqkv, delta))
-    print(f"family fwd,dq,dkv = {fam}: fwd {tf*1e3:7.3f} ms {fl/tf/1e12:7.1f} TF/s | bwd {tb*1e3:7.3f} ms {2.5*fl/tb/1e12:7.1f} TF/s (algorithmic) | "
+    tf = timeit(lambda: _C.attention_forward(qkv, B, N, H, 0.125, out, lse, q_prescaled=PRE))
+    tb = timeit(lambda: _C.attention_backward(qkv, out, do, lse, B, N, H, 0.125, dqkv, delta, q_prescaled=PRE))
+    print(f"{'prescaled q' if PRE else 'plain q'} family fwd,dq,dkv = {fam}: fwd {tf*1e3:7.3f} ms {fl/tf/1e12:7.1f} TF/s | bwd {tb*1e3:7.3f} ms {2.5*fl/tb/1e12:7.1f} TF/s (algorithmic) | "
           + " ".join(f"{k} {v:.2e}" for k, v in worst.items()), flush=True)
 _C.attention_set_kernel(0, 0, 0)
