@@ -5,8 +5,8 @@ R=$PWD; export TMPDIR=/tmp; mkdir -p $R/gpurun_out; cd /tmp
 for FAM in "$@"; do
   TAG=$(echo $FAM | tr -d ,)
   rm -rf /tmp/pa1 /tmp/pa2
-  ITERS=3 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS -d /tmp/pa1 -o a -- python $R/tools/attn_lab.py $FAM > /dev/null 2>&1
-  ITERS=3 timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_MISC GRBM_GUI_ACTIVE -d /tmp/pa2 -o a -- python $R/tools/attn_lab.py $FAM > /dev/null 2>&1
+  ROUNDS=1 ITERS=3 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS -d /tmp/pa1 -o a -- python $R/tools/attn_lab.py $FAM > /dev/null 2>&1
+  ROUNDS=1 ITERS=3 timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_MISC GRBM_GUI_ACTIVE -d /tmp/pa2 -o a -- python $R/tools/attn_lab.py $FAM > /dev/null 2>&1
   python - "$FAM" > $R/gpurun_out/pmc_attn_$TAG.txt <<'PY'
 import sqlite3, glob, collections, sys
 print("kernel family", sys.argv[1])
