@@ -289,7 +289,7 @@ void attn_bwd_dq2_launch(const uint16_t* qkv, const uint16_t* o, const uint16_t*
 static int g_att_fwd = 0, g_att_dq = 0, g_att_dkv = 0;
 #define ATT_DEFAULT_FWD 1
 #define ATT_DEFAULT_DQ 1
-#define ATT_DEFAULT_DKV 1
+#define ATT_DEFAULT_DKV 2
 
 extern "C" int enh_attention_set_kernel(int fwd, int dq, int dkv) {
   ENH_REQUIRE(fwd >= 0 && fwd <= 3 && dq >= 0 && dq <= 3 && dkv >= 0 && dkv <= 2, ENH_E_BADARG, "enh_attention_set_kernel: fwd in 0..3, dq in 0..3, dkv in 0..2");

@@ -417,166 +417,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(const uint16_t* __
     }
 }
 
-// =================================================================================================
-// backward: dK, dV  (workgroup = 128 keys, a wave 32 of them; Q / dO tiles of 64 queries stream through LDS) — per 32-QUERY BLOCK j:
-//     phase A  S(j) = Q K^T, dP'(j) = dO V^T - delta                      [8 MFMA]  |  fragment reads for phases B, C
-//     phase B  dV += dO^T P, dK += Q^T dS of the SECOND half of block j-1  [4 MFMA]  |  P, dS of the first 16 queries of block j   [vector]
-//     phase C  the same products for the first half of block j            [4 MFMA]  |  P, dS of the second 16 queries            [vector]
-// i.e. every vector phase runs under matrix work that does not depend on it, the score tiles stay single-buffered (registers: 2 waves per SIMD), and
-// every LDS fragment is requested two or more MFMAs before it is used (the round-2 kernel waited for each group of reads where it issued them).
-// -delta enters through the C operand of the first dP product (16 registers loaded straight from the statistics in LDS); lse stays in the log2 domain.
-// Rings of 3 tiles (the second half of tile t-1 is still read, transposed, under the first block of tile t); one barrier per tile.
-// =================================================================================================
-struct Dkv2Pending { s16x8 pa, dsa; };
-
-template <bool PREV>
-__device__ __forceinline__ void dkv2_block(const unsigned char* qt, const unsigned char* dt, const float* st_lse, const float* st_negd, const int qb,
-                                           const unsigned char* pq, const unsigned char* pd, const int prow, const int lane, const float c,
-                                           const s16x8 (&kf)[4], const s16x8 (&vf)[4], f32x16 (&dk)[2], f32x16 (&dv)[2], Dkv2Pending& pend) {
-  const int l31 = lane & 31, hi = lane >> 5;
-  f32x16 s, dp;
-  s16x8 fr[3];            // row fragments, rolling
-  s16x8 tf[4];            // transposed fragments dO^T db 0, 1 ; Q^T db 0, 1: first the pending half block's (rows prow .. +15 of its tile), each replaced by
-                          // this block's first-half fragment (rows qb*32 .. +15) as soon as its product has been issued
-  f32x4 l4[2];
-  unsigned pw[4], dw[4];
-  Dkv2Pending cur;        // first half of this block
-  // C operand of the first dP product: -delta of the 16 rows this lane holds
-#pragma unroll
-  for (int g4 = 0; g4 < 4; ++g4) {
-    const f32x4 n4 = *reinterpret_cast<const f32x4*>(st_negd + qb * 32 + 8 * g4 + 4 * hi);
-    dp[g4 * 4 + 0] = n4[0]; dp[g4 * 4 + 1] = n4[1]; dp[g4 * 4 + 2] = n4[2]; dp[g4 * 4 + 3] = n4[3];
-  }
-  fr[0] = att_frag_row(qt, qb * 32, 0, l31, hi);
-  fr[1] = att_frag_row(dt, qb * 32, 0, l31, hi);
-  A2_FENCE();
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    if (k < 8) {                                                          // ---- phase A
-      const int ds = k >> 1;
-      if ((k & 1) == 0) s = (ds == 0) ? MFMA32(fr[k % 3], kf[ds], f32x16_zero()) : MFMA32(fr[k % 3], kf[ds], s);      // S[q][key]
-      else dp = MFMA32(fr[k % 3], vf[ds], dp);                                                                       // dP[q][key] - delta[q]
-      if (k + 2 < 8) fr[(k + 2) % 3] = att_frag_row(((k + 2) & 1) ? dt : qt, qb * 32, (k + 2) >> 1, l31, hi);
-      if (PREV && k < 4) tf[k] = att_frag_tr((k < 2) ? pd : pq, prow, k & 1, lane);
-      if (k == 6) l4[0] = *reinterpret_cast<const f32x4*>(st_lse + qb * 32 + 4 * hi);
-      if (k == 7) l4[1] = *reinterpret_cast<const f32x4*>(st_lse + qb * 32 + 8 + 4 * hi);
-    } else if (k < 12) {                                                  // ---- phase B: products of the pending half block
-      const int f = k - 8;
-      if (PREV) {
-        if (f < 2) dv[f] = MFMA32(tf[f], pend.pa, dv[f]);
-        else dk[f - 2] = MFMA32(tf[f], pend.dsa, dk[f - 2]);
-      }
-      tf[f] = att_frag_tr((f < 2) ? dt : qt, qb * 32, f & 1, lane);       // this block's first-half fragments, four slices before their product
-    } else {                                                              // ---- phase C: products of this block's first half
-      const int f = k - 12;
-      if (f < 2) dv[f] = MFMA32(tf[f], cur.pa, dv[f]);
-      else dk[f - 2] = MFMA32(tf[f], cur.dsa, dk[f - 2]);
-    }
-    if (k >= 8) {                                                         // ---- vector work: pair g of the block's 16 registers
-      const int g = k - 8, r = 2 * g, half = g >> 2, w = g & 3;
-      if (g == 4) { l4[0] = *reinterpret_cast<const f32x4*>(st_lse + qb * 32 + 16 + 4 * hi); l4[1] = *reinterpret_cast<const f32x4*>(st_lse + qb * 32 + 24 + 4 * hi); }
-      const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c, -l4[(r >> 2) & 1][r & 3]));
-      const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r + 1], c, -l4[(r >> 2) & 1][(r + 1) & 3]));
-      pw[w] = pack_bf16x2(p0, p1);
-      dw[w] = pack_bf16x2(p0 * dp[r], p1 * dp[r + 1]);
-      A2_PIN2(pw[w], dw[w]);
-      if (w == 3) {
-        const u32x4 up = {pw[0], pw[1], pw[2], pw[3]}, ud = {dw[0], dw[1], dw[2], dw[3]};
-        if (half == 0) { cur.pa = __builtin_bit_cast(s16x8, up); cur.dsa = __builtin_bit_cast(s16x8, ud); }
-        else { pend.pa = __builtin_bit_cast(s16x8, up); pend.dsa = __builtin_bit_cast(s16x8, ud); }
-      }
-    }
-    A2_FENCE();
-  }
-}
-
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ d_o,
-                                                               const float* __restrict__ lse, const float* __restrict__ delta, int B, int N,
-                                                               int H, float scale, float scale_log2, uint16_t* __restrict__ dqkv) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[6][ATT_TILE_BYTES];   // Q ring: slots 0-2 ; dO ring: slots 3-5
-  __shared__ __attribute__((aligned(16))) float s_stat[3][2][64];                  // [ring slot][lse * log2e | -delta]
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int l31 = lane & 31, hi = lane >> 5;
-  int blk, head;
-  if (!att_block_coords((N + 127) / 128, B * H, blk, head)) return;
-  const int b = head / H, h = head - b * H;
-  const int key0 = blk * 128 + wave * 32;
-  const int64_t RS = (int64_t)3 * H * ATT_D;
-  const int64_t OS = (int64_t)H * ATT_D;
-  const uint16_t* Qp = qkv + (int64_t)b * N * RS + h * ATT_D;
-  const uint16_t* Kp = Qp + H * ATT_D;
-  const uint16_t* Vp = Kp + H * ATT_D;
-  const uint16_t* dOp = d_o + (int64_t)b * N * OS + h * ATT_D;
-  const bool active = key0 < N;
-  const int krow = active ? key0 + l31 : l31;
-  s16x8 kf[4], vf[4];
-#pragma unroll
-  for (int ds = 0; ds < 4; ++ds) {
-    kf[ds] = *reinterpret_cast<const s16x8*>(Kp + (int64_t)krow * RS + ds * 16 + hi * 8);
-    vf[ds] = *reinterpret_cast<const s16x8*>(Vp + (int64_t)krow * RS + ds * 16 + hi * 8);
-  }
-  f32x16 dk[2] = {f32x16_zero(), f32x16_zero()}, dv[2] = {f32x16_zero(), f32x16_zero()};
-  const int nt = N / 64;
-  // statistics of a tile's 64 queries: threads 0-63 fetch lse (kept in the log2 domain), 64-127 delta (stored negated), one select-addressed load
-  const float* statp = ((t & 64) ? delta : lse) + ((int64_t)b * H + h) * N + (t & 63);
-  const float stat_mul = (t & 64) ? -1.0f : 1.4426950408889634f;
-  u32x4 rq[2], rd[2];
-  float rstat = 0.f;
-  att_gload(rq, Qp, RS, 0, t);
-  att_gload(rd, dOp, OS, 0, t);
-  rstat = statp[0];
-  att_sstore(rq, smem[0], t);
-  att_sstore(rd, smem[3], t);
-  if (t < 128) s_stat[0][t >> 6][t & 63] = rstat * stat_mul;
-#pragma unroll
-  for (int ds = 0; ds < 4; ++ds) { att_pin(kf[ds]); att_pin(vf[ds]); }
-  ATT_LOOP_ENTRY();
-  __syncthreads();
-  Dkv2Pending pend;
-  int sl = 0;   // ring slot of tile qt
-  for (int qt = 0; qt < nt; ++qt) {
-    const int sln = sl == 2 ? 0 : sl + 1, slp = sl == 0 ? 2 : sl - 1;
-    const bool more = qt + 1 < nt;
-    if (more) {
-      att_gload(rq, Qp, RS, (qt + 1) * 64, t);
-      att_gload(rd, dOp, OS, (qt + 1) * 64, t);
-      rstat = statp[(qt + 1) * 64];
-    }
-    A2_FENCE();
-    if (qt == 0) dkv2_block<false>(smem[sl], smem[3 + sl], s_stat[sl][0], s_stat[sl][1], 0, smem[slp], smem[3 + slp], 48, lane, scale_log2, kf, vf, dk, dv, pend);
-    else dkv2_block<true>(smem[sl], smem[3 + sl], s_stat[sl][0], s_stat[sl][1], 0, smem[slp], smem[3 + slp], 48, lane, scale_log2, kf, vf, dk, dv, pend);
-    dkv2_block<true>(smem[sl], smem[3 + sl], s_stat[sl][0], s_stat[sl][1], 1, smem[sl], smem[3 + sl], 16, lane, scale_log2, kf, vf, dk, dv, pend);
-    A2_FENCE();
-    if (more) {           // slot sln held tile qt-2, last read under the first block of tile qt-1: free since that tile's barrier
-      att_sstore(rq, smem[sln], t);
-      att_sstore(rd, smem[3 + sln], t);
-      if (t < 128) s_stat[sln][t >> 6][t & 63] = rstat * stat_mul;
-    }
-    __syncthreads();
-    sl = sln;
-  }
-  {   // the second half of the last block
-    const int last = sl == 0 ? 2 : sl - 1;
-    dv[0] = MFMA32(att_frag_tr(smem[3 + last], 48, 0, lane), pend.pa, dv[0]);
-    dv[1] = MFMA32(att_frag_tr(smem[3 + last], 48, 1, lane), pend.pa, dv[1]);
-    dk[0] = MFMA32(att_frag_tr(smem[last], 48, 0, lane), pend.dsa, dk[0]);
-    dk[1] = MFMA32(att_frag_tr(smem[last], 48, 1, lane), pend.dsa, dk[1]);
-  }
-  if (!active) return;
-  uint16_t* dkp = dqkv + ((int64_t)b * N + key0 + l31) * RS + H * ATT_D + h * ATT_D;
-  uint16_t* dvp = dkp + H * ATT_D;
-#pragma unroll
-  for (int db = 0; db < 2; ++db)
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      const int d0 = db * 32 + 8 * g4 + 4 * hi;
-      const u32x2 wk = {pack_bf16x2(dk[db][g4 * 4 + 0] * scale, dk[db][g4 * 4 + 1] * scale), pack_bf16x2(dk[db][g4 * 4 + 2] * scale, dk[db][g4 * 4 + 3] * scale)};
-      const u32x2 wv = {pack_bf16x2(dv[db][g4 * 4 + 0], dv[db][g4 * 4 + 1]), pack_bf16x2(dv[db][g4 * 4 + 2], dv[db][g4 * 4 + 3])};
-      *reinterpret_cast<u32x2*>(dkp + d0) = wk;
-      *reinterpret_cast<u32x2*>(dvp + d0) = wv;
-    }
-}
-
 // launchers used by attention.hip's C ABI (enh_attention_set_kernel selects the family)
 void attn_fwd2_launch(const uint16_t* qkv, int B, int N, int H, float scale_log2, uint16_t* out, float* lse, bool ones, bool pre, dim3 grid, hipStream_t s) {
   if (ones) {
@@ -591,8 +431,4 @@ void attn_bwd_dq2_launch(const uint16_t* qkv, const uint16_t* o, const uint16_t*
                          float scale_log2, uint16_t* dqkv, bool pre, dim3 grid, hipStream_t s) {
   if (pre) attn_bwd_dq2_kernel<true><<<grid, 256, 0, s>>>(qkv, o, d_o, lse, delta, B, N, H, scale, scale_log2, dqkv);
   else attn_bwd_dq2_kernel<false><<<grid, 256, 0, s>>>(qkv, o, d_o, lse, delta, B, N, H, scale, scale_log2, dqkv);
-}
-void attn_bwd_dkv2_launch(const uint16_t* qkv, const uint16_t* d_o, const float* lse, const float* delta, int B, int N, int H, float scale,
-                          float scale_log2, uint16_t* dqkv, dim3 grid, hipStream_t s) {
-  attn_bwd_dkv2_kernel<<<grid, 256, 0, s>>>(qkv, d_o, lse, delta, B, N, H, scale, scale_log2, dqkv);
 }

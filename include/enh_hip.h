@@ -251,7 +251,8 @@ typedef struct enh_conv_geom {
  *   mode 3: lrelu(acc + bias[n], slope p0) * p1     (EqualConv2d + FusedLeakyReLU, layers.py:220-264 / fused_act.py:48-76; bias optional)
  *   mode 4: acc + p0 * add[o,n]                     (StyleBlock's (out + skip) / sqrt(2), layers.py:262, folded into the skip convolution) */
 int enh_conv_nhwc_bf16(const enh_bf16* src, const enh_bf16* wt, const enh_conv_geom* g, int mode, const float* bias, const enh_bf16* aux,
-                       const enh_bf16* add, float p0, float p1, enh_bf16* out, void* stream);
+                       const enh_bf16* add, float p0, float p1, enh_bf16* out, float* out_f32 /* optional f32 copy of a DENSE output, else NULL */,
+                       void* stream);
 /* kernel choice of enh_conv_nhwc_bf16 for A/B measurements (explicit library state, like enh_gemm_set_kernel): 0 = per shape (LDS-DMA kernel when
  * C % 64 == 0, register-staged otherwise), 1 = register-staged everywhere */
 int enh_conv_set_kernel(int variant);
@@ -309,7 +310,8 @@ int enh_unpatchify_loss_f32(const float* pix, const float* target, int B, int C,
  *                                                                  activation this gradient is for, add = optional extra gradient at that activation)
  *   mode 2: out = acc                                             (input gradient in front of a max-pool) */
 int enh_conv3x3_nhwc_bf16(const enh_bf16* x, const enh_bf16* wt, int B, int H, int W, int Cin, int Cout, const float* bias, int mode,
-                          const enh_bf16* aux, const enh_bf16* add, enh_bf16* out, void* stream);
+                          const enh_bf16* aux, const enh_bf16* add, enh_bf16* out, float* out_f32 /* optional f32 copy of the output, else NULL */,
+                          void* stream);
 /* ScalingLayer + first convolution: img [B,3,H,W] f32 -> relu(conv3x3(((a img + b) - shift) / scale, w [64,3,3,3]) + bias) as [B,H,W,64] bf16, with
  * (a, b) = (2, -1) if normalize (images in [0,1]: lpips' normalize=True, = the inputs*2-1 of vqperceptual.py:43) else (1, 0); lpips ScalingLayer: shift
  * (-.030,-.088,-.188), scale (.458,.448,.450) ; and its gradient w.r.t. img given the gradient at the convolution output before the ReLU */
@@ -321,8 +323,10 @@ int enh_maxpool2_nhwc_bf16_backward(const enh_bf16* x, const enh_bf16* gy, const
 /* LPIPS head of one slice: feat [2B,h,w,C] (images 0..B-1 = references, B..2B-1 = reconstructions), lin [C] = the slice's 1x1 "lin" weights;
  * out[b] (+)= mean over pixels of sum_c lin[c] (f0/(|f0|+1e-10) - f1/(|f1|+1e-10))_c^2 ; val_ws [B*h*w] f32 scratch (deterministic two-stage sum).
  * Backward: gradient w.r.t. the reconstruction features only, dfeat1 [B,h,w,C] bf16, given gout[B] */
-int enh_lpips_head(const enh_bf16* feat, const float* lin, int B, int64_t HW, int C, float* val_ws, float* out, int accumulate, void* stream);
-int enh_lpips_head_backward(const enh_bf16* feat, const float* lin, const float* gout, int B, int64_t HW, int C, enh_bf16* dfeat1, void* stream);
+/* feat: bf16 (feat_f32 = 0) or the f32 mirror of the slice's last convolution (feat_f32 = 1; enh_conv3x3_nhwc_bf16 out_f32) — the normalised
+ * DIFFERENCE of the two feature maps amplifies their rounding, so the f32 form is what the loss module uses */
+int enh_lpips_head(const void* feat, int feat_f32, const float* lin, int B, int64_t HW, int C, float* val_ws, float* out, int accumulate, void* stream);
+int enh_lpips_head_backward(const void* feat, int feat_f32, const float* lin, const float* gout, int B, int64_t HW, int C, enh_bf16* dfeat1, void* stream);
 
 #ifdef __cplusplus
 }
