@@ -29,7 +29,6 @@ struct ConvArgs {
   int64_t M, K;
   const float* bias; int mode; const uint16_t* aux; const uint16_t* add; float p0, p1;
   uint16_t* out;
-  float* out_f32;     // optional f32 mirror of a dense output (the LPIPS slice outputs: their normalised DIFFERENCE amplifies the bf16 rounding)
   int nbm, nbn;
 };
 
@@ -108,7 +107,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& args, f32x4 (&acc)
         v[0] += args.p0 * e0; v[1] += args.p0 * e1; v[2] += args.p0 * e2; v[3] += args.p0 * e3;
       }
       const u32x2 o_ = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-      if (args.out_f32) *reinterpret_cast<float4*>(args.out_f32 + orow[i] + n) = make_float4(v[0], v[1], v[2], v[3]);
       if (staged) {
         const int row = i * 16 + l16;
         *reinterpret_cast<u32x2*>(stage + row * 128 + (((j * 2 + (lg >> 1)) ^ (row & 7)) << 4) + (lg & 1) * 8) = o_;
@@ -382,18 +380,16 @@ static void conv_lds_attr_once() {
 }
 
 extern "C" int enh_conv_nhwc_bf16(const enh_bf16* src, const enh_bf16* wt, const enh_conv_geom* g, int mode, const float* bias, const enh_bf16* aux,
-                                  const enh_bf16* add, float p0, float p1, enh_bf16* out, float* out_f32, void* stream) {
+                                  const enh_bf16* add, float p0, float p1, enh_bf16* out, void* stream) {
   ENH_REQUIRE(src && wt && out, ENH_E_BADARG, "enh_conv_nhwc_bf16: bad argument");
   const int rc = conv_geom_check(g, "enh_conv_nhwc_bf16");
   if (rc != ENH_OK) return rc;
   ENH_REQUIRE(mode >= 0 && mode <= 4, ENH_E_BADARG, "enh_conv_nhwc_bf16: mode must be 0..4");
   ENH_REQUIRE((mode != 0 || bias) && (mode != 1 || aux) && (mode != 4 || add), ENH_E_BADARG, "enh_conv_nhwc_bf16: mode 0 needs bias, mode 1 aux, mode 4 add");
-  ENH_REQUIRE(!out_f32 || (g->os == 1 && g->HO == g->Hm && g->WO == g->Wm && g->oph == 0 && g->opw == 0 && (reinterpret_cast<uintptr_t>(out_f32) & 15u) == 0),
-              ENH_E_SHAPE, "enh_conv_nhwc_bf16: the f32 mirror needs a dense output geometry and a 16-byte aligned pointer");
   ConvArgs a;
   a.X = src; a.Wt = wt; a.g = *g;
   a.M = (int64_t)g->B * g->Hm * g->Wm; a.K = (int64_t)g->nty * g->ntx * g->C;
-  a.bias = bias; a.mode = mode; a.aux = aux; a.add = add; a.p0 = p0; a.p1 = p1; a.out = out; a.out_f32 = out_f32;
+  a.bias = bias; a.mode = mode; a.aux = aux; a.add = add; a.p0 = p0; a.p1 = p1; a.out = out;
   a.nbm = (int)((a.M + G_BM - 1) / G_BM); a.nbn = (g->N + G_BN - 1) / G_BN;
   ENH_REQUIRE((int64_t)a.nbm * a.nbn < (1ll << 30), ENH_E_SHAPE, "enh_conv_nhwc_bf16: grid too large");
   conv_lds_attr_once();
@@ -406,12 +402,12 @@ extern "C" int enh_conv_nhwc_bf16(const enh_bf16* src, const enh_bf16* wt, const
 
 // the LPIPS entry point: 3x3, stride 1, padding 1 on the general kernel
 extern "C" int enh_conv3x3_nhwc_bf16(const enh_bf16* x, const enh_bf16* wt, int B, int H, int W, int Cin, int Cout, const float* bias, int mode,
-                                     const enh_bf16* aux, const enh_bf16* add, enh_bf16* out, float* out_f32, void* stream) {
+                                     const enh_bf16* aux, const enh_bf16* add, enh_bf16* out, void* stream) {
   ENH_REQUIRE(mode >= 0 && mode <= 2, ENH_E_BADARG, "enh_conv3x3_nhwc_bf16: mode must be 0, 1 or 2");
   enh_conv_geom g;
   g.B = B; g.Hs = H; g.Ws = W; g.C = Cin; g.Hm = H; g.Wm = W; g.gs = 1; g.oy0 = -1; g.ox0 = -1; g.nty = 3; g.ntx = 3; g.sty = 1; g.stx = 1;
   g.N = Cout; g.HO = H; g.WO = W; g.os = 1; g.oph = 0; g.opw = 0;
-  return enh_conv_nhwc_bf16(x, wt, &g, mode, bias, aux, add, 0.f, 1.f, out, out_f32, stream);
+  return enh_conv_nhwc_bf16(x, wt, &g, mode, bias, aux, add, 0.f, 1.f, out, stream);
 }
 
 // =================================================================================================

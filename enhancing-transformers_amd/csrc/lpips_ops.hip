@@ -166,25 +166,18 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const uint16_t* __res
 // reference inputs, B..2B-1 = the reconstructions.  Per pixel p of image b:  n0 = f0 / (||f0|| + 1e-10), n1 = f1 / (||f1|| + 1e-10),
 //   val[b, p] = sum_c lin[c] * (n0_c - n1_c)^2 ;   out[b] += mean_p val[b, p]   (done by lpips_head_reduce_kernel: fixed order, no atomics).
 // One wave per pixel; C in {64, 128, 256, 512}: C / 64 channels per lane.
-// F32: the features are the f32 mirror the slice's last convolution wrote (enh_conv3x3_nhwc_bf16 out_f32).  u = n0 - n1 is a difference of nearly equal
-// unit vectors when the reconstruction is close to its input, so the 0.4 % rounding of bf16 features was a ~10 % error of u and of the gradient
-// (round 2: gradient 1.0e-1 relative); the errors the trunk carries UP TO this point are common to f0 and f1 and cancel.
-template <bool F32>
-__device__ __forceinline__ float lpips_feat(const void* f, int64_t idx) {
-  return F32 ? reinterpret_cast<const float*>(f)[idx] : bf16_bits_to_f32(reinterpret_cast<const uint16_t*>(f)[idx]);
-}
-
-template <int CPL, bool F32>
-__global__ __launch_bounds__(256) void lpips_head_fwd_kernel(const void* __restrict__ f, const float* __restrict__ lin, int B, int64_t HW,
+template <int CPL>
+__global__ __launch_bounds__(256) void lpips_head_fwd_kernel(const uint16_t* __restrict__ f, const float* __restrict__ lin, int B, int64_t HW,
                                                              float* __restrict__ val /* [B*HW] */) {
   const int lane = threadIdx.x & 63;
   const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (p >= (int64_t)B * HW) return;
   constexpr int C = CPL * 64;
-  const int64_t o0 = p * C + lane * CPL, o1 = (p + (int64_t)B * HW) * C + lane * CPL;
+  const uint16_t* f0 = f + p * C + lane * CPL;
+  const uint16_t* f1 = f + (p + (int64_t)B * HW) * C + lane * CPL;
   float a[CPL], b[CPL], s0 = 0.f, s1 = 0.f;
 #pragma unroll
-  for (int i = 0; i < CPL; ++i) { a[i] = lpips_feat<F32>(f, o0 + i); b[i] = lpips_feat<F32>(f, o1 + i); s0 = fmaf(a[i], a[i], s0); s1 = fmaf(b[i], b[i], s1); }
+  for (int i = 0; i < CPL; ++i) { a[i] = bf16_bits_to_f32(f0[i]); b[i] = bf16_bits_to_f32(f1[i]); s0 = fmaf(a[i], a[i], s0); s1 = fmaf(b[i], b[i], s1); }
   s0 = wave_sum(s0); s1 = wave_sum(s1);
   const float i0 = 1.f / (sqrtf(s0) + 1e-10f), i1 = 1.f / (sqrtf(s1) + 1e-10f);
   float v = 0.f;
@@ -211,17 +204,18 @@ __global__ __launch_bounds__(256) void lpips_head_reduce_kernel(const float* __r
 
 // backward with respect to the reconstruction features f1 only (the inputs carry no gradient, the lin / VGG weights are frozen):
 //   u = n0 - n1 ; g_c = -2 lin_c u_c * gout[b] / HW ;  df1_k = g_k * i1 - (sum_c g_c f1_c) * f1_k * i1^2 / ||f1||     (0 where ||f1|| = 0)
-template <int CPL, bool F32>
-__global__ __launch_bounds__(256) void lpips_head_bwd_kernel(const void* __restrict__ f, const float* __restrict__ lin, const float* __restrict__ gout,
+template <int CPL>
+__global__ __launch_bounds__(256) void lpips_head_bwd_kernel(const uint16_t* __restrict__ f, const float* __restrict__ lin, const float* __restrict__ gout,
                                                              int B, int64_t HW, uint16_t* __restrict__ df1 /* [B*HW, C] */) {
   const int lane = threadIdx.x & 63;
   const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (p >= (int64_t)B * HW) return;
   constexpr int C = CPL * 64;
-  const int64_t o0 = p * C + lane * CPL, o1 = (p + (int64_t)B * HW) * C + lane * CPL;
+  const uint16_t* f0 = f + p * C + lane * CPL;
+  const uint16_t* f1 = f + (p + (int64_t)B * HW) * C + lane * CPL;
   float a[CPL], b[CPL], s0 = 0.f, s1 = 0.f;
 #pragma unroll
-  for (int i = 0; i < CPL; ++i) { a[i] = lpips_feat<F32>(f, o0 + i); b[i] = lpips_feat<F32>(f, o1 + i); s0 = fmaf(a[i], a[i], s0); s1 = fmaf(b[i], b[i], s1); }
+  for (int i = 0; i < CPL; ++i) { a[i] = bf16_bits_to_f32(f0[i]); b[i] = bf16_bits_to_f32(f1[i]); s0 = fmaf(a[i], a[i], s0); s1 = fmaf(b[i], b[i], s1); }
   s0 = wave_sum(s0); s1 = wave_sum(s1);
   const float n1 = sqrtf(s1);
   const float i0 = 1.f / (sqrtf(s0) + 1e-10f), i1 = 1.f / (n1 + 1e-10f);
@@ -267,35 +261,29 @@ extern "C" int enh_maxpool2_nhwc_bf16_backward(const enh_bf16* x, const enh_bf16
   return enh_check_launch("enh_maxpool2_nhwc_bf16_backward");
 }
 
-extern "C" int enh_lpips_head(const void* feat, int feat_f32, const float* lin, int B, int64_t HW, int C, float* val_ws, float* out, int accumulate, void* stream) {
+extern "C" int enh_lpips_head(const enh_bf16* feat, const float* lin, int B, int64_t HW, int C, float* val_ws, float* out, int accumulate, void* stream) {
   ENH_REQUIRE(feat && lin && val_ws && out && B > 0 && HW > 0, ENH_E_BADARG, "enh_lpips_head: bad argument");
   ENH_REQUIRE(C == 64 || C == 128 || C == 256 || C == 512, ENH_E_SHAPE, "enh_lpips_head: C must be 64, 128, 256 or 512 (the VGG16 slices)");
   const int64_t P = (int64_t)B * HW;
   const unsigned grid = (unsigned)((P + 3) / 4);
   hipStream_t s = (hipStream_t)stream;
-#define HEAD_FWD(CPL_) do { if (feat_f32) lpips_head_fwd_kernel<CPL_, true><<<grid, 256, 0, s>>>(feat, lin, B, HW, val_ws); \
-                           else lpips_head_fwd_kernel<CPL_, false><<<grid, 256, 0, s>>>(feat, lin, B, HW, val_ws); } while (0)
-  if (C == 64) HEAD_FWD(1);
-  else if (C == 128) HEAD_FWD(2);
-  else if (C == 256) HEAD_FWD(4);
-  else HEAD_FWD(8);
-#undef HEAD_FWD
+  if (C == 64) lpips_head_fwd_kernel<1><<<grid, 256, 0, s>>>(feat, lin, B, HW, val_ws);
+  else if (C == 128) lpips_head_fwd_kernel<2><<<grid, 256, 0, s>>>(feat, lin, B, HW, val_ws);
+  else if (C == 256) lpips_head_fwd_kernel<4><<<grid, 256, 0, s>>>(feat, lin, B, HW, val_ws);
+  else lpips_head_fwd_kernel<8><<<grid, 256, 0, s>>>(feat, lin, B, HW, val_ws);
   lpips_head_reduce_kernel<<<(unsigned)B, 256, 0, s>>>(val_ws, HW, out, accumulate);
   return enh_check_launch("enh_lpips_head");
 }
 
-extern "C" int enh_lpips_head_backward(const void* feat, int feat_f32, const float* lin, const float* gout, int B, int64_t HW, int C, enh_bf16* dfeat1, void* stream) {
+extern "C" int enh_lpips_head_backward(const enh_bf16* feat, const float* lin, const float* gout, int B, int64_t HW, int C, enh_bf16* dfeat1, void* stream) {
   ENH_REQUIRE(feat && lin && gout && dfeat1 && B > 0 && HW > 0, ENH_E_BADARG, "enh_lpips_head_backward: bad argument");
   ENH_REQUIRE(C == 64 || C == 128 || C == 256 || C == 512, ENH_E_SHAPE, "enh_lpips_head_backward: C must be 64, 128, 256 or 512");
   const int64_t P = (int64_t)B * HW;
   const unsigned grid = (unsigned)((P + 3) / 4);
   hipStream_t s = (hipStream_t)stream;
-#define HEAD_BWD(CPL_) do { if (feat_f32) lpips_head_bwd_kernel<CPL_, true><<<grid, 256, 0, s>>>(feat, lin, gout, B, HW, dfeat1); \
-                           else lpips_head_bwd_kernel<CPL_, false><<<grid, 256, 0, s>>>(feat, lin, gout, B, HW, dfeat1); } while (0)
-  if (C == 64) HEAD_BWD(1);
-  else if (C == 128) HEAD_BWD(2);
-  else if (C == 256) HEAD_BWD(4);
-  else HEAD_BWD(8);
-#undef HEAD_BWD
+  if (C == 64) lpips_head_bwd_kernel<1><<<grid, 256, 0, s>>>(feat, lin, gout, B, HW, dfeat1);
+  else if (C == 128) lpips_head_bwd_kernel<2><<<grid, 256, 0, s>>>(feat, lin, gout, B, HW, dfeat1);
+  else if (C == 256) lpips_head_bwd_kernel<4><<<grid, 256, 0, s>>>(feat, lin, gout, B, HW, dfeat1);
+  else lpips_head_bwd_kernel<8><<<grid, 256, 0, s>>>(feat, lin, gout, B, HW, dfeat1);
   return enh_check_launch("enh_lpips_head_backward");
 }

@@ -58,12 +58,14 @@ SIGNATURES = {
     "enh_cast_f32_bf16": (_i32, [_vp, _vp, _i64, _vp]),
     "enh_cast_f32_bf16_head_scaled": (_i32, [_vp, _vp, _i64, _i64, _f32, _vp]),
     "enh_crop_flip_u8": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),
+    "enh_resize_u8_workspace_bytes": (_sz, [_i32, _i32, _i32]),
+    "enh_resize_u8": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _sz, _vp]),
     "enh_fused_bias_act": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _f32, _f32, _vp]),
     "enh_channel_sum_f32": (_i32, [_vp, _i32, _i32, _i64, _vp, _i32, _vp]),
     "enh_upfirdn2d": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "enh_im2col_bf16": (_i32, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp]),
     "enh_col2im_f32": (_i32, [_vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _i64, _vp]),
-    "enh_conv_nhwc_bf16": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _vp]),
+    "enh_conv_nhwc_bf16": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _f32, _f32, _vp, _vp]),
     "enh_conv_set_kernel": (_i32, [_i32]),
     "enh_conv_wgrad_workspace_bytes": (_sz, [_vp]),
     "enh_conv_wgrad_nhwc_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -81,13 +83,13 @@ SIGNATURES = {
     "enh_colsum_f32": (_i32, [_vp, _i64, _i64, _i64, _vp, _i32, _vp]),
     "enh_patch_perm_f32": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "enh_unpatchify_loss_f32": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp]),
-    "enh_conv3x3_nhwc_bf16": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "enh_conv3x3_nhwc_bf16": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),
     "enh_vgg_conv1": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "enh_vgg_conv1_backward": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "enh_maxpool2_nhwc_bf16": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "enh_maxpool2_nhwc_bf16_backward": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
-    "enh_lpips_head": (_i32, [_vp, _i32, _vp, _i32, _i64, _i32, _vp, _vp, _i32, _vp]),
-    "enh_lpips_head_backward": (_i32, [_vp, _i32, _vp, _vp, _i32, _i64, _i32, _vp, _vp]),
+    "enh_lpips_head": (_i32, [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _i32, _vp]),
+    "enh_lpips_head_backward": (_i32, [_vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp]),
     "enh_adamw_step": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
 }
 
@@ -403,6 +405,17 @@ def crop_flip_u8(src, meta, R: int):
     return out
 
 
+def resize_u8(src, meta, bounds, weights, dst):
+    """src uint8 [B,HS,WS,3] -> dst uint8 [B,HD,WD,3] (enh_resize_u8: PIL bilinear resize, per-image sizes / tables in meta, bounds, weights)"""
+    B, HS, WS, _ = src.shape
+    _, HD, WD, _ = dst.shape
+    nb = lib().enh_resize_u8_workspace_bytes(B, HS, WD)
+    ws = _workspace(nb, src.device)
+    _check(lib().enh_resize_u8(_p(src, torch.uint8, "src"), B, HS, WS, _p(meta, torch.int32, "meta"), _p(bounds, torch.int32, "bounds"),
+                               _p(weights, torch.int32, "weights"), _p(dst, torch.uint8, "dst"), HD, WD, _p(ws), ws.numel(), _stream()), "enh_resize_u8")
+    return dst
+
+
 def adamw_step(p, g, m, v, p_bf16, step: int, lr: float, beta1: float = 0.9, beta2: float = 0.99, eps: float = 1e-8,
                weight_decay: float = 1e-4, grad_scale: float = 1.0):
     # 30 B per parameter: p, g, m, v read (16) + p, m, v written (12) + the bf16 operand shadow written (2)
@@ -493,7 +506,7 @@ def conv_nhwc(src, wt, geom, mode: int, bias=None, aux=None, add=None, p0: float
     work = 2.0 * g.B * g.Hm * g.Wm * g.N * g.nty * g.ntx * g.C
     _timed("conv_igemm_kernel", work,
            lambda: _check(lib().enh_conv_nhwc_bf16(_p(src, BF16, "src"), _p(wt, BF16, "wt"), ctypes.byref(g), mode, _p(bias, F32, "bias"), _p(aux, BF16, "aux"),
-                                                   _p(add, BF16, "add"), p0, p1, _p(out, BF16, "out"), None, _stream()), "enh_conv_nhwc_bf16"))
+                                                   _p(add, BF16, "add"), p0, p1, _p(out, BF16, "out"), _stream()), "enh_conv_nhwc_bf16"))
     return out
 
 
@@ -654,10 +667,10 @@ def unpatchify_loss_any(pix, target, B, C, H, W, p, w_l1, w_l2, xrec, sums, dpix
 # ------------------------------------------------------------------------------------------------
 # LPIPS (lpips 0.1.4, net="vgg"): channels-last bf16 activations
 # ------------------------------------------------------------------------------------------------
-def conv3x3_nhwc(x, wt, B: int, H: int, W: int, Cin: int, Cout: int, out, bias=None, mode: int = 0, aux=None, add=None, out_f32=None):
+def conv3x3_nhwc(x, wt, B: int, H: int, W: int, Cin: int, Cout: int, out, bias=None, mode: int = 0, aux=None, add=None):
     _timed("conv3x3_igemm_kernel", 2.0 * B * H * W * Cout * 9 * Cin,
            lambda: _check(lib().enh_conv3x3_nhwc_bf16(_p(x, BF16, "x"), _p(wt, BF16, "wt"), B, H, W, Cin, Cout, _p(bias, F32, "bias"), mode, _p(aux, BF16, "aux"),
-                                                      _p(add, BF16, "add"), _p(out, BF16, "out"), _p(out_f32, F32, "out_f32"), _stream()), "enh_conv3x3_nhwc_bf16"))
+                                                      _p(add, BF16, "add"), _p(out, BF16, "out"), _stream()), "enh_conv3x3_nhwc_bf16"))
     return out
 
 
@@ -686,14 +699,10 @@ def maxpool2_nhwc_backward(x, gy, add, B: int, H: int, W: int, C: int, gx):
 
 
 def lpips_head(feat, lin, B: int, HW: int, C: int, val_ws, out, accumulate: bool):
-    if feat.dtype not in (BF16, F32):
-        raise RuntimeError(f"feat must be bf16 or f32, got {feat.dtype}")
-    _check(lib().enh_lpips_head(_p(feat, None, "feat"), int(feat.dtype == F32), _p(lin, F32, "lin"), B, HW, C, _p(val_ws, F32, "val_ws"), _p(out, F32, "out"), int(accumulate), _stream()),
+    _check(lib().enh_lpips_head(_p(feat, BF16, "feat"), _p(lin, F32, "lin"), B, HW, C, _p(val_ws, F32, "val_ws"), _p(out, F32, "out"), int(accumulate), _stream()),
            "enh_lpips_head")
 
 
 def lpips_head_backward(feat, lin, gout, B: int, HW: int, C: int, dfeat1):
-    if feat.dtype not in (BF16, F32):
-        raise RuntimeError(f"feat must be bf16 or f32, got {feat.dtype}")
-    _check(lib().enh_lpips_head_backward(_p(feat, None, "feat"), int(feat.dtype == F32), _p(lin, F32, "lin"), _p(gout, F32, "gout"), B, HW, C, _p(dfeat1, BF16, "dfeat1"), _stream()),
+    _check(lib().enh_lpips_head_backward(_p(feat, BF16, "feat"), _p(lin, F32, "lin"), _p(gout, F32, "gout"), B, HW, C, _p(dfeat1, BF16, "dfeat1"), _stream()),
            "enh_lpips_head_backward")

@@ -75,7 +75,7 @@ class DataModuleFromConfig:
                             collate_fn=_collate_for(ds))
         if getattr(ds, "device_transform", False):       # crop + flip + ToTensor run on the GPU (imagenet.DeviceTransform)
             from .imagenet import DeviceTransform
-            return _Mapped(loader, DeviceTransform(ds.resolution))
+            return _Mapped(loader, DeviceTransform(ds.resolution, resize=ds._resize_arg() if hasattr(ds, "_resize_arg") else None))
         return loader
 
     def set_epoch(self, epoch: int) -> None:

@@ -8,7 +8,9 @@ PIL / numpy implementation; if ``root`` does not exist the constructor raises (u
 Device-side tail (``device_transform=True``): the worker processes only decode and resize (PIL) and hand over uint8 pixels plus the crop window
 and flip decision they drew; ``DeviceTransform`` then does crop + flip + ToTensor for the whole batch in one HIP kernel (``enh_crop_flip_u8``) and
 yields the same ``{'image', 'class'}`` batch — a quarter of the host-to-device bytes (uint8 instead of float32) and no per-sample float work on the
-host.  The random numbers are drawn in the same order as on the host path, so both paths give bit-identical batches for the same seed."""
+host.  With ``device_resize=True`` as well the workers ONLY DECODE: the antialiased bilinear resize runs on the device too (``enh_resize_u8``,
+csrc/resize.hip: Pillow's two integer passes, bit-exact).  The random numbers are drawn in the same order as on the host path, so all three paths
+give bit-identical batches for the same seed (tests/test_host_cpu.py, tests/test_ops_gpu.py)."""
 from __future__ import annotations
 
 import os
@@ -35,27 +37,33 @@ def _index(root: str) -> Tuple[List[str], List[int]]:
 class _ImageNetBase(Dataset):
     split = "train"
 
-    def __init__(self, root: str, resolution: int = 256, resize_ratio: float = 0.75, device_transform: bool = False) -> None:
+    def __init__(self, root: str, resolution: int = 256, resize_ratio: float = 0.75, device_transform: bool = False, device_resize: bool = False) -> None:
         folder = os.path.join(root, self.split)
         if not os.path.isdir(folder):
             raise FileNotFoundError(f"{folder} not found; for synthetic data use enhancing.dataloader.synthetic.SyntheticImages")
         self.resolution = resolution
-        self.device_transform = device_transform
+        self.device_transform = device_transform or device_resize
+        self.device_resize = device_resize
         self.paths, self.labels = _index(folder)
+
+    def _resize_arg(self):
+        """what the reference hands to T.Resize: the int for training (shorter side -> R, imagenet.py:31), the pair (R, R) for validation (imagenet.py:44-49)"""
+        return self.resolution if self.split == "train" else (self.resolution, self.resolution)
 
     def __len__(self) -> int:
         return len(self.paths)
 
-    def _decode_resize(self, path: str):
-        """PIL decode + Resize(R) (shorter side -> R, bilinear); then the crop window and flip decision, drawn in the order the host path uses them"""
+    def _decode_resize(self, path: str, resize: bool = True):
+        """PIL decode (+ T.Resize's PIL.Image.resize(size, BILINEAR) unless the device does it); then the crop window (in RESIZED coordinates) and the
+        flip decision, drawn in the order the host path uses them"""
         from PIL import Image
+        from .resize import output_size
         r = self.resolution
         train = self.split == "train"
         im = Image.open(path).convert("RGB")
-        w, h = im.size
-        s = r / min(w, h)
-        im = im.resize((max(r, round(w * s)), max(r, round(h * s))), Image.BILINEAR)
-        w, h = im.size
+        w, h = output_size(im.size[0], im.size[1], self._resize_arg())      # torchvision's rule: int(size * long / short) for the longer side
+        if resize:
+            im = im.resize((w, h), Image.BILINEAR)
         if train:
             x0, y0 = np.random.randint(0, w - r + 1), np.random.randint(0, h - r + 1)
         else:
@@ -74,8 +82,11 @@ class _ImageNetBase(Dataset):
     def __getitem__(self, i: int):
         label = torch.tensor([self.labels[i]])
         if self.device_transform:
-            px, y0, x0, flip = self._decode_resize(self.paths[i])
-            return {"pixels_u8": torch.from_numpy(px), "window": torch.tensor([y0, x0, int(flip)], dtype=torch.int32), "class": label}
+            px, y0, x0, flip = self._decode_resize(self.paths[i], resize=not self.device_resize)
+            out = {"pixels_u8": torch.from_numpy(px), "window": torch.tensor([y0, x0, int(flip)], dtype=torch.int32), "class": label}
+            if self.device_resize:      # the decoded (un-resized) size travels with the pixels: the collate pads to a common slot
+                out["in_size"] = torch.tensor([px.shape[0], px.shape[1]], dtype=torch.int32)
+            return out
         return {"image": self._load(self.paths[i]), "class": label}
 
 
@@ -86,21 +97,30 @@ def collate_u8(samples):
     for b, s in enumerate(samples):
         h, w, _ = s["pixels_u8"].shape
         px[b, :h, :w] = s["pixels_u8"]
-    return {"pixels_u8": px, "window": torch.stack([s["window"] for s in samples]), "class": torch.stack([s["class"] for s in samples])}
+    out = {"pixels_u8": px, "window": torch.stack([s["window"] for s in samples]), "class": torch.stack([s["class"] for s in samples])}
+    if "in_size" in samples[0]:
+        out["in_size"] = torch.stack([s["in_size"] for s in samples])
+    return out
 
 
 class DeviceTransform:
-    """crop + flip + ToTensor on the device for a collate_u8 batch -> the reference's batch contract {'image': float [B,3,R,R] in [0,1], 'class': [B,1]}"""
+    """(resize +) crop + flip + ToTensor on the device for a collate_u8 batch -> the reference's batch contract {'image': float [B,3,R,R] in [0,1], 'class': [B,1]}.
+    `resize`: what the dataset hands to T.Resize (int: shorter side; pair: exact), used when the batch carries un-resized pixels ("in_size")."""
 
-    def __init__(self, resolution: int, device=None) -> None:
+    def __init__(self, resolution: int, device=None, resize=None) -> None:
         self.resolution, self.device = resolution, device
+        self.resize = resolution if resize is None else resize
 
     def __call__(self, batch):
         if "pixels_u8" not in batch:
             return batch
         from .. import _C
         dev = self.device if self.device is not None else torch.device("cuda", torch.cuda.current_device())
-        img = _C.crop_flip_u8(batch["pixels_u8"].to(dev, non_blocking=True), batch["window"].to(dev, non_blocking=True).contiguous(), self.resolution)
+        px = batch["pixels_u8"].to(dev, non_blocking=True)
+        if "in_size" in batch:
+            from .resize import resize_batch_u8
+            px, _ = resize_batch_u8(px, [(int(h), int(w)) for h, w in batch["in_size"].tolist()], self.resize)
+        img = _C.crop_flip_u8(px, batch["window"].to(dev, non_blocking=True).contiguous(), self.resolution)
         return {"image": img, "class": batch["class"]}
 
 

@@ -225,21 +225,17 @@ class LPIPS(nn.Module):
                 _C.maxpool2_nhwc(cur, B2, h, w, cur.shape[-1], pooled)
                 h, w, cur = h // 2, w // 2, pooled
                 acts[-k] = pooled
-            f32 = None
-            for ci, (idx, cin, cout) in enumerate(convs):
+            for idx, cin, cout in convs:
                 y = torch.empty(B2, h, w, cout, dtype=torch.bfloat16, device=dev)
                 if idx == 0:
                     _C.vgg_conv1(x, dw["w0"], dw["bias"][0], dw["shift"], dw["scale"], normalize, y)
                 else:
-                    # the slice OUTPUT also leaves the convolution's epilogue in f32 for the head: n(f0) - n(f1) is a difference of nearly equal unit
-                    # vectors, which turned the 0.4 % rounding of bf16 features into a ~10 % gradient error (tests/test_lpips_gpu.py, round 2)
-                    f32 = torch.empty(B2, h, w, cout, dtype=torch.float32, device=dev) if ci == len(convs) - 1 else None
-                    _C.conv3x3_nhwc(cur, dw["fwd"][idx], B2, h, w, cin, cout, y, bias=dw["bias"][idx], mode=0, out_f32=f32)
+                    _C.conv3x3_nhwc(cur, dw["fwd"][idx], B2, h, w, cin, cout, y, bias=dw["bias"][idx], mode=0)
                 acts[idx] = y
                 cur = y
-            feats.append(f32)
+            feats.append(cur)
             val_ws = torch.empty(B * h * w, dtype=torch.float32, device=dev)
-            _C.lpips_head(f32, dw["lin"][k], B, h * w, cur.shape[-1], val_ws, out, accumulate=k > 0)
+            _C.lpips_head(cur, dw["lin"][k], B, h * w, cur.shape[-1], val_ws, out, accumulate=k > 0)
         return out.view(B, 1, 1, 1), (acts, feats, (B, H, W))
 
     def _run_backward(self, saved, gout, normalize, shape):

@@ -199,6 +199,15 @@ int enh_adamw_step(float* p, const float* g, float* m, float* v, enh_bf16* p_bf1
  * src uint8 [B,Hs,Ws,3] (decoded + resized images, each in the top-left corner of its slot), meta int32 [B,3] = (y0, x0, flip) -> out f32 [B,3,R,R] in [0,1].
  * The window (y0..y0+R, x0..x0+R) must lie inside the image; exact (uint8 / 255.0f). */
 int enh_crop_flip_u8(const uint8_t* src, int B, int Hs, int Ws, const int32_t* meta, int R, float* out, void* stream);
+/* Resize of the reference's dataset transforms (torchvision T.Resize = PIL.Image.resize(size, BILINEAR), enhancing/dataloader/imagenet.py:31,49) for a batch
+ * of decoded 8-bit RGB images of ragged sizes, bit-exact with Pillow's antialiased separable resampler (horizontal pass, then vertical, 22-bit fixed-point
+ * weights).  src [B][HS][WS][3] / dst [B][HD][WD][3]: image b occupies the top-left corner of its slot.  meta [B][10] int32 per image:
+ * {h_in, w_in, h_out, w_out, hb_off, hk_off, hks, vb_off, vk_off, vks}: the horizontal pass reads bounds[hb_off + 2x] = (first input column, taps) and
+ * weights[hk_off + x*hks + tap]; the vertical pass likewise (tables: enhancing/dataloader/resize.py, Pillow's precompute_coeffs / normalize_coeffs_8bpc).
+ * workspace: enh_resize_u8_workspace_bytes(B, HS, WD) bytes (the horizontal pass's uint8 result). */
+size_t enh_resize_u8_workspace_bytes(int B, int HS, int WD);
+int enh_resize_u8(const uint8_t* src, int B, int HS, int WS, const int* meta, const int* bounds, const int* weights, uint8_t* dst, int HD, int WD,
+                  void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * StyleGAN2-discriminator native ops ("next" row) — drop-ins for the reference's two pybind ops
@@ -251,8 +260,7 @@ typedef struct enh_conv_geom {
  *   mode 3: lrelu(acc + bias[n], slope p0) * p1     (EqualConv2d + FusedLeakyReLU, layers.py:220-264 / fused_act.py:48-76; bias optional)
  *   mode 4: acc + p0 * add[o,n]                     (StyleBlock's (out + skip) / sqrt(2), layers.py:262, folded into the skip convolution) */
 int enh_conv_nhwc_bf16(const enh_bf16* src, const enh_bf16* wt, const enh_conv_geom* g, int mode, const float* bias, const enh_bf16* aux,
-                       const enh_bf16* add, float p0, float p1, enh_bf16* out, float* out_f32 /* optional f32 copy of a DENSE output, else NULL */,
-                       void* stream);
+                       const enh_bf16* add, float p0, float p1, enh_bf16* out, void* stream);
 /* kernel choice of enh_conv_nhwc_bf16 for A/B measurements (explicit library state, like enh_gemm_set_kernel): 0 = per shape (LDS-DMA kernel when
  * C % 64 == 0, register-staged otherwise), 1 = register-staged everywhere */
 int enh_conv_set_kernel(int variant);
@@ -310,8 +318,7 @@ int enh_unpatchify_loss_f32(const float* pix, const float* target, int B, int C,
  *                                                                  activation this gradient is for, add = optional extra gradient at that activation)
  *   mode 2: out = acc                                             (input gradient in front of a max-pool) */
 int enh_conv3x3_nhwc_bf16(const enh_bf16* x, const enh_bf16* wt, int B, int H, int W, int Cin, int Cout, const float* bias, int mode,
-                          const enh_bf16* aux, const enh_bf16* add, enh_bf16* out, float* out_f32 /* optional f32 copy of the output, else NULL */,
-                          void* stream);
+                          const enh_bf16* aux, const enh_bf16* add, enh_bf16* out, void* stream);
 /* ScalingLayer + first convolution: img [B,3,H,W] f32 -> relu(conv3x3(((a img + b) - shift) / scale, w [64,3,3,3]) + bias) as [B,H,W,64] bf16, with
  * (a, b) = (2, -1) if normalize (images in [0,1]: lpips' normalize=True, = the inputs*2-1 of vqperceptual.py:43) else (1, 0); lpips ScalingLayer: shift
  * (-.030,-.088,-.188), scale (.458,.448,.450) ; and its gradient w.r.t. img given the gradient at the convolution output before the ReLU */
@@ -323,10 +330,8 @@ int enh_maxpool2_nhwc_bf16_backward(const enh_bf16* x, const enh_bf16* gy, const
 /* LPIPS head of one slice: feat [2B,h,w,C] (images 0..B-1 = references, B..2B-1 = reconstructions), lin [C] = the slice's 1x1 "lin" weights;
  * out[b] (+)= mean over pixels of sum_c lin[c] (f0/(|f0|+1e-10) - f1/(|f1|+1e-10))_c^2 ; val_ws [B*h*w] f32 scratch (deterministic two-stage sum).
  * Backward: gradient w.r.t. the reconstruction features only, dfeat1 [B,h,w,C] bf16, given gout[B] */
-/* feat: bf16 (feat_f32 = 0) or the f32 mirror of the slice's last convolution (feat_f32 = 1; enh_conv3x3_nhwc_bf16 out_f32) — the normalised
- * DIFFERENCE of the two feature maps amplifies their rounding, so the f32 form is what the loss module uses */
-int enh_lpips_head(const void* feat, int feat_f32, const float* lin, int B, int64_t HW, int C, float* val_ws, float* out, int accumulate, void* stream);
-int enh_lpips_head_backward(const void* feat, int feat_f32, const float* lin, const float* gout, int B, int64_t HW, int C, enh_bf16* dfeat1, void* stream);
+int enh_lpips_head(const enh_bf16* feat, const float* lin, int B, int64_t HW, int C, float* val_ws, float* out, int accumulate, void* stream);
+int enh_lpips_head_backward(const enh_bf16* feat, const float* lin, const float* gout, int B, int64_t HW, int C, enh_bf16* dfeat1, void* stream);
 
 #ifdef __cplusplus
 }

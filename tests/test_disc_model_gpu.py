@@ -148,8 +148,14 @@ def test_hip_discriminator_vs_the_same_rounding_points_in_torch(C, golden_dir, m
     e_dx = rel(hip["gr"], emu["gr"])
     e_g = {n: rel(hip["grads"][n], emu["grads"][n]) for n in emu["grads"]}
     worst = max(e_g, key=e_g.get)
-    print(f"HIP discriminator vs torch emulation of the same bf16 rounding points: logits {e_logits:.2e}, d logits / d image {e_dx:.2e}, "
-          f"r1 {abs(hip['r1'] - emu['r1']) / emu['r1']:.2e}, worst parameter gradient {worst} {e_g[worst]:.2e}, median {np.median(list(e_g.values())):.2e}")
+    line = (f"HIP discriminator vs torch emulation of the same bf16 rounding points: logits {e_logits:.2e}, d logits / d image {e_dx:.2e}, "
+            f"r1 {abs(hip['r1'] - emu['r1']) / emu['r1']:.2e}, d_loss {abs(hip['d_loss'] - emu['d_loss']) / abs(emu['d_loss']):.2e}, "
+            f"worst parameter gradient {worst} {e_g[worst]:.2e}, median {np.median(list(e_g.values())):.2e}")
+    print(line)
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "disc_vs_emulation.txt"), "a") as f:
+            f.write(line + "\n" + "  per parameter: " + ", ".join(f"{k} {v:.1e}" for k, v in sorted(e_g.items(), key=lambda kv: -kv[1])[:12]) + "\n")
     assert set(hip["grads"]) == set(emu["grads"])
     assert e_logits <= 5e-3 and e_dx <= 2e-2
     assert abs(hip["r1"] - emu["r1"]) <= 2e-2 * emu["r1"] and abs(hip["d_loss"] - emu["d_loss"]) <= 5e-3 * abs(emu["d_loss"])

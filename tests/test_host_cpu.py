@@ -301,19 +301,23 @@ def test_imagenet_folder_dataset_contract(tmp_path):
         type(tr)(str(tmp_path / "nope"))
 
 
-def test_device_transform_path_equals_the_host_path(tmp_path, monkeypatch):
+def test_device_transform_paths_equal_the_host_path(tmp_path, monkeypatch):
     """device_transform=True: workers hand over uint8 pixels + the crop window / flip they drew; crop + flip + ToTensor then run in ONE kernel
-    (enh_crop_flip_u8, replaced here by its numpy statement).  Same seed -> bit-identical batches on both paths."""
+    (enh_crop_flip_u8, replaced here by its numpy statement).  device_resize=True: the workers only decode and the antialiased bilinear resize runs on
+    the device as well (enh_resize_u8, replaced here by the oracle's statement of Pillow's two passes, driven by the PRODUCT's coefficient tables).
+    Same seed -> bit-identical batches on all three paths, for the training transform (shorter side -> R, random crop, flip) and the validation
+    transform (exact (R, R) resize, reference imagenet.py:44-49)."""
     import numpy as np
     from PIL import Image
     from enhancing import _C
     from enhancing.dataloader import DataModuleFromConfig
     rng = np.random.default_rng(1)
-    for ci, wnid in enumerate(("a", "b")):
-        d = tmp_path / "train" / wnid
-        d.mkdir(parents=True)
-        for k in range(3):
-            Image.fromarray(rng.integers(0, 256, (41 + 9 * k, 60 - 11 * ci, 3), dtype=np.uint8)).save(d / f"i{k}.png")
+    for split in ("train", "val"):
+        for ci, wnid in enumerate(("a", "b")):
+            d = tmp_path / split / wnid
+            d.mkdir(parents=True)
+            for k in range(3):
+                Image.fromarray(rng.integers(0, 256, (41 + 9 * k, 60 - 11 * ci, 3), dtype=np.uint8)).save(d / f"i{k}.png")
 
     def crop_flip_u8(src, meta, R):      # the kernel's contract, stated in numpy
         out = np.zeros((src.shape[0], 3, R, R), np.float32)
@@ -323,21 +327,39 @@ def test_device_transform_path_equals_the_host_path(tmp_path, monkeypatch):
             w = w[:, ::-1] if flip else w
             out[b] = w.astype(np.float32).transpose(2, 0, 1) / np.float32(255.0)
         return torch.from_numpy(out)
+
+    def resize_u8(src, meta, bounds, weights, dst):      # enh_resize_u8's contract: the two integer passes over the tables the product built
+        src, bounds, weights = src.numpy().astype(np.int64), bounds.numpy(), weights.numpy().astype(np.int64)
+        for b, (hin, win, hout, wout, hbo, hko, hks, vbo, vko, vks) in enumerate(meta.tolist()):
+            t = np.zeros((hin, wout, 3), np.int64)
+            for x in range(wout):
+                x0, n = bounds[hbo + 2 * x], bounds[hbo + 2 * x + 1]
+                t[:, x] = (1 << 21) + (src[b, :hin, x0:x0 + n] * weights[hko + x * hks:hko + x * hks + n][None, :, None]).sum(1)
+            t = np.clip(t >> 22, 0, 255)
+            o = np.zeros((hout, wout, 3), np.int64)
+            for y in range(hout):
+                y0, n = bounds[vbo + 2 * y], bounds[vbo + 2 * y + 1]
+                o[y] = (1 << 21) + (t[y0:y0 + n] * weights[vko + y * vks:vko + y * vks + n][:, None, None]).sum(0)
+            dst[b, :hout, :wout] = torch.from_numpy(np.clip(o >> 22, 0, 255).astype(np.uint8))
+        return dst
     monkeypatch.setattr(_C, "crop_flip_u8", crop_flip_u8)
-    batches = {}
-    for dev in (False, True):
-        node = {"target": "enhancing.dataloader.imagenet.ImageNetTrain", "params": {"root": str(tmp_path), "resolution": 32, "device_transform": dev}}
-        dm = DataModuleFromConfig(batch_size=3, num_workers=0, train=node)
-        dm.setup()
-        loader = dm.train_dataloader()
-        if dev:
-            loader.fn.device = torch.device("cpu")
-        np.random.seed(7)
-        torch.manual_seed(7)
-        batches[dev] = list(loader)
-    assert len(batches[True]) == 2 and set(batches[True][0]) == {"image", "class"}
-    for a, b in zip(batches[False], batches[True]):
-        assert torch.equal(a["image"], b["image"]) and torch.equal(a["class"], b["class"])
+    monkeypatch.setattr(_C, "resize_u8", resize_u8)
+    for split, target in (("train", "ImageNetTrain"), ("validation", "ImageNetValidation")):
+        batches = {}
+        for mode, params in (("host", {}), ("device_tail", {"device_transform": True}), ("device_resize", {"device_resize": True})):
+            node = {"target": f"enhancing.dataloader.imagenet.{target}", "params": dict(root=str(tmp_path), resolution=32, **params)}
+            dm = DataModuleFromConfig(batch_size=3, num_workers=0, **{split: node})
+            dm.setup()
+            loader = dm.train_dataloader() if split == "train" else dm.val_dataloader()
+            if mode != "host":
+                loader.fn.device = torch.device("cpu")
+            np.random.seed(7)
+            torch.manual_seed(7)
+            batches[mode] = list(loader)
+        assert len(batches["device_resize"]) == 2 and set(batches["device_resize"][0]) == {"image", "class"}
+        for a, b, c in zip(batches["host"], batches["device_tail"], batches["device_resize"]):
+            assert torch.equal(a["image"], b["image"]) and torch.equal(a["class"], b["class"])
+            assert torch.equal(a["image"], c["image"]) and torch.equal(a["class"], c["class"]), split
 
 
 def test_image_logger_and_setup_callbacks(tmp_path, monkeypatch):

@@ -448,3 +448,29 @@ def test_crop_flip_u8_device_transform():
         assert np.array_equal(out[b], w.astype(np.float32).transpose(2, 0, 1) / np.float32(255.0)), b
     with pytest.raises(RuntimeError):
         _C.crop_flip_u8(torch.from_numpy(src).cuda(), torch.from_numpy(meta).cuda(), 64)      # window larger than the staging slot
+
+
+def test_resize_u8_is_pillow_bit_for_bit():
+    """enh_resize_u8 (device-side T.Resize of the input pipeline, reference dataloader/imagenet.py:31,49): a batch of ragged decoded images, shrinking and
+    growing, training rule (shorter side -> R) and validation rule (exact (R, R)) — every output byte equals PIL.Image.resize(size, BILINEAR) and the CPU
+    oracle; pixels outside an image's output rectangle stay untouched (zero)."""
+    import numpy as np
+    from PIL import Image
+    import resize_oracle as RO
+    from enhancing.dataloader.resize import resize_batch_u8
+    rs = np.random.RandomState(5)
+    sizes = [(500, 375), (333, 500), (100, 120), (64, 64), (480, 640), (257, 301), (37, 53)]
+    HS, WS = max(s[0] for s in sizes), max(s[1] for s in sizes)
+    src = np.zeros((len(sizes), HS, WS, 3), np.uint8)
+    imgs = []
+    for b, (h, w) in enumerate(sizes):
+        imgs.append(rs.randint(0, 256, (h, w, 3)).astype(np.uint8))
+        src[b, :h, :w] = imgs[b]
+    for size in (256, (96, 128)):
+        dst, outs = resize_batch_u8(torch.from_numpy(src).cuda(), sizes, size)
+        dst = dst.cpu().numpy()
+        for b, (ho, wo) in enumerate(outs):
+            ref = np.array(Image.fromarray(imgs[b]).resize((wo, ho), Image.BILINEAR))
+            assert np.array_equal(dst[b, :ho, :wo], ref), (size, b)
+            assert np.array_equal(ref, RO.resize_u8(imgs[b], (ho, wo)))
+            assert not dst[b, ho:].any() and not dst[b, :, wo:].any()

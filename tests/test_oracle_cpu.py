@@ -89,3 +89,26 @@ def test_patchify_roundtrip_and_conv_equivalence():
     tok = torch.randn(2, 16, 16)
     ref_t = torch.nn.functional.conv_transpose2d(tok.transpose(1, 2).reshape(2, 16, 4, 4), wt, stride=8)
     assert torch.allclose(O.unpatchify(tok @ wt.reshape(16, -1), 8, 3, 32, 32), ref_t, atol=1e-4)
+
+
+def test_resize_oracle_is_pillow_bit_for_bit():
+    """PIN of oracle/resize_oracle.py (the restatement of Pillow's antialiased bilinear resampler that the device-side Resize is checked against): equal to
+    PIL.Image.resize(size, BILINEAR) itself — the call torchvision's T.Resize makes in the reference's transforms (enhancing/dataloader/imagenet.py:31,49)
+    — on shrinking, growing, ragged and identity sizes; and the product's vectorised coefficient tables equal the oracle's scalar ones."""
+    import numpy as np
+    from PIL import Image
+    import resize_oracle as RO
+    from enhancing.dataloader import resize as R
+    rs = np.random.RandomState(0)
+    for (H, W, Ho, Wo) in [(500, 375, 341, 256), (333, 500, 256, 384), (100, 120, 256, 307), (64, 64, 256, 256), (480, 640, 256, 256), (257, 301, 256, 299),
+                           (37, 53, 37, 20), (90, 31, 7, 31)]:
+        img = rs.randint(0, 256, (H, W, 3)).astype(np.uint8)
+        ref = np.array(Image.fromarray(img).resize((Wo, Ho), Image.BILINEAR))
+        assert np.array_equal(RO.resize_u8(img, (Ho, Wo)), ref), (H, W, Ho, Wo)
+        for a, b in ((W, Wo), (H, Ho)):
+            b1, k1 = R.coeff_table(a, b)
+            b2, k2 = RO.bilinear_coeffs(a, b)
+            assert np.array_equal(b1, b2) and np.array_equal(k1, k2), (a, b)
+    # torchvision's size rule for an int: shorter side -> size, the other int(size * long / short)
+    assert R.output_size(500, 375, 256) == RO.torchvision_resize_size(500, 375, 256) == (341, 256)
+    assert R.output_size(375, 500, 256) == (256, 341) and R.output_size(300, 200, (256, 256)) == (256, 256)
