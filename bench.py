@@ -319,15 +319,28 @@ def main():
             chk = eng.forward_backward(batches[0], w_l1=0.0, w_l2=1.0, codebook_weight=1.0)
             torch.cuda.synchronize()
             q = model.quantizer
-            mr = vq_match_rate(chk["h"].clone(), chk["indices"].clone(), eng.store.w["quantizer.embedding.weight"].clone(), q.depth, bool(q.use_residual))
+            h_chk, E_chk = chk["h"].clone(), eng.store.w["quantizer.embedding.weight"].clone()
+            mr = vq_match_rate(h_chk, chk["indices"].clone(), E_chk, q.depth, bool(q.use_residual))
             res["vq_match_rate"] = mr["value"]
             res["vq_match"] = mr
+            # the same kernel on the same 131 072 quantizer inputs against a codebook with a TRAINED-LIKE usage spread (jittered l2-normalised rows of h):
+            # synthetic training collapses usage to a handful of codes (distinct_codes above), which exercises the 8192-way argmin very little
+            if not q.use_residual:
+                gcb = torch.Generator(device=dev).manual_seed(4321)
+                hn = torch.nn.functional.normalize(h_chk.view(-1, h_chk.shape[-1]).float(), dim=-1)
+                pick = torch.randint(0, hn.shape[0], (E_chk.shape[0],), device=dev, generator=gcb)
+                E_sp = torch.nn.functional.normalize(hn[pick] + 0.1 * torch.randn(E_chk.shape, device=dev, generator=gcb) / E_chk.shape[1] ** 0.5, dim=-1).contiguous()
+                _, _, idx_sp, _ = _C.vq_forward(h_chk.view(-1, h_chk.shape[-1]).contiguous(), E_sp, float(getattr(q, "beta", 0.25)), 1, True, want_bf16=False)
+                torch.cuda.synchronize()
+                ms = vq_match_rate(h_chk, idx_sp, E_sp, 1, False)
+                ms["codebook"] = "jittered l2-normalised rows of the same h (trained-like spread); same kernel, same inputs"
+                res["vq_match_spread"] = ms
         res["cpu_baseline"] = cpu_baseline()
     print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    if res.get("vq_match", {}).get("status") == "FAIL":
+    if "FAIL" in (res.get("vq_match", {}).get("status"), res.get("vq_match_spread", {}).get("status")):
         sys.exit(3)      # an index mismatch that is NOT an fp32 near-tie: the line above says which token
 
 

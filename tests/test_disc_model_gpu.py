@@ -111,8 +111,11 @@ def test_hip_discriminator_vs_the_same_rounding_points_in_torch(C, golden_dir, m
     """the loose bounds above (logits 2e-2, gradients 0.15 - 0.2 against the fp32 golden) mix two things — the bf16 ROUNDING POINTS
     the design chose (operands and stored activations in bf16: leaky-ReLU gates of a random-init network flip) and the error of the KERNELS themselves.
     tests/hip_emulation.py with exact=False reproduces exactly those rounding points in plain torch (fp32 accumulation, bf16 containers, the same
-    geometry structs tap by tap); against it the HIP discriminator must agree to summation order: logits 5e-3, every gradient 2e-2 (first order, and
-    the R1 penalty's second order through the backward pass)."""
+    geometry structs tap by tap).  Run on the golden case as it is, HIP and emulation disagree as much as each disagrees with fp32 (logits 9.9e-3,
+    bias gradients 1e-1: measured, round 3) — they flip DIFFERENT gates, because a pre-activation within one summation-order ulp of zero decides a
+    gate and a random-init network has thousands of those.  So the gates are taken out of the comparison instead: every activation bias is raised by
+    +4 (pre-activations ~N(4, 1): a few gates in 10^5 are off, almost none near zero), the same state dict on both sides.  What is left is the
+    kernels' arithmetic: logits 5e-3, every gradient 2e-2 (first order, and the R1 penalty's second order through the backward pass)."""
     import copy
     import hip_emulation
     from enhancing.engine.stage1 import ParamStore
@@ -120,6 +123,10 @@ def test_hip_discriminator_vs_the_same_rounding_points_in_torch(C, golden_dir, m
     from enhancing.losses.op import conv2d_gradfix
     G = np.load(os.path.join(golden_dir, "disc_tiny.npz"))
     D, real, fake = disc_case(G)
+    with torch.no_grad():
+        for n, p_ in D.named_parameters():
+            if n.endswith("bias") and p_.ndim == 1 and "final_linear.1" not in n:
+                p_.add_(4.0)
     sd = {k: v.detach().clone() for k, v in D.state_dict().items()}
 
     def run(Dm, dev):
