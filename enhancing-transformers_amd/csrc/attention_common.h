@@ -182,6 +182,10 @@ __device__ __forceinline__ void attn_fwd_exact(const uint16_t* __restrict__ qkv,
         }
       l_part = l_part * alpha + (ps2[0] + ps2[1]);
     }
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
     // ---- O^T[d][q] += V^T P^T ----
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
