@@ -20,13 +20,12 @@
 // =================================================================================================
 // forward
 // =================================================================================================
-template <bool PK>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, int B, int N, int H, float scale_log2,
                                                           uint16_t* __restrict__ out, float* __restrict__ lse) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][ATT_TILE_BYTES];  // [stage][K | V]
   int blk, head;
   if (!att_block_coords((N + 127) / 128, B * H, blk, head)) return;
-  attn_fwd_exact<PK>(qkv, B, N, H, scale_log2, out, lse, smem, blk, head);
+  attn_fwd_exact(qkv, B, N, H, scale_log2, out, lse, smem, blk, head);
 }
 
 // =================================================================================================
@@ -293,7 +292,7 @@ static int g_att_fwd = 0, g_att_dq = 0, g_att_dkv = 0;
 #define ATT_DEFAULT_DKV 2
 
 extern "C" int enh_attention_set_kernel(int fwd, int dq, int dkv) {
-  ENH_REQUIRE(fwd >= 0 && fwd <= 4 && dq >= 0 && dq <= 4 && dkv >= 0 && dkv <= 2, ENH_E_BADARG, "enh_attention_set_kernel: fwd in 0..4, dq in 0..4, dkv in 0..2");
+  ENH_REQUIRE(fwd >= 0 && fwd <= 3 && dq >= 0 && dq <= 3 && dkv >= 0 && dkv <= 2, ENH_E_BADARG, "enh_attention_set_kernel: fwd in 0..3, dq in 0..3, dkv in 0..2");
   g_att_fwd = fwd; g_att_dq = dq; g_att_dkv = dkv;
   return ENH_OK;
 }
@@ -309,8 +308,7 @@ extern "C" int enh_attention_forward(const enh_bf16* qkv, int B, int N, int H, f
   const dim3 grid((unsigned)(((heads + 7) / 8) * 8 * nblk));  // 1-D: see att_block_coords
   const int fam = g_att_fwd ? g_att_fwd : ATT_DEFAULT_FWD;
   const float sl2 = q_prescaled ? 1.0f : scale * ATT_LOG2E;       // pre-scaled q: the products are log2-domain scores already
-  if (fam == 1) attn_fwd_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(qkv, B, N, H, sl2, out, lse);
-  else if (fam == 4) attn_fwd_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(qkv, B, N, H, sl2, out, lse);
+  if (fam == 1) attn_fwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(qkv, B, N, H, sl2, out, lse);
   else attn_fwd2_launch(qkv, B, N, H, sl2, out, lse, fam == 2, q_prescaled != 0, grid, (hipStream_t)stream);
   return enh_check_launch("enh_attention_forward");
 }
@@ -332,8 +330,8 @@ extern "C" int enh_attention_backward(const enh_bf16* qkv, const enh_bf16* out, 
   const int fq = g_att_dq ? g_att_dq : ATT_DEFAULT_DQ, fk = g_att_dkv ? g_att_dkv : ATT_DEFAULT_DKV;
   if (fq == 1) attn_bwd_dq_kernel<0><<<grid, 256, 0, s>>>(qkv, out, dout, lse, delta_ws, B, N, H, scale, sl2, dqkv);
   else if (fq == 2) attn_bwd_dq2_launch(qkv, out, dout, lse, delta_ws, B, N, H, scale, sl2, dqkv, pre, grid, s);
-  else if (fq == 3 && pre) attn_bwd_dq_kernel<2><<<grid, 256, 0, s>>>(qkv, out, dout, lse, delta_ws, B, N, H, scale, sl2, dqkv);
-  else attn_bwd_dq_kernel<1><<<grid, 256, 0, s>>>(qkv, out, dout, lse, delta_ws, B, N, H, scale, sl2, dqkv);     // 4 (and 3 without pre-scaled q): -delta only, three waves per SIMD
+  else if (pre) attn_bwd_dq_kernel<2><<<grid, 256, 0, s>>>(qkv, out, dout, lse, delta_ws, B, N, H, scale, sl2, dqkv);
+  else attn_bwd_dq_kernel<1><<<grid, 256, 0, s>>>(qkv, out, dout, lse, delta_ws, B, N, H, scale, sl2, dqkv);
   if (fk == 1) attn_bwd_dkv_kernel<false, false><<<grid, 256, 0, s>>>(qkv, dout, lse, delta_ws, B, N, H, kscale, sl2, dqkv);
   else if (pre) attn_bwd_dkv_kernel<true, true><<<grid, 256, 0, s>>>(qkv, dout, lse, delta_ws, B, N, H, kscale, sl2, dqkv);
   else attn_bwd_dkv_kernel<true, false><<<grid, 256, 0, s>>>(qkv, dout, lse, delta_ws, B, N, H, kscale, sl2, dqkv);

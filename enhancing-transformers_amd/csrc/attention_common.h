@@ -72,15 +72,6 @@ __device__ __forceinline__ bool att_block_coords(int nblk, int n_heads_total, in
 
 // The round-1/2 forward pass of one 128-query block (exact running maximum, O rescaled every tile): the body of attn_fwd_kernel, and the FALLBACK of the
 // pipelined kernel of attention_v2.hip for a workgroup whose scores outgrow its fixed reference.  smem: [2][2][ATT_TILE_BYTES] ([stage][K | V]).
-// PK: the per-score vector work written on float PAIRS (v_pk_fma_f32 / v_pk_add_f32: half the instructions for the scale-and-subtract and the row sum),
-// the maximum through v_max3_f32 and the half-wave exchange through v_permlane32_swap — the kernels are bound by the NUMBER of vector instructions
-// (profiles/r03_attention_lab.txt), so the same arithmetic in fewer instructions is time.
-__device__ __forceinline__ float att_max3(float a, float b, float c) {
-  float r;
-  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
-}
-template <bool PK>
 __device__ __forceinline__ void attn_fwd_exact(const uint16_t* __restrict__ qkv, int B, int N, int H, float scale_log2, uint16_t* __restrict__ out,
                                                float* __restrict__ lse, unsigned char (*smem)[2][ATT_TILE_BYTES], int blk, int head) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -133,55 +124,25 @@ __device__ __forceinline__ void attn_fwd_exact(const uint16_t* __restrict__ qkv,
       for (int ds = 0; ds < 4; ++ds) s[kb] = MFMA32(att_frag_row(kt_, kb * 32, ds, l31, hi), qf[ds], s[kb]);
     }
     // ---- online softmax for this lane's query column ----
+    float mx = s[0][0];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx * scale_log2);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
     float p[2][16];
-    float alpha;
-    if (!PK) {
-      float mx = s[0][0];
+    float psum = 0.f;
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run, mx * scale_log2);
-      alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      m_run = m_new;
-      float psum = 0.f;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          p[kb][r] = __builtin_amdgcn_exp2f(s[kb][r] * scale_log2 - m_new);
-          psum += p[kb][r];
-        }
-      l_part = l_part * alpha + psum;
-    } else {
-      float mx = s[0][0];
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) mx = att_max3(mx, s[kb][r], s[kb][r + 1]);
-      {
-        const unsigned u = __builtin_bit_cast(unsigned, mx);
-        const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);      // (v[lane & 31], v[(lane & 31) + 32]) in every lane (hw_probe P4)
-        mx = fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
+      for (int r = 0; r < 16; ++r) {
+        p[kb][r] = __builtin_amdgcn_exp2f(s[kb][r] * scale_log2 - m_new);
+        psum += p[kb][r];
       }
-      const float m_new = fmaxf(m_run, mx * scale_log2);
-      alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      m_run = m_new;
-      const f32x2 c2 = {scale_log2, scale_log2}, nm2 = {-m_new, -m_new};
-      f32x2 ps2 = {0.f, 0.f};
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          const f32x2 s2 = {s[kb][r], s[kb][r + 1]};
-          const f32x2 x2 = __builtin_elementwise_fma(s2, c2, nm2);
-          const f32x2 e2 = {__builtin_amdgcn_exp2f(x2[0]), __builtin_amdgcn_exp2f(x2[1])};
-          p[kb][r] = e2[0]; p[kb][r + 1] = e2[1];
-          ps2 += e2;
-        }
-      l_part = l_part * alpha + (ps2[0] + ps2[1]);
-    }
+    l_part = l_part * alpha + psum;
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll

@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const uint16_t* __res
   // every wave reads the flag after the same barrier: the decision is workgroup-uniform (flags raised in the last iterations included)
   if (bad | *reinterpret_cast<volatile int*>(&s_bad)) {
     __syncthreads();
-    attn_fwd_exact<false>(qkv, B, N, H, scale_log2, out, lse, reinterpret_cast<unsigned char (*)[2][ATT_TILE_BYTES]>(&smem[0][0]), blk, head);
+    attn_fwd_exact(qkv, B, N, H, scale_log2, out, lse, reinterpret_cast<unsigned char (*)[2][ATT_TILE_BYTES]>(&smem[0][0]), blk, head);
     return;
   }
 
