@@ -6,9 +6,18 @@ training step of configs/imagenet_vitvq_base.yaml on one synthetic ImageNet-shap
 gradient all-reduce + fused AdamW, loss = 1.0*L2 + 1.0*codebook (LPIPS / GAN weights 0 — stated in config.workload).
 Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 
-Extra objects: "roofline" (dominant kernel = the bf16 MFMA GEMM instantiation with the largest share of the step, timed
-live with HIP events on the launch stream inside the timed region) and "cpu_baseline" (the CPU oracle — a port of the
-reference's PyTorch path, oracle/vitvq_oracle.py — timed on the host cores on a bounded sample, rank 0 / N=1 only).
+Extra objects (rank 0, N = 1 unless noted):
+  "roofline"   the kernel with the largest share of the step over ALL timed kernels (every GEMM instantiation, attention, convolutions, the quantizer,
+               LayerNorm backward, AdamW — each priced against its own roofline: bf16 MFMA 2.5 PF, exact-f32 MFMA 157.3 TF, HBM 8 TB/s), timed live
+               with HIP events on the launch stream inside the timed region; `traffic` = PMC bytes per launch from profiles/pmc_step.json, attached only
+               when that file records the SAME config and per-GPU batch, else null.  "kernels" carries the same figures for every timed kernel.
+  "vq"         the quantizer launch: tokens/s, exact-f32 TF/s and its fraction of 157.3 TF, algorithmic bytes, PMC bytes and GB/s against the HBM peak.
+  "vq_match"   second half of BASELINE's metric: the argmin match-rate at the op boundary on ONE extra forward pass (h, indices and codebook snapshotted
+               together), every mismatch audited in fp64 (side holding the exact argmin, gap in ulps) and ENFORCED against the derived near-tie bound —
+               the process exits with code 3 on a violation; "vq_match_spread": the same kernel and inputs against a trained-like codebook
+               (~1000 distinct codes in play instead of the handful synthetic training collapses to).
+  "cpu_baseline"  the CPU oracle — a port of the reference's PyTorch path, oracle/vitvq_oracle.py — timed on the host cores on a bounded sample.
+  "comm"       (N > 1) per rank: exposed communication of the timed steps (compute-stream wait and host wait), buckets, bytes reduced, un-announced elements.
 """
 import argparse
 import json
