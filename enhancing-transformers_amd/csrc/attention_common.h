@@ -11,10 +11,16 @@
 // fragments and the 4-row x 64-B transpose reads (gfx950 bank model; tools/lds_bank_check.py).
 __device__ __forceinline__ int att_off(int r, int c) { return r * 128 + ((c ^ ((((r >> 1) & 1) << 2) | ((r >> 2) & 3))) << 4); }
 
+// rows row0 .. row0+63 of a [*][rs] bf16 matrix, 2 x 16 B per thread.  The address is split into a WAVE-UNIFORM part (base + row0 * rs: scalar registers,
+// advanced by the scalar unit) and a 32-bit per-lane byte offset that does not depend on the tile (hoisted out of the loop): the loads then use the
+// scalar-base + vector-offset form and cost no vector instructions per tile (the 64-bit per-lane address arithmetic was 13 of dK/dV's ~170 vector
+// instructions per tile, and the kernels' time follows that count: profiles/r03_attention_lab.txt).
 __device__ __forceinline__ void att_gload(u32x4 (&r)[2], const uint16_t* __restrict__ base, int64_t rs, int row0, int t) {
   const int c = t & 7, r0 = t >> 3;
+  const unsigned char* ub = reinterpret_cast<const unsigned char*>(base + (int64_t)row0 * rs);
+  const unsigned lane_off = (unsigned)(r0 * (int)rs + c * 8) * 2u;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) r[i] = *reinterpret_cast<const u32x4*>(base + (int64_t)(row0 + r0 + 32 * i) * rs + c * 8);
+  for (int i = 0; i < 2; ++i) r[i] = *reinterpret_cast<const u32x4*>(ub + (size_t)(unsigned)(i * 32 * (int)rs * 2) + lane_off);
 }
 __device__ __forceinline__ void att_sstore(const u32x4 (&r)[2], unsigned char* tile, int t) {
   const int c = t & 7, r0 = t >> 3;
