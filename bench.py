@@ -261,7 +261,7 @@ def main():
     if world > 1:
         # per-rank exposed communication (so that the first real multi-GPU run explains itself) + the bucket accounting the DDP tests insist on
         mine = eng.comm.comm_wait_ms(last=args.steps)
-        mine.update(rank=rank, bytes_reduced_per_step=eng.comm.bytes_reduced / max(len(eng.comm.host_wait_ms), 1), gap_elems=eng.comm.gap_elems)
+        mine.update(rank=rank, bytes_reduced_per_step=eng.comm.bytes_reduced / max(args.warmup + args.steps, 1), gap_elems=eng.comm.gap_elems)
         allr = [None] * world
         dist.all_gather_object(allr, mine)
         comm_info = {"backend": dist.get_backend(), "algo": args.grad_algo, "bucket_dtype": "bf16" if args.grad_bf16 else "fp32",

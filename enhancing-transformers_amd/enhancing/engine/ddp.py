@@ -133,6 +133,9 @@ class GradSync:
         if on_gpu:
             ev[1].record()
             self._wait_events.append(ev)
+        if len(self.host_wait_ms) > 4096:        # a long training run keeps the most recent window only
+            del self.host_wait_ms[:2048]
+            del self._wait_events[:max(len(self._wait_events) - 2048, 0)]
         self.buckets_last_step = len(self._handles)
         for b, e in self._copyback:
             self.store.g[b:e].copy_(self._g16[b:e])
