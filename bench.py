@@ -148,10 +148,17 @@ def kernel_rooflines(ks: dict, steps_timed: int, ms_per_step: float, pmc: dict):
         ach = v["work"] / (v["total_ms"] * 1e-3) / div
         sym = k.split(" (")[0]
         tr = None
-        for name, rec in (pmc or {}).items():
-            if name == sym or name.startswith(sym + "<") or (k.startswith("vq_forward") and name == "vq_nn_kernel") or \
-                    (k.startswith("attn_bwd") and name.startswith("attn_bwd")):
-                tr = (tr or 0.0) + rec.get("hbm_bytes_per_launch", 0.0)
+        if pmc:
+            if k.startswith("attn_bwd"):          # one timed call = one dQ launch + one dK/dV launch: their bytes add
+                parts = [rec.get("hbm_bytes_per_launch", 0.0) for name, rec in pmc.items() if name.startswith("attn_bwd")]
+                tr = sum(parts) if parts else None
+            elif k.startswith("vq_forward"):
+                tr = pmc.get("vq_nn_kernel", {}).get("hbm_bytes_per_launch")
+            else:                                  # exact symbol, or the instantiations of a template timed under one name: launch-weighted mean
+                hits = [rec for name, rec in pmc.items() if name == sym or name.startswith(sym + "<")]
+                n = sum(r.get("launches", 0) for r in hits)
+                if hits and n:
+                    tr = sum(r.get("hbm_bytes_per_launch", 0.0) * r.get("launches", 0) for r in hits) / n
         out[k] = {"kernel": k, "bound": bound, "achieved": round(ach, 1), "peak": pk, "unit": unit, "frac": round(ach / pk, 4), "traffic": tr,
                   "launches_timed": v["launches"], "avg_launch_ms": round(v["avg_ms"], 4),
                   "share_of_step": round((v["total_ms"] / steps_timed) / ms_per_step, 4)}
