@@ -533,6 +533,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   } while (0)
 #define W2_MM(Q, FA, FB)                                                                                                          \
   acc[(Q) >> 2][(Q) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, FB[(Q) & 3]), __builtin_bit_cast(bf16x8, FA[(Q) >> 2]), acc[(Q) >> 2][(Q) & 3], 0, 0, 0)
+#define W2_MMZ(Q, FA, FB)                                                                                                         \
+  acc[(Q) >> 2][(Q) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, FB[(Q) & 3]), __builtin_bit_cast(bf16x8, FA[(Q) >> 2]), zero16, 0, 0, 0)
 #define W2_FENCE() __builtin_amdgcn_sched_barrier(0)
   // one k16 step: 16 MFMAs on (FA, FB); under MFMAs 0-7 one fragment read each (k-step RS of slot RSLOT into RA / RB); under every odd MFMA one
   // global_load_lds (pieces G0 .. G0+7 into slot GSLOT).  The step opens with lgkmcnt(0): its fragments were read >= 8 MFMAs ago.
@@ -544,6 +546,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       W2_MM(q_, FA, FB);                                                                                                          \
       if ((DO_READ) && q_ < 8) { W2_READ_ONE(RA, RB, RSLOT, RS, q_); }                                                            \
       if ((DO_ISSUE) && (q_ & 1)) { W2_ISSUE_ONE(GSLOT, (G0) + (q_ >> 1)); }                                                      \
+      W2_FENCE();                                                                                                                 \
+    }                                                                                                                             \
+  } while (0)
+
+  // the first k16 step of a tile in the persistent kernel: C operand = 0 instead of cleared accumulators; reads k-step RS, requests nothing
+#define W2_KSTEP_Z(FA, FB, RA, RB, RSLOT, RS)                                                                                     \
+  do {                                                                                                                            \
+    if (TA || TB) __builtin_amdgcn_s_waitcnt(0xC07F);                                                                             \
+    W2_FENCE();                                                                                                                   \
+    _Pragma("unroll") for (int q_ = 0; q_ < 16; ++q_) {                                                                           \
+      W2_MMZ(q_, FA, FB);                                                                                                         \
+      if (q_ < 8) { W2_READ_ONE(RA, RB, RSLOT, RS, q_); }                                                                         \
       W2_FENCE();                                                                                                                 \
     }                                                                                                                             \
   } while (0)
@@ -587,24 +601,268 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     W2_KSTEP(fa0, fb0, fa1, fb1, slot ^ 1, 3, true, 0, 0, false);
     W2_KSTEP(fa1, fb1, fa0, fb0, 0, 0, false, 0, 0, false);
   }
-#undef W2_ISSUE_ONE
-#undef W2_ADVANCE
-#undef W2_READ_ONE
-#undef W2_MM
-#undef W2_FENCE
-#undef W2_KSTEP
   gemm_epilogue32_loops<EPI, 4, false>(args, acc, m0 + wm * 128, n0 + wn * 128, lane, split,
                                        reinterpret_cast<float*>(smem + 2 * W2_SLOT) + wave * 128, smem + wave * 8192, smem + wave * 16384);
 }
 
+// =================================================================================================
+// "w256p": the w256 main loop as a PERSISTENT kernel (round 3; laboratory notes: profiles/r03_gemm_persistent_lab.txt).  One workgroup per CU walks
+// its tiles (virtual block ids b, b + grid, ...: the same XCD-grouped order as w256), and the K stages of consecutive tiles form ONE load stream: the
+// next tile's stage 0 is requested under the last stage's MFMAs and has landed before the epilogue starts; its stage 1 is requested before the first
+// store.  No launch gap, no cold prologue per tile, and the stores drain under the next tile's first stage instead of in front of a workgroup exit.
+// vmcnt counts loads and stores in one counter and a wait can only name how many of the youngest operations may remain, so the epilogue is arranged so
+// that nothing it READS is waited for behind one of its stores:
+//   * the saved tanh output is requested for all four row-blocks before the first store; the f32 residual for two row-blocks at a time (the second
+//     pair's wait is the one place where a load is awaited with stores in flight);
+//   * outputs leave through a wave-private 4-KiB LDS tile that does NOT overlay the K slots (32 rows x 128 B per block: whole 128-byte lines per row),
+//     so no barrier separates the K loop from the epilogue and the next tile's operands are already in LDS while the stores drain;
+//   * accumulators are copied out with explicit v_accvgpr_read at the point of use and every lane-derived address is recomputed per tile: left to the
+//     register allocator the epilogue held all 256 accumulators in vector registers and spilled — and a scratch reload is a vector-memory load, i.e.
+//     a vmcnt wait on the next tile's requests.
+// Accumulators are not cleared: the first k16 step of a tile multiplies into a zero C operand.
+// LDS: [2 slots, 128 KiB][bias strips, 2 KiB][4 x 4 KiB store tiles] = 146 KiB.  Forward / input-gradient roles only (A stored [M][K], no split-K).
+// =================================================================================================
+#define W2P_STAGE_BYTES 4096
+#define W2P_LDS_BYTES (2 * W2_SLOT + W2_BIAS_BYTES + 4 * W2P_STAGE_BYTES)
+
+// accumulator -> vector register AT THIS POINT of the instruction stream (the register allocator otherwise copies all 256 accumulators out at the top
+// of the epilogue: 256 live registers, spills, and scratch reloads are vector-memory operations that wait on the next tile's requests)
+__device__ __forceinline__ float acc_read(float a) {
+  float x;
+  asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(a));
+  return x;
+}
+
+template <int MODE>
+__device__ __forceinline__ void gemm_epilogue_p(const GemmArgs& args, f32x16 (&acc)[4][4], int64_t mw, int64_t nw, int lane_in, float* wave_bias, unsigned char* st) {
+  // everything lane-derived is recomputed per tile: hoisted out of the persistent loop, the ~40 loop-invariant addresses would be carried through the
+  // K loop and spilled (scratch reloads are vector-memory operations: they would put vmcnt waits on the next tile's requests into the epilogue)
+  int lane = lane_in;
+  asm volatile("" : "+v"(lane));
+  const int l31 = lane & 31, hi = lane >> 5;
+  constexpr bool HAS_BIAS = MODE == EPI_BF16_BIAS_TANH || MODE == EPI_F32_BIAS_RES;
+  constexpr bool OUT16 = MODE == EPI_BF16 || MODE == EPI_BF16_BIAS_TANH || MODE == EPI_BF16_DTANH;
+  if (HAS_BIAS && lane < 32) *reinterpret_cast<float4*>(wave_bias + lane * 4) = *reinterpret_cast<const float4*>(args.bias + nw + lane * 4);
+  const int rrow = lane >> 3, rc = lane & 7;
+  if (OUT16) {
+    EpiIn in[4][4][4];
+    const unsigned aux_off = (unsigned)l31 * (unsigned)args.ldaux + 4u * (unsigned)hi;
+    // the saved tanh output: all four row-blocks before the first store (128 registers; the K loop's fragment registers are dead here)
+    constexpr int AUX_AHEAD = 4;
+    if (MODE == EPI_BF16_DTANH) {
+#pragma unroll
+      for (int i = 0; i < AUX_AHEAD; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4)
+            in[i][j][g4].aux = *reinterpret_cast<const uint2*>(args.aux + ((mw + i * 32) * args.ldaux + nw + j * 32 + 8 * g4) + aux_off);
+    }
+    const int wsw = (l31 >> 1) & 7;
+    const unsigned out_off = (unsigned)rrow * (unsigned)args.ldc + (unsigned)rc * 8u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int jh = 0; jh < 2; ++jh) {
+#pragma unroll
+        for (int j2 = 0; j2 < 2; ++j2)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const int j = jh * 2 + j2;
+            float v[4] = {acc_read(acc[i][j][g4 * 4 + 0]), acc_read(acc[i][j][g4 * 4 + 1]), acc_read(acc[i][j][g4 * 4 + 2]), acc_read(acc[i][j][g4 * 4 + 3])};
+            const float4 b4 = HAS_BIAS ? *reinterpret_cast<const float4*>(wave_bias + j * 32 + 8 * g4 + 4 * hi) : make_float4(0.f, 0.f, 0.f, 0.f);
+            epi_value<MODE>(args, v, in[MODE == EPI_BF16_DTANH ? i % AUX_AHEAD : 0][MODE == EPI_BF16_DTANH ? j : 0][MODE == EPI_BF16_DTANH ? g4 : 0], b4, nw + j * 32 + 8 * g4 + 4 * hi);
+            const u32x2 o_ = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            *reinterpret_cast<u32x2*>(st + l31 * 128 + (((j2 * 4 + g4) ^ wsw) << 4) + hi * 8) = o_;
+          }
+        u32x4 w[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int row = p * 8 + rrow;
+          w[p] = *reinterpret_cast<const u32x4*>(st + row * 128 + ((rc ^ ((row >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+          if (!(args.dbg & 1)) *reinterpret_cast<u32x4*>(args.c_bf16 + ((mw + i * 32 + p * 8) * args.ldc + nw + jh * 64) + out_off) = w[p];   // uniform base + 32-bit lane offset
+        __builtin_amdgcn_sched_barrier(0);   // one block at a time: the scheduler otherwise reads all 256 accumulators first
+      }
+  } else {
+    float* dst = args.c_f32 + mw * args.ldc + nw;
+    // the residual comes in the accumulator layout, two row-blocks (128 registers) at a time: the first pair is requested before any store; the second
+    // pair's wait is the one place where this mode waits with its own stores in flight
+    EpiIn in[2][4][4];
+    const unsigned out_off = (unsigned)rrow * (unsigned)args.ldc + (unsigned)rc * 4u;
+    const unsigned res_off = (unsigned)l31 * (unsigned)args.ldres + 4u * (unsigned)hi;
+#pragma unroll
+    for (int ih = 0; ih < 2; ++ih) {
+      if (MODE == EPI_F32_BIAS_RES) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)   // res_rows == M here (launcher): no row wrap
+              in[ii][j][g4].res = *reinterpret_cast<const float4*>(args.res + ((mw + (ih * 2 + ii) * 32) * args.ldres + nw + j * 32 + 8 * g4) + res_off);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int i = ih * 2 + ii;
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            if (MODE == EPI_F32_BIAS_RES) {
+              const float4 b4 = *reinterpret_cast<const float4*>(wave_bias + j * 32 + 8 * g4 + 4 * hi);
+              const float4 r4 = in[ii][j][g4].res;
+              const f32x4 o_ = {acc_read(acc[i][j][g4 * 4 + 0]) + b4.x + r4.x, acc_read(acc[i][j][g4 * 4 + 1]) + b4.y + r4.y,
+                                acc_read(acc[i][j][g4 * 4 + 2]) + b4.z + r4.z, acc_read(acc[i][j][g4 * 4 + 3]) + b4.w + r4.w};
+              *reinterpret_cast<f32x4*>(st + l31 * 128 + (((g4 * 2 + hi) ^ (l31 & 7)) << 4)) = o_;
+            } else {
+              const f32x4 o_ = {acc[i][j][g4 * 4 + 0], acc[i][j][g4 * 4 + 1], acc[i][j][g4 * 4 + 2], acc[i][j][g4 * 4 + 3]};
+              *reinterpret_cast<f32x4*>(st + l31 * 128 + (((g4 * 2 + hi) ^ (l31 & 7)) << 4)) = o_;
+            }
+          }
+          f32x4 w[4];
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            const int row = p * 8 + rrow;
+            w[p] = *reinterpret_cast<const f32x4*>(st + row * 128 + ((rc ^ (row & 7)) << 4));
+          }
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            const int row = p * 8 + rrow;
+            (void)row;
+            if (!(args.dbg & 1)) *reinterpret_cast<f32x4*>(dst + ((int64_t)(i * 32 + p * 8) * args.ldc + j * 32) + out_off) = w[p];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+  }
+}
+
+template <bool TA, bool TB, int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_bf16_w256p_kernel(const GemmArgs args) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntiles = args.nbm * args.nbn;
+  const int nst = (int)(args.K / G_BK);   // >= 3 (launcher); no split-K in this kernel
+
+  const bool stage_a = wave < 2;
+  const bool my_tr = stage_a ? TA : TB;
+  const int64_t my_ld = stage_a ? args.lda : args.ldb;
+  const int64_t pair_step = (my_tr ? 8 : 16) * my_ld;
+  const int64_t stage_step = my_tr ? (int64_t)G_BK * my_ld : (int64_t)G_BK;
+  const int64_t x_step = my_tr ? 1 : my_ld;                    // elements per unit of the wave's row / column origin
+  const int xw = stage_a ? wave * 128 : (wave - 2) * 128;
+  // lane pointers of the two slab parities at origin 0, K offset 0; a tile adds its (wave-uniform) origin
+  const uint16_t* const base_e = stage_a ? w256_src<TA>(args.A, args.lda, 0, 0, 0, lane) : w256_src<TB>(args.B, args.ldb, 0, 0, 0, lane);
+  const uint16_t* const base_o = stage_a ? w256_src<TA>(args.A, args.lda, 0, 0, 1, lane) : w256_src<TB>(args.B, args.ldb, 0, 0, 1, lane);
+  unsigned char* const my_sub = smem + wave * G_TILE_BYTES;
+  float* const wave_bias = reinterpret_cast<float*>(smem + 2 * W2_SLOT) + wave * 128;
+  unsigned char* const st = smem + 2 * W2_SLOT + W2_BIAS_BYTES + wave * W2P_STAGE_BYTES;
+
+  int vt = (int)blockIdx.x, split_, tile_m, tile_n;
+  gemm_tile_coords_of(args, vt, split_, tile_m, tile_n);
+  const uint16_t *gsrc_e, *gsrc_o;
+  {
+    const int64_t x0 = (stage_a ? (int64_t)((args.dbg & 4) ? (tile_m & 7) : tile_m) : (int64_t)tile_n) * 256 + xw;
+    gsrc_e = base_e + x0 * x_step; gsrc_o = base_o + x0 * x_step;
+  }
+  f32x16 acc[4][4];
+  s16x8 fa0[4], fb0[4], fa1[4], fb1[4];
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  // XCD stagger (laboratory: dbg bits 8..15 = units of ~512 cycles per XCD step): the eight XCDs' epilogues — and their store bursts — stop coinciding
+  for (int i = ((int)blockIdx.x & 7) * ((args.dbg >> 8) & 255); i > 0; --i) __builtin_amdgcn_s_sleep(8);
+  // prologue of the workgroup: stages 0 and 1 of its first tile
+#pragma unroll
+  for (int u = 0; u < 16; ++u) W2_ISSUE_ONE(0, u);
+  W2_ADVANCE();
+#pragma unroll
+  for (int u = 0; u < 16; ++u) W2_ISSUE_ONE(1, u);
+  W2_ADVANCE();
+  __builtin_amdgcn_s_waitcnt(0x4F70);   // vmcnt(16): stage 0 landed
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int u = 0; u < 8; ++u) W2_READ_ONE(fa0, fb0, 0, 0, u);
+  W2_FENCE();
+
+  int par = 0;   // slot of the current tile's stage 0
+  for (;;) {
+    // invariant: stage 0 of this tile is in slot par and its first fragments in fa0 / fb0; stage 1 is completely requested into slot par ^ 1;
+    // the source pointers are at stage 2
+    const int64_t m0 = (int64_t)tile_m * 256, n0 = (int64_t)tile_n * 256;
+    int vnext = vt + (int)gridDim.x;
+    const bool last_tile = vnext >= ntiles;
+    if (last_tile) vnext = vt;   // the last tile re-requests its own first stages (never consumed; drained before the kernel ends)
+    {
+      W2_KSTEP_Z(fa0, fb0, fa1, fb1, par, 1);
+      W2_KSTEP(fa1, fb1, fa0, fb0, par, 2, true, 0, 0, false);
+      W2_KSTEP(fa0, fb0, fa1, fb1, par, 3, true, 0, 0, false);
+      __builtin_amdgcn_s_waitcnt(0x0070);    // vmcnt(0): stage 1 landed (and the previous tile's stores are acknowledged)
+      __builtin_amdgcn_s_barrier();
+      W2_FENCE();
+      W2_KSTEP(fa1, fb1, fa0, fb0, par ^ 1, 0, true, par, 0, true);      // + pieces 0-7 of stage 2
+    }
+    for (int j = 1; j < nst; ++j) {
+      const int slot = par ^ (j & 1);
+      W2_KSTEP(fa0, fb0, fa1, fb1, slot, 1, true, slot ^ 1, 8, true);      // + pieces 8-15 of stage j+1
+      if (j == nst - 2) {   // stage j+2 is the NEXT tile's stage 0
+        gemm_tile_coords_of(args, vnext, split_, tile_m, tile_n);
+        const int64_t x0 = (stage_a ? (int64_t)((args.dbg & 4) ? (tile_m & 7) : tile_m) : (int64_t)tile_n) * 256 + xw;
+        gsrc_e = base_e + x0 * x_step; gsrc_o = base_o + x0 * x_step;
+      } else {
+        W2_ADVANCE();
+      }
+      W2_KSTEP(fa1, fb1, fa0, fb0, slot, 2, true, 0, 0, false);
+      W2_KSTEP(fa0, fb0, fa1, fb1, slot, 3, true, 0, 0, false);
+      __builtin_amdgcn_s_waitcnt(0x0070);
+      __builtin_amdgcn_s_barrier();
+      W2_FENCE();
+      W2_KSTEP(fa1, fb1, fa0, fb0, slot ^ 1, 0, true, slot, 0, true);      // + pieces 0-7 of stage j+2 into the slot just vacated
+    }
+    {   // the rest of the next tile's stage 1, before any store of this tile
+      const int slot = par ^ ((nst - 1) & 1);
+#pragma unroll
+      for (int u = 8; u < 16; ++u) W2_ISSUE_ONE(slot, u);
+      W2_ADVANCE();
+    }
+    // (laboratory, dbg & 8: every tile of the workgroup is written to one fixed 128 x 128 block -> the stores stay in L2)
+    if (!(args.dbg & 2)) gemm_epilogue_p<EPI>(args, acc, (args.dbg & 8) ? (int64_t)(blockIdx.x & 255) * 128 : m0 + wm * 128,
+                                              (args.dbg & 8) ? 0 : n0 + wn * 128, lane, wave_bias, st);
+    W2_FENCE();
+    if (last_tile) break;
+    vt = vnext;
+    par ^= nst & 1;
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // the dummy requests write LDS: they must have landed before the workgroup's LDS is released
+}
+#undef W2_ISSUE_ONE
+#undef W2_ADVANCE
+#undef W2_READ_ONE
+#undef W2_MM
+#undef W2_MMZ
+#undef W2_FENCE
+#undef W2_KSTEP
+#undef W2_KSTEP_Z
+
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-// kernel family: 0 = register-staged fallback (any K % 8), 3 = pipe2 (128x128), 7 = w256 (256x256, 4 waves)
+// kernel family: 0 = register-staged fallback (any K % 8), 3 = pipe2 (128x128), 7 = w256 (256x256, 4 waves), 8 = w256 with the persistent form (w256p)
+// wherever that serves (the per-shape default does the same; 7 pins the one-tile-per-workgroup form everywhere)
 static int g_kernel_override = -1;   // set by enh_gemm_set_kernel(): explicit state behind an explicit call, no environment lookups in the library
+static int g_gemm_debug = 0;
+extern "C" int enh_gemm_set_debug(int bits) { g_gemm_debug = bits; return ENH_OK; }   // laboratory only (tools/gemm_p_lab.py); not in the public header
 
 extern "C" int enh_gemm_set_kernel(int family) {
-  ENH_REQUIRE(family == -1 || family == 0 || family == 3 || family == 7, ENH_E_BADARG, "enh_gemm_set_kernel: family must be -1 (auto), 0, 3 or 7");
+  ENH_REQUIRE(family == -1 || family == 0 || family == 3 || family == 7 || family == 8, ENH_E_BADARG,
+              "enh_gemm_set_kernel: family must be -1 (auto), 0, 3, 7 or 8");
   g_kernel_override = family;
   return ENH_OK;
 }
@@ -629,6 +887,7 @@ static GemmPlan gemm_plan(int trans_a, int trans_b, int64_t M, int64_t N, int64_
   };
   const bool w256_ok = M % 256 == 0 && N % 256 == 0 && ksteps >= 2;
   int family = g_kernel_override >= 0 ? g_kernel_override : -1;
+  if (family == 8) family = 7;   // the persistent form shares w256's plan; the launcher upgrades the calls it covers
   if (family == 7 && !w256_ok) family = -1;
   if (family < 0) {
     // w256 whenever its tiles (times K slices) occupy at least 3/4 of the CUs; else the 128x128 pipe2 kernel (four times as many workgroups)
@@ -653,6 +912,19 @@ static GemmPlan gemm_plan(int trans_a, int trans_b, int64_t M, int64_t N, int64_
 
 static bool gemm_splittable(int accumulate, const float* c_f32, const enh_bf16* c_bf16, const float* bias, int act, const float* res) {
   return accumulate == 1 && c_f32 && !c_bf16 && !bias && act == ENH_ACT_NONE && !res;
+}
+
+extern "C" const char* enh_gemm_bf16_variant(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K);
+// the persistent form of w256 serves: A stored [M][K], no split-K, at least three K stages, one of the five epilogue modes it implements
+static bool gemm_persistent(const GemmPlan& pl, int trans_a, int64_t K, int mode) {
+  if (g_kernel_override == 7 || pl.family != 7 || trans_a || pl.splits != 1 || K / G_BK < 3) return false;
+  return mode == EPI_BF16 || mode == EPI_BF16_BIAS_TANH || mode == EPI_BF16_DTANH || mode == EPI_F32_BIAS_RES || mode == EPI_F32;
+}
+
+extern "C" const char* enh_gemm_bf16_variant_mode(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, int epi_mode) {
+  const GemmPlan pl = gemm_plan(trans_a, trans_b, M, N, K, epi_mode == EPI_WS || epi_mode == EPI_ATOMIC);
+  if (gemm_persistent(pl, trans_a, K, epi_mode)) return "gemm_bf16_w256p_kernel";
+  return enh_gemm_bf16_variant(trans_a, trans_b, M, N, K);
 }
 
 extern "C" const char* enh_gemm_bf16_variant(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K) {
@@ -692,6 +964,7 @@ extern "C" int enh_gemm_bf16_ws(const enh_bf16* A, int64_t lda, int trans_a, con
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.M = M; g.N = N; g.K = K;
   g.bias = bias; g.act = act; g.aux = aux; g.ldaux = ldaux; g.res = res; g.ldres = ldres; g.res_rows = res_rows;
   g.accumulate = accumulate; g.c_f32 = c_f32; g.c_bf16 = c_bf16; g.ldc = ldc; g.ws = nullptr;
+  g.dbg = g_gemm_debug;
   g.nbm = (int)((M + bm - 1) / bm);
   g.nbn = (int)((N + bn - 1) / bn);
   const int64_t tiles = (int64_t)g.nbm * g.nbn;
@@ -745,7 +1018,26 @@ extern "C" int enh_gemm_bf16_ws(const enh_bf16* A, int64_t lda, int trans_a, con
       return true;
     }();
     (void)w2_attr;
-    hipLaunchKernelGGL(table[(trans_a ? 2 : 0) + (trans_b ? 1 : 0)][epi_mode(g)], grid, dim3(256), (size_t)(2 * W2_SLOT + W2_BIAS_BYTES), s, g);
+    const int mode = epi_mode(g);
+    if (gemm_persistent(pl, trans_a, K, mode) && (!res || res_rows == M)) {
+      // persistent form: one workgroup per CU walks the tiles
+#define W2P_ROW(TB_) {nullptr, gemm_bf16_w256p_kernel<false, TB_, EPI_BF16>, gemm_bf16_w256p_kernel<false, TB_, EPI_BF16_BIAS_TANH>, gemm_bf16_w256p_kernel<false, TB_, EPI_BF16_DTANH>, \
+                      gemm_bf16_w256p_kernel<false, TB_, EPI_F32_BIAS_RES>, gemm_bf16_w256p_kernel<false, TB_, EPI_F32>, nullptr, nullptr}
+      static const w256_fn ptable[2][EPI_NMODES] = {W2P_ROW(false), W2P_ROW(true)};
+#undef W2P_ROW
+      static const int n_cu = [] {
+        int dev = 0, n = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        for (int l = 0; l < 2; ++l)
+          for (int e = 0; e < EPI_NMODES; ++e)
+            if (ptable[l][e]) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ptable[l][e]), hipFuncAttributeMaxDynamicSharedMemorySize, W2P_LDS_BYTES);
+        return n > 0 ? n : 256;
+      }();
+      const int64_t wgs = tiles < n_cu ? tiles : n_cu;
+      hipLaunchKernelGGL(ptable[trans_b ? 1 : 0][mode], dim3((unsigned)wgs), dim3(256), (size_t)W2P_LDS_BYTES, s, g);
+    } else
+    hipLaunchKernelGGL(table[(trans_a ? 2 : 0) + (trans_b ? 1 : 0)][mode], grid, dim3(256), (size_t)(2 * W2_SLOT + W2_BIAS_BYTES), s, g);
   } else if (family == 3) LAUNCH(gemm_bf16_pipe2_kernel, 256, lds2);
   else LAUNCH(gemm_bf16_kernel, 256, lds2);
 #undef LAUNCH

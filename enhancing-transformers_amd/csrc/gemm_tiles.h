@@ -32,6 +32,7 @@ struct GemmArgs {
   float* c_f32; uint16_t* c_bf16; int64_t ldc;
   int nbm, nbn;
   int splits;  // number of K-slices (1 = no split-K; otherwise a multiple of 8)
+  int dbg;     // laboratory switches of the persistent kernel (0 in every product call)
 };
 
 // global -> registers: one 128 x 64 (row layout) or 64 x 128 (kmaj layout) bf16 operand tile, 4 x 16 B per thread
@@ -234,15 +235,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& args, f32x4 (&acc)
 }
 
 // tile scheduling shared by both kernels
-__device__ __forceinline__ void gemm_tile_coords(const GemmArgs& args, int& split, int& tile_m, int& tile_n) {
+__device__ __forceinline__ void gemm_tile_coords_of(const GemmArgs& args, int block, int& split, int& tile_m, int& tile_n) {
   // (1) XCD-aware: workgroup b runs on XCD b % 8 -> give each XCD a contiguous run of tile slots;
   // (2) grouped order inside the run: 8 row-panels x all column tiles, row-fastest, so the ~64 tiles an XCD has in
   //     flight form an ~8 x 8 patch whose A and B panels (8 x 196 KB each at K = 768) both stay in its 4 MiB L2.
   const int nwg = args.nbm * args.nbn;  // tiles per K-split
   // (tried: pinning each K-slice of a split-K launch to one XCD halves the fabric traffic PMC reports, but runs 10-15 % slower —
   //  the duplicated fetches were Infinity-Cache hits, and spreading a slice over all XCDs gives more channel parallelism)
-  split = blockIdx.x / nwg;
-  int bid = blockIdx.x - split * nwg;
+  split = block / nwg;
+  int bid = block - split * nwg;
   {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, pos = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
@@ -252,6 +253,9 @@ __device__ __forceinline__ void gemm_tile_coords(const GemmArgs& args, int& spli
   const int rows = (args.nbm - grp * 8) < 8 ? (args.nbm - grp * 8) : 8;
   tile_m = grp * 8 + within % rows;
   tile_n = within / rows;
+}
+__device__ __forceinline__ void gemm_tile_coords(const GemmArgs& args, int& split, int& tile_m, int& tile_n) {
+  gemm_tile_coords_of(args, (int)blockIdx.x, split, tile_m, tile_n);
 }
 
 

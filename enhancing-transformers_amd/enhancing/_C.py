@@ -47,6 +47,7 @@ SIGNATURES = {
     "enh_gemm_bf16_workspace_bytes": (_sz, [_i32, _i32, _i64, _i64, _i64]),
     "enh_gemm_set_kernel": (_i32, [_i32]),
     "enh_gemm_bf16_variant": (_c.c_char_p, [_i32, _i32, _i64, _i64, _i64]),
+    "enh_gemm_bf16_variant_mode": (_c.c_char_p, [_i32, _i32, _i64, _i64, _i64, _i32]),
     "enh_attention_set_kernel": (_i32, [_i32, _i32, _i32]),
     "enh_attention_forward": (_i32, [_vp, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp]),
     "enh_attention_backward": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp]),
@@ -94,7 +95,7 @@ SIGNATURES = {
 }
 
 _LIB = None
-ABI_VERSION = 6   # ENH_ABI_VERSION of the include/enh_hip.h these signatures were written against
+ABI_VERSION = 7   # ENH_ABI_VERSION of the include/enh_hip.h these signatures were written against
 
 
 def lib():
@@ -115,9 +116,9 @@ def lib():
         # the binding, never inside the library (reg = 0, pipe2 = 3, w256 = 7)
         sel = os.environ.get("ENH_GEMM_KERNEL")
         if sel:
-            fam = {"reg": 0, "pipe2": 3, "w256": 7}.get(sel)
+            fam = {"reg": 0, "pipe2": 3, "w256": 7, "w256p": 8}.get(sel)
             if fam is None:
-                raise RuntimeError(f"ENH_GEMM_KERNEL={sel!r}: expected reg | pipe2 | w256")
+                raise RuntimeError(f"ENH_GEMM_KERNEL={sel!r}: expected reg | pipe2 | w256 | w256p")
             _check_rc = L.enh_gemm_set_kernel(fam)
             if _check_rc != 0:
                 raise RuntimeError(L.enh_last_error().decode())
@@ -307,10 +308,12 @@ def gemm(a, b, M: int, N: int, K: int, trans_a: bool = False, trans_b: bool = Fa
     if TIMER is None:
         _check(lib().enh_gemm_bf16_ws(*args), "enh_gemm_bf16")
     else:  # label with the symbol rocprofv3 will report, e.g. "gemm_bf16_pipe2_kernel<false, true>" / "gemm_bf16_w256_kernel<false, false, 1>"
-        fam = lib().enh_gemm_bf16_variant(int(trans_a), int(trans_b), M, N, K).decode()
+        mode = _epi_mode_label(accumulate, ws is not None, out_f32 is not None, out_bf16 is not None, bias is not None, act, res is not None)
+        # (a position-table residual, res_rows != M, is not the persistent kernel's case: ask with the generic mode)
+        fam = lib().enh_gemm_bf16_variant_mode(int(trans_a), int(trans_b), M, N, K, 0 if (res is not None and res_rows != M) else mode).decode()
         targs = f"{'true' if trans_a else 'false'}, {'true' if trans_b else 'false'}"
-        if fam == "gemm_bf16_w256_kernel":   # its epilogue mode is a template parameter (gemm.hip epi_mode(), mirrored here for the label only)
-            targs += f", {_epi_mode_label(accumulate, ws is not None, out_f32 is not None, out_bf16 is not None, bias is not None, act, res is not None)}"
+        if fam in ("gemm_bf16_w256_kernel", "gemm_bf16_w256p_kernel"):   # the epilogue mode is a template parameter (gemm.hip epi_mode(), mirrored here for the label only)
+            targs += f", {mode}"
         TIMER.run(f"{fam}<{targs}>", 2.0 * M * N * K, lambda: _check(lib().enh_gemm_bf16_ws(*args), "enh_gemm_bf16"))
 
 
