@@ -624,6 +624,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // =================================================================================================
 #define W2P_STAGE_BYTES 4096
 #define W2P_LDS_BYTES (2 * W2_SLOT + W2_BIAS_BYTES + 4 * W2P_STAGE_BYTES)
+#define W2P_LDS_BYTES_DTANH (2 * W2_SLOT + 8 * W2P_STAGE_BYTES)   // 160 KiB: the whole LDS of a CU
 
 // accumulator -> vector register AT THIS POINT of the instruction stream (the register allocator otherwise copies all 256 accumulators out at the top
 // of the epilogue: 256 live registers, spills, and scratch reloads are vector-memory operations that wait on the next tile's requests)
@@ -634,7 +635,8 @@ __device__ __forceinline__ float acc_read(float a) {
 }
 
 template <int MODE>
-__device__ __forceinline__ void gemm_epilogue_p(const GemmArgs& args, f32x16 (&acc)[4][4], int64_t mw, int64_t nw, int lane_in, float* wave_bias, unsigned char* st) {
+__device__ __forceinline__ void gemm_epilogue_p(const GemmArgs& args, f32x16 (&acc)[4][4], int64_t mw, int64_t nw, int lane_in, float* wave_bias, unsigned char* st,
+                                                unsigned char* at) {
   // everything lane-derived is recomputed per tile: hoisted out of the persistent loop, the ~40 loop-invariant addresses would be carried through the
   // K loop and spilled (scratch reloads are vector-memory operations: they would put vmcnt waits on the next tile's requests into the epilogue)
   int lane = lane_in;
@@ -645,25 +647,39 @@ __device__ __forceinline__ void gemm_epilogue_p(const GemmArgs& args, f32x16 (&a
   if (HAS_BIAS && lane < 32) *reinterpret_cast<float4*>(wave_bias + lane * 4) = *reinterpret_cast<const float4*>(args.bias + nw + lane * 4);
   const int rrow = lane >> 3, rc = lane & 7;
   if (OUT16) {
-    EpiIn in[4][4][4];
-    const unsigned aux_off = (unsigned)l31 * (unsigned)args.ldaux + 4u * (unsigned)hi;
-    // the saved tanh output: all four row-blocks before the first store (128 registers; the K loop's fragment registers are dead here)
-    constexpr int AUX_AHEAD = 4;
+    // The saved tanh output (tanh' mode) is read the way the output is written: whole 128-byte row segments, 16 bytes per lane (32 x 64 block = four
+    // loads), all eight blocks of the wave's tile requested before the first store (128 registers; the K loop's fragment registers are dead here),
+    // and brought into the accumulator layout through a second wave-private LDS tile.  Read in the accumulator layout directly (8 bytes per lane,
+    // 32 rows x 16 B per instruction) the same bytes cost the L1 eight times the line accesses: ~4 us of a 32-us tile.
+    u32x4 a4[8][4];
+    const unsigned aux_off = (unsigned)rrow * (unsigned)args.ldaux + (unsigned)rc * 8u;
     if (MODE == EPI_BF16_DTANH) {
 #pragma unroll
-      for (int i = 0; i < AUX_AHEAD; ++i)
+      for (int b = 0; b < 8; ++b)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int g4 = 0; g4 < 4; ++g4)
-            in[i][j][g4].aux = *reinterpret_cast<const uint2*>(args.aux + ((mw + i * 32) * args.ldaux + nw + j * 32 + 8 * g4) + aux_off);
+        for (int p = 0; p < 4; ++p)
+          a4[b][p] = *reinterpret_cast<const u32x4*>(args.aux + ((mw + (b >> 1) * 32 + p * 8) * args.ldaux + nw + (b & 1) * 64) + aux_off);
     }
     const int wsw = (l31 >> 1) & 7;
     const unsigned out_off = (unsigned)rrow * (unsigned)args.ldc + (unsigned)rc * 8u;
+    uint2 hq[2][8];   // the block's saved values in the accumulator layout; the next block's are fetched from LDS while this one is computed
+    if (MODE == EPI_BF16_DTANH) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) *reinterpret_cast<u32x4*>(at + (p * 8 + rrow) * 128 + ((rc ^ (((p * 8 + rrow) >> 1) & 7)) << 4)) = a4[0][p];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) hq[0][c] = *reinterpret_cast<const uint2*>(at + l31 * 128 + ((c ^ wsw) << 4) + hi * 8);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int jh = 0; jh < 2; ++jh) {
+        const int b = i * 2 + jh;
+        if (MODE == EPI_BF16_DTANH && b + 1 < 8) {
+#pragma unroll
+          for (int p = 0; p < 4; ++p) *reinterpret_cast<u32x4*>(at + (p * 8 + rrow) * 128 + ((rc ^ (((p * 8 + rrow) >> 1) & 7)) << 4)) = a4[b + 1][p];
+#pragma unroll
+          for (int c = 0; c < 8; ++c) hq[(b + 1) & 1][c] = *reinterpret_cast<const uint2*>(at + l31 * 128 + ((c ^ wsw) << 4) + hi * 8);
+        }
 #pragma unroll
         for (int j2 = 0; j2 < 2; ++j2)
 #pragma unroll
@@ -671,7 +687,9 @@ __device__ __forceinline__ void gemm_epilogue_p(const GemmArgs& args, f32x16 (&a
             const int j = jh * 2 + j2;
             float v[4] = {acc_read(acc[i][j][g4 * 4 + 0]), acc_read(acc[i][j][g4 * 4 + 1]), acc_read(acc[i][j][g4 * 4 + 2]), acc_read(acc[i][j][g4 * 4 + 3])};
             const float4 b4 = HAS_BIAS ? *reinterpret_cast<const float4*>(wave_bias + j * 32 + 8 * g4 + 4 * hi) : make_float4(0.f, 0.f, 0.f, 0.f);
-            epi_value<MODE>(args, v, in[MODE == EPI_BF16_DTANH ? i % AUX_AHEAD : 0][MODE == EPI_BF16_DTANH ? j : 0][MODE == EPI_BF16_DTANH ? g4 : 0], b4, nw + j * 32 + 8 * g4 + 4 * hi);
+            EpiIn in;
+            in.aux = hq[MODE == EPI_BF16_DTANH ? (b & 1) : 0][MODE == EPI_BF16_DTANH ? j2 * 4 + g4 : 0];
+            epi_value<MODE>(args, v, in, b4, nw + j * 32 + 8 * g4 + 4 * hi);
             const u32x2 o_ = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
             *reinterpret_cast<u32x2*>(st + l31 * 128 + (((j2 * 4 + g4) ^ wsw) << 4) + hi * 8) = o_;
           }
@@ -687,57 +705,54 @@ __device__ __forceinline__ void gemm_epilogue_p(const GemmArgs& args, f32x16 (&a
         __builtin_amdgcn_sched_barrier(0);   // one block at a time: the scheduler otherwise reads all 256 accumulators first
       }
   } else {
+    // f32 outputs: 32 x 32 blocks.  The residual stream is read in the OUTPUT's layout (whole 128-byte row segments, 16 bytes per lane) and added after
+    // the transposition, two row-blocks (128 registers) ahead: the first two before any store, the others as their registers come free.
     float* dst = args.c_f32 + mw * args.ldc + nw;
-    // the residual comes in the accumulator layout, two row-blocks (128 registers) at a time: the first pair is requested before any store; the second
-    // pair's wait is the one place where this mode waits with its own stores in flight
-    EpiIn in[2][4][4];
     const unsigned out_off = (unsigned)rrow * (unsigned)args.ldc + (unsigned)rc * 4u;
-    const unsigned res_off = (unsigned)l31 * (unsigned)args.ldres + 4u * (unsigned)hi;
+    const unsigned res_off = (unsigned)rrow * (unsigned)args.ldres + (unsigned)rc * 4u;   // res_rows == M here (launcher): no row wrap
+    f32x4 rr[2][4][4];
+    if (MODE == EPI_F32_BIAS_RES) {
 #pragma unroll
-    for (int ih = 0; ih < 2; ++ih) {
-      if (MODE == EPI_F32_BIAS_RES) {
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
+          for (int p = 0; p < 4; ++p)
+            rr[i][j][p] = *reinterpret_cast<const f32x4*>(args.res + ((mw + i * 32 + p * 8) * args.ldres + nw + j * 32) + res_off);
+    }
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4)   // res_rows == M here (launcher): no row wrap
-              in[ii][j][g4].res = *reinterpret_cast<const float4*>(args.res + ((mw + (ih * 2 + ii) * 32) * args.ldres + nw + j * 32 + 8 * g4) + res_off);
-        __builtin_amdgcn_s_waitcnt(0x0F70);
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const f32x4 o_ = {acc[i][j][g4 * 4 + 0], acc[i][j][g4 * 4 + 1], acc[i][j][g4 * 4 + 2], acc[i][j][g4 * 4 + 3]};
+          *reinterpret_cast<f32x4*>(st + l31 * 128 + (((g4 * 2 + hi) ^ (l31 & 7)) << 4)) = o_;
+        }
+        f32x4 w[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int row = p * 8 + rrow;
+          w[p] = *reinterpret_cast<const f32x4*>(st + row * 128 + ((rc ^ (row & 7)) << 4));
+        }
+        if (MODE == EPI_F32_BIAS_RES) {
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(wave_bias + j * 32 + rc * 4);
+#pragma unroll
+          for (int p = 0; p < 4; ++p) w[p] = (w[p] + b4) + rr[i & 1][j][p];   // (acc + bias) + residual, the order of every other kernel family
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+          if (!(args.dbg & 1)) *reinterpret_cast<f32x4*>(dst + ((int64_t)(i * 32 + p * 8) * args.ldc + j * 32) + out_off) = w[p];
         __builtin_amdgcn_sched_barrier(0);
       }
+      if (MODE == EPI_F32_BIAS_RES && i + 2 < 4) {
 #pragma unroll
-      for (int ii = 0; ii < 2; ++ii)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int i = ih * 2 + ii;
-#pragma unroll
-          for (int g4 = 0; g4 < 4; ++g4) {
-            if (MODE == EPI_F32_BIAS_RES) {
-              const float4 b4 = *reinterpret_cast<const float4*>(wave_bias + j * 32 + 8 * g4 + 4 * hi);
-              const float4 r4 = in[ii][j][g4].res;
-              const f32x4 o_ = {acc_read(acc[i][j][g4 * 4 + 0]) + b4.x + r4.x, acc_read(acc[i][j][g4 * 4 + 1]) + b4.y + r4.y,
-                                acc_read(acc[i][j][g4 * 4 + 2]) + b4.z + r4.z, acc_read(acc[i][j][g4 * 4 + 3]) + b4.w + r4.w};
-              *reinterpret_cast<f32x4*>(st + l31 * 128 + (((g4 * 2 + hi) ^ (l31 & 7)) << 4)) = o_;
-            } else {
-              const f32x4 o_ = {acc[i][j][g4 * 4 + 0], acc[i][j][g4 * 4 + 1], acc[i][j][g4 * 4 + 2], acc[i][j][g4 * 4 + 3]};
-              *reinterpret_cast<f32x4*>(st + l31 * 128 + (((g4 * 2 + hi) ^ (l31 & 7)) << 4)) = o_;
-            }
-          }
-          f32x4 w[4];
-#pragma unroll
-          for (int p = 0; p < 4; ++p) {
-            const int row = p * 8 + rrow;
-            w[p] = *reinterpret_cast<const f32x4*>(st + row * 128 + ((rc ^ (row & 7)) << 4));
-          }
-#pragma unroll
-          for (int p = 0; p < 4; ++p) {
-            const int row = p * 8 + rrow;
-            (void)row;
-            if (!(args.dbg & 1)) *reinterpret_cast<f32x4*>(dst + ((int64_t)(i * 32 + p * 8) * args.ldc + j * 32) + out_off) = w[p];
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
+          for (int p = 0; p < 4; ++p)
+            rr[i & 1][j][p] = *reinterpret_cast<const f32x4*>(args.res + ((mw + (i + 2) * 32 + p * 8) * args.ldres + nw + j * 32) + res_off);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   }
 }
@@ -763,8 +778,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const uint16_t* const base_e = stage_a ? w256_src<TA>(args.A, args.lda, 0, 0, 0, lane) : w256_src<TB>(args.B, args.ldb, 0, 0, 0, lane);
   const uint16_t* const base_o = stage_a ? w256_src<TA>(args.A, args.lda, 0, 0, 1, lane) : w256_src<TB>(args.B, args.ldb, 0, 0, 1, lane);
   unsigned char* const my_sub = smem + wave * G_TILE_BYTES;
+  // behind the two slots: bias strips (2 KiB) + four store tiles; the tanh' mode has no bias and puts four more tiles (the saved tanh output on its
+  // way into the accumulator layout) in front of the store tiles: 160 KiB in all
   float* const wave_bias = reinterpret_cast<float*>(smem + 2 * W2_SLOT) + wave * 128;
-  unsigned char* const st = smem + 2 * W2_SLOT + W2_BIAS_BYTES + wave * W2P_STAGE_BYTES;
+  unsigned char* const at = smem + 2 * W2_SLOT + wave * W2P_STAGE_BYTES;
+  unsigned char* const st = smem + 2 * W2_SLOT + (EPI == EPI_BF16_DTANH ? 4 * W2P_STAGE_BYTES : W2_BIAS_BYTES) + wave * W2P_STAGE_BYTES;
 
   int vt = (int)blockIdx.x, split_, tile_m, tile_n;
   gemm_tile_coords_of(args, vt, split_, tile_m, tile_n);
@@ -834,7 +852,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     // (laboratory, dbg & 8: every tile of the workgroup is written to one fixed 128 x 128 block -> the stores stay in L2)
     if (!(args.dbg & 2)) gemm_epilogue_p<EPI>(args, acc, (args.dbg & 8) ? (int64_t)(blockIdx.x & 255) * 128 : m0 + wm * 128,
-                                              (args.dbg & 8) ? 0 : n0 + wn * 128, lane, wave_bias, st);
+                                              (args.dbg & 8) ? 0 : n0 + wn * 128, lane, wave_bias, st, at);
     W2_FENCE();
     if (last_tile) break;
     vt = vnext;
@@ -1031,11 +1049,12 @@ extern "C" int enh_gemm_bf16_ws(const enh_bf16* A, int64_t lda, int trans_a, con
         (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
         for (int l = 0; l < 2; ++l)
           for (int e = 0; e < EPI_NMODES; ++e)
-            if (ptable[l][e]) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ptable[l][e]), hipFuncAttributeMaxDynamicSharedMemorySize, W2P_LDS_BYTES);
+            if (ptable[l][e]) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ptable[l][e]), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        e == EPI_BF16_DTANH ? W2P_LDS_BYTES_DTANH : W2P_LDS_BYTES);
         return n > 0 ? n : 256;
       }();
       const int64_t wgs = tiles < n_cu ? tiles : n_cu;
-      hipLaunchKernelGGL(ptable[trans_b ? 1 : 0][mode], dim3((unsigned)wgs), dim3(256), (size_t)W2P_LDS_BYTES, s, g);
+      hipLaunchKernelGGL(ptable[trans_b ? 1 : 0][mode], dim3((unsigned)wgs), dim3(256), (size_t)(mode == EPI_BF16_DTANH ? W2P_LDS_BYTES_DTANH : W2P_LDS_BYTES), s, g);
     } else
     hipLaunchKernelGGL(table[(trans_a ? 2 : 0) + (trans_b ? 1 : 0)][mode], grid, dim3(256), (size_t)(2 * W2_SLOT + W2_BIAS_BYTES), s, g);
   } else if (family == 3) LAUNCH(gemm_bf16_pipe2_kernel, 256, lds2);
