@@ -636,7 +636,7 @@ __device__ __forceinline__ float acc_read(float a) {
 
 template <int MODE>
 __device__ __forceinline__ void gemm_epilogue_p(const GemmArgs& args, f32x16 (&acc)[4][4], int64_t mw, int64_t nw, int lane_in, float* wave_bias, unsigned char* st,
-                                                unsigned char* at) {
+                                                unsigned char* at, const float4& bias4) {
   // everything lane-derived is recomputed per tile: hoisted out of the persistent loop, the ~40 loop-invariant addresses would be carried through the
   // K loop and spilled (scratch reloads are vector-memory operations: they would put vmcnt waits on the next tile's requests into the epilogue)
   int lane = lane_in;
@@ -644,7 +644,9 @@ __device__ __forceinline__ void gemm_epilogue_p(const GemmArgs& args, f32x16 (&a
   const int l31 = lane & 31, hi = lane >> 5;
   constexpr bool HAS_BIAS = MODE == EPI_BF16_BIAS_TANH || MODE == EPI_F32_BIAS_RES;
   constexpr bool OUT16 = MODE == EPI_BF16 || MODE == EPI_BF16_BIAS_TANH || MODE == EPI_BF16_DTANH;
-  if (HAS_BIAS && lane < 32) *reinterpret_cast<float4*>(wave_bias + lane * 4) = *reinterpret_cast<const float4*>(args.bias + nw + lane * 4);
+  // the tile's bias values were requested by the caller a K loop ago (bias4, lanes 0-31): requested here, the wait for them would also be a wait for
+  // the next tile's operand requests, which are older (vmcnt retires in order)
+  if (HAS_BIAS && lane < 32) *reinterpret_cast<float4*>(wave_bias + lane * 4) = bias4;
   const int rrow = lane >> 3, rc = lane & 7;
   if (OUT16) {
     // The saved tanh output (tanh' mode) is read the way the output is written: whole 128-byte row segments, 16 bytes per lane (32 x 64 block = four
@@ -701,7 +703,7 @@ __device__ __forceinline__ void gemm_epilogue_p(const GemmArgs& args, f32x16 (&a
         }
 #pragma unroll
         for (int p = 0; p < 4; ++p)
-          if (!(args.dbg & 1)) *reinterpret_cast<u32x4*>(args.c_bf16 + ((mw + i * 32 + p * 8) * args.ldc + nw + jh * 64) + out_off) = w[p];   // uniform base + 32-bit lane offset
+          *reinterpret_cast<u32x4*>(args.c_bf16 + ((mw + i * 32 + p * 8) * args.ldc + nw + jh * 64) + out_off) = w[p];   // uniform base + 32-bit lane offset
         __builtin_amdgcn_sched_barrier(0);   // one block at a time: the scheduler otherwise reads all 256 accumulators first
       }
   } else {
@@ -742,7 +744,7 @@ __device__ __forceinline__ void gemm_epilogue_p(const GemmArgs& args, f32x16 (&a
         }
 #pragma unroll
         for (int p = 0; p < 4; ++p)
-          if (!(args.dbg & 1)) *reinterpret_cast<f32x4*>(dst + ((int64_t)(i * 32 + p * 8) * args.ldc + j * 32) + out_off) = w[p];
+          *reinterpret_cast<f32x4*>(dst + ((int64_t)(i * 32 + p * 8) * args.ldc + j * 32) + out_off) = w[p];
         __builtin_amdgcn_sched_barrier(0);
       }
       if (MODE == EPI_F32_BIAS_RES && i + 2 < 4) {
@@ -788,15 +790,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   gemm_tile_coords_of(args, vt, split_, tile_m, tile_n);
   const uint16_t *gsrc_e, *gsrc_o;
   {
-    const int64_t x0 = (stage_a ? (int64_t)((args.dbg & 4) ? (tile_m & 7) : tile_m) : (int64_t)tile_n) * 256 + xw;
+    const int64_t x0 = (stage_a ? (int64_t)tile_m : (int64_t)tile_n) * 256 + xw;
     gsrc_e = base_e + x0 * x_step; gsrc_o = base_o + x0 * x_step;
   }
   f32x16 acc[4][4];
   s16x8 fa0[4], fb0[4], fa1[4], fb1[4];
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-  // XCD stagger (laboratory: dbg bits 8..15 = units of ~512 cycles per XCD step): the eight XCDs' epilogues — and their store bursts — stop coinciding
-  for (int i = ((int)blockIdx.x & 7) * ((args.dbg >> 8) & 255); i > 0; --i) __builtin_amdgcn_s_sleep(8);
   // prologue of the workgroup: stages 0 and 1 of its first tile
 #pragma unroll
   for (int u = 0; u < 16; ++u) W2_ISSUE_ONE(0, u);
@@ -827,12 +827,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       W2_FENCE();
       W2_KSTEP(fa1, fb1, fa0, fb0, par ^ 1, 0, true, par, 0, true);      // + pieces 0-7 of stage 2
     }
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);   // this tile's bias, for the epilogue's LDS strip: requested now, consumed a K loop later
+    if ((EPI == EPI_BF16_BIAS_TANH || EPI == EPI_F32_BIAS_RES) && lane < 32) bias4 = *reinterpret_cast<const float4*>(args.bias + n0 + wn * 128 + lane * 4);
     for (int j = 1; j < nst; ++j) {
       const int slot = par ^ (j & 1);
       W2_KSTEP(fa0, fb0, fa1, fb1, slot, 1, true, slot ^ 1, 8, true);      // + pieces 8-15 of stage j+1
       if (j == nst - 2) {   // stage j+2 is the NEXT tile's stage 0
         gemm_tile_coords_of(args, vnext, split_, tile_m, tile_n);
-        const int64_t x0 = (stage_a ? (int64_t)((args.dbg & 4) ? (tile_m & 7) : tile_m) : (int64_t)tile_n) * 256 + xw;
+        const int64_t x0 = (stage_a ? (int64_t)tile_m : (int64_t)tile_n) * 256 + xw;
         gsrc_e = base_e + x0 * x_step; gsrc_o = base_o + x0 * x_step;
       } else {
         W2_ADVANCE();
@@ -850,15 +852,194 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int u = 8; u < 16; ++u) W2_ISSUE_ONE(slot, u);
       W2_ADVANCE();
     }
-    // (laboratory, dbg & 8: every tile of the workgroup is written to one fixed 128 x 128 block -> the stores stay in L2)
-    if (!(args.dbg & 2)) gemm_epilogue_p<EPI>(args, acc, (args.dbg & 8) ? (int64_t)(blockIdx.x & 255) * 128 : m0 + wm * 128,
-                                              (args.dbg & 8) ? 0 : n0 + wn * 128, lane, wave_bias, st, at);
+    gemm_epilogue_p<EPI>(args, acc, m0 + wm * 128, n0 + wn * 128, lane, wave_bias, st, at, bias4);
     W2_FENCE();
     if (last_tile) break;
     vt = vnext;
     par ^= nst & 1;
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);   // the dummy requests write LDS: they must have landed before the workgroup's LDS is released
+}
+// =================================================================================================
+// "w256r": w256p with the A operand REGISTER-STAGED (round 3).  The two-slot LDS ring gives a request at most ~3/4 of a K stage (~0.8 us) to land
+// — enough for the L2-resident weights, not for the activation rows that stream from HBM while the previous tile's stores drain
+// (profiles/r03_gemm_persistent_lab.txt: with A resident in L2 the same kernel is 6-15 % faster, and only when it also stores).  LDS has no room for
+// a third slot, the register file does (the main loop needs ~100 of 256 vector registers): under the first k-step of stage j every wave writes its
+// 8 KiB share of A(j+1) from registers into the slot stage j+1 will read and re-uses the registers at once for its share of A(j+3).  B still arrives by
+// LDS-DMA, each wave's 8 KiB share requested under the last k-step of stage j for stage j+2.  vmcnt retires in order, so A(j+3) has to be complete
+// when B(j+2) — requested after it — is awaited at the end of stage j+1: 1.75 stages after its request instead of 0.5-0.75 (a deeper register
+// pipeline would not be allowed to stay in flight any longer: two sets are all the scheme can use).
+// Per stage and wave: 8 global loads (A) + 8 LDS-DMA (B) — the same 16 vector-memory operations as w256 — plus 8 ds_write_b128.
+// Waits: B(j+1) is awaited with vmcnt(8) (the 8 A loads of this stage are the only younger operations; everything older, the A registers about to be
+// written included, is then complete) — except in a tile's first stage, where the previous tile's stores are younger too and are NOT waited for.
+// Needs an even number of K stages, at least 6.
+// =================================================================================================
+#define W2R_D 2
+template <bool TB, int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_bf16_w256r_kernel(const GemmArgs args) {
+  constexpr bool TA = false;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntiles = args.nbm * args.nbn;
+  const int nst = (int)(args.K / G_BK);   // even, >= 6 (launcher)
+  const int sub = wave >> 1, half = wave & 1;   // this wave stages slabs half*8 .. half*8+7 of sub-tile `sub` of BOTH operands
+
+  const uint16_t* const baseA_e = w256_src<false>(args.A, args.lda, sub * 128 + half * 64, 0, 0, lane);
+  const uint16_t* const baseA_o = w256_src<false>(args.A, args.lda, sub * 128 + half * 64, 0, 1, lane);
+  const uint16_t* const baseB_e = TB ? w256_src<true>(args.B, args.ldb, sub * 128, half * 32, 0, lane) : w256_src<false>(args.B, args.ldb, sub * 128 + half * 64, 0, 0, lane);
+  const uint16_t* const baseB_o = TB ? w256_src<true>(args.B, args.ldb, sub * 128, half * 32, 1, lane) : w256_src<false>(args.B, args.ldb, sub * 128 + half * 64, 0, 1, lane);
+  const int64_t pairA = 16 * args.lda, pairB = (TB ? 8 : 16) * args.ldb;
+  const int64_t stageB = TB ? (int64_t)G_BK * args.ldb : (int64_t)G_BK;
+  const int64_t xB_step = TB ? 1 : args.ldb;
+  const int a_lds = sub * G_TILE_BYTES + half * 8192;
+  const int b_lds = (2 + sub) * G_TILE_BYTES + half * 8192;
+  float* const wave_bias = reinterpret_cast<float*>(smem + 2 * W2_SLOT) + wave * 128;
+  unsigned char* const at = smem + 2 * W2_SLOT + wave * W2P_STAGE_BYTES;
+  unsigned char* const st = smem + 2 * W2_SLOT + (EPI == EPI_BF16_DTANH ? 4 * W2P_STAGE_BYTES : W2_BIAS_BYTES) + wave * W2P_STAGE_BYTES;
+
+  int vt = (int)blockIdx.x, split_, tile_m, tile_n;
+  gemm_tile_coords_of(args, vt, split_, tile_m, tile_n);
+  const uint16_t *gA_e = baseA_e + (int64_t)tile_m * 256 * args.lda, *gA_o = baseA_o + (int64_t)tile_m * 256 * args.lda;
+  const uint16_t *gB_e = baseB_e + (int64_t)tile_n * 256 * xB_step, *gB_o = baseB_o + (int64_t)tile_n * 256 * xB_step;
+
+  f32x16 acc[4][4];
+  s16x8 fa0[4], fb0[4], fa1[4], fb1[4];
+  u32x4 ra[W2R_D][8];
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  // vmcnt(8 + the epilogue's stores), lgkmcnt(0): 32 stores for bf16 outputs -> vmcnt(40); 64 for f32 -> more than the counter holds (63): B(1) is
+  // then complete by the time the 8 loads behind the stores have issued at all
+  constexpr int EPI_STORES_WAIT = (EPI == EPI_F32 || EPI == EPI_F32_BIAS_RES) ? 0xC07F : 0x8078;
+
+#define W2R_APTR(U, KOFF) ((((U) & 1) ? gA_o : gA_e) + ((U) >> 1) * pairA + (KOFF))
+#define W2R_BPTR(U, KOFF) ((((U) & 1) ? gB_o : gB_e) + ((U) >> 1) * pairB + (KOFF))
+#define W2R_A_LOAD(SET, U, KOFF) ra[SET][U] = *reinterpret_cast<const u32x4*>(W2R_APTR(U, KOFF))
+#define W2R_A_WRITE(SLOT, SET, U) *reinterpret_cast<u32x4*>(smem + (SLOT) * W2_SLOT + a_lds + (U) * 1024 + lane * 16) = ra[SET][U]
+#define W2R_A_DMA(SLOT, U, KOFF) __builtin_amdgcn_global_load_lds((const GLB_AS void*)W2R_APTR(U, KOFF), (LDS_AS void*)(smem + (SLOT) * W2_SLOT + a_lds + (U) * 1024), 16, 0, 0)
+#define W2R_B_DMA(SLOT, U, KOFF) __builtin_amdgcn_global_load_lds((const GLB_AS void*)W2R_BPTR(U, KOFF), (LDS_AS void*)(smem + (SLOT) * W2_SLOT + b_lds + (U) * 1024), 16, 0, 0)
+  // k16 step 0 of a stage: + fragment reads of k-step 1 ; under every odd MFMA: the A share of the next stage leaves its registers for LDS and the
+  // registers are re-used at once for the share three stages further on
+#define W2R_K0(FA, FB, RA, RB, RSLOT, ZERO, WSLOT, SET)                                                                           \
+  do {                                                                                                                            \
+    if (TA || TB) __builtin_amdgcn_s_waitcnt(0xC07F);                                                                             \
+    W2_FENCE();                                                                                                                   \
+    _Pragma("unroll") for (int q_ = 0; q_ < 16; ++q_) {                                                                           \
+      if (ZERO) { W2_MMZ(q_, FA, FB); } else { W2_MM(q_, FA, FB); }                                                               \
+      if (q_ < 8) { W2_READ_ONE(RA, RB, RSLOT, 1, q_); }                                                                          \
+      if (q_ & 1) { W2R_A_WRITE(WSLOT, SET, q_ >> 1); W2R_A_LOAD(SET, q_ >> 1, 0); }                                              \
+      W2_FENCE();                                                                                                                 \
+    }                                                                                                                             \
+  } while (0)
+#define W2R_K12(FA, FB, RA, RB, RSLOT, RS)                                                                                        \
+  do {                                                                                                                            \
+    if (TA || TB) __builtin_amdgcn_s_waitcnt(0xC07F);                                                                             \
+    W2_FENCE();                                                                                                                   \
+    _Pragma("unroll") for (int q_ = 0; q_ < 16; ++q_) {                                                                           \
+      W2_MM(q_, FA, FB);                                                                                                          \
+      if (q_ < 8) { W2_READ_ONE(RA, RB, RSLOT, RS, q_); }                                                                         \
+      W2_FENCE();                                                                                                                 \
+    }                                                                                                                             \
+  } while (0)
+#define W2R_K3(FA, FB, RA, RB, RSLOT, BSLOT)                                                                                      \
+  do {                                                                                                                            \
+    if (TA || TB) __builtin_amdgcn_s_waitcnt(0xC07F);                                                                             \
+    W2_FENCE();                                                                                                                   \
+    _Pragma("unroll") for (int q_ = 0; q_ < 16; ++q_) {                                                                           \
+      W2_MM(q_, FA, FB);                                                                                                          \
+      if (q_ < 8) { W2_READ_ONE(RA, RB, RSLOT, 0, q_); }                                                                          \
+      if (q_ & 1) { W2R_B_DMA(BSLOT, q_ >> 1, 0); }                                                                               \
+      W2_FENCE();                                                                                                                 \
+    }                                                                                                                             \
+  } while (0)
+  // one K stage (local index j): SET = (j + 1) % 2 is the register set that holds A(j+1)
+#define W2R_STAGE(ZERO, SET, WAIT)                                                                                                     \
+  do {                                                                                                                            \
+    const int slot_ = j & 1;                                                                                                      \
+    if (j == nst - 1 - W2R_D) { gA_e = baseA_e + offA_next; gA_o = baseA_o + offA_next; }   /* A(j+3) is the next tile's stage 0 */ \
+    W2R_K0(fa0, fb0, fa1, fb1, slot_, ZERO, slot_ ^ 1, SET);                                                                      \
+    gA_e += G_BK; gA_o += G_BK;                                                                                                   \
+    W2R_K12(fa1, fb1, fa0, fb0, slot_, 2);                                                                                        \
+    W2R_K12(fa0, fb0, fa1, fb1, slot_, 3);                                                                                        \
+    /* B(j+1) landed (only this stage's 8 A loads are younger; after an epilogue its stores are younger too and stay in flight) ; A(j+1) written */ \
+    __builtin_amdgcn_s_waitcnt(WAIT);                                                                                             \
+    __builtin_amdgcn_s_barrier();                                                                                                 \
+    W2_FENCE();                                                                                                                   \
+    if (j == nst - 2) { gB_e = baseB_e + offB_next; gB_o = baseB_o + offB_next; }           /* B(j+2) is the next tile's stage 0 */ \
+    W2R_K3(fa1, fb1, fa0, fb0, slot_ ^ 1, slot_);                                                                                 \
+    gB_e += stageB; gB_o += stageB;                                                                                               \
+    ++j;                                                                                                                          \
+  } while (0)
+
+  // prologue of the workgroup: A(0) by DMA -> slot 0 | A(1) -> set 1 | B(0) -> slot 0 | A(2) -> set 0 | B(1) -> slot 1   (in THIS order: the
+  // wait below leaves the last 16 in flight; fenced, because the scheduler clusters the two register groups by address otherwise)
+#pragma unroll
+  for (int u = 0; u < 8; ++u) W2R_A_DMA(0, u, 0);
+  W2_FENCE();
+#pragma unroll
+  for (int u = 0; u < 8; ++u) W2R_A_LOAD(1, u, G_BK);
+  W2_FENCE();
+#pragma unroll
+  for (int u = 0; u < 8; ++u) W2R_B_DMA(0, u, 0);
+  W2_FENCE();
+#pragma unroll
+  for (int u = 0; u < 8; ++u) W2R_A_LOAD(0, u, 2 * G_BK);
+  W2_FENCE();
+#pragma unroll
+  for (int u = 0; u < 8; ++u) W2R_B_DMA(1, u, stageB);
+  W2_FENCE();
+  gA_e += 3 * G_BK; gA_o += 3 * G_BK;
+  gB_e += 2 * stageB; gB_o += 2 * stageB;
+  __builtin_amdgcn_s_waitcnt(0x4F70);   // vmcnt(16): stage 0 landed (set 0 and B(1) are younger)
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int u = 0; u < 8; ++u) W2_READ_ONE(fa0, fb0, 0, 0, u);
+  W2_FENCE();
+
+  // The tile loop is rotated — its body runs stages 1 .. nst-1, the epilogue and the NEXT tile's stage 0 — so that the two forms of stage 0's wait
+  // (vmcnt(8) in the workgroup's first tile, vmcnt(8 + stores) after an epilogue) sit on separate paths: with one stage-0 body and a runtime flag the
+  // compiler has to assume the permissive wait on the path from the prologue and puts a vmcnt(0) in front of the next stage's register writes.  For the
+  // same reason the loop has ONE exit, at its top (a counted loop, no break): the last tile runs a stage 0 of its own re-requested operands for nothing
+  // (~1 us per launch) — a mid-loop exit left a never-taken edge from the exit path back into the loop, and with it the same vmcnt(0).
+  const int my_tiles = __builtin_amdgcn_readfirstlane((ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x);
+  int64_t m0 = (int64_t)tile_m * 256, n0 = (int64_t)tile_n * 256;
+  int vnext = vt + (int)gridDim.x;
+  if (vnext >= ntiles) vnext = vt;   // the last tile re-requests its own first stages (never consumed; drained before the kernel ends)
+  gemm_tile_coords_of(args, vnext, split_, tile_m, tile_n);
+  int64_t offA_next = (int64_t)tile_m * 256 * args.lda, offB_next = (int64_t)tile_n * 256 * xB_step;
+  int j = 0;
+  W2R_STAGE(true, 1, 0x0078);
+  for (int it = 0; it < my_tiles; ++it) {
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);   // this tile's bias, for the epilogue's LDS strip: requested now, consumed a K loop later
+    if ((EPI == EPI_BF16_BIAS_TANH || EPI == EPI_F32_BIAS_RES) && lane < 32) bias4 = *reinterpret_cast<const float4*>(args.bias + n0 + wn * 128 + lane * 4);
+    W2R_STAGE(false, 0, 0x0078);
+    while (j < nst) {
+      W2R_STAGE(false, 1, 0x0078);
+      W2R_STAGE(false, 0, 0x0078);
+    }
+    gemm_epilogue_p<EPI>(args, acc, m0 + wm * 128, n0 + wn * 128, lane, wave_bias, st, at, bias4);   // (the next wait counts this epilogue's stores)
+    W2_FENCE();
+    vt = vnext;
+    m0 = (int64_t)tile_m * 256; n0 = (int64_t)tile_n * 256;
+    vnext = vt + (int)gridDim.x;
+    if (vnext >= ntiles) vnext = vt;
+    gemm_tile_coords_of(args, vnext, split_, tile_m, tile_n);
+    offA_next = (int64_t)tile_m * 256 * args.lda; offB_next = (int64_t)tile_n * 256 * xB_step;
+    j = 0;
+    W2R_STAGE(true, 1, EPI_STORES_WAIT);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // the dummy requests write LDS / registers: landed before the workgroup's resources are released
+#undef W2R_APTR
+#undef W2R_BPTR
+#undef W2R_A_LOAD
+#undef W2R_A_WRITE
+#undef W2R_A_DMA
+#undef W2R_B_DMA
+#undef W2R_K0
+#undef W2R_K12
+#undef W2R_K3
+#undef W2R_STAGE
 }
 #undef W2_ISSUE_ONE
 #undef W2_ADVANCE
@@ -872,15 +1053,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-// kernel family: 0 = register-staged fallback (any K % 8), 3 = pipe2 (128x128), 7 = w256 (256x256, 4 waves), 8 = w256 with the persistent form (w256p)
-// wherever that serves (the per-shape default does the same; 7 pins the one-tile-per-workgroup form everywhere)
+// kernel family: 0 = register-staged fallback (any K % 8), 3 = pipe2 (128x128), 7 = w256 (256x256, 4 waves, one tile per workgroup everywhere),
+// 8 = w256 with the persistent form w256p wherever that serves, 9 = as 8 with the A-in-registers form w256r where THAT serves (= the per-shape default)
 static int g_kernel_override = -1;   // set by enh_gemm_set_kernel(): explicit state behind an explicit call, no environment lookups in the library
-static int g_gemm_debug = 0;
-extern "C" int enh_gemm_set_debug(int bits) { g_gemm_debug = bits; return ENH_OK; }   // laboratory only (tools/gemm_p_lab.py); not in the public header
 
 extern "C" int enh_gemm_set_kernel(int family) {
-  ENH_REQUIRE(family == -1 || family == 0 || family == 3 || family == 7 || family == 8, ENH_E_BADARG,
-              "enh_gemm_set_kernel: family must be -1 (auto), 0, 3, 7 or 8");
+  ENH_REQUIRE(family == -1 || family == 0 || family == 3 || family == 7 || family == 8 || family == 9, ENH_E_BADARG,
+              "enh_gemm_set_kernel: family must be -1 (auto), 0, 3, 7, 8 or 9");
   g_kernel_override = family;
   return ENH_OK;
 }
@@ -905,7 +1084,7 @@ static GemmPlan gemm_plan(int trans_a, int trans_b, int64_t M, int64_t N, int64_
   };
   const bool w256_ok = M % 256 == 0 && N % 256 == 0 && ksteps >= 2;
   int family = g_kernel_override >= 0 ? g_kernel_override : -1;
-  if (family == 8) family = 7;   // the persistent form shares w256's plan; the launcher upgrades the calls it covers
+  if (family == 8 || family == 9) family = 7;   // the persistent forms share w256's plan; the launcher upgrades the calls it covers
   if (family == 7 && !w256_ok) family = -1;
   if (family < 0) {
     // w256 whenever its tiles (times K slices) occupy at least 3/4 of the CUs; else the 128x128 pipe2 kernel (four times as many workgroups)
@@ -939,9 +1118,15 @@ static bool gemm_persistent(const GemmPlan& pl, int trans_a, int64_t K, int mode
   return mode == EPI_BF16 || mode == EPI_BF16_BIAS_TANH || mode == EPI_BF16_DTANH || mode == EPI_F32_BIAS_RES || mode == EPI_F32;
 }
 
+// ... and, of those, the A-in-registers form: bf16 / bf16 + bias + tanh / f32 outputs, an even number (>= 6) of K stages
+static bool gemm_regstaged(int64_t K, int mode) {
+  const int64_t nst = K / G_BK;
+  return g_kernel_override != 8 && (mode == EPI_BF16 || mode == EPI_BF16_BIAS_TANH || mode == EPI_F32) && nst % 2 == 0 && nst >= 6;
+}
+
 extern "C" const char* enh_gemm_bf16_variant_mode(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, int epi_mode) {
   const GemmPlan pl = gemm_plan(trans_a, trans_b, M, N, K, epi_mode == EPI_WS || epi_mode == EPI_ATOMIC);
-  if (gemm_persistent(pl, trans_a, K, epi_mode)) return "gemm_bf16_w256p_kernel";
+  if (gemm_persistent(pl, trans_a, K, epi_mode)) return gemm_regstaged(K, epi_mode) ? "gemm_bf16_w256r_kernel" : "gemm_bf16_w256p_kernel";
   return enh_gemm_bf16_variant(trans_a, trans_b, M, N, K);
 }
 
@@ -982,7 +1167,6 @@ extern "C" int enh_gemm_bf16_ws(const enh_bf16* A, int64_t lda, int trans_a, con
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.M = M; g.N = N; g.K = K;
   g.bias = bias; g.act = act; g.aux = aux; g.ldaux = ldaux; g.res = res; g.ldres = ldres; g.res_rows = res_rows;
   g.accumulate = accumulate; g.c_f32 = c_f32; g.c_bf16 = c_bf16; g.ldc = ldc; g.ws = nullptr;
-  g.dbg = g_gemm_debug;
   g.nbm = (int)((M + bm - 1) / bm);
   g.nbn = (int)((N + bn - 1) / bn);
   const int64_t tiles = (int64_t)g.nbm * g.nbn;
@@ -1054,6 +1238,19 @@ extern "C" int enh_gemm_bf16_ws(const enh_bf16* A, int64_t lda, int trans_a, con
         return n > 0 ? n : 256;
       }();
       const int64_t wgs = tiles < n_cu ? tiles : n_cu;
+      if (gemm_regstaged(K, mode)) {
+#define W2R_ROW(TB_) {nullptr, gemm_bf16_w256r_kernel<TB_, EPI_BF16>, gemm_bf16_w256r_kernel<TB_, EPI_BF16_BIAS_TANH>, nullptr, nullptr, gemm_bf16_w256r_kernel<TB_, EPI_F32>, nullptr, nullptr}
+        static const w256_fn rtable[2][EPI_NMODES] = {W2R_ROW(false), W2R_ROW(true)};
+#undef W2R_ROW
+        static const bool r_attr = [] {
+          for (int l = 0; l < 2; ++l)
+            for (int e = 0; e < EPI_NMODES; ++e)
+              if (rtable[l][e]) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtable[l][e]), hipFuncAttributeMaxDynamicSharedMemorySize, W2P_LDS_BYTES);
+          return true;
+        }();
+        (void)r_attr;
+        hipLaunchKernelGGL(rtable[trans_b ? 1 : 0][mode], dim3((unsigned)wgs), dim3(256), (size_t)W2P_LDS_BYTES, s, g);
+      } else
       hipLaunchKernelGGL(ptable[trans_b ? 1 : 0][mode], dim3((unsigned)wgs), dim3(256), (size_t)(mode == EPI_BF16_DTANH ? W2P_LDS_BYTES_DTANH : W2P_LDS_BYTES), s, g);
     } else
     hipLaunchKernelGGL(table[(trans_a ? 2 : 0) + (trans_b ? 1 : 0)][mode], grid, dim3(256), (size_t)(2 * W2_SLOT + W2_BIAS_BYTES), s, g);

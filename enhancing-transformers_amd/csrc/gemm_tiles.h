@@ -32,7 +32,6 @@ struct GemmArgs {
   float* c_f32; uint16_t* c_bf16; int64_t ldc;
   int nbm, nbn;
   int splits;  // number of K-slices (1 = no split-K; otherwise a multiple of 8)
-  int dbg;     // laboratory switches of the persistent kernel (0 in every product call)
 };
 
 // global -> registers: one 128 x 64 (row layout) or 64 x 128 (kmaj layout) bf16 operand tile, 4 x 16 B per thread

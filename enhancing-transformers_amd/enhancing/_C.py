@@ -116,9 +116,9 @@ def lib():
         # the binding, never inside the library (reg = 0, pipe2 = 3, w256 = 7)
         sel = os.environ.get("ENH_GEMM_KERNEL")
         if sel:
-            fam = {"reg": 0, "pipe2": 3, "w256": 7, "w256p": 8}.get(sel)
+            fam = {"reg": 0, "pipe2": 3, "w256": 7, "w256p": 8, "w256r": 9}.get(sel)
             if fam is None:
-                raise RuntimeError(f"ENH_GEMM_KERNEL={sel!r}: expected reg | pipe2 | w256 | w256p")
+                raise RuntimeError(f"ENH_GEMM_KERNEL={sel!r}: expected reg | pipe2 | w256 | w256p | w256r")
             _check_rc = L.enh_gemm_set_kernel(fam)
             if _check_rc != 0:
                 raise RuntimeError(L.enh_last_error().decode())
@@ -312,7 +312,9 @@ def gemm(a, b, M: int, N: int, K: int, trans_a: bool = False, trans_b: bool = Fa
         # (a position-table residual, res_rows != M, is not the persistent kernel's case: ask with the generic mode)
         fam = lib().enh_gemm_bf16_variant_mode(int(trans_a), int(trans_b), M, N, K, 0 if (res is not None and res_rows != M) else mode).decode()
         targs = f"{'true' if trans_a else 'false'}, {'true' if trans_b else 'false'}"
-        if fam in ("gemm_bf16_w256_kernel", "gemm_bf16_w256p_kernel"):   # the epilogue mode is a template parameter (gemm.hip epi_mode(), mirrored here for the label only)
+        if fam == "gemm_bf16_w256r_kernel":   # template <TB, EPI>: A is never transposed there
+            targs = f"{'true' if trans_b else 'false'}, {mode}"
+        elif fam in ("gemm_bf16_w256_kernel", "gemm_bf16_w256p_kernel"):   # the epilogue mode is a template parameter (gemm.hip epi_mode(), mirrored here for the label only)
             targs += f", {mode}"
         TIMER.run(f"{fam}<{targs}>", 2.0 * M * N * K, lambda: _check(lib().enh_gemm_bf16_ws(*args), "enh_gemm_bf16"))
 

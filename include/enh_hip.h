@@ -141,12 +141,14 @@ size_t enh_gemm_bf16_workspace_bytes(int trans_a, int trans_b, int64_t M, int64_
  * the symbol a profiler will report); the choice is per shape */
 const char* enh_gemm_bf16_variant(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K);
 /* the same for a call with a given fused epilogue (epi_mode: 0 generic, 1 bf16, 2 bf16 + bias + tanh, 3 bf16 * tanh', 4 f32 + bias + residual stream,
- * 5 f32, 6 / 7 split-K partials): forward / input-gradient calls of modes 1-5 on whole 256 x 256 tiles run the PERSISTENT form of the 256 x 256
- * kernel ("gemm_bf16_w256p_kernel": one workgroup per CU walks the tiles, the next tile's operands are requested before the stores of this one) */
+ * 5 f32, 6 / 7 split-K partials): forward / input-gradient calls of modes 1-5 on whole 256 x 256 tiles run a PERSISTENT form of the 256 x 256
+ * kernel — "gemm_bf16_w256p_kernel": one workgroup per CU walks the tiles, the next tile's operands are requested before the stores of this one;
+ * "gemm_bf16_w256r_kernel" (modes 1, 2, 5; an even number >= 6 of 64-deep K stages): the same with the A operand staged through registers two
+ * stages ahead, which lets its requests stay in flight 1.75 stages instead of 0.75 */
 const char* enh_gemm_bf16_variant_mode(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, int epi_mode);
 /* A/B measurement aid: force a kernel family for every later call that it can serve (-1 = per-shape choice [default], 0 = register-staged
- * fallback, 3 = pipe2 128x128, 7 = w256 256x256 / 4 waves with one tile per workgroup everywhere, 8 = w256 with the persistent form where it
- * serves [what the default picks]).  Process-global, set explicitly by the caller (the Python
+ * fallback, 3 = pipe2 128x128, 7 = w256 256x256 / 4 waves with one tile per workgroup everywhere, 8 = w256 with the persistent form w256p where it
+ * serves, 9 = as 8 plus w256r where that serves [what the default picks]).  Process-global, set explicitly by the caller (the Python
  * binding maps the ENH_GEMM_KERNEL environment variable onto it); the library itself reads no environment. */
 int enh_gemm_set_kernel(int family);
 

@@ -215,17 +215,19 @@ def test_gemm_epilogues(C, kernel_shape):
 
 @pytest.mark.parametrize("kind", ["fwd", "dgrad", "fwd_tanh", "dgrad_dtanh", "fwd_res", "fwd_f32"])
 def test_persistent_gemm_is_bitwise_the_one_tile_kernel(C, kind):
-    """gemm_bf16_w256p_kernel (one workgroup per CU walks the tiles; the next tile's operands are requested before this tile's stores) issues the same
-    MFMA sequence per output element as gemm_bf16_w256_kernel and the same epilogue arithmetic: every output must be BIT-identical — on fewer tiles
-    than CUs, on a ragged last round (300 tiles), on odd and minimal stage counts, in both B layouts and every fused mode; one case is also checked
-    against fp64."""
+    """gemm_bf16_w256p_kernel (one workgroup per CU walks the tiles; the next tile's operands are requested before this tile's stores) and
+    gemm_bf16_w256r_kernel (the same with the A operand staged through registers) issue the same MFMA sequence per output element as
+    gemm_bf16_w256_kernel and the same epilogue arithmetic: every output must be BIT-identical — on fewer tiles than CUs, on a ragged last round
+    (300 tiles), on odd and minimal stage counts (w256r needs an even count >= 6: 448 / 64 = 7 falls back to w256p), in both B layouts and every
+    fused mode; one case is also checked against fp64."""
     L = C.lib()
     g = torch.Generator().manual_seed(31)
     tb = kind.startswith("dgrad")
     try:
-        for (m, n, k) in ((1024, 768, 192), (256 * 100, 768, 320), (256 * 37, 2304, 448), (8192, 3072, 768)):
+        for (m, n, k) in ((1024, 768, 192), (256 * 100, 768, 320), (256 * 37, 2304, 448), (256 * 50, 768, 384), (8192, 3072, 768)):
             if not os.environ.get("ENH_GEMM_KERNEL"):   # (a family override re-runs this file with that family pinned)
-                assert L.enh_gemm_bf16_variant_mode(0, int(tb), 131072, n, k, 1).decode() == "gemm_bf16_w256p_kernel"    # the per-shape default at training sizes
+                want = "gemm_bf16_w256r_kernel" if (k // 64) % 2 == 0 and k // 64 >= 6 else "gemm_bf16_w256p_kernel"
+                assert L.enh_gemm_bf16_variant_mode(0, int(tb), 131072, n, k, 1).decode() == want    # the per-shape default at training sizes
             A, B = _mk((m, k), g, 0.5), _mk((n, k), g, 0.1)
             a = A.to(torch.bfloat16).cuda()
             b = (B.t().contiguous() if tb else B).to(torch.bfloat16).cuda()
@@ -243,9 +245,10 @@ def test_persistent_gemm_is_bitwise_the_one_tile_kernel(C, kind):
                 kw.update(out_bf16=out, act=C.ACT_DTANH, aux=torch.tanh(torch.randn(m, n, generator=g)).to(torch.bfloat16).cuda())
             assert L.enh_gemm_set_kernel(7) == 0
             out.zero_(); C.gemm(a, b, m, n, k, **kw); torch.cuda.synchronize(); ref = out.clone()
-            assert L.enh_gemm_set_kernel(8) == 0
-            out.fill_(7.0); C.gemm(a, b, m, n, k, **kw); torch.cuda.synchronize()
-            assert torch.equal(out, ref), f"{kind} M={m} N={n} K={k}: {(out != ref).sum().item()} elements differ"
+            for fam in (8, 9):
+                assert L.enh_gemm_set_kernel(fam) == 0
+                out.fill_(7.0); C.gemm(a, b, m, n, k, **kw); torch.cuda.synchronize()
+                assert torch.equal(out, ref), f"family {fam} {kind} M={m} N={n} K={k}: {(out != ref).sum().item()} elements differ"
             if kind == "fwd_res" and m == 1024:
                 assert rel(out, A.double() @ B.double().t() + kw["bias"].double().cpu() + kw["res"].double().cpu()) <= F32_TOL
     finally:
@@ -455,7 +458,7 @@ def test_colsum_cast_adamw(C):
 # ---------------------------------------------------------------------------------------------
 # every GEMM kernel family on every shape it can serve (the per-shape default only exercises one of them)
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("sel,symbol", [("w256", "gemm_bf16_w256_kernel"), ("w256p", "gemm_bf16_w256_kernel"), ("pipe2", "gemm_bf16_pipe2_kernel")])
+@pytest.mark.parametrize("sel,symbol", [("w256", "gemm_bf16_w256_kernel"), ("w256p", "gemm_bf16_w256_kernel"), ("w256r", "gemm_bf16_w256_kernel"), ("pipe2", "gemm_bf16_pipe2_kernel")])
 def test_gemm_suite_under_each_kernel_family(sel, symbol):
     """the family override is process-global (enh_gemm_set_kernel, mapped from ENH_GEMM_KERNEL by the binding), so the GEMM tests are re-run
     in a child process per family; shapes a family cannot serve fall back to the per-shape choice"""
