@@ -239,8 +239,22 @@ __device__ __forceinline__ void gemm_tile_coords_of(const GemmArgs& args, int bl
   // (2) grouped order inside the run: 8 row-panels x all column tiles, row-fastest, so the ~64 tiles an XCD has in
   //     flight form an ~8 x 8 patch whose A and B panels (8 x 196 KB each at K = 768) both stay in its 4 MiB L2.
   const int nwg = args.nbm * args.nbn;  // tiles per K-split
-  // (tried: pinning each K-slice of a split-K launch to one XCD halves the fabric traffic PMC reports, but runs 10-15 % slower —
-  //  the duplicated fetches were Infinity-Cache hits, and spreading a slice over all XCDs gives more channel parallelism)
+  if (args.splits > 1) {
+    // split-K (weight gradients): the (K slice, row, column) space is ONE line — the shorter of the two tile dimensions fastest — and each XCD takes a
+    // contiguous run of it (W/8 +- 1 workgroups: one round).  The tiles of a K slice that share an operand slice (the column tiles of a row share
+    // A's, the rows share B's) then run on the SAME XCD, i.e. behind one L2: with the slices spread over all XCDs (round 2) every slice was fetched
+    // by ~3 XCDs and the launch moved 2.7 GB through the fabric for 0.9 GB of operands (PMC) — at 6.3 TB/s that WAS its run time.  Same-box A/B
+    // (tools/wgrad_lab.py, B = 128): qkv 0.436 -> 0.417 ms, out 0.179 -> 0.160, fc1 0.578 -> 0.539, fc2 0.561 -> 0.537; bit-identical sums.
+    // (Round 2's "pin each K slice to XCD (slice mod 8)" was slower because 9 or 28 slices do not divide by 8: two rounds on some XCDs.)
+    const int total = nwg * args.splits;
+    const int q = total >> 3, r = total & 7, xcd = block & 7, pos = block >> 3;
+    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+    split = lin / nwg;
+    const int tl = lin - split * nwg;
+    if (args.nbm < args.nbn) { tile_n = tl / args.nbm; tile_m = tl - tile_n * args.nbm; }   // rows fastest
+    else { tile_m = tl / args.nbn; tile_n = tl - tile_m * args.nbn; }                       // columns fastest
+    return;
+  }
   split = block / nwg;
   int bid = block - split * nwg;
   {

@@ -1,0 +1,60 @@
+"""Split-K weight-gradient timing at the training step's four shapes (gemm_bf16_w256_kernel<true, true, EPI_WS> + the fixed-order reduce pass).
+Dev tool, GPU box:  python tools/wgrad_lab.py [batch].  The workgroup -> XCD mapping A/B of round 3 (profiles/r03_gemm_persistent_lab.txt section 8)
+was run with a laboratory switch (LAB_BITS) that has since been removed from the library: a library without it only times the product mapping."""
+import os
+import statistics
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "enhancing-transformers_amd"))
+from enhancing import _C  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+LABS = [int(x) for x in os.environ.get("LAB_BITS", "0").split(",")]
+HAVE_SWITCH = hasattr(_C.lib(), "enh_gemm_set_lab")
+ROUNDS = int(os.environ.get("LAB_ROUNDS", "4"))
+TOK = B * 1024
+L = _C.lib()
+dev = "cuda"
+
+
+def set_lab(bits):
+    if HAVE_SWITCH:
+        L.enh_gemm_set_lab(bits)
+
+
+def bf(*shape, scale=0.5):
+    return (torch.randn(*shape, device=dev) * scale).to(torch.bfloat16)
+
+
+def case(name, n_out, k_in, iters=10):
+    dy, x = bf(TOK, n_out, scale=0.1), bf(TOK, k_in)
+    dw = torch.zeros(n_out, k_in, device=dev)
+    fn = lambda: _C.gemm(dy, x, n_out, k_in, TOK, trans_a=True, trans_b=True, accumulate=True, out_f32=dw)
+    outs = {}
+    for lab in LABS:
+        set_lab(lab); dw.zero_(); fn(); torch.cuda.synchronize(); outs[lab] = dw.clone()
+    same = all(torch.equal(outs[LABS[0]], outs[l]) for l in LABS)
+    times = {l: [] for l in LABS}
+    for _ in range(ROUNDS):
+        for lab in LABS:
+            set_lab(lab)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            fn(); s.record()
+            for _ in range(iters):
+                fn()
+            e.record(); torch.cuda.synchronize()
+            times[lab].append(s.elapsed_time(e) / iters)
+    fl = 2.0 * n_out * k_in * TOK
+    cells = [f"lab{l} {min(times[l]):6.3f}/{statistics.median(times[l]):6.3f} {fl / min(times[l]) / 1e9:5.0f}" for l in LABS]
+    print(f"{name:10s} [{n_out:4d} x {k_in:4d}] {'bitwise equal' if same else 'MISMATCH'} | " + " | ".join(cells), flush=True)
+
+
+print(f"tokens {TOK}: min / median ms (incl. the split-K reduce pass), TF/s at the minimum")
+case("wgrad qkv", 2304, 768)
+case("wgrad out", 768, 768)
+case("wgrad fc1", 3072, 768)
+case("wgrad fc2", 768, 3072)
+set_lab(0)
