@@ -19,6 +19,7 @@ typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4_t;
 
 void enh_set_error(const char* fmt, ...);
 int enh_check_launch(const char* what);
+int enh_colsum_reduce_launch(const float* part, int chunks, int64_t N, float* out, int accumulate, hipStream_t s);   // elementwise.hip
 
 #define ENH_REQUIRE(cond, code, ...)                  \
   do {                                                \

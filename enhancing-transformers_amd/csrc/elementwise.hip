@@ -224,6 +224,12 @@ __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restr
   if ((threadIdx.x >> 4) == 0 && n < N) out[n] = accumulate ? out[n] + t : t;
 }
 
+// fixed-order sum of `chunks` partial rows [chunks][N] into out[N] — also the second pass of the bias gradient that gemm.hip's tanh' epilogue produces
+int enh_colsum_reduce_launch(const float* part, int chunks, int64_t N, float* out, int accumulate, hipStream_t s) {
+  colsum_reduce_kernel<<<dim3((unsigned)((N + 15) / 16)), 256, 0, s>>>(part, chunks, N, out, accumulate);
+  return enh_check_launch("colsum_reduce");
+}
+
 static int64_t colsum_chunks(int64_t M) {
   const int64_t chunks = (M + 511) / 512;
   return chunks > 256 ? 256 : chunks;

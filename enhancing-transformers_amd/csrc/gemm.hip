@@ -665,6 +665,7 @@ __device__ __forceinline__ void gemm_epilogue_p(const GemmArgs& args, f32x16 (&a
     const int wsw = (l31 >> 1) & 7;
     const unsigned out_off = (unsigned)rrow * (unsigned)args.ldc + (unsigned)rc * 8u;
     uint2 hq[2][8];   // the block's saved values in the accumulator layout; the next block's are fetched from LDS while this one is computed
+    float cs[2][8] = {{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}};   // column sums (tanh' mode with args.colpart)
     if (MODE == EPI_BF16_DTANH) {
 #pragma unroll
       for (int p = 0; p < 4; ++p) *reinterpret_cast<u32x4*>(at + (p * 8 + rrow) * 128 + ((rc ^ (((p * 8 + rrow) >> 1) & 7)) << 4)) = a4[0][p];
@@ -704,8 +705,34 @@ __device__ __forceinline__ void gemm_epilogue_p(const GemmArgs& args, f32x16 (&a
 #pragma unroll
         for (int p = 0; p < 4; ++p)
           *reinterpret_cast<u32x4*>(args.c_bf16 + ((mw + i * 32 + p * 8) * args.ldc + nw + jh * 64) + out_off) = w[p];   // uniform base + 32-bit lane offset
+        if (MODE == EPI_BF16_DTANH && args.colpart) {   // column sums of what was just stored (the ROUNDED values): this lane's 8 columns of 4 rows
+#pragma unroll
+          for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              cs[jh][2 * e] += __builtin_bit_cast(float, w[p][e] << 16);
+              cs[jh][2 * e + 1] += __builtin_bit_cast(float, w[p][e] & 0xffff0000u);
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);   // one block at a time: the scheduler otherwise reads all 256 accumulators first
       }
+    if (MODE == EPI_BF16_DTANH && args.colpart) {
+      // lane (rrow, rc) holds, per column half, the sums of its 8 columns over rows rrow, rrow + 8, ... of the wave's 128: the 8 row classes meet in
+      // the (now idle) input tile [8][128] f32, lane l adds columns 2l, 2l + 1 in the fixed order 0..7 and writes the wave's partial row
+#pragma unroll
+      for (int jh = 0; jh < 2; ++jh) {
+        const f32x4 lo = {cs[jh][0], cs[jh][1], cs[jh][2], cs[jh][3]}, up = {cs[jh][4], cs[jh][5], cs[jh][6], cs[jh][7]};
+        *reinterpret_cast<f32x4*>(at + rrow * 512 + (jh * 64 + rc * 8) * 4) = lo;
+        *reinterpret_cast<f32x4*>(at + rrow * 512 + (jh * 64 + rc * 8) * 4 + 16) = up;
+      }
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const float2 v2 = *reinterpret_cast<const float2*>(at + r * 512 + lane * 8);
+        s0 += v2.x; s1 += v2.y;
+      }
+      *reinterpret_cast<float2*>(args.colpart + (mw >> 7) * args.N + nw + lane * 2) = make_float2(s0, s1);
+    }
   } else {
     // f32 outputs: 32 x 32 blocks.  The residual stream is read in the OUTPUT's layout (whole 128-byte row segments, 16 bytes per lane) and added after
     // the transposition, two row-blocks (128 registers) ahead: the first two before any store, the others as their registers come free.
@@ -1141,10 +1168,11 @@ extern "C" size_t enh_gemm_bf16_workspace_bytes(int trans_a, int trans_b, int64_
   return pl.splits > 1 ? (size_t)pl.splits * (size_t)M * (size_t)N * sizeof(float) : 0;
 }
 
-extern "C" int enh_gemm_bf16_ws(const enh_bf16* A, int64_t lda, int trans_a, const enh_bf16* B, int64_t ldb, int trans_b,
-                                int64_t M, int64_t N, int64_t K, const float* bias, int act, const enh_bf16* aux,
-                                int64_t ldaux, const float* res, int64_t ldres, int64_t res_rows, int accumulate,
-                                float* c_f32, enh_bf16* c_bf16, int64_t ldc, void* workspace, size_t workspace_bytes, void* stream) {
+// colpart != null: the caller (enh_gemm_bf16_dtanh_colsum) has checked that the persistent tanh' kernel serves this call
+static int gemm_bf16_impl(const enh_bf16* A, int64_t lda, int trans_a, const enh_bf16* B, int64_t ldb, int trans_b,
+                          int64_t M, int64_t N, int64_t K, const float* bias, int act, const enh_bf16* aux,
+                          int64_t ldaux, const float* res, int64_t ldres, int64_t res_rows, int accumulate,
+                          float* c_f32, enh_bf16* c_bf16, int64_t ldc, void* workspace, size_t workspace_bytes, void* stream, float* colpart) {
   ENH_REQUIRE(A && B && (c_f32 || c_bf16), ENH_E_BADARG, "enh_gemm_bf16: null pointer");
   ENH_REQUIRE(M > 0 && N > 0 && K > 0, ENH_E_BADARG, "enh_gemm_bf16: M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
   ENH_REQUIRE(K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && aligned16(A) && aligned16(B), ENH_E_SHAPE,
@@ -1167,6 +1195,7 @@ extern "C" int enh_gemm_bf16_ws(const enh_bf16* A, int64_t lda, int trans_a, con
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.M = M; g.N = N; g.K = K;
   g.bias = bias; g.act = act; g.aux = aux; g.ldaux = ldaux; g.res = res; g.ldres = ldres; g.res_rows = res_rows;
   g.accumulate = accumulate; g.c_f32 = c_f32; g.c_bf16 = c_bf16; g.ldc = ldc; g.ws = nullptr;
+  g.colpart = colpart;
   g.nbm = (int)((M + bm - 1) / bm);
   g.nbn = (int)((N + bn - 1) / bn);
   const int64_t tiles = (int64_t)g.nbm * g.nbn;
@@ -1262,6 +1291,41 @@ extern "C" int enh_gemm_bf16_ws(const enh_bf16* A, int64_t lda, int trans_a, con
     splitk_reduce_kernel<<<dim3((unsigned)((MN / 4 + 255) / 256)), 256, 0, s>>>(g.ws, pl.splits, MN, N, c_f32, ldc, accumulate);
   }
   return enh_check_launch("enh_gemm_bf16");
+}
+
+extern "C" int enh_gemm_bf16_ws(const enh_bf16* A, int64_t lda, int trans_a, const enh_bf16* B, int64_t ldb, int trans_b,
+                                int64_t M, int64_t N, int64_t K, const float* bias, int act, const enh_bf16* aux,
+                                int64_t ldaux, const float* res, int64_t ldres, int64_t res_rows, int accumulate,
+                                float* c_f32, enh_bf16* c_bf16, int64_t ldc, void* workspace, size_t workspace_bytes, void* stream) {
+  return gemm_bf16_impl(A, lda, trans_a, B, ldb, trans_b, M, N, K, bias, act, aux, ldaux, res, ldres, res_rows, accumulate, c_f32, c_bf16, ldc,
+                        workspace, workspace_bytes, stream, nullptr);
+}
+
+// C = (A B) * (1 - aux^2) -> bf16, AND colsum[n] (+)= sum_m C[m][n] over the stored (rounded) values: the input gradient through a tanh together with
+// the bias gradient of the Linear in front of it (the reference's autograd of FeedForward: layers.py:99-101 Linear -> nn.Tanh -> Linear).  Where the
+// persistent tanh' kernel serves the call, its epilogue leaves one partial row per 128 rows in `ws` and a fixed-order second pass adds them (the
+// separate column-sum kernel would re-read all of C: 805 MB at the base config); otherwise: the plain GEMM, then enh_colsum_bf16_ws.
+static bool dtanh_colsum_fused(int trans_b, int64_t M, int64_t N, int64_t K) {
+  const GemmPlan pl = gemm_plan(0, trans_b, M, N, K, false);
+  return gemm_persistent(pl, 0, K, EPI_BF16_DTANH) && M % 256 == 0 && N % 256 == 0;
+}
+extern "C" size_t enh_gemm_bf16_dtanh_colsum_workspace_bytes(int trans_b, int64_t M, int64_t N, int64_t K) {
+  if (M <= 0 || N <= 0) return 0;
+  return dtanh_colsum_fused(trans_b, M, N, K) ? (size_t)(M / 128) * (size_t)N * sizeof(float) : enh_colsum_bf16_workspace_bytes(M, N);
+}
+extern "C" int enh_gemm_bf16_dtanh_colsum(const enh_bf16* A, int64_t lda, const enh_bf16* B, int64_t ldb, int trans_b, int64_t M, int64_t N, int64_t K,
+                                          const enh_bf16* aux, int64_t ldaux, enh_bf16* c_bf16, int64_t ldc, float* colsum, int accumulate_colsum,
+                                          void* ws, size_t ws_bytes, void* stream) {
+  ENH_REQUIRE(colsum && ws && c_bf16 && aux, ENH_E_BADARG, "enh_gemm_bf16_dtanh_colsum: null pointer");
+  ENH_REQUIRE(ws_bytes >= enh_gemm_bf16_dtanh_colsum_workspace_bytes(trans_b, M, N, K) && aligned16(ws), ENH_E_WORKSPACE,
+              "enh_gemm_bf16_dtanh_colsum: workspace of %zu bytes needed, %zu given", enh_gemm_bf16_dtanh_colsum_workspace_bytes(trans_b, M, N, K), ws_bytes);
+  if (!dtanh_colsum_fused(trans_b, M, N, K)) {
+    const int rc = enh_gemm_bf16(A, lda, 0, B, ldb, trans_b, M, N, K, nullptr, ENH_ACT_DTANH, aux, ldaux, nullptr, 0, 0, 0, nullptr, c_bf16, ldc, stream);
+    return rc ? rc : enh_colsum_bf16_ws(c_bf16, M, N, ldc, colsum, accumulate_colsum, ws, ws_bytes, stream);
+  }
+  const int rc = gemm_bf16_impl(A, lda, 0, B, ldb, trans_b, M, N, K, nullptr, ENH_ACT_DTANH, aux, ldaux, nullptr, 0, 0, 0, nullptr, c_bf16, ldc, nullptr, 0,
+                                stream, (float*)ws);
+  return rc ? rc : enh_colsum_reduce_launch((const float*)ws, (int)(M / 128), N, colsum, accumulate_colsum, (hipStream_t)stream);
 }
 
 extern "C" int enh_gemm_bf16(const enh_bf16* A, int64_t lda, int trans_a, const enh_bf16* B, int64_t ldb, int trans_b,

@@ -48,6 +48,8 @@ SIGNATURES = {
     "enh_gemm_set_kernel": (_i32, [_i32]),
     "enh_gemm_bf16_variant": (_c.c_char_p, [_i32, _i32, _i64, _i64, _i64]),
     "enh_gemm_bf16_variant_mode": (_c.c_char_p, [_i32, _i32, _i64, _i64, _i64, _i32]),
+    "enh_gemm_bf16_dtanh_colsum_workspace_bytes": (_c.c_size_t, [_i32, _i64, _i64, _i64]),
+    "enh_gemm_bf16_dtanh_colsum": (_i32, [_vp, _i64, _vp, _i64, _i32, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _c.c_size_t, _vp]),
     "enh_attention_set_kernel": (_i32, [_i32, _i32, _i32]),
     "enh_attention_forward": (_i32, [_vp, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp]),
     "enh_attention_backward": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp]),
@@ -95,7 +97,7 @@ SIGNATURES = {
 }
 
 _LIB = None
-ABI_VERSION = 7   # ENH_ABI_VERSION of the include/enh_hip.h these signatures were written against
+ABI_VERSION = 8   # ENH_ABI_VERSION of the include/enh_hip.h these signatures were written against
 
 
 def lib():
@@ -317,6 +319,21 @@ def gemm(a, b, M: int, N: int, K: int, trans_a: bool = False, trans_b: bool = Fa
         elif fam in ("gemm_bf16_w256_kernel", "gemm_bf16_w256p_kernel"):   # the epilogue mode is a template parameter (gemm.hip epi_mode(), mirrored here for the label only)
             targs += f", {mode}"
         TIMER.run(f"{fam}<{targs}>", 2.0 * M * N * K, lambda: _check(lib().enh_gemm_bf16_ws(*args), "enh_gemm_bf16"))
+
+
+def gemm_dtanh_colsum(a, b, M: int, N: int, K: int, aux, out_bf16, colsum_out, trans_b: bool = True, accumulate_colsum: bool = True):
+    """out = (a b) * (1 - aux^2) -> bf16 and colsum_out (+)= column sums of out: enh_gemm_bf16_dtanh_colsum (the tanh' input gradient with the bias
+    gradient of the Linear in front of the tanh taken in the GEMM's epilogue instead of by a second pass over `out`)"""
+    nb = lib().enh_gemm_bf16_dtanh_colsum_workspace_bytes(int(trans_b), M, N, K)
+    ws = _workspace(nb, a.device)
+    args = (_p(a, BF16, "A"), a.stride(0), _p(b, BF16, "B"), b.stride(0), int(trans_b), M, N, K, _p(aux, BF16, "aux"), aux.stride(0),
+            _p(out_bf16, BF16, "out_bf16"), out_bf16.stride(0), _p(colsum_out, F32, "colsum"), int(accumulate_colsum), _p(ws), ws.numel(), _stream())
+    call = lambda: _check(lib().enh_gemm_bf16_dtanh_colsum(*args), "enh_gemm_bf16_dtanh_colsum")
+    if TIMER is None:
+        call()
+    else:   # labelled with the GEMM kernel's symbol (the partial-row second pass and, off the tile grid, the column-sum kernel ride along)
+        fam = lib().enh_gemm_bf16_variant_mode(0, int(trans_b), M, N, K, 3).decode()
+        TIMER.run(f"{fam}<false, {'true' if trans_b else 'false'}" + (", 3>" if "w256" in fam else ">"), 2.0 * M * N * K, call)
 
 
 def _epi_mode_label(accumulate, have_ws, f32, bf16, bias, act, res) -> int:

@@ -219,9 +219,12 @@ class _Tower:
             P, A = self.L[i], b["layers"][i]
             # ---- MLP: x_out = fc2(tanh(fc1(a2))) + x_mid ----
             _C.mm(gA16, A["hid"], dim, mlp, M, g[P["w2"]], trans_a=True, trans_b=True, accumulate=True)
-            _C.mm(gA16, s.wa[P["w2"]], M, mlp, dim, b["dhid16"], trans_b=True, act=_C.ACT_DTANH, aux=A["hid"])
+            if gA16.dtype == torch.bfloat16:   # input gradient through the tanh + fc1's bias gradient (column sums of it) in one launch
+                _C.gemm_dtanh_colsum(gA16, s.wa[P["w2"]], M, mlp, dim, A["hid"], b["dhid16"], g[P["b1"]], trans_b=True, accumulate_colsum=True)
+            else:                               # exact-f32 mode
+                _C.mm(gA16, s.wa[P["w2"]], M, mlp, dim, b["dhid16"], trans_b=True, act=_C.ACT_DTANH, aux=A["hid"])
+                _C.colsum_any(b["dhid16"], M, mlp, g[P["b1"]], accumulate=True)
             _C.mm(b["dhid16"], A["a2"], mlp, dim, M, g[P["w1"]], trans_a=True, trans_b=True, accumulate=True)
-            _C.colsum_any(b["dhid16"], M, mlp, g[P["b1"]], accumulate=True)
             _C.mm(b["dhid16"], s.wa[P["w1"]], M, dim, mlp, dA, trans_b=True)
             _C.ln_bwd(dA, A["x_mid"], s.w[P["ln2_w"]], A["mean2"], A["rstd2"], gA, gB, gB16, g[P["ln2_w"]], g[P["ln2_b"]], g[P["bout"]])
             # ---- attention: x_mid = to_out(attn(to_qkv(a1))) + x_in ----

@@ -36,7 +36,7 @@ extern "C" {
 typedef uint16_t enh_bf16; /* raw bfloat16 bits */
 
 const char* enh_last_error(void);
-#define ENH_ABI_VERSION 7   /* bumped whenever a signature below changes; the bindings check it at load */
+#define ENH_ABI_VERSION 8   /* bumped whenever a signature below changes; the bindings check it at load */
 int enh_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -134,6 +134,15 @@ int enh_gemm_bf16_ws(const enh_bf16* A, int64_t lda, int trans_a, const enh_bf16
                      int64_t M, int64_t N, int64_t K, const float* bias, int act, const enh_bf16* aux,
                      int64_t ldaux, const float* res, int64_t ldres, int64_t res_rows, int accumulate,
                      float* c_f32, enh_bf16* c_bf16, int64_t ldc, void* workspace, size_t workspace_bytes, void* stream);
+/* C[M,N] = (A B) * (1 - aux^2) -> bf16 AND colsum[n] (+)= sum_m C[m][n] over the stored (rounded) values: the input gradient through a tanh plus the
+ * bias gradient of the Linear in front of it — the autograd of `nn.Linear -> nn.Tanh` in FeedForward (layers.py:99-101).  On whole 256 x 256 tiles
+ * the tanh' kernel's epilogue leaves one partial row per 128 rows in `ws` and a fixed-order second pass adds them (bit-reproducible; the separate
+ * column-sum kernel re-reads all of C: 805 MB per layer at the base config); any other shape runs enh_gemm_bf16 then enh_colsum_bf16_ws.
+ * A is [M][K] (never transposed here); trans_b as in enh_gemm_bf16. */
+size_t enh_gemm_bf16_dtanh_colsum_workspace_bytes(int trans_b, int64_t M, int64_t N, int64_t K);
+int enh_gemm_bf16_dtanh_colsum(const enh_bf16* A, int64_t lda, const enh_bf16* B, int64_t ldb, int trans_b, int64_t M, int64_t N, int64_t K,
+                               const enh_bf16* aux, int64_t ldaux, enh_bf16* c_bf16, int64_t ldc, float* colsum, int accumulate_colsum,
+                               void* ws, size_t ws_bytes, void* stream);
 /* bytes of workspace the split-K plan of this shape needs (0 = the shape is not split) */
 size_t enh_gemm_bf16_workspace_bytes(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K);
 

@@ -255,6 +255,33 @@ def test_persistent_gemm_is_bitwise_the_one_tile_kernel(C, kind):
         L.enh_gemm_set_kernel(-1)
 
 
+@pytest.mark.parametrize("M,N,K", [(2048, 768, 192), (256 * 37, 3072, 768), (1000, 192, 256)])
+def test_gemm_dtanh_with_fused_bias_gradient(C, M, N, K):
+    """enh_gemm_bf16_dtanh_colsum: C = (A B) * (1 - aux^2) exactly as enh_gemm_bf16 with act = tanh' produces it (bit for bit), and the column sums of
+    the STORED values as enh_colsum_bf16_ws adds them (same inputs, another fixed summation order: f32 rounding only) — on the tile grid (epilogue
+    partials + second pass) and off it (the two-call fallback); accumulate adds to the previous bias gradient; two runs are bit-identical."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = _mk((M, K), g, 0.5).to(torch.bfloat16).cuda()
+    b = _mk((K, N), g, 0.1).to(torch.bfloat16).cuda()       # B stored [K][N] (trans_b): the input-gradient role
+    h = torch.tanh(torch.randn(M, N, generator=g)).to(torch.bfloat16).cuda()
+    ref = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    C.gemm(a, b, M, N, K, trans_b=True, act=C.ACT_DTANH, aux=h, out_bf16=ref)
+    base = torch.randn(N, generator=g).cuda()
+    runs = []
+    for _ in range(2):
+        out = torch.empty_like(ref)
+        cs = base.clone()
+        C.gemm_dtanh_colsum(a, b, M, N, K, h, out, cs, trans_b=True, accumulate_colsum=True)
+        runs.append((out, cs))
+    assert torch.equal(runs[0][0], ref)
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    want = base.double() + ref.double().sum(0)
+    assert rel(runs[0][1], want) <= 2e-6
+    cs0 = torch.full((N,), 3.0, device="cuda")
+    C.gemm_dtanh_colsum(a, b, M, N, K, h, out, cs0, trans_b=True, accumulate_colsum=False)
+    assert rel(cs0, ref.double().sum(0)) <= 2e-6
+
+
 def test_gemm_wgrad_splitk(C):
     """dW[N_out, K_in] += dY^T X over many tokens: the split-K (f32 atomics) path."""
     g = torch.Generator().manual_seed(9)
