@@ -255,6 +255,38 @@ def test_persistent_gemm_is_bitwise_the_one_tile_kernel(C, kind):
         L.enh_gemm_set_kernel(-1)
 
 
+@pytest.mark.parametrize("kind", ["fwd", "fwd_tanh", "dgrad_dtanh", "fwd_res"])
+def test_persistent_gemm_with_row_strides(C, kind):
+    """leading dimensions larger than the row length (output, saved tanh output and residual stream living in wider buffers): the persistent kernels
+    address rows through ldc / ldaux / ldres like the one-tile kernel — bit-identical results, and the columns beyond N stay untouched"""
+    L = C.lib()
+    g = torch.Generator().manual_seed(77)
+    M, N, K, LD = 2048, 768, 768, 1024
+    tb = kind.startswith("dgrad")
+    a = _mk((M, K), g, 0.5).to(torch.bfloat16).cuda()
+    B = _mk((N, K), g, 0.1)
+    b = (B.t().contiguous() if tb else B).to(torch.bfloat16).cuda()
+    kw = dict(trans_b=tb, ldc=LD)
+    if kind == "fwd_res":
+        out = torch.full((M, LD), 5.0, device="cuda"); kw.update(out_f32=out, bias=torch.randn(N, generator=g).cuda(), res=torch.randn(M, LD, generator=g).cuda(), res_rows=M)
+    else:
+        out = torch.full((M, LD), 5.0, dtype=torch.bfloat16, device="cuda"); kw["out_bf16"] = out
+        if kind == "fwd_tanh":
+            kw.update(bias=torch.randn(N, generator=g).cuda(), act=C.ACT_TANH)
+        if kind == "dgrad_dtanh":
+            kw.update(act=C.ACT_DTANH, aux=torch.tanh(torch.randn(M, LD, generator=g)).to(torch.bfloat16).cuda())
+    try:
+        assert L.enh_gemm_set_kernel(7) == 0
+        C.gemm(a, b, M, N, K, **kw); torch.cuda.synchronize(); ref = out.clone()
+        for fam in (8, 9):
+            assert L.enh_gemm_set_kernel(fam) == 0
+            out.fill_(5.0); C.gemm(a, b, M, N, K, **kw); torch.cuda.synchronize()
+            assert torch.equal(out, ref), f"family {fam}: {(out != ref).sum().item()} elements differ"
+        assert bool((out[:, N:] == 5.0).all()) and not bool((out[:, :N] == 5.0).all())
+    finally:
+        L.enh_gemm_set_kernel(-1)
+
+
 @pytest.mark.parametrize("M,N,K", [(2048, 768, 192), (256 * 37, 3072, 768), (1000, 192, 256)])
 def test_gemm_dtanh_with_fused_bias_gradient(C, M, N, K):
     """enh_gemm_bf16_dtanh_colsum: C = (A B) * (1 - aux^2) exactly as enh_gemm_bf16 with act = tanh' produces it (bit for bit), and the column sums of
