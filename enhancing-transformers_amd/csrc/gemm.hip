@@ -612,15 +612,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // store.  No launch gap, no cold prologue per tile, and the stores drain under the next tile's first stage instead of in front of a workgroup exit.
 // vmcnt counts loads and stores in one counter and a wait can only name how many of the youngest operations may remain, so the epilogue is arranged so
 // that nothing it READS is waited for behind one of its stores:
-//   * the saved tanh output is requested for all four row-blocks before the first store; the f32 residual for two row-blocks at a time (the second
-//     pair's wait is the one place where a load is awaited with stores in flight);
+//   * the saved tanh output is requested for all eight blocks before the first store (as whole row segments, brought into the accumulator layout
+//     through a second LDS tile); the f32 residual two row-blocks ahead, in the output's layout (the later row-blocks' requests follow earlier
+//     stores: their waits are the one place where a load is awaited with stores in flight); the bias a K loop early;
 //   * outputs leave through a wave-private 4-KiB LDS tile that does NOT overlay the K slots (32 rows x 128 B per block: whole 128-byte lines per row),
 //     so no barrier separates the K loop from the epilogue and the next tile's operands are already in LDS while the stores drain;
 //   * accumulators are copied out with explicit v_accvgpr_read at the point of use and every lane-derived address is recomputed per tile: left to the
 //     register allocator the epilogue held all 256 accumulators in vector registers and spilled — and a scratch reload is a vector-memory load, i.e.
 //     a vmcnt wait on the next tile's requests.
 // Accumulators are not cleared: the first k16 step of a tile multiplies into a zero C operand.
-// LDS: [2 slots, 128 KiB][bias strips, 2 KiB][4 x 4 KiB store tiles] = 146 KiB.  Forward / input-gradient roles only (A stored [M][K], no split-K).
+// LDS: [2 slots, 128 KiB][bias strips, 2 KiB][4 x 4 KiB store tiles] = 146 KiB (tanh' mode: [2 slots][4 input tiles][4 store tiles] = 160 KiB).
+// Forward / input-gradient roles only (A stored [M][K], no split-K).
 // =================================================================================================
 #define W2P_STAGE_BYTES 4096
 #define W2P_LDS_BYTES (2 * W2_SLOT + W2_BIAS_BYTES + 4 * W2P_STAGE_BYTES)
