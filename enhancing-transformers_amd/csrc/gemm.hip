@@ -788,7 +788,35 @@ __device__ __forceinline__ void gemm_epilogue_p(const GemmArgs& args, f32x16 (&a
   }
 }
 
-template <bool TA, bool TB, int EPI>
+// ---- dynamic tile schedule of the persistent kernels (round 4; measured in profiles/r04_comm_contention.txt) -------------------------------------
+// With a static partition (workgroup b walks tiles b, b + grid, ...) and grid = CU count, every workgroup MUST get a CU at once: one wave per SIMD with
+// all 512 registers and 146-160 KiB of LDS shares a CU with nothing.  A collective's kernel (RCCL under data-parallel training, engine/ddp.py) that
+// holds k CUs when the GEMM is dispatched leaves k workgroups waiting for another to retire — the launch takes up to twice as long.  DYN: tiles are
+// CLAIMED instead — one queue per XCD (workgroups of XCD x take virtual tiles x, x + 8, x + 16, ... in order, i.e. exactly the XCD-grouped walk of
+// the static form, so operand slices still meet in one L2), an atomic counter per queue.  A workgroup that starts late finds its queue empty and
+// exits; the ones that got a CU absorb its share: the launch slows by k / CUs, not 2x.  The claim for the NEXT tile is issued at the top of a tile
+// (thread 0; it is the oldest vector-memory operation of everything the K loop then counts, so no counted wait changes), handed to the other waves
+// through an LDS word behind the first K-stage barrier, and consumed nst - 2 stages later.  The counters reset themselves: every workgroup makes
+// exactly one failing claim, so the claim that returns (tiles of the queue) + (workgroups of the XCD) - 1 is the launch's last and stores 0.
+// the mailbox word is read and written with explicit LDS instructions: through a (volatile) generic pointer the compiler emits FLAT accesses, which count in
+// vmcnt as well and drew an s_waitcnt vmcnt(0) — a drain of the whole operand pipeline — at every tile (found in the ISA)
+__device__ __forceinline__ void lds_store_u32(const void* lds_ptr, unsigned v) {
+  asm volatile("ds_write_b32 %0, %1" ::"v"((unsigned)(uintptr_t)(LDS_AS const void*)lds_ptr), "v"(v) : "memory");
+}
+__device__ __forceinline__ unsigned lds_load_u32_sync(const void* lds_ptr) {
+  unsigned v;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(uintptr_t)(LDS_AS const void*)lds_ptr) : "memory");
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+// (gemm.o is compiled with -amdgpu-atomic-optimizer-strategy=None: the optimizer turns a one-lane atomic with a uniform address into a wave reduction that
+// needs its result AT ONCE, i.e. s_waitcnt vmcnt(0) right behind the atomic)
+__device__ __forceinline__ unsigned tile_claim(unsigned* ctr) { return __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void tile_claim_retire(unsigned* ctr, unsigned f, int ntiles, int xcd) {
+  const unsigned n_q = ntiles > xcd ? (unsigned)(ntiles - xcd + 7) >> 3 : 0u, w_q = ((unsigned)gridDim.x - (unsigned)xcd + 7u) >> 3;
+  if (f == n_q + w_q - 1u) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <bool TA, bool TB, int EPI, bool DYN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_bf16_w256p_kernel(const GemmArgs args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int t = threadIdx.x;
@@ -797,6 +825,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int wm = wave >> 1, wn = wave & 1;
   const int ntiles = args.nbm * args.nbn;
   const int nst = (int)(args.K / G_BK);   // >= 3 (launcher); no split-K in this kernel
+  const int xcd = (int)blockIdx.x & 7;
+  unsigned* const ctr = DYN ? args.tile_ctr + xcd : nullptr;
 
   const bool stage_a = wave < 2;
   const bool my_tr = stage_a ? TA : TB;
@@ -814,8 +844,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   float* const wave_bias = reinterpret_cast<float*>(smem + 2 * W2_SLOT) + wave * 128;
   unsigned char* const at = smem + 2 * W2_SLOT + wave * W2P_STAGE_BYTES;
   unsigned char* const st = smem + 2 * W2_SLOT + (EPI == EPI_BF16_DTANH ? 4 * W2P_STAGE_BYTES : W2_BIAS_BYTES) + wave * W2P_STAGE_BYTES;
+  // mailbox of the dynamic schedule: the first word of wave 0's store tile (idle from the end of an epilogue to the next one)
+  const unsigned char* const s_next = smem + 2 * W2_SLOT + (EPI == EPI_BF16_DTANH ? 4 * W2P_STAGE_BYTES : W2_BIAS_BYTES);
 
   int vt = (int)blockIdx.x, split_, tile_m, tile_n;
+  if (DYN) {
+    if (t == 0) {
+      const unsigned f = tile_claim(ctr);
+      tile_claim_retire(ctr, f, ntiles, xcd);
+      lds_store_u32(s_next, f);
+    }
+    __syncthreads();
+    vt = xcd + 8 * (int)lds_load_u32_sync(s_next);
+    if (vt >= ntiles) return;     // a workgroup that started late: its queue is empty
+    __syncthreads();
+  }
   gemm_tile_coords_of(args, vt, split_, tile_m, tile_n);
   const uint16_t *gsrc_e, *gsrc_o;
   {
@@ -845,15 +888,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // the source pointers are at stage 2
     const int64_t m0 = (int64_t)tile_m * 256, n0 = (int64_t)tile_n * 256;
     int vnext = vt + (int)gridDim.x;
-    const bool last_tile = vnext >= ntiles;
+    bool last_tile = vnext >= ntiles;
     if (last_tile) vnext = vt;   // the last tile re-requests its own first stages (never consumed; drained before the kernel ends)
+    unsigned fnext = 0;
+    if (DYN && t == 0) fnext = tile_claim(ctr);     // the next tile of this XCD's queue: in flight under the first K stage
     {
       W2_KSTEP_Z(fa0, fb0, fa1, fb1, par, 1);
       W2_KSTEP(fa1, fb1, fa0, fb0, par, 2, true, 0, 0, false);
       W2_KSTEP(fa0, fb0, fa1, fb1, par, 3, true, 0, 0, false);
-      __builtin_amdgcn_s_waitcnt(0x0070);    // vmcnt(0): stage 1 landed (and the previous tile's stores are acknowledged)
+      __builtin_amdgcn_s_waitcnt(0x0070);    // vmcnt(0): stage 1 landed (and the previous tile's stores are acknowledged, and the claim has returned)
+      if (DYN) {
+        if (t == 0) { tile_claim_retire(ctr, fnext, ntiles, xcd); lds_store_u32(s_next, fnext); }
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // the mailbox write is performed before the barrier lets anybody read it
+      }
       __builtin_amdgcn_s_barrier();
       W2_FENCE();
+      if (DYN) {
+        vnext = xcd + 8 * (int)lds_load_u32_sync(s_next);
+        last_tile = vnext >= ntiles;
+        if (last_tile) vnext = vt;
+      }
       W2_KSTEP(fa1, fb1, fa0, fb0, par ^ 1, 0, true, par, 0, true);      // + pieces 0-7 of stage 2
     }
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);   // this tile's bias, for the epilogue's LDS strip: requested now, consumed a K loop later
@@ -904,7 +958,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // Needs an even number of K stages, at least 6.
 // =================================================================================================
 #define W2R_D 2
-template <bool TB, int EPI>
+template <bool TB, int EPI, bool DYN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_bf16_w256r_kernel(const GemmArgs args) {
   constexpr bool TA = false;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -915,6 +969,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int ntiles = args.nbm * args.nbn;
   const int nst = (int)(args.K / G_BK);   // even, >= 6 (launcher)
   const int sub = wave >> 1, half = wave & 1;   // this wave stages slabs half*8 .. half*8+7 of sub-tile `sub` of BOTH operands
+  const int xcd = (int)blockIdx.x & 7;
+  unsigned* const ctr = DYN ? args.tile_ctr + xcd : nullptr;     // dynamic tile schedule: see gemm_bf16_w256p_kernel
+  const unsigned char* const s_next = smem + 2 * W2_SLOT + (EPI == EPI_BF16_DTANH ? 4 * W2P_STAGE_BYTES : W2_BIAS_BYTES);
 
   const uint16_t* const baseA_e = w256_src<false>(args.A, args.lda, sub * 128 + half * 64, 0, 0, lane);
   const uint16_t* const baseA_o = w256_src<false>(args.A, args.lda, sub * 128 + half * 64, 0, 1, lane);
@@ -930,6 +987,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   unsigned char* const st = smem + 2 * W2_SLOT + (EPI == EPI_BF16_DTANH ? 4 * W2P_STAGE_BYTES : W2_BIAS_BYTES) + wave * W2P_STAGE_BYTES;
 
   int vt = (int)blockIdx.x, split_, tile_m, tile_n;
+  if (DYN) {
+    if (t == 0) {
+      const unsigned f = tile_claim(ctr);
+      tile_claim_retire(ctr, f, ntiles, xcd);
+      lds_store_u32(s_next, f);
+    }
+    __syncthreads();
+    vt = xcd + 8 * (int)lds_load_u32_sync(s_next);
+    if (vt >= ntiles) return;     // a workgroup that started late: its queue is empty
+    __syncthreads();
+  }
   gemm_tile_coords_of(args, vt, split_, tile_m, tile_n);
   const uint16_t *gA_e = baseA_e + (int64_t)tile_m * 256 * args.lda, *gA_o = baseA_o + (int64_t)tile_m * 256 * args.lda;
   const uint16_t *gB_e = baseB_e + (int64_t)tile_n * 256 * xB_step, *gB_o = baseB_o + (int64_t)tile_n * 256 * xB_step;
@@ -983,7 +1051,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }                                                                                                                             \
   } while (0)
   // one K stage (local index j): SET = (j + 1) % 2 is the register set that holds A(j+1)
-#define W2R_STAGE(ZERO, SET, WAIT)                                                                                                     \
+#define W2R_STAGE(ZERO, SET, WAIT, HOOK)                                                                                               \
   do {                                                                                                                            \
     const int slot_ = j & 1;                                                                                                      \
     if (j == nst - 1 - W2R_D) { gA_e = baseA_e + offA_next; gA_o = baseA_o + offA_next; }   /* A(j+3) is the next tile's stage 0 */ \
@@ -993,6 +1061,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     W2R_K12(fa0, fb0, fa1, fb1, slot_, 3);                                                                                        \
     /* B(j+1) landed (only this stage's 8 A loads are younger; after an epilogue its stores are younger too and stay in flight) ; A(j+1) written */ \
     __builtin_amdgcn_s_waitcnt(WAIT);                                                                                             \
+    HOOK;                                                                                                                         \
     __builtin_amdgcn_s_barrier();                                                                                                 \
     W2_FENCE();                                                                                                                   \
     if (j == nst - 2) { gB_e = baseB_e + offB_next; gB_o = baseB_o + offB_next; }           /* B(j+2) is the next tile's stage 0 */ \
@@ -1035,28 +1104,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   int64_t m0 = (int64_t)tile_m * 256, n0 = (int64_t)tile_n * 256;
   int vnext = vt + (int)gridDim.x;
   if (vnext >= ntiles) vnext = vt;   // the last tile re-requests its own first stages (never consumed; drained before the kernel ends)
-  gemm_tile_coords_of(args, vnext, split_, tile_m, tile_n);
+  if (!DYN) gemm_tile_coords_of(args, vnext, split_, tile_m, tile_n);
   int64_t offA_next = (int64_t)tile_m * 256 * args.lda, offB_next = (int64_t)tile_n * 256 * xB_step;
   int j = 0;
-  W2R_STAGE(true, 1, 0x0078);
-  for (int it = 0; it < my_tiles; ++it) {
+  W2R_STAGE(true, 1, 0x0078, (void)0);
+  // DYN: the loop runs while the tile in hand is real; the claim for the next one is issued at the top of the body (older than everything stage 1
+  // counts), returns under stage 1 and is handed round behind stage 1's barrier — two stages before stage nst - 3 needs the next tile's A origin.
+  bool more = true;
+  for (int it = 0; DYN ? more : it < my_tiles; ++it) {
+    unsigned fnext = 0;
+    if (DYN && t == 0) fnext = tile_claim(ctr);
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);   // this tile's bias, for the epilogue's LDS strip: requested now, consumed a K loop later
     if ((EPI == EPI_BF16_BIAS_TANH || EPI == EPI_F32_BIAS_RES) && lane < 32) bias4 = *reinterpret_cast<const float4*>(args.bias + n0 + wn * 128 + lane * 4);
-    W2R_STAGE(false, 0, 0x0078);
+    if (DYN) {
+      W2R_STAGE(false, 0, 0x0078, do { if (t == 0) { tile_claim_retire(ctr, fnext, ntiles, xcd); lds_store_u32(s_next, fnext); } __builtin_amdgcn_s_waitcnt(0xC07F); } while (0));
+      vnext = xcd + 8 * (int)lds_load_u32_sync(s_next);
+      more = vnext < ntiles;
+      if (!more) vnext = vt;
+      gemm_tile_coords_of(args, vnext, split_, tile_m, tile_n);
+      offA_next = (int64_t)tile_m * 256 * args.lda; offB_next = (int64_t)tile_n * 256 * xB_step;
+    } else {
+      W2R_STAGE(false, 0, 0x0078, (void)0);
+    }
     while (j < nst) {
-      W2R_STAGE(false, 1, 0x0078);
-      W2R_STAGE(false, 0, 0x0078);
+      W2R_STAGE(false, 1, 0x0078, (void)0);
+      W2R_STAGE(false, 0, 0x0078, (void)0);
     }
     gemm_epilogue_p<EPI>(args, acc, m0 + wm * 128, n0 + wn * 128, lane, wave_bias, st, at, bias4);   // (the next wait counts this epilogue's stores)
     W2_FENCE();
     vt = vnext;
     m0 = (int64_t)tile_m * 256; n0 = (int64_t)tile_n * 256;
-    vnext = vt + (int)gridDim.x;
-    if (vnext >= ntiles) vnext = vt;
-    gemm_tile_coords_of(args, vnext, split_, tile_m, tile_n);
-    offA_next = (int64_t)tile_m * 256 * args.lda; offB_next = (int64_t)tile_n * 256 * xB_step;
+    if (!DYN) {
+      vnext = vt + (int)gridDim.x;
+      if (vnext >= ntiles) vnext = vt;
+      gemm_tile_coords_of(args, vnext, split_, tile_m, tile_n);
+      offA_next = (int64_t)tile_m * 256 * args.lda; offB_next = (int64_t)tile_n * 256 * xB_step;
+    }
     j = 0;
-    W2R_STAGE(true, 1, EPI_STORES_WAIT);
+    W2R_STAGE(true, 1, EPI_STORES_WAIT, (void)0);
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);   // the dummy requests write LDS / registers: landed before the workgroup's resources are released
 #undef W2R_APTR
@@ -1093,6 +1178,48 @@ extern "C" int enh_gemm_set_kernel(int family) {
   return ENH_OK;
 }
 
+// CU budget (round 4): how many CUs the GEMM launches may count on.  Data-parallel training runs RCCL's kernels beside the backward GEMMs
+// (engine/ddp.py); a persistent grid or a one-round split-K plan sized for ALL CUs then has workgroups that wait for a CU until another retires.
+// 0 = every CU of the device.  Explicit state behind an explicit call (the library reads no environment).
+static int g_cu_budget = 0;
+static int device_cus() {
+  static const int n = [] {
+    int dev = 0, c = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev);
+    return c > 0 ? c : 256;
+  }();
+  return n;
+}
+static int cu_budget() { return g_cu_budget > 0 && g_cu_budget < device_cus() ? g_cu_budget : device_cus(); }
+extern "C" int enh_set_cu_budget(int n_cus) {
+  ENH_REQUIRE(n_cus >= 0, ENH_E_BADARG, "enh_set_cu_budget: n_cus must be >= 0 (0 = all)");
+  g_cu_budget = n_cus;
+  return ENH_OK;
+}
+extern "C" int enh_get_cu_budget(void) { return cu_budget(); }
+
+// tile schedule of the persistent kernels: 0 = static partition (workgroup b walks b, b + grid, ...), 1 = tiles claimed from per-XCD queues (see
+// gemm_bf16_w256p_kernel).  The counters are library-owned device words (not an allocation): 64 launch slots x 8 queues, used round-robin — a slot is
+// reused 64 persistent launches later, by which time the launch that used it has long retired (they run in stream order on one stream; two streams
+// would have to keep 64 persistent GEMMs in flight to collide).
+static int g_dyn_schedule = 1;
+__device__ unsigned int g_tile_ctr[64][8];
+extern "C" int enh_gemm_set_scheduler(int dynamic) {
+  ENH_REQUIRE(dynamic == 0 || dynamic == 1, ENH_E_BADARG, "enh_gemm_set_scheduler: 0 (static) or 1 (dynamic)");
+  g_dyn_schedule = dynamic;
+  return ENH_OK;
+}
+static unsigned int* next_tile_counters() {
+  static unsigned int* base = [] {
+    void* p = nullptr;
+    (void)hipGetSymbolAddress(&p, HIP_SYMBOL(g_tile_ctr));
+    return (unsigned int*)p;
+  }();
+  static unsigned seq = 0;
+  return base ? base + (size_t)((seq++) & 63u) * 8 : nullptr;
+}
+
 struct GemmPlan { int family, splits; int64_t k_per_split; };
 
 static GemmPlan gemm_plan(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, bool splittable) {
@@ -1120,15 +1247,15 @@ static GemmPlan gemm_plan(int trans_a, int trans_b, int64_t M, int64_t N, int64_
     family = 3;
     if (w256_ok) {
       const int64_t tiles = (M / 256) * (N / 256);
-      const int sp = split_for(tiles, 256, 64);
+      const int sp = split_for(tiles, cu_budget(), 64);
       const int64_t per = (ksteps + sp - 1) / sp;
-      if (tiles * sp >= 192 && ksteps - (sp - 1) * per >= 2) family = 7;
+      if (tiles * sp >= (3 * cu_budget()) / 4 && ksteps - (sp - 1) * per >= 2) family = 7;
     }
   }
   pl.family = family;
   const int64_t bm = family == 7 ? 256 : 128;
   const int64_t tiles = ((M + bm - 1) / bm) * ((N + bm - 1) / bm);
-  pl.splits = split_for(tiles, family == 7 ? 256 : 512, 64);
+  pl.splits = split_for(tiles, family == 7 ? cu_budget() : 2 * cu_budget(), 64);
   const int64_t per = (ksteps + pl.splits - 1) / pl.splits;
   pl.k_per_split = per * G_BK;
   pl.splits = (int)((ksteps + per - 1) / per);
@@ -1198,6 +1325,7 @@ static int gemm_bf16_impl(const enh_bf16* A, int64_t lda, int trans_a, const enh
   g.bias = bias; g.act = act; g.aux = aux; g.ldaux = ldaux; g.res = res; g.ldres = ldres; g.res_rows = res_rows;
   g.accumulate = accumulate; g.c_f32 = c_f32; g.c_bf16 = c_bf16; g.ldc = ldc; g.ws = nullptr;
   g.colpart = colpart;
+  g.tile_ctr = nullptr;
   g.nbm = (int)((M + bm - 1) / bm);
   g.nbn = (int)((N + bn - 1) / bn);
   const int64_t tiles = (int64_t)g.nbm * g.nbn;
@@ -1252,37 +1380,43 @@ static int gemm_bf16_impl(const enh_bf16* A, int64_t lda, int trans_a, const enh
     }();
     (void)w2_attr;
     const int mode = epi_mode(g);
-    if (gemm_persistent(pl, trans_a, K, mode) && (!res || res_rows == M)) {
+    // (the persistent epilogues use 16-byte accesses everywhere: operands that only meet the API's weaker alignment rules take the one-tile kernel)
+    const bool p_aligned = aligned16(c_bf16) && aligned16(aux) && aligned16(res) && aligned16(bias) && (!c_bf16 || ldc % 8 == 0) && (!aux || ldaux % 8 == 0);
+    if (gemm_persistent(pl, trans_a, K, mode) && (!res || res_rows == M) && p_aligned) {
       // persistent form: one workgroup per CU walks the tiles
-#define W2P_ROW(TB_) {nullptr, gemm_bf16_w256p_kernel<false, TB_, EPI_BF16>, gemm_bf16_w256p_kernel<false, TB_, EPI_BF16_BIAS_TANH>, gemm_bf16_w256p_kernel<false, TB_, EPI_BF16_DTANH>, \
-                      gemm_bf16_w256p_kernel<false, TB_, EPI_F32_BIAS_RES>, gemm_bf16_w256p_kernel<false, TB_, EPI_F32>, nullptr, nullptr}
-      static const w256_fn ptable[2][EPI_NMODES] = {W2P_ROW(false), W2P_ROW(true)};
+#define W2P_ROW(TB_, D_) {nullptr, gemm_bf16_w256p_kernel<false, TB_, EPI_BF16, D_>, gemm_bf16_w256p_kernel<false, TB_, EPI_BF16_BIAS_TANH, D_>, gemm_bf16_w256p_kernel<false, TB_, EPI_BF16_DTANH, D_>, \
+                          gemm_bf16_w256p_kernel<false, TB_, EPI_F32_BIAS_RES, D_>, gemm_bf16_w256p_kernel<false, TB_, EPI_F32, D_>, nullptr, nullptr}
+      static const w256_fn ptable[4][EPI_NMODES] = {W2P_ROW(false, false), W2P_ROW(true, false), W2P_ROW(false, true), W2P_ROW(true, true)};   // [2 * DYN + TB]
 #undef W2P_ROW
-      static const int n_cu = [] {
-        int dev = 0, n = 256;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-        for (int l = 0; l < 2; ++l)
+      static const bool p_attr = [] {
+        for (int l = 0; l < 4; ++l)
           for (int e = 0; e < EPI_NMODES; ++e)
             if (ptable[l][e]) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ptable[l][e]), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                         e == EPI_BF16_DTANH ? W2P_LDS_BYTES_DTANH : W2P_LDS_BYTES);
-        return n > 0 ? n : 256;
+        return true;
       }();
+      (void)p_attr;
+      const int n_cu = cu_budget();
       const int64_t wgs = tiles < n_cu ? tiles : n_cu;
+      const int dyn = g_dyn_schedule && wgs >= 8 ? 1 : 0;     // (every XCD queue needs a workgroup that serves it)
+      if (dyn) {
+        g.tile_ctr = next_tile_counters();
+        ENH_REQUIRE(g.tile_ctr, ENH_E_BADARG, "enh_gemm_bf16: tile counters unavailable");
+      }
       if (gemm_regstaged(K, mode)) {
-#define W2R_ROW(TB_) {nullptr, gemm_bf16_w256r_kernel<TB_, EPI_BF16>, gemm_bf16_w256r_kernel<TB_, EPI_BF16_BIAS_TANH>, nullptr, nullptr, gemm_bf16_w256r_kernel<TB_, EPI_F32>, nullptr, nullptr}
-        static const w256_fn rtable[2][EPI_NMODES] = {W2R_ROW(false), W2R_ROW(true)};
+#define W2R_ROW(TB_, D_) {nullptr, gemm_bf16_w256r_kernel<TB_, EPI_BF16, D_>, gemm_bf16_w256r_kernel<TB_, EPI_BF16_BIAS_TANH, D_>, nullptr, nullptr, gemm_bf16_w256r_kernel<TB_, EPI_F32, D_>, nullptr, nullptr}
+        static const w256_fn rtable[4][EPI_NMODES] = {W2R_ROW(false, false), W2R_ROW(true, false), W2R_ROW(false, true), W2R_ROW(true, true)};
 #undef W2R_ROW
         static const bool r_attr = [] {
-          for (int l = 0; l < 2; ++l)
+          for (int l = 0; l < 4; ++l)
             for (int e = 0; e < EPI_NMODES; ++e)
               if (rtable[l][e]) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rtable[l][e]), hipFuncAttributeMaxDynamicSharedMemorySize, W2P_LDS_BYTES);
           return true;
         }();
         (void)r_attr;
-        hipLaunchKernelGGL(rtable[trans_b ? 1 : 0][mode], dim3((unsigned)wgs), dim3(256), (size_t)W2P_LDS_BYTES, s, g);
+        hipLaunchKernelGGL(rtable[2 * dyn + (trans_b ? 1 : 0)][mode], dim3((unsigned)wgs), dim3(256), (size_t)W2P_LDS_BYTES, s, g);
       } else
-      hipLaunchKernelGGL(ptable[trans_b ? 1 : 0][mode], dim3((unsigned)wgs), dim3(256), (size_t)(mode == EPI_BF16_DTANH ? W2P_LDS_BYTES_DTANH : W2P_LDS_BYTES), s, g);
+      hipLaunchKernelGGL(ptable[2 * dyn + (trans_b ? 1 : 0)][mode], dim3((unsigned)wgs), dim3(256), (size_t)(mode == EPI_BF16_DTANH ? W2P_LDS_BYTES_DTANH : W2P_LDS_BYTES), s, g);
     } else
     hipLaunchKernelGGL(table[(trans_a ? 2 : 0) + (trans_b ? 1 : 0)][mode], grid, dim3(256), (size_t)(2 * W2_SLOT + W2_BIAS_BYTES), s, g);
   } else if (family == 3) LAUNCH(gemm_bf16_pipe2_kernel, 256, lds2);

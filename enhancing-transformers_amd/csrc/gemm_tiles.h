@@ -33,6 +33,7 @@ struct GemmArgs {
   int nbm, nbn;
   int splits;  // number of K-slices (1 = no split-K; otherwise a multiple of 8)
   float* colpart;  // tanh' mode of the persistent kernel: per-128-row partial column sums of the bf16 result, [M / 128][N] (or null)
+  unsigned int* tile_ctr;  // persistent kernels, dynamic schedule: the launch's 8 per-XCD tile counters (zero at launch, reset by the kernel itself)
 };
 
 // global -> registers: one 128 x 64 (row layout) or 64 x 128 (kmaj layout) bf16 operand tile, 4 x 16 B per thread

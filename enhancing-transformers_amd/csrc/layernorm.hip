@@ -6,11 +6,13 @@
 // backward fuses the residual-stream gradient add and emits the bf16 copy the wgrad/dgrad GEMMs consume.
 #include "common.h"
 
-template <int NCH>
+// X3: additionally writes the split-bf16 operand row y3 [M][3*D] = [hi | lo | hi] with hi = bf16(y), lo = bf16(y - hi) (x3.hip: the A operand of a
+// K-concatenated three-pass product); statistics and y are the same bits as in the plain form.
+template <int NCH, bool X3>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ b, int64_t M, int D, float eps,
                                                      uint16_t* __restrict__ y16, float* __restrict__ y32,
-                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out, uint16_t* __restrict__ y3) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -52,7 +54,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
       o.z = (v[i].z - mean) * rstd * g.z + be.z;
       o.w = (v[i].w - mean) * rstd * g.w + be.w;
       if (y32) reinterpret_cast<float4*>(y32 + (size_t)row * D)[c] = o;
-      if (y16) reinterpret_cast<uint2*>(y16 + (size_t)row * D)[c] = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
+      const uint2 hi2 = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
+      if (y16) reinterpret_cast<uint2*>(y16 + (size_t)row * D)[c] = hi2;
+      if (X3) {
+        const uint2 lo2 = make_uint2(pack_bf16x2(o.x - __builtin_bit_cast(float, hi2.x << 16), o.y - __builtin_bit_cast(float, hi2.x & 0xffff0000u)),
+                                     pack_bf16x2(o.z - __builtin_bit_cast(float, hi2.y << 16), o.w - __builtin_bit_cast(float, hi2.y & 0xffff0000u)));
+        uint2* r3 = reinterpret_cast<uint2*>(y3 + (size_t)row * 3 * D);
+        r3[c] = hi2; r3[nch + c] = lo2; r3[2 * nch + c] = hi2;
+      }
     }
   }
 }
@@ -219,21 +228,33 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
   }
 }
 
+template <bool X3>
+static void ln_fwd_launch(int grid, hipStream_t s, const float* x, const float* w, const float* b, int64_t M, int D, float eps, enh_bf16* y_bf16, float* y_f32,
+                          float* mean, float* rstd, enh_bf16* y3) {
+  switch ((D + 255) / 256) {  // float4 chunks per lane: registers (hence occupancy) scale with it
+    case 1: ln_fwd_kernel<1, X3><<<grid, 256, 0, s>>>(x, w, b, M, D, eps, y_bf16, y_f32, mean, rstd, y3); break;
+    case 2: ln_fwd_kernel<2, X3><<<grid, 256, 0, s>>>(x, w, b, M, D, eps, y_bf16, y_f32, mean, rstd, y3); break;
+    case 3: ln_fwd_kernel<3, X3><<<grid, 256, 0, s>>>(x, w, b, M, D, eps, y_bf16, y_f32, mean, rstd, y3); break;
+    case 4: ln_fwd_kernel<4, X3><<<grid, 256, 0, s>>>(x, w, b, M, D, eps, y_bf16, y_f32, mean, rstd, y3); break;
+    case 5: ln_fwd_kernel<5, X3><<<grid, 256, 0, s>>>(x, w, b, M, D, eps, y_bf16, y_f32, mean, rstd, y3); break;
+    default: ln_fwd_kernel<8, X3><<<grid, 256, 0, s>>>(x, w, b, M, D, eps, y_bf16, y_f32, mean, rstd, y3); break;
+  }
+}
+
 extern "C" int enh_layernorm_forward(const float* x, const float* w, const float* b, int64_t M, int D, float eps,
                                      enh_bf16* y_bf16, float* y_f32, float* mean, float* rstd, void* stream) {
   ENH_REQUIRE(x && w && b && (y_bf16 || y_f32), ENH_E_BADARG, "enh_layernorm_forward: null pointer");
   ENH_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 2048, ENH_E_SHAPE, "enh_layernorm_forward: need D %% 4 == 0 and D <= 2048, got M=%lld D=%d", (long long)M, D);
-  hipStream_t s = (hipStream_t)stream;
-  const int grid = (int)((M + 3) / 4);
-  switch ((D + 255) / 256) {  // float4 chunks per lane: registers (hence occupancy) scale with it
-    case 1: ln_fwd_kernel<1><<<grid, 256, 0, s>>>(x, w, b, M, D, eps, y_bf16, y_f32, mean, rstd); break;
-    case 2: ln_fwd_kernel<2><<<grid, 256, 0, s>>>(x, w, b, M, D, eps, y_bf16, y_f32, mean, rstd); break;
-    case 3: ln_fwd_kernel<3><<<grid, 256, 0, s>>>(x, w, b, M, D, eps, y_bf16, y_f32, mean, rstd); break;
-    case 4: ln_fwd_kernel<4><<<grid, 256, 0, s>>>(x, w, b, M, D, eps, y_bf16, y_f32, mean, rstd); break;
-    case 5: ln_fwd_kernel<5><<<grid, 256, 0, s>>>(x, w, b, M, D, eps, y_bf16, y_f32, mean, rstd); break;
-    default: ln_fwd_kernel<8><<<grid, 256, 0, s>>>(x, w, b, M, D, eps, y_bf16, y_f32, mean, rstd); break;
-  }
+  ln_fwd_launch<false>((int)((M + 3) / 4), (hipStream_t)stream, x, w, b, M, D, eps, y_bf16, y_f32, mean, rstd, nullptr);
   return enh_check_launch("enh_layernorm_forward");
+}
+
+extern "C" int enh_layernorm_forward_x3(const float* x, const float* w, const float* b, int64_t M, int D, float eps, enh_bf16* y3,
+                                        enh_bf16* y_bf16, float* y_f32, float* mean, float* rstd, void* stream) {
+  ENH_REQUIRE(x && w && b && y3, ENH_E_BADARG, "enh_layernorm_forward_x3: null pointer");
+  ENH_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 2048, ENH_E_SHAPE, "enh_layernorm_forward_x3: need D %% 4 == 0 and D <= 2048, got M=%lld D=%d", (long long)M, D);
+  ln_fwd_launch<true>((int)((M + 3) / 4), (hipStream_t)stream, x, w, b, M, D, eps, y_bf16, y_f32, mean, rstd, y3);
+  return enh_check_launch("enh_layernorm_forward_x3");
 }
 
 template <bool DY16>

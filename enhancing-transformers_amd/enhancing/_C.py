@@ -46,6 +46,10 @@ SIGNATURES = {
                                 _i32, _vp, _vp, _i64, _vp, _sz, _vp]),
     "enh_gemm_bf16_workspace_bytes": (_sz, [_i32, _i32, _i64, _i64, _i64]),
     "enh_gemm_set_kernel": (_i32, [_i32]),
+    "enh_gemm_set_scheduler": (_i32, [_i32]),
+    "enh_set_cu_budget": (_i32, [_i32]),
+    "enh_get_cu_budget": (_i32, []),
+    "enh_debug_occupy_cus": (_i32, [_i32, _f32, _vp]),
     "enh_gemm_bf16_variant": (_c.c_char_p, [_i32, _i32, _i64, _i64, _i64]),
     "enh_gemm_bf16_variant_mode": (_c.c_char_p, [_i32, _i32, _i64, _i64, _i64, _i32]),
     "enh_gemm_bf16_dtanh_colsum_workspace_bytes": (_c.c_size_t, [_i32, _i64, _i64, _i64]),
@@ -93,11 +97,15 @@ SIGNATURES = {
     "enh_maxpool2_nhwc_bf16_backward": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "enh_lpips_head": (_i32, [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _i32, _vp]),
     "enh_lpips_head_backward": (_i32, [_vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp]),
+    "enh_split3_bf16": (_i32, [_vp, _i64, _i64, _i64, _vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp]),
+    "enh_split2_bf16": (_i32, [_vp, _i64, _vp, _vp, _vp]),
+    "enh_layernorm_forward_x3": (_i32, [_vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "enh_attention_forward_x3": (_i32, [_vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp]),
     "enh_adamw_step": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
 }
 
 _LIB = None
-ABI_VERSION = 8   # ENH_ABI_VERSION of the include/enh_hip.h these signatures were written against
+ABI_VERSION = 9   # ENH_ABI_VERSION of the include/enh_hip.h these signatures were written against
 
 
 def lib():
@@ -124,6 +132,10 @@ def lib():
             _check_rc = L.enh_gemm_set_kernel(fam)
             if _check_rc != 0:
                 raise RuntimeError(L.enh_last_error().decode())
+        sched = os.environ.get("ENH_GEMM_SCHEDULER")      # "static" | "dynamic" tile schedule of the persistent GEMMs (A/B)
+        if sched:
+            if sched not in ("static", "dynamic") or L.enh_gemm_set_scheduler(int(sched == "dynamic")) != 0:
+                raise RuntimeError(f"ENH_GEMM_SCHEDULER={sched!r}: expected static | dynamic")
         att = os.environ.get("ENH_ATTN_KERNEL")       # "fwd,dq,dkv" families, e.g. "2,2,1" (0 = library default, 1 = round-2 kernels, 2 = pipelined)
         if att:
             f, q, k = (int(x) for x in att.split(","))
@@ -334,6 +346,25 @@ def gemm_dtanh_colsum(a, b, M: int, N: int, K: int, aux, out_bf16, colsum_out, t
     else:   # labelled with the GEMM kernel's symbol (the partial-row second pass and, off the tile grid, the column-sum kernel ride along)
         fam = lib().enh_gemm_bf16_variant_mode(0, int(trans_b), M, N, K, 3).decode()
         TIMER.run(f"{fam}<false, {'true' if trans_b else 'false'}" + (", 3>" if "w256" in fam else ">"), 2.0 * M * N * K, call)
+
+
+def set_cu_budget(n: int) -> None:
+    """CUs the GEMM launches may count on (0 = all); see include/enh_hip.h"""
+    _check(lib().enh_set_cu_budget(int(n)), "enh_set_cu_budget")
+
+
+def get_cu_budget() -> int:
+    return int(lib().enh_get_cu_budget())
+
+
+def gemm_set_scheduler(dynamic: bool) -> None:
+    _check(lib().enh_gemm_set_scheduler(int(bool(dynamic))), "enh_gemm_set_scheduler")
+
+
+def occupy_cus(n_wg: int, ms: float, stream=None) -> None:
+    """measurement aid: hold n_wg CUs for ms milliseconds on `stream` (a torch stream; default: the current one)"""
+    st = ctypes.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+    _check(lib().enh_debug_occupy_cus(int(n_wg), float(ms), st), "enh_debug_occupy_cus")
 
 
 def _epi_mode_label(accumulate, have_ws, f32, bf16, bias, act, res) -> int:
@@ -661,6 +692,36 @@ def attn_bwd(qkv, out, dout, lse, B, N, H, scale, dqkv, delta_ws, q_prescaled: b
     else:
         _check(lib().enh_attention_backward_f32(_p(qkv, F32, "qkv"), _p(out, F32, "out"), _p(dout, F32, "dout"), _p(lse, F32, "lse"), B, N, H, scale,
                                                 _p(dqkv, F32, "dqkv"), _p(delta_ws, F32, "delta_ws"), _stream()), "enh_attention_backward_f32")
+
+
+# ------------------------------------------------------------------------------------------------
+# x3 split-bf16 operands (parity-grade encoder forward; include/enh_hip.h "x3")
+# ------------------------------------------------------------------------------------------------
+def split3(x, y3, bias=None, act: int = ACT_NONE, order: int = 0, y_hi=None):
+    """x f32 [M,K] -> y3 bf16 [M,3K] = [hi | lo | hi] (order 0) / [hi | hi | lo] (order 1) of f(x + bias); y_hi: optional bf16 [M,K] copy of the hi plane"""
+    M, K = x.shape
+    # algorithmic HBM bytes: 4 in + 6 out (+ 2)
+    _timed("split3_kernel", (10.0 + (2.0 if y_hi is not None else 0.0)) * M * K,
+           lambda: _check(lib().enh_split3_bf16(_p(x, F32, "x"), x.stride(0), M, K, _p(bias, F32, "bias"), act, order, _p(y3, BF16, "y3"), y3.stride(0),
+                                                _p(y_hi, BF16, "y_hi"), y_hi.stride(0) if y_hi is not None else 0, _stream()), "enh_split3_bf16"), unit="byte")
+
+
+def split2(x, hi, lo):
+    _timed("split2_kernel", 8.0 * x.numel(),
+           lambda: _check(lib().enh_split2_bf16(_p(x, F32, "x"), x.numel(), _p(hi, BF16, "hi"), _p(lo, BF16, "lo"), _stream()), "enh_split2_bf16"), unit="byte")
+
+
+def ln_fwd_x3(x, w, b, y3, mean, rstd, y_bf16=None, y_f32=None):
+    M, D = x.shape
+    _check(lib().enh_layernorm_forward_x3(_p(x, F32, "x"), _p(w, F32, "w"), _p(b, F32, "b"), M, D, 1e-5, _p(y3, BF16, "y3"), _p(y_bf16, BF16, "y_bf16"),
+                                          _p(y_f32, F32, "y_f32"), _p(mean, F32, "mean"), _p(rstd, F32, "rstd"), _stream()), "enh_layernorm_forward_x3")
+
+
+def attention_forward_x3(qkv_hi, qkv_lo, B: int, N: int, H: int, scale: float, out3, out_bf16, lse):
+    # executed MFMA work: three passes of the 4 N^2 64 algorithmic FLOP per (image, head)
+    _timed("attn_fwd_x3_kernel", 3 * 4.0 * B * H * N * N * 64,
+           lambda: _check(lib().enh_attention_forward_x3(_p(qkv_hi, BF16, "qkv_hi"), _p(qkv_lo, BF16, "qkv_lo"), B, N, H, scale, _p(out3, BF16, "out3"),
+                                                         _p(out_bf16, BF16, "out_bf16"), _p(lse, F32, "lse"), _stream()), "enh_attention_forward_x3"))
 
 
 def colsum_any(x, M, N, out, accumulate=False):

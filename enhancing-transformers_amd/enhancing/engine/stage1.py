@@ -61,6 +61,7 @@ class ParamStore:
         # GEMM operand view of every weight: the bf16 shadow (product path) or the fp32 master itself (exact mode)
         self.wa = self.w16 if precision == "bf16" else self.w
         self.step_count = 0
+        self.version = 0                   # bumped whenever the fp32 masters may have changed: lazily rebuilt operand images (the x3 weights) compare it
         self.operand_hooks: List = []      # callables that rebuild derived GEMM operands (e.g. the towers' pre-scaled q | k | v weights) from the masters
         self.refresh_shadows()
 
@@ -91,6 +92,7 @@ class ParamStore:
         self.refresh_operands()
 
     def refresh_operands(self) -> None:
+        self.version += 1
         for hook in self.operand_hooks:
             hook()
 
@@ -178,6 +180,59 @@ class _Tower:
     def input_buffer(self, B: int, save: bool) -> torch.Tensor:
         return self.bufs(B, save)["x"][0]
 
+    # ---- x3 (split-bf16) operands: the parity-grade forward (csrc/x3.hip) -----------------------
+    def x3_weights(self) -> List[dict]:
+        """K-concatenated [hi | hi | lo] images of the layer weights (B operands of the three-pass products), rebuilt lazily after the masters changed"""
+        if getattr(self, "_w3_version", None) != self.s.version:
+            if not hasattr(self, "_w3"):
+                e = lambda n, k: torch.empty(n, 3 * k, dtype=torch.bfloat16, device=self.s.device)
+                self._w3 = [dict(wqkv=e(3 * self.inner, self.dim), wout=e(self.dim, self.inner), w1=e(self.mlp, self.dim), w2=e(self.dim, self.mlp))
+                            for _ in range(self.depth)]
+            for P, W in zip(self.L, self._w3):
+                for k in ("wqkv", "wout", "w1", "w2"):
+                    _C.split3(self.s.w[P[k]], W[k], order=1)
+            self._w3_version = self.s.version
+        return self._w3
+
+    def x3_bufs(self, B: int) -> dict:
+        """scratch of the x3 forward, shared by all layers: nothing here is read by the backward (it reads the hi planes saved in the layer arena)"""
+        cache = self.__dict__.setdefault("_x3_bufs", {})
+        if B not in cache:
+            dev, M = self.s.device, B * self.n_tok
+            e = lambda *shape, dt=torch.bfloat16: torch.empty(*shape, dtype=dt, device=dev)
+            f32 = e(M * max(3 * self.inner, self.mlp), dt=F32)            # the qkv projection / fc1 pre-activation in f32 (never alive together)
+            big3 = e(M * 3 * max(self.inner, self.mlp))                    # x3 rows of the attention output / of tanh(fc1)
+            cache[B] = dict(a3=e(M, 3 * self.dim), qkv32=f32[:M * 3 * self.inner].view(M, 3 * self.inner), fc32=f32[:M * self.mlp].view(M, self.mlp),
+                            qkv_lo=e(M, 3 * self.inner), o3=big3[:M * 3 * self.inner].view(M, 3 * self.inner), hid3=big3[:M * 3 * self.mlp].view(M, 3 * self.mlp),
+                            xf3=e(M, 3 * self.dim))
+        return cache[B]
+
+    def forward_x3(self, B: int, save: bool, want_f32: bool = False) -> dict:
+        """forward() with every product formed from split-bf16 operands (reference layers.py:118-132,145-150 in ~fp32 precision on the bf16 matrix
+        cores).  With save=True the arena receives exactly what the bf16 forward would have saved (the hi planes), so backward() is unchanged —
+        except that q is NOT pre-scaled here (recorded in the buffer dict)."""
+        s, b, X, W3 = self.s, self.bufs(B, save), self.x3_bufs(B), self.x3_weights()
+        M, dim, inner, mlp = B * self.n_tok, self.dim, self.inner, self.mlp
+        x = b["x"][0]
+        for i, P in enumerate(self.L):
+            A, W = b["layers"][i if save else 0], W3[i]
+            _C.ln_fwd_x3(x, s.w[P["ln1_w"]], s.w[P["ln1_b"]], X["a3"], A["mean1"], A["rstd1"], y_bf16=A["a1"] if save else None)
+            _C.mm(X["a3"], W["wqkv"], M, 3 * inner, 3 * dim, X["qkv32"])
+            _C.split2(X["qkv32"], A["qkv"], X["qkv_lo"])
+            _C.attention_forward_x3(A["qkv"], X["qkv_lo"], B, self.n_tok, self.heads, self.scale, X["o3"], A["o"] if save else None, A["lse"])
+            _C.mm(X["o3"], W["wout"], M, dim, 3 * inner, A["x_mid"], bias=s.w[P["bout"]], res=x, res_rows=M)
+            _C.ln_fwd_x3(A["x_mid"], s.w[P["ln2_w"]], s.w[P["ln2_b"]], X["a3"], A["mean2"], A["rstd2"], y_bf16=A["a2"] if save else None)
+            _C.mm(X["a3"], W["w1"], M, mlp, 3 * dim, X["fc32"])
+            _C.split3(X["fc32"], X["hid3"], bias=s.w[P["b1"]], act=_C.ACT_TANH, y_hi=A["hid"] if save else None)
+            x_next = b["x"][i + 1] if save else b["x"][(i + 1) & 1]
+            _C.mm(X["hid3"], W["w2"], M, dim, 3 * mlp, x_next, bias=s.w[P["b2"]], res=A["x_mid"], res_rows=M)
+            x = x_next
+        b["x_last"] = x
+        _C.ln_fwd_x3(x, s.w[self.lnf_w], s.w[self.lnf_b], X["xf3"], b["meanf"], b["rstdf"], y_bf16=b["xf16"] if save else None,
+                     y_f32=b["xf32"] if want_f32 else None)
+        b["xf3"], b["x3"], b["q_prescaled"] = X["xf3"], True, False
+        return b
+
     # ---- forward -----------------------------------------------------------------------------
     def forward(self, B: int, save: bool, want_f32: bool = False) -> dict:
         """x[0] must already hold the tower input.  Returns the buffer dict; output = b['xf16'] (+ b['xf32'])."""
@@ -199,6 +254,7 @@ class _Tower:
         _C.ln_fwd(x, s.w[self.lnf_w], s.w[self.lnf_b], b["xf16"], b["meanf"], b["rstdf"], b["xf32"] if want_f32 else None)
         if want_f32 and b["xf16"].dtype == F32:
             b["xf32"] = b["xf16"]
+        b["x3"], b["q_prescaled"] = False, self.q_prescaled
         return b
 
     # ---- backward ----------------------------------------------------------------------------
@@ -208,6 +264,7 @@ class _Tower:
         s, b = self.s, self.bufs(B, True)
         M, dim, inner, mlp = B * self.n_tok, self.dim, self.inner, self.mlp
         g = s.grad
+        q_pre = b.get("q_prescaled", self.q_prescaled)      # convention of the qkv tensor the LAST forward saved (the x3 forward stores unscaled q)
         gA, gA16, gB, gB16, dA = b["gA"], b["gA16"], b["gB"], b["gB16"], b["dA"]
         # every LN backward also emits the column sums of the residual-stream gradient it produces = the bias gradient of
         # the Linear (fc2 / to_out) that wrote that stream
@@ -230,7 +287,7 @@ class _Tower:
             # ---- attention: x_mid = to_out(attn(to_qkv(a1))) + x_in ----
             _C.mm(gB16, A["o"], dim, inner, M, g[P["wout"]], trans_a=True, trans_b=True, accumulate=True)
             _C.mm(gB16, s.wa[P["wout"]], M, inner, dim, b["do16"], trans_b=True)
-            _C.attn_bwd(A["qkv"], A["o"], b["do16"], A["lse"], B, self.n_tok, self.heads, self.scale, b["dqkv16"], b["delta"], self.q_prescaled)
+            _C.attn_bwd(A["qkv"], A["o"], b["do16"], A["lse"], B, self.n_tok, self.heads, self.scale, b["dqkv16"], b["delta"], q_pre)
             _C.mm(b["dqkv16"], A["a1"], 3 * inner, dim, M, g[P["wqkv"]], trans_a=True, trans_b=True, accumulate=True)
             _C.mm(b["dqkv16"], s.wa[P["wqkv"]], M, dim, 3 * inner, dA, trans_b=True)
             _C.ln_bwd(dA, b["x"][i], s.w[P["ln1_w"]], A["mean1"], A["rstd1"], gB, gA, gA16, g[P["ln1_w"]], g[P["ln1_b"]],
@@ -268,14 +325,24 @@ class _AEFunction(torch.autograd.Function):
 class Stage1Engine:
     """Binds a ``ViTVQ`` module tree to the HIP schedule on one device."""
 
-    def __init__(self, model: nn.Module, device: Optional[torch.device] = None, precision: Optional[str] = None) -> None:
+    def __init__(self, model: nn.Module, device: Optional[torch.device] = None, precision: Optional[str] = None,
+                 encoder_precision: Optional[str] = None, codes_precision: Optional[str] = None) -> None:
         """precision: "bf16" (product path: bf16 MFMA operands, fp32 accumulation / residual stream / master weights) or "fp32" (exact
-        mode for parity runs: every operand fp32); default from ENH_PRECISION, else "bf16"."""
+        mode for parity runs: every operand fp32, vector-ALU kernels); default from ENH_PRECISION, else "bf16".
+        Within the bf16 product path the ENCODER forward (patch embedding .. pre_quant, the part that decides the codes) can run on split-bf16
+        ("x3") operands — three MFMA passes, ~1e-5 relative, codes equal to the fp32 reference's up to its own near-ties (csrc/x3.hip):
+          encoder_precision  "bf16" | "x3": training / reconstruct / forward (ENH_ENCODER_PRECISION, default "bf16": the measured headline path)
+          codes_precision    "bf16" | "x3": encode_codes, i.e. the tokens stage 2 consumes (ENH_CODES_PRECISION, default "x3")"""
         import os
         precision = precision or os.environ.get("ENH_PRECISION", "bf16")
         if precision not in ("bf16", "fp32"):
             raise ValueError(f"precision must be 'bf16' or 'fp32', got {precision!r}")
         self.precision = precision
+        self.encoder_precision = encoder_precision or os.environ.get("ENH_ENCODER_PRECISION", "bf16")
+        self.codes_precision = codes_precision or os.environ.get("ENH_CODES_PRECISION", "x3")
+        for name, v in (("encoder_precision", self.encoder_precision), ("codes_precision", self.codes_precision)):
+            if v not in ("bf16", "x3"):
+                raise ValueError(f"{name} must be 'bf16' or 'x3', got {v!r}")
         self.adt = BF16 if precision == "bf16" else F32
         if not torch.cuda.is_available():
             raise RuntimeError("Stage1Engine needs a ROCm device (MI355X); the HIP path has no CPU fallback")
@@ -329,19 +396,46 @@ class Stage1Engine:
         return img.to(device=self.device, dtype=F32).contiguous()
 
     # ---- forward pieces ----------------------------------------------------------------------
-    def _encode_tokens(self, img: torch.Tensor, save: bool, want_f32: bool = False) -> dict:
-        """patch-embed GEMM (+bias +pos table) -> encoder tower.  reference layers.py:177-182"""
+    def _x3_io(self, B: int) -> dict:
+        """x3 operands outside the tower: the split patch / pre_quant weights (rebuilt lazily after the masters changed) and the split patches"""
+        s = self.store
+        X = self.__dict__.setdefault("_x3", dict(version=None, io={}))
+        if X["version"] != s.version:
+            if "wpe" not in X:
+                X["wpe"] = torch.empty(self.enc.dim, 3 * self.pd, dtype=BF16, device=self.device)
+                X["wpre"] = torch.empty(self.ed, 3 * self.enc.dim, dtype=BF16, device=self.device)
+            _C.split3(s.w["encoder.to_patch_embedding.0.weight"].view(self.enc.dim, self.pd), X["wpe"], order=1)
+            _C.split3(s.w["pre_quant.weight"], X["wpre"], order=1)
+            X["version"] = s.version
+        if B not in X["io"]:
+            M = B * self.n_tok
+            X["io"][B] = dict(patches32=torch.empty(M, self.pd, dtype=F32, device=self.device), patches3=torch.empty(M, 3 * self.pd, dtype=BF16, device=self.device))
+        return dict(wpe=X["wpe"], wpre=X["wpre"], **X["io"][B])
+
+    def _encode_tokens(self, img: torch.Tensor, save: bool, want_f32: bool = False, x3: bool = False) -> dict:
+        """patch-embed GEMM (+bias +pos table) -> encoder tower.  reference layers.py:177-182.  x3: on split-bf16 operands (product path only)."""
         B, s, io = img.shape[0], self.store, self._io_bufs(img.shape[0])
         M = B * self.n_tok
+        if x3 and self.precision == "bf16":
+            X = self._x3_io(B)
+            _C.patchify_any(img, self.patch, X["patches32"])
+            _C.split3(X["patches32"], X["patches3"], y_hi=io["patches"] if save else None)
+            _C.mm(X["patches3"], X["wpe"], M, self.enc.dim, 3 * self.pd, self.enc.input_buffer(B, save), bias=s.w["encoder.to_patch_embedding.0.bias"],
+                  res=s.w["encoder.en_pos_embedding"].view(self.n_tok, self.enc.dim), res_rows=self.n_tok)
+            return self.enc.forward_x3(B, save, want_f32)
         _C.patchify_any(img, self.patch, io["patches"])
         w16 = s.wa["encoder.to_patch_embedding.0.weight"].view(self.enc.dim, self.pd)
         _C.mm(io["patches"], w16, M, self.enc.dim, self.pd, self.enc.input_buffer(B, save), bias=s.w["encoder.to_patch_embedding.0.bias"],
               res=s.w["encoder.en_pos_embedding"].view(self.n_tok, self.enc.dim), res_rows=self.n_tok)
         return self.enc.forward(B, save, want_f32)
 
-    def _pre_quant(self, xf16: torch.Tensor, B: int) -> torch.Tensor:
+    def _pre_quant(self, eb: dict, B: int) -> torch.Tensor:
+        """h = pre_quant(final LayerNorm output) for the buffer dict a tower forward returned (vitvqgan.py:63)"""
         s, io = self.store, self._io_bufs(B)
-        _C.mm(xf16, s.wa["pre_quant.weight"], B * self.n_tok, self.ed, self.enc.dim, io["h"], bias=s.w["pre_quant.bias"])
+        if eb.get("x3"):
+            _C.mm(eb["xf3"], self._x3_io(B)["wpre"], B * self.n_tok, self.ed, 3 * self.enc.dim, io["h"], bias=s.w["pre_quant.bias"])
+        else:
+            _C.mm(eb["xf16"], s.wa["pre_quant.weight"], B * self.n_tok, self.ed, self.enc.dim, io["h"], bias=s.w["pre_quant.bias"])
         return io["h"]
 
     def _decode_tokens(self, zq16: torch.Tensor, B: int, save: bool) -> torch.Tensor:
@@ -358,12 +452,13 @@ class Stage1Engine:
 
     # ---- inference API (reference vitvqgan.py:44-90) -------------------------------------------
     @torch.no_grad()
-    def encode_codes(self, img: torch.Tensor) -> torch.Tensor:
+    def encode_codes(self, img: torch.Tensor, precision: Optional[str] = None) -> torch.Tensor:
+        """precision: "x3" | "bf16" for this call (default: self.codes_precision = "x3": the codes stage 2 consumes follow the fp32 reference)"""
         self._invalidate_saved()
         img = self._check_img(img)
         B = img.shape[0]
-        b = self._encode_tokens(img, save=False)
-        h = self._pre_quant(b["xf16"], B)
+        b = self._encode_tokens(img, save=False, x3=(precision or self.codes_precision) == "x3")
+        h = self._pre_quant(b, B)
         _, _, idx, _ = _C.vq_forward(h, self.store.w["quantizer.embedding.weight"], float(self.q.beta), self.q.depth, self.q.use_norm, False)
         return idx.view(B, self.n_tok, self.q.depth) if self.q.use_residual else idx.view(B, self.n_tok)
 
@@ -373,8 +468,8 @@ class Stage1Engine:
         self._invalidate_saved()
         img = self._check_img(img)
         B, io = img.shape[0], self._io_bufs(img.shape[0])
-        b = self._encode_tokens(img, save=False)
-        h = self._pre_quant(b["xf16"], B)
+        b = self._encode_tokens(img, save=False, x3=self.encoder_precision == "x3")
+        h = self._pre_quant(b, B)
         exact = self.precision != "bf16"
         zq, zq16, idx, qloss = _C.vq_forward(h, self.store.w["quantizer.embedding.weight"], float(self.q.beta), self.q.depth, self.q.use_norm,
                                              want_bf16=not exact)
@@ -398,7 +493,7 @@ class Stage1Engine:
     def encoder_forward(self, img: torch.Tensor) -> torch.Tensor:
         self._invalidate_saved()
         img = self._check_img(img)
-        b = self._encode_tokens(img, save=False, want_f32=True)
+        b = self._encode_tokens(img, save=False, want_f32=True, x3=self.encoder_precision == "x3")
         return b["xf32"].view(img.shape[0], self.n_tok, self.enc.dim).clone()
 
     @torch.no_grad()
@@ -422,8 +517,8 @@ class Stage1Engine:
         outstanding per batch size: a later forward_train overwrites the arena (checked through `_fwd_serial`)."""
         img = self._check_img(img)
         B, s = img.shape[0], self.store
-        eb = self._encode_tokens(img, save=True)
-        h = self._pre_quant(eb["xf16"], B)
+        eb = self._encode_tokens(img, save=True, x3=self.encoder_precision == "x3")
+        h = self._pre_quant(eb, B)
         E = s.w["quantizer.embedding.weight"]
         exact = self.precision != "bf16"
         zq, zq16, idx, qloss = _C.vq_forward(h, E, float(self.q.beta), self.q.depth, self.q.use_norm, want_bf16=not exact)
@@ -563,6 +658,11 @@ class Stage1Engine:
         _C.adamw_step(s.p, s.g, s.m, s.v, s.p16 if self.precision == "bf16" else None, s.step_count, lr, betas[0], betas[1], eps, weight_decay,
                       grad_scale)
         s.refresh_operands()      # operands derived from the masters (the towers' pre-scaled q | k | v weights): 24 small launches at base
+        if self.encoder_precision == "x3" and self.precision == "bf16":
+            # the x3 weight images are otherwise rebuilt lazily by the next x3 forward — which a HIP-graph replay never runs on the host
+            self.enc.x3_weights()
+            for B in list(self.__dict__.get("_x3", {}).get("io", {})):
+                self._x3_io(B)
 
     def train_step(self, img: torch.Tensor, lr: float, **loss_kw) -> dict:
         out = self.forward_backward(img, **loss_kw)

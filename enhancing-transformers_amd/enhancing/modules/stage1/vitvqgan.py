@@ -50,6 +50,10 @@ class ViTVQ(nn.Module):
         self.post_quant = nn.Linear(_get(quantizer, "embed_dim"), _get(decoder, "dim"))
         self._engine = None
         self.precision = None  # None -> ENH_PRECISION or "bf16"; set to "fp32" BEFORE first use for the exact (parity) mode
+        # encoder forward of the bf16 product path: "bf16" | "x3" (split-bf16 operands, ~1e-5: codes follow the fp32 reference).  None -> the engine's
+        # defaults (ENH_ENCODER_PRECISION / "bf16" for training and reconstruction; ENH_CODES_PRECISION / "x3" for encode_codes)
+        self.encoder_precision = None
+        self.codes_precision = None
 
         if path is not None:
             self.init_from_ckpt(path, ignore_keys)
@@ -59,7 +63,7 @@ class ViTVQ(nn.Module):
     def engine(self):
         if self._engine is None:
             from ...engine.stage1 import Stage1Engine
-            self._engine = Stage1Engine(self, precision=self.precision)
+            self._engine = Stage1Engine(self, precision=self.precision, encoder_precision=self.encoder_precision, codes_precision=self.codes_precision)
         return self._engine
 
     @property
@@ -99,23 +103,25 @@ class ViTVQ(nn.Module):
         quant, emb_loss, _ = self.quantizer(h)
         return quant, emb_loss
 
-    def pre_quant_tokens(self, x: torch.Tensor) -> torch.Tensor:
-        """h = pre_quant(encoder(x)) as f32 [B, N, embed_dim] (the quantizer's input: op-boundary parity point)."""
+    def pre_quant_tokens(self, x: torch.Tensor, precision: Optional[str] = None) -> torch.Tensor:
+        """h = pre_quant(encoder(x)) as f32 [B, N, embed_dim] (the quantizer's input: op-boundary parity point).  precision: "bf16" | "x3" for
+        this call (default: the engine's encoder_precision)."""
         eng = self.engine
         x = eng._check_img(x)
         eng._invalidate_saved()
         with torch.no_grad():
-            b = eng._encode_tokens(x, save=False)
-            h = eng._pre_quant(b["xf16"], x.shape[0])
+            b = eng._encode_tokens(x, save=False, x3=(precision or eng.encoder_precision) == "x3")
+            h = eng._pre_quant(b, x.shape[0])
         return h.view(x.shape[0], eng.n_tok, eng.ed).clone()
 
     def decode(self, quant: torch.Tensor) -> torch.Tensor:
         """reference vitvqgan.py:68-72"""
         return self.engine.decode_from_quant(quant)
 
-    def encode_codes(self, x: torch.Tensor) -> torch.Tensor:
-        """reference vitvqgan.py:74-79 -> int64 [B, N] or [B, N, D]"""
-        return self.engine.encode_codes(x)
+    def encode_codes(self, x: torch.Tensor, precision: Optional[str] = None) -> torch.Tensor:
+        """reference vitvqgan.py:74-79 -> int64 [B, N] or [B, N, D].  The encoder runs on split-bf16 ("x3") operands by default, so the codes are the
+        fp32 reference's up to its own near-ties; precision="bf16" selects the faster single-pass encoder (~2 % of the codes differ)."""
+        return self.engine.encode_codes(x, precision)
 
     def decode_codes(self, code: torch.Tensor) -> torch.Tensor:
         """reference vitvqgan.py:81-90"""

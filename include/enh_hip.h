@@ -36,7 +36,7 @@ extern "C" {
 typedef uint16_t enh_bf16; /* raw bfloat16 bits */
 
 const char* enh_last_error(void);
-#define ENH_ABI_VERSION 8   /* bumped whenever a signature below changes; the bindings check it at load */
+#define ENH_ABI_VERSION 9   /* bumped whenever a signature below changes; the bindings check it at load */
 int enh_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -160,6 +160,19 @@ const char* enh_gemm_bf16_variant_mode(int trans_a, int trans_b, int64_t M, int6
  * serves, 9 = as 8 plus w256r where that serves [what the default picks]).  Process-global, set explicitly by the caller (the Python
  * binding maps the ENH_GEMM_KERNEL environment variable onto it); the library itself reads no environment. */
 int enh_gemm_set_kernel(int family);
+/* Tile schedule of the persistent 256 x 256 kernels: 1 [default] = tiles are CLAIMED from one queue per XCD (atomic counters in library-owned device
+ * words; the queue order is the static walk's, so operand slices still meet in one L2) — a workgroup that gets its CU late finds the queue empty and
+ * exits, the launch slows by (CUs held by others) / CUs; 0 = static partition (workgroup b walks tiles b, b + grid, ...: every workgroup must run, a
+ * collective's kernel holding k CUs at dispatch costs up to 2x on that launch).  Same result bits either way.  Process-global measurement switch. */
+int enh_gemm_set_scheduler(int dynamic);
+/* CU budget: the number of CUs GEMM launches may count on (persistent grid size, one-round split-K plans); 0 = all CUs of the device [default].
+ * Data-parallel training sets it to (CUs - the collective's channels) while gradient buckets are in flight (engine/ddp.py; reference main.py:54-57 is
+ * DDP over NCCL).  enh_get_cu_budget returns the effective value. */
+int enh_set_cu_budget(int n_cus);
+int enh_get_cu_budget(void);
+/* Measurement aid: holds n_wg CUs (one workgroup each, the CU's whole LDS) for ms milliseconds (clamped to 2000) on `stream` — the stand-in for a
+ * collective's kernel in the one-GPU contention experiment (tools/comm_contention.py). */
+int enh_debug_occupy_cus(int n_wg, float ms, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused attention — Attention.forward layers.py:122-132 without materialising the N x N matrix
@@ -183,6 +196,29 @@ int enh_attention_set_kernel(int fwd, int dq, int dkv);
 /* dqkv [B,N,3*H*64] bf16 ; delta_ws [B,H,N] f32 scratch */
 int enh_attention_backward(const enh_bf16* qkv, const enh_bf16* out, const enh_bf16* dout, const float* lse,
                            int B, int N, int H, float scale, int q_prescaled, enh_bf16* dqkv, float* delta_ws, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * "x3" split-bf16 operands — the parity-grade ENCODER forward (round 4).  The reference's forward is fp32 end to end
+ * (layers.py:118-132,145-150; vitvqgan.py:61-66; quantizers.py:74-92 consumes its output); bf16 operands flip ~2 % of the argmin decisions
+ * downstream.  A value v is carried as hi = bf16(v), lo = bf16(v - hi) and a product as a_hi b_hi + a_lo b_hi + a_hi b_lo in the fp32 MFMA
+ * accumulator: ~1e-5 relative end to end at a third of the bf16 MFMA rate (the exact-f32 MFMA has a sixteenth).
+ * A GEMM is ONE enh_gemm_bf16 call with K' = 3K on K-concatenated rows  A' = [a_hi | a_lo | a_hi],  B' = [b_hi | b_hi | b_lo].
+ * ------------------------------------------------------------------------------------------------ */
+/* y3[m] = the x3 row of f(x[m] (+ bias)), f = identity (act 0) or tanh (act 1: FeedForward's activation, layers.py:99-100);
+ * order 0: [hi | lo | hi] (A operand), order 1: [hi | hi | lo] (B operand = weights).  x f32 [M,K] (ldx), y3 bf16 [M,3K] (ldy3),
+ * y_hi optional bf16 [M,K] (ldy_hi): the hi plane alone (= what the bf16 path stores; the backward's operand).  K % 8 == 0. */
+int enh_split3_bf16(const float* x, int64_t ldx, int64_t M, int64_t K, const float* bias, int act, int order, enh_bf16* y3, int64_t ldy3,
+                    enh_bf16* y_hi, int64_t ldy_hi, void* stream);
+/* hi[i] = bf16(x[i]), lo[i] = bf16(x[i] - hi[i]); n % 8 == 0 (the packed q | k | v projection for enh_attention_forward_x3) */
+int enh_split2_bf16(const float* x, int64_t n, enh_bf16* hi, enh_bf16* lo, void* stream);
+/* enh_layernorm_forward that writes the x3 row y3 [M,3D] (and, optionally, the plain bf16 / f32 outputs); same statistics bits */
+int enh_layernorm_forward_x3(const float* x, const float* w, const float* b, int64_t M, int D, float eps, enh_bf16* y3, enh_bf16* y_bf16,
+                             float* y_f32, float* mean, float* rstd, void* stream);
+/* enh_attention_forward on split operands: qkv_hi / qkv_lo [B,N,3*H*64] (unscaled q); S = Q K^T and O = P V as three MFMA passes each,
+ * softmax statistics in fp32.  out3 [B,N,3*H*64] = the x3 row [hi | lo | hi] of the 'b n (h d)' output (A operand of to_out);
+ * out_bf16 optional [B,N,H*64] (= the hi plane, what enh_attention_backward reads); lse as enh_attention_forward. */
+int enh_attention_forward_x3(const enh_bf16* qkv_hi, const enh_bf16* qkv_lo, int B, int N, int H, float scale, enh_bf16* out3,
+                             enh_bf16* out_bf16, float* lse, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Patch (un)embedding data movement, pixel loss, reductions, optimizer

@@ -246,13 +246,58 @@ def test_persistent_gemm_is_bitwise_the_one_tile_kernel(C, kind):
             assert L.enh_gemm_set_kernel(7) == 0
             out.zero_(); C.gemm(a, b, m, n, k, **kw); torch.cuda.synchronize(); ref = out.clone()
             for fam in (8, 9):
-                assert L.enh_gemm_set_kernel(fam) == 0
-                out.fill_(7.0); C.gemm(a, b, m, n, k, **kw); torch.cuda.synchronize()
-                assert torch.equal(out, ref), f"family {fam} {kind} M={m} N={n} K={k}: {(out != ref).sum().item()} elements differ"
+                for dyn in (0, 1):       # static partition / tiles claimed from the per-XCD queues (round 4): the same bits
+                    assert L.enh_gemm_set_kernel(fam) == 0 and L.enh_gemm_set_scheduler(dyn) == 0
+                    out.fill_(7.0); C.gemm(a, b, m, n, k, **kw); torch.cuda.synchronize()
+                    assert torch.equal(out, ref), f"family {fam} dyn {dyn} {kind} M={m} N={n} K={k}: {(out != ref).sum().item()} elements differ"
             if kind == "fwd_res" and m == 1024:
                 assert rel(out, A.double() @ B.double().t() + kw["bias"].double().cpu() + kw["res"].double().cpu()) <= F32_TOL
     finally:
         L.enh_gemm_set_kernel(-1)
+        L.enh_gemm_set_scheduler(1)
+
+
+def test_dynamic_tile_schedule_under_cu_contention(C):
+    """the claimed-tile schedule of the persistent GEMMs with a side-stream kernel HOLDING 24 CUs (the stand-in for a collective's channels,
+    enh_debug_occupy_cus): workgroups that get their CU late find their queue empty — every tile is still computed exactly once (bit-identical output),
+    over more launches than there are counter slots (64: each launch must leave its counters at zero), with and without a CU budget, for a
+    register-staged (K = 768) and an LDS-DMA (K = 448) kernel and the tanh' mode that owns the whole LDS."""
+    L = C.lib()
+    g = torch.Generator().manual_seed(5)
+    side = torch.cuda.Stream()
+    try:
+        for (m, n, k, mode) in ((256 * 40, 2304, 768, "bf16"), (256 * 23, 768, 448, "res"), (256 * 12, 3072, 768, "dtanh")):
+            a = _mk((m, k), g, 0.5).to(torch.bfloat16).cuda()
+            tb = mode == "dtanh"
+            Bm = _mk((n, k), g, 0.1)
+            b = (Bm.t().contiguous() if tb else Bm).to(torch.bfloat16).cuda()
+            kw = dict(trans_b=tb)
+            if mode == "bf16":
+                out = torch.empty(m, n, dtype=torch.bfloat16, device="cuda"); kw["out_bf16"] = out
+            elif mode == "res":
+                out = torch.empty(m, n, device="cuda"); kw.update(out_f32=out, bias=torch.randn(n, generator=g).cuda(), res=torch.randn(m, n, generator=g).cuda(), res_rows=m)
+            else:
+                out = torch.empty(m, n, dtype=torch.bfloat16, device="cuda")
+                kw.update(out_bf16=out, act=C.ACT_DTANH, aux=torch.tanh(torch.randn(m, n, generator=g)).to(torch.bfloat16).cuda())
+            assert L.enh_gemm_set_kernel(7) == 0
+            C.gemm(a, b, m, n, k, **kw); torch.cuda.synchronize(); ref = out.clone()
+            assert L.enh_gemm_set_kernel(-1) == 0 and L.enh_gemm_set_scheduler(1) == 0
+            for budget in (0, 232):
+                C.set_cu_budget(budget)
+                torch.cuda.synchronize()
+                with torch.cuda.stream(side):
+                    C.occupy_cus(24, 400.0, side)
+                for it in range(70):
+                    out.fill_(3.0)
+                    C.gemm(a, b, m, n, k, **kw)
+                    if it % 23 == 0 or it == 69:
+                        torch.cuda.synchronize()
+                        assert torch.equal(out, ref), f"{mode} budget {budget} launch {it}: {(out != ref).sum().item()} elements differ"
+                torch.cuda.synchronize()
+    finally:
+        C.set_cu_budget(0)
+        L.enh_gemm_set_kernel(-1)
+        L.enh_gemm_set_scheduler(1)
 
 
 @pytest.mark.parametrize("kind", ["fwd", "fwd_tanh", "dgrad_dtanh", "fwd_res"])
