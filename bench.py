@@ -191,6 +191,8 @@ def parity_mode_block(model, eng, cfg, batches, B, lr, dev):
         m32.load_state_dict({k: v for k, v in model.state_dict().items() if not k.startswith("loss.")}, strict=False)
         e32, b32 = m32.engine, 8
         x8 = x[:b32].contiguous()
+        c32 = e32.encode_codes(xs).cpu()         # parity first: the timed training steps below move this copy's weights
+        out["vs_fp32_cpu_oracle_2_images"]["fp32_exact_mode"] = {"code_match_end_to_end": float((c32.view(o_idx.shape) == o_idx).float().mean())}
         out["encode_only_images_per_s"]["fp32_exact_mode"] = rate(lambda: e32.encode_codes(x8), b32, 2)
 
         def tstep32():
@@ -198,8 +200,6 @@ def parity_mode_block(model, eng, cfg, batches, B, lr, dev):
             e32.optimizer_step(lr)
         out["train_images_per_s"]["fp32_exact_mode"] = rate(tstep32, b32, 1)
         out["fp32_exact_mode_batch"] = b32
-        c32 = e32.encode_codes(xs).cpu()
-        out["vs_fp32_cpu_oracle_2_images"]["fp32_exact_mode"] = {"code_match_end_to_end": float((c32.view(o_idx.shape) == o_idx).float().mean())}
         del m32, e32
         torch.cuda.empty_cache()
     except Exception as ex:      # the block is a report, not the product: never lose the headline line to it
@@ -250,6 +250,8 @@ def main():
     ap.add_argument("--graphs", action="store_true", help="replay the fused AE step from a captured HIP graph (for launch-bound small batches); the per-kernel "
                                                           "timing of the roofline block then comes from two extra eager steps after the timed region")
     ap.add_argument("--grad-bf16", action="store_true", help="all-reduce the gradient buckets as bf16 (half the xGMI bytes); default fp32")
+    ap.add_argument("--comm-cus", type=int, default=0, help="N > 1: CUs conceded to RCCL's channel workgroups while gradient buckets are in flight (sizes the "
+                                                             "split-K / LayerNorm-backward launches; also caps NCCL_MAX_NCHANNELS to it); 0 = no reservation [default]")
     ap.add_argument("--grad-algo", choices=["allreduce", "rs_ag"], default="allreduce",
                     help="per bucket: one RCCL all-reduce (default) or reduce-scatter + all-gather (SURVEY.md 8e's direct exchange); same sums")
     args = ap.parse_args()
@@ -260,6 +262,8 @@ def main():
     from enhancing.engine.ddp import GradSync, init_process_group_from_env
     from enhancing.utils.general import get_config_from_file, initialize_from_config, set_seed
 
+    if args.comm_cus > 0:
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", str(args.comm_cus))      # RCCL: one workgroup per channel
     rank, local_rank, world = init_process_group_from_env("nccl" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if os.environ.get("ENH_FORCE_DEVICE") is not None:  # test hook: several ranks on one GPU (with ENH_DIST_BACKEND=gloo)
@@ -278,7 +282,7 @@ def main():
         lpips_info = {"perceptual_weight": pw, "weights_loaded": bool(pl.weights_loaded), "random_init": bool(pl.random_init)}
     eng = model.engine
     if world > 1:
-        eng.comm = GradSync(eng.store, compress="bf16" if args.grad_bf16 else None, algo=args.grad_algo)
+        eng.comm = GradSync(eng.store, compress="bf16" if args.grad_bf16 else None, algo=args.grad_algo, comm_cus=args.comm_cus)
         eng.comm.broadcast_parameters(0)
         eng.store.refresh_shadows()
     B, size = args.batch, cfg.model.params.image_size
@@ -345,7 +349,7 @@ def main():
         mine.update(rank=rank, bytes_reduced_per_step=eng.comm.bytes_reduced / max(args.warmup + args.steps, 1), gap_elems=eng.comm.gap_elems)
         allr = [None] * world
         dist.all_gather_object(allr, mine)
-        comm_info = {"backend": dist.get_backend(), "algo": args.grad_algo, "bucket_dtype": "bf16" if args.grad_bf16 else "fp32",
+        comm_info = {"backend": dist.get_backend(), "algo": args.grad_algo, "comm_cus": args.comm_cus, "bucket_dtype": "bf16" if args.grad_bf16 else "fp32",
                      "n_params": int(eng.store.g.numel()), "per_rank": allr,
                      "note": "stream_ms = time the compute stream waited for the collectives after backward (HIP events), host_ms = host time in wait()"}
     if rank != 0:

@@ -23,3 +23,25 @@ int enh_check_launch(const char* what) {
 
 extern "C" const char* enh_last_error(void) { return g_err; }
 extern "C" int enh_abi_version(void) { return ENH_ABI_VERSION; }
+
+// CU budget (round 4): how many CUs the launches that size themselves by the CU count may count on — persistent GEMM grids, one-round split-K plans,
+// the LayerNorm backward's one-workgroup-per-CU grid.  Data-parallel training runs RCCL's kernels beside the backward pass (enhancing/engine/ddp.py;
+// reference main.py:54-57); a grid sized for ALL CUs then has workgroups that wait for a CU until another retires (2x on that launch, measured in
+// profiles/r04_comm_contention.txt).  0 = every CU of the device.  Explicit state behind an explicit call: the library reads no environment.
+static int g_cu_budget = 0;
+int enh_device_cus() {
+  static const int n = [] {
+    int dev = 0, c = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev);
+    return c > 0 ? c : 256;
+  }();
+  return n;
+}
+int enh_cu_budget() { return g_cu_budget > 0 && g_cu_budget < enh_device_cus() ? g_cu_budget : enh_device_cus(); }
+extern "C" int enh_set_cu_budget(int n_cus) {
+  ENH_REQUIRE(n_cus >= 0, ENH_E_BADARG, "enh_set_cu_budget: n_cus must be >= 0 (0 = all)");
+  g_cu_budget = n_cus;
+  return ENH_OK;
+}
+extern "C" int enh_get_cu_budget(void) { return enh_cu_budget(); }

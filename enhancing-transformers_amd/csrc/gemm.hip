@@ -1178,26 +1178,11 @@ extern "C" int enh_gemm_set_kernel(int family) {
   return ENH_OK;
 }
 
-// CU budget (round 4): how many CUs the GEMM launches may count on.  Data-parallel training runs RCCL's kernels beside the backward GEMMs
-// (engine/ddp.py); a persistent grid or a one-round split-K plan sized for ALL CUs then has workgroups that wait for a CU until another retires.
-// 0 = every CU of the device.  Explicit state behind an explicit call (the library reads no environment).
-static int g_cu_budget = 0;
-static int device_cus() {
-  static const int n = [] {
-    int dev = 0, c = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev);
-    return c > 0 ? c : 256;
-  }();
-  return n;
-}
-static int cu_budget() { return g_cu_budget > 0 && g_cu_budget < device_cus() ? g_cu_budget : device_cus(); }
-extern "C" int enh_set_cu_budget(int n_cus) {
-  ENH_REQUIRE(n_cus >= 0, ENH_E_BADARG, "enh_set_cu_budget: n_cus must be >= 0 (0 = all)");
-  g_cu_budget = n_cus;
-  return ENH_OK;
-}
-extern "C" int enh_get_cu_budget(void) { return cu_budget(); }
+// CU budget (common.cpp, enh_set_cu_budget): persistent grids take cu_budget() workgroups; one-round split-K plans count on whole XCD rows of it —
+// workgroups go to the XCDs round-robin and so do a collective's, so with b CUs free the fullest XCD has floor(b / 8) of them (measured: a 252-workgroup
+// plan against 4 held CUs overflowed XCDs 0-3 and took 2 rounds, profiles/r04_comm_contention.txt)
+static int cu_budget() { return enh_cu_budget(); }
+static int cu_budget_rows() { const int b = enh_cu_budget(); return b >= 8 ? (b / 8) * 8 : b; }
 
 // tile schedule of the persistent kernels: 0 = static partition (workgroup b walks b, b + grid, ...), 1 = tiles claimed from per-XCD queues (see
 // gemm_bf16_w256p_kernel).  The counters are library-owned device words (not an allocation): 64 launch slots x 8 queues, used round-robin — a slot is
@@ -1247,7 +1232,7 @@ static GemmPlan gemm_plan(int trans_a, int trans_b, int64_t M, int64_t N, int64_
     family = 3;
     if (w256_ok) {
       const int64_t tiles = (M / 256) * (N / 256);
-      const int sp = split_for(tiles, cu_budget(), 64);
+      const int sp = split_for(tiles, cu_budget_rows(), 64);
       const int64_t per = (ksteps + sp - 1) / sp;
       if (tiles * sp >= (3 * cu_budget()) / 4 && ksteps - (sp - 1) * per >= 2) family = 7;
     }
@@ -1255,7 +1240,7 @@ static GemmPlan gemm_plan(int trans_a, int trans_b, int64_t M, int64_t N, int64_
   pl.family = family;
   const int64_t bm = family == 7 ? 256 : 128;
   const int64_t tiles = ((M + bm - 1) / bm) * ((N + bm - 1) / bm);
-  pl.splits = split_for(tiles, family == 7 ? cu_budget() : 2 * cu_budget(), 64);
+  pl.splits = split_for(tiles, family == 7 ? cu_budget_rows() : 2 * cu_budget_rows(), 64);
   const int64_t per = (ksteps + pl.splits - 1) / pl.splits;
   pl.k_per_split = per * G_BK;
   pl.splits = (int)((ksteps + per - 1) / per);

@@ -282,16 +282,19 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
   if ((threadIdx.x >> 4) == 0 && j < D) out[j] += t;
 }
 
-static int ln_bwd_grid(int64_t M) {
+static int ln_bwd_grid(int64_t M, bool for_workspace = false) {
   // Persistent grid, ONE workgroup per CU: with the row loop software-pipelined a workgroup keeps its CU's memory pipe busy by itself, and whole
   // multiples of the 256 CUs matter more than occupancy — measured 294 / 343 / 317 / 340 / 345 / 373 us at 256 / 384 / 512 / 768 / 1024 / 2048
   // workgroups (M = 131072, D = 768, bf16 dy; the atomic form of round 1 was best at 512).
+  // The row partition is static (the per-workgroup partial sums and their fixed-order second pass are what makes the gradient bits reproducible), so
+  // under a CU budget (collectives beside the backward pass) the grid shrinks with it: a workgroup without a CU would wait for another to retire.
   const int64_t want = (M + 3) / 4;
-  return (int)(want < 256 ? want : 256);
+  const int cus = for_workspace ? enh_device_cus() : enh_cu_budget();
+  return (int)(want < cus ? want : cus);
 }
 
 extern "C" size_t enh_layernorm_backward_workspace_bytes(int64_t M, int D) {
-  return M > 0 && D > 0 ? (size_t)ln_bwd_grid(M) * 3 * D * sizeof(float) : 0;
+  return M > 0 && D > 0 ? (size_t)ln_bwd_grid(M, true) * 3 * D * sizeof(float) : 0;
 }
 
 static int ln_bwd_impl(const float* dy, const enh_bf16* dy_bf16, const float* x, const float* w, const float* mean, const float* rstd, const float* dres,

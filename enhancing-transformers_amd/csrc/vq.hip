@@ -241,42 +241,63 @@ __global__ void vq_loss_finalize_kernel(const float* __restrict__ partials, int 
 }
 
 // ---------------------------------------------------------------------------------------------
-// codebook-gradient scatter: at initialisation a few dozen codes receive every token (27-34 distinct
-// codes), so per-token global atomics serialise on ~1000 addresses.  Each workgroup therefore first aggregates its 128
-// tokens in an LDS hash table keyed by code (linear probing, LDS float atomics), then issues ONE global atomic per
-// distinct code per column.
+// codebook gradient, deterministic (round 4).  dE[k] = sum over the (token, depth) entries that picked code k of their contribution vector — a
+// scatter-add whose natural forms (per-token atomics; the LDS hash + one global atomic per distinct code of rounds 1-3) add in an order that changes
+// from run to run.  Here the backward kernel only WRITES each entry's vector and code (entry e = depth * M + token), and the sum is an "owner scans"
+// reduction with a fixed order: a workgroup owns 32 consecutive codes and one of 8 token slices; it walks its slice's codes in ascending entry order
+// (256 per step, hits compacted in order by ballot), and each half-wave adds the vectors of ITS 4 codes (code mod 8 = half-wave id) one column per
+// lane, in that order; the 8 slice partials of a code are then added in slice order.  No sort, no float atomics: the same bits on every run, which is
+// what a diff of two data-parallel runs needs (quantizers.py:85-90 is the reference's autograd scatter).  A code that attracts
+// every token makes one half-wave walk its whole slice (n / 8 entries) — the pathological bound; with the ~30 hot codes of an untrained model the
+// pass takes tens of microseconds.
 // ---------------------------------------------------------------------------------------------
-#define VQ_HT 256       // slots (>= 2x the 128 tokens of a workgroup)
-#define VQ_HT_PITCH 33  // floats per slot row (33: rows land on different LDS banks)
-__device__ __forceinline__ void vq_scatter_block(int* s_keys, float* s_acc, int code, bool live, int hi, const float (&v)[16],
-                                                 float* __restrict__ dE) {
-  const int t = threadIdx.x;
-  s_keys[t] = -1;
+#define VQ_CPW 32   // codes per workgroup
+#define VQ_RS 8     // token slices
+__global__ __launch_bounds__(256) void vq_de_partial_kernel(const int* __restrict__ codes, const float* __restrict__ contrib, int64_t n, int K,
+                                                            float* __restrict__ part) {
+  __shared__ int s_list[256];
+  __shared__ int s_wc[4];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, grp = t >> 5, gl = t & 31;
+  const int cb = blockIdx.x * VQ_CPW, slice = blockIdx.y;
+  const int64_t per = ((n + (int64_t)VQ_RS * 256 - 1) / ((int64_t)VQ_RS * 256)) * 256;
+  const int64_t e0 = (int64_t)slice * per, e1 = e0 + per < n ? e0 + per : n;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;    // codes cb + grp + 8 c, column gl
+  for (int64_t base = e0; base < e1; base += 256) {
+    const int64_t e = base + t;
+    const unsigned lc = e < e1 ? (unsigned)(codes[e] - cb) : 0xffffffffu;
+    const bool hit = lc < (unsigned)VQ_CPW;
+    const unsigned long long m = __ballot(hit);
+    if (lane == 0) s_wc[wave] = __popcll(m);
+    __syncthreads();
+    int off = 0, total = 0;
 #pragma unroll
-  for (int k = 0; k < (VQ_HT * VQ_HT_PITCH + 255) / 256; ++k) {
-    const int e = t + 256 * k;
-    if (e < VQ_HT * VQ_HT_PITCH) s_acc[e] = 0.f;
-  }
-  __syncthreads();
-  if (live) {
-    unsigned h = ((unsigned)code * 2654435761u) >> 24;
-    for (int probe = 0; probe < VQ_HT; ++probe) {
-      const int prev = atomicCAS(&s_keys[h], -1, code);
-      if (prev == -1 || prev == code) break;
-      h = (h + 1) & (VQ_HT - 1);
+    for (int w = 0; w < 4; ++w) { const int c = s_wc[w]; if (w < wave) off += c; total += c; }
+    if (hit) s_list[off + __popcll(m & ((1ull << lane) - 1ull))] = t | ((int)lc << 8);
+    __syncthreads();
+    for (int q = 0; q < total; ++q) {
+      const int item = s_list[q], lcq = item >> 8;
+      if ((lcq & 7) == grp) {
+        const float v = contrib[(size_t)(base + (item & 255)) * VQ_D + gl];
+        const int c = lcq >> 3;
+        if (c == 0) a0 += v; else if (c == 1) a1 += v; else if (c == 2) a2 += v; else a3 += v;
+      }
     }
+    __syncthreads();
+  }
+  const float acc[4] = {a0, a1, a2, a3};
 #pragma unroll
-    for (int j = 0; j < 16; ++j) atomicAdd(&s_acc[h * VQ_HT_PITCH + hi * 16 + j], v[j]);
+  for (int c = 0; c < 4; ++c) {
+    const int code = cb + grp + 8 * c;
+    if (code < K) part[((size_t)slice * K + code) * VQ_D + gl] = acc[c];
   }
-  __syncthreads();
-#pragma unroll 4
-  for (int k = 0; k < VQ_HT * VQ_D / 256; ++k) {
-    const int e = t + 256 * k;
-    const int row = e >> 5, j = e & 31;
-    const int key = s_keys[row];
-    if (key >= 0) atomicAdd(&dE[(size_t)key * VQ_D + j], s_acc[row * VQ_HT_PITCH + j]);
-  }
-  __syncthreads();
+}
+__global__ __launch_bounds__(256) void vq_de_finalize_kernel(const float* __restrict__ part, int K, float* __restrict__ dE) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)K * VQ_D) return;
+  float s = part[i];
+#pragma unroll
+  for (int r = 1; r < VQ_RS; ++r) s += part[(size_t)r * K * VQ_D + i];
+  dE[i] += s;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -287,9 +308,7 @@ __global__ __launch_bounds__(256) void vq_bwd_kernel(
     const float* __restrict__ z, const float* __restrict__ E, const float* __restrict__ en,
     const float* __restrict__ enrm, const int64_t* __restrict__ idx, const float* __restrict__ g_out, float g_loss,
     const float* __restrict__ g_loss_dev, int64_t M, int depth, int use_norm, int use_residual, float beta,
-    float* __restrict__ dz, uint16_t* __restrict__ dz_bf16, float* __restrict__ dE) {
-  __shared__ int s_keys[VQ_HT];
-  __shared__ float s_acc[VQ_HT * VQ_HT_PITCH];
+    float* __restrict__ dz, uint16_t* __restrict__ dz_bf16, float* __restrict__ contrib, int* __restrict__ codes) {
   const int lane = threadIdx.x & 63;
   const int col = lane & 31, hi = lane >> 5;
   const int64_t tok = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 32 + col;
@@ -342,7 +361,13 @@ __global__ __launch_bounds__(256) void vq_bwd_kernel(
 #pragma unroll
         for (int j = 0; j < 16; ++j) v[j] = (v[j] - e[i][j] * dot) / nr;
       }
-      vq_scatter_block(s_keys, s_acc, code[i], live, hi, v, dE);
+      if (live) {     // this entry's share of the codebook gradient: summed per code, in a fixed order, by vq_de_partial_kernel
+        const size_t e = (size_t)i * (size_t)M + (size_t)tok;
+        float4* cp = reinterpret_cast<float4*>(contrib + e * VQ_D + hi * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cp[q] = make_float4(v[q * 4], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]);
+        if (hi == 0) codes[e] = code[i];
+      }
       // encoder side: own_i = J^T(r_i)[ gL*beta*c*(zn - en) ]
       float w[16], dp2 = 0.f;
 #pragma unroll
@@ -406,7 +431,7 @@ __global__ void vq_lookup_kernel(const float* __restrict__ E, const int64_t* __r
 static inline int vq_kpad(int K) { return (K + VQ_TILE - 1) / VQ_TILE * VQ_TILE; }
 static inline int64_t vq_nblocks(int64_t M) { return (M + 127) / 128; }
 
-struct VqWs { float *en, *ee, *enrm, *partials; };
+struct VqWs { float *en, *ee, *enrm, *partials, *contrib, *depart; int* codes; };
 static VqWs vq_carve(void* ws, int K, int64_t M, int depth) {
   const size_t kp = (size_t)vq_kpad(K);
   VqWs w;
@@ -414,12 +439,18 @@ static VqWs vq_carve(void* ws, int K, int64_t M, int depth) {
   w.ee = w.en + kp * VQ_D;
   w.enrm = w.ee + kp;
   w.partials = w.enrm + kp;
+  const size_t n = (size_t)M * (size_t)(depth < 1 ? 1 : depth);
+  // (backward only) per-entry contribution vectors, the 8 slice partials of the codebook gradient, per-entry codes — each 16-byte aligned
+  w.contrib = w.partials + ((size_t)vq_nblocks(M) * (size_t)(depth < 1 ? 1 : depth) + 3) / 4 * 4;
+  w.depart = w.contrib + n * VQ_D;
+  w.codes = reinterpret_cast<int*>(w.depart + (size_t)VQ_RS * (size_t)K * VQ_D);
   return w;
 }
 
 extern "C" size_t enh_vq_workspace_bytes(int64_t M, int n_embed, int depth) {
   const size_t kp = (size_t)vq_kpad(n_embed);
-  return (kp * VQ_D + 2 * kp + (size_t)vq_nblocks(M) * (size_t)(depth < 1 ? 1 : depth)) * sizeof(float) + 256;
+  const size_t d = (size_t)(depth < 1 ? 1 : depth), n = (size_t)M * d;
+  return (kp * VQ_D + 2 * kp + ((size_t)vq_nblocks(M) * d + 3) / 4 * 4 + n * VQ_D + (size_t)VQ_RS * (size_t)n_embed * VQ_D + n) * sizeof(float) + 256;
 }
 
 extern "C" int enh_vq_forward(const float* z, const float* codebook, int64_t M, int n_embed, int embed_dim,
@@ -456,11 +487,13 @@ extern "C" int enh_vq_backward(const float* z, const float* codebook, const int6
   vq_prep_kernel<<<(kp + 255) / 256, 256, 0, s>>>(codebook, w.en, w.ee, w.enrm, n_embed, kp, use_norm);
   const int nb = (int)vq_nblocks(M);
   if (D == 1)
-    vq_bwd_kernel<1><<<nb, 256, 0, s>>>(z, codebook, w.en, w.enrm, idx, g_out, g_loss, g_loss_dev, M, D, use_norm, use_residual, beta, dz, dz_bf16, d_codebook);
+    vq_bwd_kernel<1><<<nb, 256, 0, s>>>(z, codebook, w.en, w.enrm, idx, g_out, g_loss, g_loss_dev, M, D, use_norm, use_residual, beta, dz, dz_bf16, w.contrib, w.codes);
   else if (D <= 4)
-    vq_bwd_kernel<4><<<nb, 256, 0, s>>>(z, codebook, w.en, w.enrm, idx, g_out, g_loss, g_loss_dev, M, D, use_norm, use_residual, beta, dz, dz_bf16, d_codebook);
+    vq_bwd_kernel<4><<<nb, 256, 0, s>>>(z, codebook, w.en, w.enrm, idx, g_out, g_loss, g_loss_dev, M, D, use_norm, use_residual, beta, dz, dz_bf16, w.contrib, w.codes);
   else
-    vq_bwd_kernel<8><<<nb, 256, 0, s>>>(z, codebook, w.en, w.enrm, idx, g_out, g_loss, g_loss_dev, M, D, use_norm, use_residual, beta, dz, dz_bf16, d_codebook);
+    vq_bwd_kernel<8><<<nb, 256, 0, s>>>(z, codebook, w.en, w.enrm, idx, g_out, g_loss, g_loss_dev, M, D, use_norm, use_residual, beta, dz, dz_bf16, w.contrib, w.codes);
+  vq_de_partial_kernel<<<dim3((unsigned)((n_embed + VQ_CPW - 1) / VQ_CPW), VQ_RS), 256, 0, s>>>(w.codes, w.contrib, M * (int64_t)D, n_embed, w.depart);
+  vq_de_finalize_kernel<<<(unsigned)(((int64_t)n_embed * VQ_D + 255) / 256), 256, 0, s>>>(w.depart, n_embed, d_codebook);
   return enh_check_launch("enh_vq_backward");
 }
 

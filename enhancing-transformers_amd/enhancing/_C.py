@@ -357,6 +357,20 @@ def get_cu_budget() -> int:
     return int(lib().enh_get_cu_budget())
 
 
+def device_cus() -> int:
+    """CUs of the current device"""
+    L = lib()
+    cur = int(L.enh_get_cu_budget())
+    if _DEVICE_CUS[0] is None:
+        L.enh_set_cu_budget(0)
+        _DEVICE_CUS[0] = int(L.enh_get_cu_budget())
+        L.enh_set_cu_budget(cur if cur != _DEVICE_CUS[0] else 0)
+    return _DEVICE_CUS[0]
+
+
+_DEVICE_CUS = [None]
+
+
 def gemm_set_scheduler(dynamic: bool) -> None:
     _check(lib().enh_gemm_set_scheduler(int(bool(dynamic))), "enh_gemm_set_scheduler")
 

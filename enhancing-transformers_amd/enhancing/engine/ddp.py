@@ -25,13 +25,19 @@ import torch.distributed as dist
 
 
 class GradSync:
-    def __init__(self, store, process_group=None, min_bucket_elems: int = 1 << 20, compress: Optional[str] = None, algo: str = "allreduce") -> None:
+    def __init__(self, store, process_group=None, min_bucket_elems: int = 1 << 20, compress: Optional[str] = None, algo: str = "allreduce",
+                 comm_cus: int = 0) -> None:
         """algo = "allreduce": one all-reduce per bucket (RCCL chooses the schedule).  algo = "rs_ag": the bucket is reduce-scattered (each rank sums
         1/world of it) and all-gathered back — the direct exchange SURVEY.md §8e prefers on a fully connected xGMI node (every rank talks to all 7
         peers at once, (world-1)/world of the bucket each way, instead of a ring bounded by one link); the elements beyond a multiple of `world`
         go through a small all-reduce.  Both give the same sums.  Which is faster on 8 x MI355X is a measurement this build has not been able to make.
         compress = "bf16": buckets travel as bfloat16 (half the xGMI bytes: 341 MB instead of 683 MB per step at base); the sum is
-        formed in bf16 by the collective, so this trades ~3 significant digits of the summed gradient for bandwidth — off by default"""
+        formed in bf16 by the collective, so this trades ~3 significant digits of the summed gradient for bandwidth — off by default.
+        comm_cus > 0: while gradient buckets are in flight (first bucket of a step .. finish()) the compute library plans its CU-count-sized launches
+        for (CUs - comm_cus) — the one-round split-K weight-gradient plans and the LayerNorm backward's one-workgroup-per-CU grid, which otherwise
+        wait for a second round when RCCL's channel workgroups hold CUs (profiles/r04_comm_contention.txt: +45 % on those launches; the persistent
+        GEMMs claim their tiles dynamically and need no budget).  Off by default: the collectives of the base config are in flight for a few per cent
+        of the step, a standing reservation costs more than the occasional second round."""
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.store = store
@@ -52,6 +58,8 @@ class GradSync:
         if compress not in (None, "bf16"):
             raise ValueError("compress must be None or 'bf16'")
         self.compress = compress
+        self.comm_cus = int(comm_cus)
+        self._budget_on = False
         self._g16 = torch.empty_like(store.g, dtype=torch.bfloat16) if compress == "bf16" else None
         self._copyback: List[Tuple[int, int]] = []
         self._shards: List[torch.Tensor] = []
@@ -88,7 +96,14 @@ class GradSync:
             self._reduce(b, e)
         self._pending = []
 
+    def _set_budget(self, on: bool) -> None:
+        if self.comm_cus > 0 and self.store.g.is_cuda and on != self._budget_on:
+            from .. import _C
+            _C.set_cu_budget(max(_C.device_cus() - self.comm_cus, 8) if on else 0)
+            self._budget_on = on
+
     def _reduce(self, b: int, e: int) -> None:
+        self._set_budget(True)
         view = self.store.g[b:e]
         if self._g16 is not None:
             view = self._g16[b:e]
@@ -137,6 +152,7 @@ class GradSync:
             del self.host_wait_ms[:2048]
             del self._wait_events[:max(len(self._wait_events) - 2048, 0)]
         self.buckets_last_step = len(self._handles)
+        self._set_budget(False)
         for b, e in self._copyback:
             self.store.g[b:e].copy_(self._g16[b:e])
         self._copyback = []

@@ -322,6 +322,44 @@ class _AEFunction(torch.autograd.Function):
         return None, None, None
 
 
+class _EncodeFn(torch.autograd.Function):
+    """image -> h (quantizer input) over the static schedule, for quantizers that are NOT the fused kernel (GumbelQuantizer: plain torch between the two
+    halves).  The state dict is shared with _DecodeFn through the engine (one outstanding forward)."""
+
+    @staticmethod
+    def forward(ctx, engine, img, anchor):
+        st = engine.encode_train(img)
+        engine._split_st = st
+        ctx.engine, ctx.st = engine, st
+        return st["h"].view(st["B"], engine.n_tok, engine.ed).clone()
+
+    @staticmethod
+    def backward(ctx, g_h):
+        engine, st = ctx.engine, ctx.st
+        dh = g_h.reshape(st["B"] * engine.n_tok, engine.ed).to(dtype=F32).contiguous()
+        engine.backward_encoder(st, dh if engine.precision != "bf16" else dh.to(BF16), announce_quantizer=False)
+        return None, None, None
+
+
+class _DecodeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, engine, quant, anchor):
+        st = engine._split_st
+        B, io = st["B"], engine._io_bufs(st["B"])
+        engine.decode_train(st, quant.detach().reshape(B * engine.n_tok, engine.ed).to(dtype=engine.adt).contiguous())
+        _C.unpatchify_loss(st["pix"], None, B, engine.C, engine.size, engine.size, engine.patch, 0.0, 0.0, io["xrec"], None, None)
+        ctx.engine, ctx.st, ctx.qshape = engine, st, quant.shape
+        return io["xrec"].clone()
+
+    @staticmethod
+    def backward(ctx, g_xrec):
+        engine, st = ctx.engine, ctx.st
+        io = engine._io_bufs(st["B"])
+        _C.patchify_any(g_xrec.to(dtype=F32).contiguous(), engine.patch, io["dpix16"])
+        dzq = engine.backward_decoder(st, io["dpix16"])
+        return None, dzq.view(ctx.qshape).clone(), None
+
+
 class Stage1Engine:
     """Binds a ``ViTVQ`` module tree to the HIP schedule on one device."""
 
@@ -512,31 +550,41 @@ class Stage1Engine:
         return io["xrec"].clone()
 
     # ---- training: forward (activations saved) / backward, used fused by training_step and split by autograd -----
+    def encode_train(self, img: torch.Tensor) -> dict:
+        """first half of forward_train: encoder + pre_quant with the activations saved -> state dict with h (quantizer input, f32 [M, embed_dim])"""
+        img = self._check_img(img)
+        B = img.shape[0]
+        eb = self._encode_tokens(img, save=True, x3=self.encoder_precision == "x3")
+        h = self._pre_quant(eb, B)
+        self._fwd_serial = getattr(self, "_fwd_serial", 0) + 1
+        return dict(img=img, B=B, eb=eb, h=h, serial=self._fwd_serial)
+
+    def decode_train(self, st: dict, zq16: torch.Tensor) -> dict:
+        """second half: post_quant + decoder + to_pixel from the quantized tokens [M, embed_dim] (operand dtype of this precision mode), saved"""
+        st.update(zq16=zq16, pix=self._decode_tokens(zq16, st["B"], save=True))
+        return st
+
     def forward_train(self, img: torch.Tensor) -> dict:
         """Forward with every activation the backward needs kept in the arena of this batch size.  ONE forward may be
         outstanding per batch size: a later forward_train overwrites the arena (checked through `_fwd_serial`)."""
-        img = self._check_img(img)
-        B, s = img.shape[0], self.store
-        eb = self._encode_tokens(img, save=True, x3=self.encoder_precision == "x3")
-        h = self._pre_quant(eb, B)
-        E = s.w["quantizer.embedding.weight"]
+        st = self.encode_train(img)
+        E = self.store.w["quantizer.embedding.weight"]
         exact = self.precision != "bf16"
-        zq, zq16, idx, qloss = _C.vq_forward(h, E, float(self.q.beta), self.q.depth, self.q.use_norm, want_bf16=not exact)
-        if exact:
-            zq16 = zq
-        pix = self._decode_tokens(zq16, B, save=True)
-        self._fwd_serial = getattr(self, "_fwd_serial", 0) + 1
-        return dict(img=img, B=B, eb=eb, h=h, zq16=zq16, idx=idx, qloss=qloss, pix=pix, serial=self._fwd_serial)
+        zq, zq16, idx, qloss = _C.vq_forward(st["h"], E, float(self.q.beta), self.q.depth, self.q.use_norm, want_bf16=not exact)
+        st.update(idx=idx, qloss=qloss)
+        return self.decode_train(st, zq if exact else zq16)
 
-    def backward_from(self, st: dict, dpix16: torch.Tensor, g_loss: float, g_loss_dev: Optional[torch.Tensor] = None) -> None:
-        """Backward of forward_train given dpix16 = d loss / d pix in the patch layout [M, C*p*p] (bf16) and the gradient
-        flowing into the codebook loss (host scalar g_loss times optional device scalar).  ACCUMULATES into the flat grads."""
+    def _check_serial(self, st: dict) -> None:
         if st["serial"] != self._fwd_serial:
             raise RuntimeError("backward called for a forward whose saved activations were overwritten by a later forward_train")
+
+    def backward_decoder(self, st: dict, dpix16: torch.Tensor) -> torch.Tensor:
+        """to_pixel + decoder tower + post_quant backward given dpix16 = d loss / d pix in the patch layout [M, C*p*p]; ACCUMULATES the parameter
+        gradients, returns d loss / d (quantized tokens) as f32 [M, embed_dim] (an engine buffer)."""
+        self._check_serial(st)
         B, s, io = st["B"], self.store, self._io_bufs(st["B"])
         M, g = B * self.n_tok, s.grad
-        eb, h, zq16, idx = st["eb"], st["h"], st["zq16"], st["idx"]
-        E = s.w["quantizer.embedding.weight"]
+        zq16 = st["zq16"]
         db = self.dec.bufs(B, True)
         notify = self.comm.layer_done if self.comm is not None and self.sync_grads else None
         d_xf = io["d_xf_dec"]
@@ -550,22 +598,38 @@ class Stage1Engine:
         g0, g016 = self.dec.backward(B, d_xf, notify)
         _C.mm(g016, zq16, self.dec.dim, self.ed, M, g["post_quant.weight"], trans_a=True, trans_b=True, accumulate=True)
         _C.mm(g016, s.wa["post_quant.weight"], M, self.ed, self.dec.dim, io["dzq"], trans_b=True)
-        exact = self.precision != "bf16"
-        dh, dh16 = _C.vq_backward(h, E, idx, io["dzq"], g_loss, g_loss_dev, float(self.q.beta), self.q.depth, bool(self.q.use_residual),
-                                  self.q.use_norm, g["quantizer.embedding.weight"], want_bf16=not exact)
-        if exact:
-            dh16 = dh
+        if notify:
+            notify("post_quant.")
+        return io["dzq"]
+
+    def backward_encoder(self, st: dict, dh16: torch.Tensor, announce_quantizer: bool = True) -> None:
+        """pre_quant + encoder tower + patch embedding backward given d loss / d h [M, embed_dim] in the operand dtype; ACCUMULATES the gradients."""
+        self._check_serial(st)
+        B, s, io = st["B"], self.store, self._io_bufs(st["B"])
+        M, g, eb = B * self.n_tok, s.grad, st["eb"]
+        notify = self.comm.layer_done if self.comm is not None and self.sync_grads else None
         _C.mm(dh16, eb["xf16"], self.ed, self.enc.dim, M, g["pre_quant.weight"], trans_a=True, trans_b=True, accumulate=True)
         _C.colsum_any(dh16, M, self.ed, g["pre_quant.bias"], accumulate=True)
         d_xe = io["d_xf_enc"]
         _C.mm(dh16, s.wa["pre_quant.weight"], M, self.enc.dim, self.ed, d_xe, trans_b=True)
         if notify:
-            notify("post_quant."); notify("pre_quant."); notify("quantizer.")
+            notify("pre_quant.")
+            if announce_quantizer:      # (a quantizer differentiated by torch autograd may still be accumulating: its slice is left to GradSync.finish())
+                notify("quantizer.")
         e0, e016 = self.enc.backward(B, d_xe, notify)
         wpe = "encoder.to_patch_embedding.0.weight"
         _C.mm(e016, io["patches"], self.enc.dim, self.pd, M, g[wpe].view(self.enc.dim, self.pd), trans_a=True, trans_b=True, accumulate=True)
         if notify:
             notify("encoder.to_patch_embedding.")
+
+    def backward_from(self, st: dict, dpix16: torch.Tensor, g_loss: float, g_loss_dev: Optional[torch.Tensor] = None) -> None:
+        """Backward of forward_train given dpix16 = d loss / d pix in the patch layout [M, C*p*p] (bf16) and the gradient
+        flowing into the codebook loss (host scalar g_loss times optional device scalar).  ACCUMULATES into the flat grads."""
+        dzq = self.backward_decoder(st, dpix16)
+        exact = self.precision != "bf16"
+        dh, dh16 = _C.vq_backward(st["h"], self.store.w["quantizer.embedding.weight"], st["idx"], dzq, g_loss, g_loss_dev, float(self.q.beta), self.q.depth,
+                                  bool(self.q.use_residual), self.q.use_norm, self.store.grad["quantizer.embedding.weight"], want_bf16=not exact)
+        self.backward_encoder(st, dh if exact else dh16)
 
     def forward_backward(self, img: torch.Tensor, w_l1: float = 0.0, w_l2: float = 1.0, codebook_weight: float = 1.0,
                          zero_grad: bool = True) -> dict:
@@ -642,6 +706,14 @@ class Stage1Engine:
         parameter gradients in `param.grad` (views of the flat buffer).  The reference's ViTVQ.forward contract
         (vitvqgan.py:44-48) for callers that bring their own loss module."""
         return _AEFunction.apply(self, img, self._anchor())
+
+    def differentiable_encode(self, img: torch.Tensor) -> torch.Tensor:
+        """h = pre_quant(encoder(img)) [B, N, embed_dim] connected to autograd; pair with differentiable_decode (a quantizer in plain torch in between)"""
+        return _EncodeFn.apply(self, img, self._anchor())
+
+    def differentiable_decode(self, quant: torch.Tensor) -> torch.Tensor:
+        """xrec = decoder(post_quant(quant)) for the forward started by differentiable_encode, connected to autograd through `quant`"""
+        return _DecodeFn.apply(self, quant, self._anchor())
 
     def _anchor(self) -> torch.Tensor:
         if getattr(self, "_anchor_t", None) is None:

@@ -125,9 +125,50 @@ class VectorQuantizer(BaseQuantizer):
 
 
 class GumbelQuantizer(BaseQuantizer):
-    """reference quantizers.py:95-126 (Gumbel-softmax relaxation, used by ViTVQGumbel).  Outside the hot-path scope of this build (no
-    shipped stage-1 config selects it): the class exists so that a config naming it fails with a clear message instead of an AttributeError."""
+    """Gumbel-softmax relaxation of the codebook lookup (reference quantizers.py:95-126; used by ViTVQGumbel).  Outside the MI355X hot path (no shipped
+    stage-1 config selects it): plain PyTorch on the device tensors, differentiated by torch autograd between the two
+    halves of the HIP schedule (Stage1Engine.differentiable_encode / _decode).  Semantics restated from the reference:
+      logits_k = -(|zn|^2 + |en_k|^2 - 2 zn.en_k)      soft = gumbel_softmax(logits, tau, hard = not training)      z_q = soft @ en
+      loss = mean_tokens sum_k p_k (log p_k + log K), p = softmax(logits)  (KL to the uniform prior)            indices = argmax soft
+    and BaseQuantizer.forward's residual loop without the straight-through estimator (quantizers.py:38-63, straight_through = False)."""
 
-    def __init__(self, *args, **kwargs) -> None:
-        raise NotImplementedError("GumbelQuantizer / ViTVQGumbel are not part of the MI355X stage-1 hot path (VectorQuantizer with use_residual for "
-                                  "RQ-VAE is); see DESIGN.md 'out of scope'")
+    def __init__(self, embed_dim: int, n_embed: int, temp_init: float = 1.0, use_norm: bool = True, use_residual: bool = False,
+                 num_quantizers: Optional[int] = None, **kwargs) -> None:
+        super().__init__(embed_dim, n_embed, False, use_norm, use_residual, num_quantizers)
+        if use_residual and not num_quantizers:
+            raise ValueError("use_residual=True needs num_quantizers")
+        self.temperature = temp_init
+
+    @property
+    def depth(self) -> int:
+        return int(self.num_quantizers) if self.use_residual else 1
+
+    def quantize(self, z: torch.Tensor, temp: Optional[float] = None):
+        import math
+        tau = self.temperature if temp is None else temp
+        zn = self.norm(z.reshape(-1, self.embed_dim))
+        en = self.norm(self.embedding.weight)
+        logits = (2.0 * zn @ en.t() - zn.pow(2).sum(1, keepdim=True) - en.pow(2).sum(1)).view(*z.shape[:-1], self.n_embed)
+        soft = torch.nn.functional.gumbel_softmax(logits, tau=tau, dim=-1, hard=not self.training)
+        z_q = soft @ en
+        logp = torch.log_softmax(logits, dim=-1)
+        loss = (logp.exp() * (logp + math.log(self.n_embed))).sum(-1).mean()
+        return z_q, loss, soft.argmax(dim=-1)
+
+    def forward(self, z: torch.Tensor):
+        if not self.use_residual:
+            return self.quantize(z)
+        z_q, residual = torch.zeros_like(z), z.detach().clone()
+        losses, idxs = [], []
+        for _ in range(int(self.num_quantizers)):
+            z_qi, l_i, i_i = self.quantize(residual.clone())
+            residual = residual - z_qi
+            z_q = z_q + z_qi
+            losses.append(l_i)
+            idxs.append(i_i)
+        return z_q, torch.stack(losses, dim=-1).mean(), torch.stack(idxs, dim=-1)
+
+    def lookup(self, code: torch.Tensor) -> torch.Tensor:
+        """decode_codes front half (reference vitvqgan.py:82-87): n(E[code]), summed over the depth axis when residual"""
+        q = self.norm(torch.nn.functional.embedding(code, self.embedding.weight))
+        return q.sum(-2) if self.use_residual else q

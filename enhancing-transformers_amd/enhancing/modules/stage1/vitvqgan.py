@@ -22,7 +22,7 @@ import torch.nn as nn
 from ...utils.general import initialize_from_config
 from .layers import ViTDecoder as Decoder
 from .layers import ViTEncoder as Encoder
-from .quantizers import VectorQuantizer
+from .quantizers import GumbelQuantizer, VectorQuantizer
 
 
 def _get(cfg, key, default=None):
@@ -93,6 +93,10 @@ class ViTVQ(nn.Module):
         are connected to autograd (one outstanding forward per batch size) so any loss module on top can call .backward()."""
         if torch.is_grad_enabled():
             return self.engine.differentiable_forward(x)
+        xrec, qloss, _ = self.engine.reconstruct(x)
+        return xrec, qloss
+
+    def _reconstruct_detached(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         xrec, qloss, _ = self.engine.reconstruct(x)
         return xrec, qloss
 
@@ -198,7 +202,7 @@ class ViTVQ(nn.Module):
             if not hasattr(self.loss, "discriminator"):
                 return None
             # reference vitvqgan.py:117-127; the reconstruction enters the discriminator loss detached, so no autoencoder graph is kept
-            xrec, qloss, _ = self.engine.reconstruct(x)
+            xrec, qloss = self._reconstruct_detached(x)
             if zero_grad:
                 self.loss.disc_store(xrec.device).zero_grad()
             discloss, log_dict_disc = self.loss(qloss, x.to(xrec.device), xrec, optimizer_idx, self.global_step, batch_idx,
@@ -243,3 +247,51 @@ class ViTVQ(nn.Module):
         x = self.get_input(batch, self.image_key)
         xrec, _ = self(x)
         return {"originals": x, "reconstructions": xrec}
+
+
+class ViTVQGumbel(ViTVQ):
+    """reference vitvqgan.py:191-212: ViTVQ with a GumbelQuantizer and an optional temperature schedule.  The two towers run on the HIP schedule; the
+    quantizer between them is plain torch under autograd (not a hot path of this build — no shipped stage-1 config names this class)."""
+
+    def __init__(self, image_key: str, image_size: int, patch_size: int, encoder, decoder, quantizer, loss, path: Optional[str] = None,
+                 ignore_keys: List[str] = list(), temperature_scheduler=None, scheduler=None) -> None:
+        super().__init__(image_key, image_size, patch_size, encoder, decoder, quantizer, loss, None, list(), scheduler)
+        self.temperature_scheduler = initialize_from_config(temperature_scheduler) if temperature_scheduler else None
+        self.quantizer = GumbelQuantizer(**quantizer)
+        if path is not None:
+            self.init_from_ckpt(path, ignore_keys)
+
+    def _fusable_loss(self) -> bool:
+        return False       # the fused training step contains the VectorQuantizer kernel
+
+    def _quantize(self, h: torch.Tensor):
+        self.quantizer.to(h.device)
+        return self.quantizer(h)
+
+    def _reconstruct_detached(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        with torch.no_grad():
+            return self(x)
+
+    def forward(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        eng = self.engine
+        if torch.is_grad_enabled():
+            quant, diff, _ = self._quantize(eng.differentiable_encode(x))
+            return eng.differentiable_decode(quant), diff
+        quant, diff, _ = self._quantize(self.pre_quant_tokens(x))
+        return self.decode(quant), diff
+
+    def encode(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        quant, emb_loss, _ = self._quantize(self.pre_quant_tokens(x))
+        return quant, emb_loss
+
+    @torch.no_grad()
+    def encode_codes(self, x: torch.Tensor, precision: Optional[str] = None) -> torch.Tensor:
+        return self._quantize(self.pre_quant_tokens(x, precision or self.engine.codes_precision))[2]
+
+    def training_step(self, batch, batch_idx: int, optimizer_idx: int = 0, zero_grad: bool = True):
+        if self.temperature_scheduler:
+            self.quantizer.temperature = self.temperature_scheduler(self.global_step)
+        loss = super().training_step(batch, batch_idx, optimizer_idx, zero_grad)
+        if optimizer_idx == 0:
+            self.log("temperature", self.quantizer.temperature)
+        return loss

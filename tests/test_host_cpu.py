@@ -198,12 +198,46 @@ def test_real_datasets_are_sharded_across_ranks():
     assert len(seen[0]) == len(seen[1]) == 20 and not set(seen[0]) & set(seen[1]) and sorted(seen[0] + seen[1]) == list(range(40))
 
 
-def test_gumbel_and_deep_rq_fail_loudly():
-    from enhancing.modules.stage1.quantizers import GumbelQuantizer, VectorQuantizer
-    with pytest.raises(NotImplementedError):
-        GumbelQuantizer(32, 1024)
+def test_deep_rq_fails_loudly():
+    from enhancing.modules.stage1.quantizers import VectorQuantizer
     with pytest.raises(ValueError, match="num_quantizers <= 8"):
         VectorQuantizer(32, 1024, use_residual=True, num_quantizers=9)
+
+
+@pytest.mark.parametrize("residual", [False, True])
+def test_gumbel_quantizer_equals_the_reference_class(residual):
+    """GumbelQuantizer (plain torch, outside the HIP hot path): same constructor, same RNG consumption, same outputs and gradients as the reference's
+    class (quantizers.py:95-126 + the residual loop of BaseQuantizer.forward) for one seed, in training (soft) and eval (hard) mode — checked against
+    the reference itself where /root/reference is present, and for its invariants everywhere."""
+    from enhancing.modules.stage1.quantizers import GumbelQuantizer
+    import _reference_loader as RL
+    kw = dict(embed_dim=32, n_embed=64, temp_init=0.7, use_residual=residual, num_quantizers=3 if residual else None)
+    torch.manual_seed(3)
+    ours = GumbelQuantizer(**kw)
+    z = torch.randn(2, 16, 32, requires_grad=True)
+    ref = None
+    if RL.available():
+        torch.manual_seed(3)
+        ref = RL.load_quantizers().GumbelQuantizer(**kw)
+        assert torch.equal(ref.embedding.weight, ours.embedding.weight)
+    for training in (True, False):
+        ours.train(training)
+        torch.manual_seed(11)
+        zq, loss, idx = ours(z)
+        assert zq.shape == z.shape and idx.shape == ((2, 16, 3) if residual else (2, 16)) and idx.dtype == torch.int64 and float(loss) >= 0
+        g = torch.autograd.grad(zq.pow(2).sum() + loss, [z, ours.embedding.weight], allow_unused=True)
+        if not training and not residual:       # hard one-hot: the output IS a normalised code
+            en = torch.nn.functional.normalize(ours.embedding.weight, dim=-1)
+            assert torch.allclose(zq, en[idx], atol=1e-6)
+        if ref is not None:
+            ref.train(training)
+            z2 = z.detach().clone().requires_grad_(True)
+            torch.manual_seed(11)
+            rq, rl, ri = ref(z2)
+            assert torch.equal(ri, idx) and torch.allclose(rq, zq, atol=1e-6) and torch.allclose(rl, loss, atol=1e-6)
+            rg = torch.autograd.grad(rq.pow(2).sum() + rl, [z2, ref.embedding.weight], allow_unused=True)
+            for a, b in zip(g, rg):
+                assert (a is None) == (b is None) and (a is None or torch.allclose(a, b, atol=1e-5))
 
 
 def test_trainer_drives_the_lightning_protocol_in_order(monkeypatch, tmp_path):
