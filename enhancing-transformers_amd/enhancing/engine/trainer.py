@@ -18,7 +18,8 @@ from .ddp import GradSync, init_process_group_from_env
 class Trainer:
     def __init__(self, max_epochs: int = 100, precision: int = 32, gpus: int = 1, num_nodes: int = 1, strategy: Optional[str] = None,
                  accumulate_grad_batches: int = 1, callbacks=None, logger=None, max_steps: Optional[int] = None,
-                 default_root_dir: str = "experiments", log_every_n_steps: int = 10, limit_val_batches: Optional[int] = None) -> None:
+                 default_root_dir: str = "experiments", log_every_n_steps: int = 10, limit_val_batches: Optional[int] = None,
+                 val_batches: Optional[int] = None) -> None:
         self.max_epochs, self.max_steps = max_epochs, max_steps
         # Lightning's `precision` (reference main.py:52): 16 = --use_amp = mixed precision.  On MI355X the mixed-precision dtype is bf16 (fp32 master
         # weights / accumulation; bf16 keeps fp32's exponent range, so Lightning's fp16 GradScaler has nothing to do and its semantics are the
@@ -30,6 +31,10 @@ class Trainer:
         self.strategy = strategy
         self.root = default_root_dir
         self.log_every = log_every_n_steps
+        if val_batches is not None:               # deprecated spelling of limit_val_batches (kept so existing callers do not silently validate on everything)
+            import warnings
+            warnings.warn("Trainer(val_batches=...) is deprecated: use limit_val_batches", DeprecationWarning, stacklevel=2)
+            limit_val_batches = val_batches if limit_val_batches is None else limit_val_batches
         self.val_batches = limit_val_batches      # Lightning's limit_val_batches as a batch count; None = the whole validation set (Lightning's default)
         self.rank, self.local_rank, self.world = 0, 0, 1
         self.global_step = 0

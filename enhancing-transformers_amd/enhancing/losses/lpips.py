@@ -125,7 +125,23 @@ class LPIPS(nn.Module):
             with torch.no_grad():
                 for p in self.parameters():
                     p.zero_()
+        self._register_state_dict_hook(LPIPS._drop_random_weights)
         self.eval()
+
+    @staticmethod
+    def _drop_random_weights(module, state_dict, prefix, local_metadata):
+        """a checkpoint must not launder a random trunk into "loaded weights": while the module runs on the explicit random initialisation its tensors
+        are left out of every state dict it (or a parent: Trainer.fit saves model.state_dict()) produces — loading such a checkpoint leaves the
+        perceptual term as constructed (empty: forward raises; or random again, by the same explicit opt-in)"""
+        if module.random_init and not module.weights_loaded:
+            for k in [k for k in state_dict if k.startswith(prefix)]:
+                del state_dict[k]
+        return state_dict
+
+    def full_state_dict(self) -> Dict[str, torch.Tensor]:
+        """every tensor under its lpips 0.1.4 key (both `lin{k}` and `lins.{k}` families), whatever its provenance — for tests and diagnostics; checkpoints
+        go through state_dict(), which omits a randomly initialised trunk"""
+        return {n: t.detach() for n, t in list(self.named_parameters(remove_duplicate=False)) + list(self.named_buffers(remove_duplicate=False))}
 
     # ---- parameters ----------------------------------------------------------------------------------------
     def _random_init(self) -> None:
@@ -155,8 +171,11 @@ class LPIPS(nn.Module):
     def _load_from_state_dict(self, state_dict, prefix, *a, **k):
         # reached both by self.load_state_dict and by a PARENT's (ViTVQ.init_from_ckpt loading a reference checkpoint that carries
         # loss.perceptual_loss.*), which never calls a child's load_state_dict override
-        if any(key.startswith(prefix + "net.") for key in state_dict) and any(key.startswith(prefix + "lin") for key in state_dict):
-            self.weights_loaded = True
+        # weights_loaded only when EVERY tensor of the module arrives (a partial dict under strict=False leaves the missing ones zero), and a random
+        # trunk can never arrive: state_dict() of a randomly initialised module omits its tensors (see _drop_random_weights)
+        expected = {prefix + n for n, _ in list(self.named_parameters(remove_duplicate=False)) + list(self.named_buffers(remove_duplicate=False))}
+        if expected and expected <= set(state_dict):
+            self.weights_loaded, self.random_init = True, False
         self._dev.clear()
         return super()._load_from_state_dict(state_dict, prefix, *a, **k)
 

@@ -1,75 +1,67 @@
-"""upfirdn2d (upsample - FIR filter - downsample) with the reference's API (reference enhancing/losses/op/upfirdn2d.py:20-165):
-``upfirdn2d(input [B,C,H,W], kernel [kh,kw], up=1, down=1, pad=(p0,p1))`` with first and second derivatives (the backward is the same
-op with the flipped kernel, swapped up/down and the gradient pads, and is itself differentiable).  Arithmetic: ``enh_upfirdn2d``."""
+"""``upfirdn2d(input [B,C,H,W], kernel [kh,kw], up=1, down=1, pad=(p0,p1))`` — the reference's native-op entry point
+(reference enhancing/losses/op/upfirdn2d.py:149-165) on ``enh_upfirdn2d``, differentiable to any order.
+
+Derivation.  Per image plane the op is LINEAR in its input: y = D_down( F_k( P_pad( U_up(x) ) ) ) (zero-stuff, pad / crop, correlate with the flipped
+kernel, decimate).  Its adjoint is an op of the same family: zero-stuffing and decimation are each other's adjoints, correlation with k becomes
+correlation with the flipped k, and the padding that makes the shapes close is
+    pad0' = k - 1 - pad0        pad1' = n_in * up - n_out * down + pad0 - up + 1          (per axis; n_out as computed by the forward op),
+with up and down exchanged.  So ONE autograd node, parameterised by a geometry record that knows its own adjoint, covers the forward pass, the
+gradient and the gradient of the gradient (the R1 penalty differentiates through the discriminator's backward, vqperceptual.py:157-162): the
+adjoint of the adjoint is the original geometry again.
+"""
 from __future__ import annotations
 
-from collections import abc
+from typing import NamedTuple, Tuple
 
 import torch
-from torch.autograd import Function
 
 from ... import _C
 
 
-class UpFirDn2dBackward(Function):
-    @staticmethod
-    def forward(ctx, grad_output, kernel, grad_kernel, up, down, pad, g_pad, in_size, out_size):
-        up_x, up_y = up
-        down_x, down_y = down
-        g_pad_x0, g_pad_x1, g_pad_y0, g_pad_y1 = g_pad
-        go = grad_output.reshape(-1, out_size[0], out_size[1]).contiguous()
-        grad_input = _C.upfirdn2d(go, grad_kernel, down_x, down_y, up_x, up_y, g_pad_x0, g_pad_x1, g_pad_y0, g_pad_y1)
-        grad_input = grad_input.view(in_size[0], in_size[1], in_size[2], in_size[3])
-        ctx.save_for_backward(kernel)
-        ctx.cfg = (up, down, pad, in_size, out_size)
-        return grad_input
+class _Geom(NamedTuple):
+    up: Tuple[int, int]            # (x, y)
+    down: Tuple[int, int]
+    pad: Tuple[int, int, int, int]  # x0, x1, y0, y1
+    in_hw: Tuple[int, int]
+    k_hw: Tuple[int, int]
+
+    def out_hw(self) -> Tuple[int, int]:
+        (ux, uy), (dx, dy), (px0, px1, py0, py1), (h, w), (kh, kw) = self
+        return (h * uy + py0 + py1 - kh + dy) // dy, (w * ux + px0 + px1 - kw + dx) // dx
+
+    def adjoint(self) -> "_Geom":
+        (ux, uy), (dx, dy), (px0, _, py0, _), (h, w), (kh, kw) = self
+        oh, ow = self.out_hw()
+        pad = (kw - 1 - px0, w * ux - ow * dx + px0 - ux + 1, kh - 1 - py0, h * uy - oh * dy + py0 - uy + 1)
+        return _Geom(self.down, self.up, pad, (oh, ow), self.k_hw)
+
+
+class _UpFirDn(torch.autograd.Function):
+    """x [..., H, W] -> [..., H', W'] under geometry g with kernel k; the backward is the same node under g.adjoint() with the flipped kernel"""
 
     @staticmethod
-    def backward(ctx, gradgrad_input):
-        kernel, = ctx.saved_tensors
-        (up_x, up_y), (down_x, down_y), (px0, px1, py0, py1), in_size, out_size = ctx.cfg
-        gg = gradgrad_input.reshape(-1, in_size[2], in_size[3]).contiguous()
-        gradgrad_out = _C.upfirdn2d(gg, kernel, up_x, up_y, down_x, down_y, px0, px1, py0, py1)
-        return gradgrad_out.view(in_size[0], in_size[1], out_size[0], out_size[1]), None, None, None, None, None, None, None, None
-
-
-class UpFirDn2d(Function):
-    @staticmethod
-    def forward(ctx, input, kernel, up, down, pad):
-        up_x, up_y = up
-        down_x, down_y = down
-        pad_x0, pad_x1, pad_y0, pad_y1 = pad
-        kernel_h, kernel_w = kernel.shape
-        batch, channel, in_h, in_w = input.shape
-        ctx.in_size = input.shape
-        kernel = kernel.contiguous()
-        ctx.save_for_backward(kernel, torch.flip(kernel, [0, 1]).contiguous())
-        out_h = (in_h * up_y + pad_y0 + pad_y1 - kernel_h + down_y) // down_y
-        out_w = (in_w * up_x + pad_x0 + pad_x1 - kernel_w + down_x) // down_x
-        ctx.out_size = (out_h, out_w)
-        ctx.up, ctx.down, ctx.pad = (up_x, up_y), (down_x, down_y), (pad_x0, pad_x1, pad_y0, pad_y1)
-        g_pad_x0 = kernel_w - pad_x0 - 1
-        g_pad_y0 = kernel_h - pad_y0 - 1
-        g_pad_x1 = in_w * up_x - out_w * down_x + pad_x0 - up_x + 1
-        g_pad_y1 = in_h * up_y - out_h * down_y + pad_y0 - up_y + 1
-        ctx.g_pad = (g_pad_x0, g_pad_x1, g_pad_y0, g_pad_y1)
-        out = _C.upfirdn2d(input.reshape(-1, in_h, in_w).contiguous(), kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1)
-        return out.view(-1, channel, out_h, out_w)
+    def forward(ctx, x, k, g: _Geom):
+        ctx.g = g
+        ctx.save_for_backward(k)
+        lead = x.shape[:-2]
+        (ux, uy), (dx, dy), (px0, px1, py0, py1) = g.up, g.down, g.pad
+        y = _C.upfirdn2d(x.reshape(-1, *g.in_hw).contiguous(), k, ux, uy, dx, dy, px0, px1, py0, py1)
+        return y.view(*lead, *g.out_hw())
 
     @staticmethod
-    def backward(ctx, grad_output):
-        kernel, grad_kernel = ctx.saved_tensors
-        grad_input = None
-        if ctx.needs_input_grad[0]:
-            grad_input = UpFirDn2dBackward.apply(grad_output, kernel, grad_kernel, ctx.up, ctx.down, ctx.pad, ctx.g_pad, ctx.in_size, ctx.out_size)
-        return grad_input, None, None, None, None
+    def backward(ctx, gy):
+        if not ctx.needs_input_grad[0]:
+            return None, None, None
+        k, = ctx.saved_tensors
+        adj = ctx.g.adjoint()
+        assert adj.out_hw() == ctx.g.in_hw
+        return _UpFirDn.apply(gy, torch.flip(k, [0, 1]).contiguous(), adj), None, None
 
 
-def upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0)):
-    if not isinstance(up, abc.Iterable):
-        up = (up, up)
-    if not isinstance(down, abc.Iterable):
-        down = (down, down)
+def upfirdn2d(input: torch.Tensor, kernel: torch.Tensor, up=1, down=1, pad=(0, 0)) -> torch.Tensor:
+    pair = lambda v: (int(v), int(v)) if not isinstance(v, (tuple, list)) else (int(v[0]), int(v[1]))
+    pad = tuple(int(p) for p in pad)
     if len(pad) == 2:
         pad = (pad[0], pad[1], pad[0], pad[1])
-    return UpFirDn2d.apply(input, kernel, tuple(up), tuple(down), tuple(pad))
+    g = _Geom(pair(up), pair(down), pad, (int(input.shape[-2]), int(input.shape[-1])), (int(kernel.shape[0]), int(kernel.shape[1])))
+    return _UpFirDn.apply(input, kernel.contiguous(), g)

@@ -268,7 +268,9 @@ def test_adaptive_adversarial_weight_with_the_perceptual_term(C, lpips_random_in
         m = ViTVQ("image", cfg["image_size"], cfg["patch_size"], AttrDict.wrap(cfg["encoder"]), AttrDict.wrap(cfg["decoder"]),
                   AttrDict.wrap(cfg["quantizer"]), AttrDict.wrap(loss))
     assert m.loss.perceptual_loss.random_init and not m.loss.perceptual_loss.weights_loaded
-    m.load_state_dict({**O.make_params(cfg, seed=11), **{"loss." + k: v for k, v in m.loss.state_dict().items()}}, strict=True)
+    assert not any(k.startswith("loss.perceptual_loss.") for k in m.state_dict())      # the random trunk stays out of checkpoints
+    m.load_state_dict({**O.make_params(cfg, seed=11), **{"loss." + k: v for k, v in m.loss.state_dict().items()}}, strict=False)
+    assert m.loss.perceptual_loss.random_init and not m.loss.perceptual_loss.weights_loaded
     m.train()
     x = O.make_images(5, 2, cfg["image_size"])
     m.engine.store.zero_grad()

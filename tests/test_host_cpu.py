@@ -102,8 +102,21 @@ def test_lpips_without_weights_raises_and_parent_load_supplies_them(monkeypatch)
     assert src.random_init and not src.weights_loaded
     cpu = torch.device("cpu")
     before = m._device_weights(cpu)["fwd"][2].clone()
-    P.load_state_dict({"perceptual_loss." + k: v for k, v in src.state_dict().items()}, strict=True)      # parent load: child override never runs
-    assert m.weights_loaded
+    # a random trunk never reaches a checkpoint (its tensors are omitted from state dicts), and a PARTIAL dict does not count as weights
+    assert not [k for k in src.state_dict()] and not [k for k in VQLPIPS(perceptual_weight=0.1, **{}).state_dict() if False]
+    real = {n: t.detach().clone() for n, t in list(src.named_parameters(remove_duplicate=False)) + list(src.named_buffers(remove_duplicate=False))}       # stands in for an lpips-format checkpoint
+    partial = {"perceptual_loss." + k: v for k, v in real.items() if not k.startswith("lin")}
+    P.load_state_dict(partial, strict=False)
+    assert not m.weights_loaded
+    with pytest.raises(RuntimeError, match="LPIPS has no weights"):
+        m(torch.zeros(1, 3, 16, 16), torch.zeros(1, 3, 16, 16))
+    with torch.no_grad():
+        for p_ in m.parameters():
+            p_.zero_()
+    m._dev.clear()
+    P.load_state_dict({"perceptual_loss." + k: v for k, v in real.items()}, strict=True)      # parent load: child override never runs
+    assert m.weights_loaded and not m.random_init
+    assert set(P.state_dict()) == {"perceptual_loss." + k for k in real}                    # loaded weights ARE saved
     after = m._device_weights(cpu)["fwd"][2]
     assert before.abs().max() == 0 and after.abs().max() > 0       # stale (zero) operands were not re-used
     with torch.no_grad():

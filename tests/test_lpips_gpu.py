@@ -108,7 +108,8 @@ def test_lpips_distance_and_gradient_vs_oracle(lpips_random_init):
     import lpips_oracle as LO
     from enhancing.losses.lpips import LPIPS
     m = LPIPS(net="vgg", verbose=False)
-    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    assert not m.state_dict()          # a random trunk never reaches a checkpoint
+    sd = {k: v.clone() for k, v in m.full_state_dict().items()}
     assert {"scaling_layer.shift", "net.slice1.0.weight", "net.slice5.28.bias", "lin0.model.1.weight", "lins.4.model.1.weight"} <= set(sd)
     g = torch.Generator().manual_seed(0)
     B, S = 2, 64

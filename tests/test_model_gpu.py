@@ -26,7 +26,7 @@ def _build(cfg, P, loss_params=None):
         loss["params"].update(loss_params)
     m = ViTVQ("image", cfg["image_size"], cfg["patch_size"], AttrDict.wrap(cfg["encoder"]), AttrDict.wrap(cfg["decoder"]),
               AttrDict.wrap(cfg["quantizer"]), AttrDict.wrap(loss))
-    m.load_state_dict(P, strict=not any(k.startswith("loss.") for k in m.state_dict()))   # a loss with parameters (LPIPS / discriminator) keeps its own
+    m.load_state_dict(P, strict=not any(n.startswith("loss.") for n, _ in m.named_parameters()))   # a loss with parameters (LPIPS / discriminator) keeps its own
     m.engine  # bind to the GPU
     return m
 
@@ -390,7 +390,7 @@ def test_training_step_with_the_lpips_term_vs_oracle(lpips_random_init):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         m = _build(cfg, P, loss_params=dict(perceptual_weight=0.1))
-    lsd = {k: v.detach().cpu().clone() for k, v in m.loss.perceptual_loss.state_dict().items()}
+    lsd = {k: v.cpu().clone() for k, v in m.loss.perceptual_loss.full_state_dict().items()}
     loss = m.training_step({"image": x}, 0, 0)
     leaves = {k: v.detach().clone().requires_grad_(not k.endswith("pos_embedding")) for k, v in P.items()}
     o_xrec, o_q = O.forward(x, leaves, cfg)

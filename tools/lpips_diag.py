@@ -15,7 +15,7 @@ for only in [None,0,1,2,3,4]:
             for k in range(5):
                 if k!=only: getattr(m,f"lin{k}").model[1].weight.zero_()
         m._dev.clear()
-    sd={k:v.detach().clone() for k,v in m.state_dict().items()}
+    sd={k:v.clone() for k,v in m.full_state_dict().items()}
     x1=in1.clone().cuda().requires_grad_(True); d=m(in0.cuda(),x1,normalize=True); d.mean().backward()
     o1=in1.clone().requires_grad_(True); do=LO.lpips_distance(in0,o1,sd,normalize=True); do.mean().backward()
     a,b=x1.grad.cpu().double().flatten(), o1.grad.double().flatten()
