@@ -62,6 +62,26 @@ __device__ __forceinline__ void att_pin(s16x8& f) {
   asm volatile("" : "+v"(u));
   f = __builtin_bit_cast(s16x8, u);
 }
+// max(a, b, c) in ONE instruction.  fmaxf on MFMA results makes the compiler canonicalise every operand first (v_max_f32 x, x, x: seven instructions
+// for a 4-way maximum, cdna_hip_programming.md "Fused attention" pitfalls); scores are finite products, nothing to canonicalise.
+__device__ __forceinline__ float max3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+// combine a per-lane value with the other half-wave's (lane ^ 32) through one v_permlane32_swap (no LDS round trip).  Verified semantics
+// (profiles/hw_probe_r01.txt P4): with both operands = v, every lane receives (v[lane & 31], v[(lane & 31) + 32]).
+__device__ __forceinline__ float xhalf_max(float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __builtin_fmaxf(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+}
+__device__ __forceinline__ float xhalf_sum(float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
 
 // Workgroup -> (block-within-head, head) mapping.  Hardware places workgroup L on XCD L % 8 (each XCD has a private L2), and the nblk

@@ -30,26 +30,6 @@ __device__ __forceinline__ f32x16 f32x16_zero() {
   const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   return z;
 }
-// max(a, b, c) in ONE instruction.  fmaxf on MFMA results makes the compiler canonicalise every operand first (v_max_f32 x, x, x: seven instructions
-// for a 4-way maximum, cdna_hip_programming.md "Fused attention" pitfalls); scores are finite products, nothing to canonicalise.
-__device__ __forceinline__ float max3(float a, float b, float c) {
-  float r;
-  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
-}
-// combine a per-lane value with the other half-wave's (lane ^ 32) through one v_permlane32_swap (no LDS round trip).  Verified semantics
-// (profiles/hw_probe_r01.txt P4): with both operands = v, every lane receives (v[lane & 31], v[(lane & 31) + 32]).
-__device__ __forceinline__ float xhalf_max(float v) {
-  const unsigned u = __builtin_bit_cast(unsigned, v);
-  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-  return __builtin_fmaxf(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
-}
-__device__ __forceinline__ float xhalf_sum(float v) {
-  const unsigned u = __builtin_bit_cast(unsigned, v);
-  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-  return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
-}
-
 // =================================================================================================
 // forward
 // =================================================================================================

@@ -1,0 +1,200 @@
+// attention_v3.hip — round-4 attention forward: EIGHT waves per workgroup in two groups that run in ANTIPHASE (the structure of
+// MI355X_MICROARCH.md "Two waves per SIMD").  Reference semantics: enhancing/modules/stage1/layers.py:123-130; data layout, MFMA shapes and LDS images are
+// those of attention.hip (attention_common.h).
+//
+// Why.  The round-2/3 kernels (four waves per workgroup, two or three workgroups per CU) spend, per SIMD, about the SUM of their matrix time
+// (32 clk x #MFMA) and their vector time (profiles/r03_attention_lab.txt §3): inside a wave every product waits for the softmax that waits for the product
+// before it, and the waves that share a SIMD belong to different workgroups and drift through those phases at random.  Re-ordering inside a wave
+// (attention_v2.hip) cannot help.  Here the two waves that share a SIMD are PARTNERS: every wave alternates a pure vector segment (the softmax of
+// tile i: row maximum, 32 exponentials, row sum, packing; plus its share of the tile staging) with a pure matrix segment (O += V(i)^T P(i) and
+// S(i+1) = K(i+1) Q^T: 16 MFMAs and their fragment reads), the partner is half a period behind, and an s_barrier separates the segments — so a SIMD
+// always has one wave feeding the matrix pipe while the other issues vector instructions:
+//
+//     half-step        2i              2i+1            2i+2            2i+3
+//     group A      softmax(i)     PV(i), S(i+1)    softmax(i+1)    PV(i+1), S(i+2)
+//     group B     PV(i-1), S(i)    softmax(i)      PV(i), S(i+1)    softmax(i+1)
+//
+// The vector segment is cut to what the exponentials need (as attention_v2.hip): q arrives pre-scaled by scale * log2(e) and -m_ref rides in the MFMA C
+// operand, so a score is exponentiated straight from the accumulator; m_ref is a REFERENCE maximum that is only raised (O, l rescaled, a wave-uniform
+// branch) when a row's tile maximum exceeds it by more than 2^8 — on the first tile and then almost never.
+// LDS: K and V each in a 2-slot ring of 8-KiB tiles (32 KiB).  K(i+1) and V(i) are read in half-steps 2i+1 (A) and 2i+2 (B); group A writes K(i+1) in its
+// vector segment 2i (from registers loaded one period earlier), group B writes V(i+1) in its vector segment 2i+1: every slot is rewritten at least one
+// barrier after its last reader and one barrier before its first.
+// Workgroup = 256 queries of one (image, head); needs N % 256 == 0 (the launcher falls back to the four-wave kernel otherwise).
+#include "attention_common.h"
+
+#define A3_THR 8.0f
+// segment boundary: this wave's LDS traffic is performed, then all eight waves meet.  (Raw barrier: __syncthreads() would also wait for the tile
+// prefetch that is meant to stay in flight across the boundary.)  The empty asm keeps IR-level passes from moving LDS accesses across it.
+#define A3_BARRIER()                          \
+  do {                                        \
+    __builtin_amdgcn_s_waitcnt(0xC07F);       \
+    asm volatile("" ::: "memory");           \
+    __builtin_amdgcn_s_barrier();             \
+    asm volatile("" ::: "memory");           \
+  } while (0)
+
+#define A3_PIN1(x) asm volatile("" : "+v"(x))
+#define A3_PIN16(x) asm volatile("" : "+v"(x))
+#define A3_PIN4(x) do { u32x4 u_ = __builtin_bit_cast(u32x4, (x)); asm volatile("" : "+v"(u_)); (x) = __builtin_bit_cast(s16x8, u_); } while (0)
+
+// matrix segment: O += V^T P (8 MFMAs, skipped for the segment in front of tile 0) and the next tile's scores S = K Q^T + (-m_ref) (8 MFMAs)
+template <bool PV, bool SNEXT, bool PRE>
+__device__ __forceinline__ void a3_matrix(const unsigned char* kbuf, const unsigned char* vbuf, int lane, const s16x8 (&qf)[4], const s16x8 (&p)[4],
+                                          const f32x16& negm, f32x16 (&o)[2], f32x16 (&s)[2]) {
+  const int l31 = lane & 31, hi = lane >> 5;
+  if (PV) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {          // P slice i = keys 16 i .. 16 i + 15 of the tile
+#pragma unroll
+      for (int db = 0; db < 2; ++db) o[db] = MFMA32(att_frag_tr(vbuf, (i >> 1) * 32 + 16 * (i & 1), db, lane), p[i], o[db]);
+    }
+  }
+  if (SNEXT) {
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {      // the two 32-key accumulators alternate: no MFMA waits for the one issued just before it
+        const s16x8 kf = att_frag_row(kbuf, kb * 32, ds, l31, hi);
+        if (ds == 0) {
+          if (PRE) s[kb] = MFMA32(kf, qf[ds], negm);
+          else {
+            f32x16 z;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = 0.f;
+            s[kb] = MFMA32(kf, qf[ds], z);
+          }
+        } else s[kb] = MFMA32(kf, qf[ds], s[kb]);
+      }
+  }
+}
+
+// vector segment: numerators of the tile whose scores are in s (relative to m_ref when PRE), row statistics, packing
+template <bool PRE>
+__device__ __forceinline__ void a3_softmax(bool first, float sl2, f32x16 (&s)[2], s16x8 (&p)[4], f32x16& negm, float& m_ref, float& l_part, f32x16 (&o)[2]) {
+  // row maximum of the tile (this lane's 32 keys, then the other half-wave's)
+  float mx = max3(s[0][0], s[0][1], s[0][2]);
+#pragma unroll
+  for (int r = 3; r < 15; r += 2) mx = max3(mx, s[0][r], s[0][r + 1]);
+  mx = max3(mx, s[0][15], s[1][0]);
+#pragma unroll
+  for (int r = 1; r < 15; r += 2) mx = max3(mx, s[1][r], s[1][r + 1]);
+  mx = __builtin_fmaxf(mx, s[1][15]);
+  mx = xhalf_max(mx);
+  if (!PRE) mx = mx * sl2 - m_ref;          // scores arrive raw: log2-domain and relative to the reference from here on
+  // raise the reference only when some row outgrew it by more than 2^THR (always on the first tile: the reference starts at 0, not at the maximum)
+  if (first || __builtin_amdgcn_ballot_w64(mx > A3_THR) != 0) {
+    const float d = first ? mx : __builtin_fmaxf(mx, 0.f);
+    const float alpha = __builtin_amdgcn_exp2f(-d);
+    m_ref += d;
+    l_part *= alpha;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+    if (PRE) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kb][r] -= d;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) negm[r] = -m_ref;
+    }
+  }
+  float e[32];
+  float ls0 = 0.f, ls1 = 0.f;
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      e[kb * 16 + r] = PRE ? __builtin_amdgcn_exp2f(s[kb][r]) : __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r], sl2, -m_ref));
+      e[kb * 16 + r + 1] = PRE ? __builtin_amdgcn_exp2f(s[kb][r + 1]) : __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r + 1], sl2, -m_ref));
+      ls0 += e[kb * 16 + r];
+      ls1 += e[kb * 16 + r + 1];
+    }
+  l_part += ls0 + ls1;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) p[i] = pack8_bf16(&e[i * 8]);
+}
+
+template <bool PRE>
+__global__ __launch_bounds__(512, 2) void attn_fwd3_kernel(const uint16_t* __restrict__ qkv, int B, int N, int H, float sl2, uint16_t* __restrict__ out,
+                                                           float* __restrict__ lse) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][ATT_TILE_BYTES];  // [K | V][slot]
+  int blk, head;
+  if (!att_block_coords(N / 256, B * H, blk, head)) return;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int grp = wave >> 2, tg = t & 255;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int b = head / H, h = head - b * H;
+  const int q0 = blk * 256 + wave * 32;
+  const int64_t RS = (int64_t)3 * H * ATT_D;
+  const uint16_t* Qp = qkv + (int64_t)b * N * RS + h * ATT_D;
+  const uint16_t* Kp = Qp + H * ATT_D;
+  const uint16_t* Vp = Kp + H * ATT_D;
+  const uint16_t* Sp = grp == 0 ? Kp : Vp;          // the operand this group stages (A: K, B: V)
+  unsigned char(*sbuf)[ATT_TILE_BYTES] = smem[grp];
+  const int nt = N / 64;
+
+  s16x8 qf[4];
+#pragma unroll
+  for (int ds = 0; ds < 4; ++ds) qf[ds] = *reinterpret_cast<const s16x8*>(Qp + (int64_t)(q0 + l31) * RS + ds * 16 + hi * 8);
+  u32x4 rs[2];
+  att_gload(rs, Sp, RS, 0, tg);                      // tile 0 of this group's operand -> slot 0
+  att_sstore(rs, sbuf[0], tg);
+  if (nt > 1) att_gload(rs, Sp, RS, 64, tg);         // tile 1 stays in registers until the group's first vector segment
+#pragma unroll
+  for (int ds = 0; ds < 4; ++ds) att_pin(qf[ds]);
+
+  f32x16 o[2], s[2], negm;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; negm[r] = 0.f; s[0][r] = 0.f; s[1][r] = 0.f; }
+  s16x8 p[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) p[i] = (s16x8){0, 0, 0, 0, 0, 0, 0, 0};
+  float m_ref = 0.f, l_part = 0.f;
+  A3_BARRIER();                                        // K(0), V(0) are in LDS
+  // Both groups run the SAME instruction stream  [ vector(i) | barrier | matrix(i) | barrier ]  — group B one barrier behind group A (its lead-in barrier
+  // here, group A's trailing one after the loop), which is what puts the partners of a SIMD in antiphase.  No group-dependent branch inside the loop:
+  // with one, the compiler merged the two variants through register copies of the in-flight tile prefetch and waited for it in the matrix segment.
+  a3_matrix<false, true, PRE>(smem[0][0], smem[1][0], lane, qf, p, negm, o, s);      // S(0), both groups at once (the only un-phased segment)
+  A3_PIN16(s[0]); A3_PIN16(s[1]);
+  if (grp == 1) A3_BARRIER();
+  for (int i = 0; i < nt; ++i) {
+    const int cur = i & 1, nxt = cur ^ 1;
+    // ---- vector segment: softmax of tile i; this group's operand tile i+1 goes from registers to LDS, tile i+2 is requested ----
+    a3_softmax<PRE>(i == 0, sl2, s, p, negm, m_ref, l_part, o);
+    if (i + 1 < nt) att_sstore(rs, sbuf[nxt], tg);
+    if (i + 2 < nt) att_gload(rs, Sp, RS, (i + 2) * 64, tg);
+    A3_PIN4(p[0]); A3_PIN4(p[1]); A3_PIN4(p[2]); A3_PIN4(p[3]);      // (pure arithmetic otherwise sinks to its first use: into the matrix segment)
+    A3_PIN1(l_part); A3_PIN1(m_ref); A3_PIN16(negm); A3_PIN16(o[0]); A3_PIN16(o[1]);
+    A3_BARRIER();
+    // ---- matrix segment: O += V(i)^T P(i), S(i+1) = K(i+1) Q^T - m_ref ----
+    if (i + 1 < nt) a3_matrix<true, true, PRE>(smem[0][nxt], smem[1][cur], lane, qf, p, negm, o, s);
+    else a3_matrix<true, false, PRE>(smem[0][nxt], smem[1][cur], lane, qf, p, negm, o, s);
+    A3_PIN16(o[0]); A3_PIN16(o[1]); A3_PIN16(s[0]); A3_PIN16(s[1]);
+    A3_BARRIER();
+  }
+  if (grp == 0) A3_BARRIER();
+
+  const float l = xhalf_sum(l_part);
+  const float inv = 1.0f / l;
+  uint16_t* op = out + ((int64_t)b * N + q0 + l31) * (H * ATT_D) + h * ATT_D;
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int d0 = db * 32 + 8 * g4 + 4 * hi;
+      u32x2 w = {pack_bf16x2(o[db][g4 * 4 + 0] * inv, o[db][g4 * 4 + 1] * inv), pack_bf16x2(o[db][g4 * 4 + 2] * inv, o[db][g4 * 4 + 3] * inv)};
+      *reinterpret_cast<u32x2*>(op + d0) = w;
+    }
+  if (hi == 0) lse[((int64_t)b * H + h) * N + q0 + l31] = (m_ref + __builtin_amdgcn_logf(l)) * 0.6931471805599453f;
+}
+
+void attn_fwd3_launch(const uint16_t* qkv, int B, int N, int H, float scale_log2, uint16_t* out, float* lse, bool pre, hipStream_t s) {
+  const int64_t nblk = N / 256, heads = (int64_t)B * H;
+  const dim3 grid((unsigned)(((heads + 7) / 8) * 8 * nblk));
+  if (pre) attn_fwd3_kernel<true><<<grid, 512, 0, s>>>(qkv, B, N, H, scale_log2, out, lse);
+  else attn_fwd3_kernel<false><<<grid, 512, 0, s>>>(qkv, B, N, H, scale_log2, out, lse);
+}

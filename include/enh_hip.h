@@ -188,7 +188,9 @@ int enh_debug_occupy_cus(int n_wg, float ms, void* stream);
 int enh_attention_forward(const enh_bf16* qkv, int B, int N, int H, float scale, int q_prescaled, enh_bf16* out, float* lse,
                           void* stream);
 /* kernel family per pass for A/B measurements (explicit library state, like enh_gemm_set_kernel), 0 = the library's choice:
- *   fwd: 1 round-2 kernel, 2 software-pipelined with row sums on the matrix pipe, 3 software-pipelined with vector row sums (csrc/attention_v2.hip)
+ *   fwd: 1 round-2 kernel, 2 software-pipelined with row sums on the matrix pipe, 3 software-pipelined with vector row sums (csrc/attention_v2.hip),
+ *        4 eight waves per workgroup in two groups in antiphase — one wave of a SIMD in its matrix segment while its partner runs the softmax
+ *        (csrc/attention_v3.hip; N % 256 == 0, otherwise family 1 serves the call)
  *   dq : 1 round-2 kernel, 2 software-pipelined, 3 round-2 skeleton with -delta (-lse too when q is pre-scaled) as MFMA C operands
  *   dkv: 1 round-2 kernel, 2 round-2 skeleton with -delta (-lse too when q is pre-scaled) as MFMA C operands
  * Same results up to rounding: every family passes the same parity tests. */
