@@ -312,7 +312,7 @@ def main():
         eng.optimizer_step(lr)
         return out
 
-    use_graphs = args.graphs and world == 1 and not adversarial
+    use_graphs = args.graphs and world == 1      # (the two-optimizer protocol replays one graph per optimizer and host-side variant: vitvqgan.py _graphed_training_step)
     eng.use_graphs = use_graphs
     for i in range(args.warmup):
         out = step(i)

@@ -167,7 +167,69 @@ class ViTVQ(nn.Module):
         L = self.loss
         return float(getattr(L, "loglaplace_weight", 0.0)), float(getattr(L, "loggaussian_weight", 1.0)), float(getattr(L, "codebook_weight", 1.0))
 
+    # ---- HIP-graph replay of the loss-module path (both optimizers of the adversarial protocol) ---------------------------------------------
+    def _step_variant(self, batch_idx: int, optimizer_idx: int) -> tuple:
+        """what the HOST decides inside one training_step of the loss-module path (everything else is device work): whether the discriminator is
+        active yet (vqperceptual.py:109) and whether this discriminator step carries the lazy R1 penalty (vqperceptual.py:157)"""
+        L = self.loss
+        disc_on = self.global_step >= int(getattr(L, "discriminator_iter_start", 0))
+        r1 = bool(optimizer_idx == 1 and L.training and disc_on and hasattr(L, "discriminator") and batch_idx % int(getattr(L, "do_r1_every", 16)) == 0)
+        return bool(disc_on), r1
+
+    def _graphed_training_step(self, batch, batch_idx: int, optimizer_idx: int, zero_grad: bool):
+        """training_step for the loss-module path (forward -> loss module -> autograd: the protocol every shipped reference config runs,
+        configs/imagenet_vitvq_*.yaml) captured ONCE per (optimizer, batch shape, host-side variant) into a HIP graph and replayed: at the reference
+        yaml's 2 images per GPU the step is ~2000 launches plus the autograd engine's bookkeeping and the host cannot issue them as fast as the GPU
+        retires them.  The captured region is the eager code itself (warmed up twice on a side stream first), so the results are bit-identical; the
+        returned loss and the logged tensors are the graph's static outputs (valid until the next replay)."""
+        from ... import _C
+        x = self.get_input(batch, self.image_key)
+        eng = self.engine
+        key = (optimizer_idx, tuple(x.shape), bool(zero_grad), bool(self.loss.training)) + self._step_variant(batch_idx, optimizer_idx)
+        graphs = self.__dict__.setdefault("_step_graphs", {})
+        entry = graphs.get(key)
+        if entry is None and len(graphs) >= 12:
+            return self._training_step_eager(batch, batch_idx, optimizer_idx, zero_grad)
+        if entry is None:
+            static_x = torch.empty(x.shape, dtype=torch.float32, device=eng.device)
+            static_x.copy_(x)
+            sb = {self.image_key: static_x}
+            stores = [eng.store] + ([self.loss.disc_store(eng.device)] if hasattr(self.loss, "discriminator") else [])
+            saved = [st.g.clone() for st in stores]            # the warm-up passes must not leak into an accumulation window
+            cur, side = torch.cuda.current_stream(), torch.cuda.Stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    self._training_step_eager(sb, batch_idx, optimizer_idx, zero_grad)
+            cur.wait_stream(side)
+            for st, g0 in zip(stores, saved):
+                st.g.copy_(g0)
+            before = dict(self.logged)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self._training_step_eager(sb, batch_idx, optimizer_idx, zero_grad)
+            for st, g0 in zip(stores, saved):
+                st.g.copy_(g0)
+            logged = {k: v for k, v in self.logged.items() if k not in before or before[k] is not v}
+            keep = (list(_C._GEMM_WS.values()), list(_C._WS.values()))      # workspaces whose addresses the graph has baked in
+            entry = graphs[key] = (graph, static_x, out, logged, keep)
+        graph, static_x, out, logged, _ = entry
+        static_x.copy_(x, non_blocking=True)
+        graph.replay()
+        eng._invalidate_saved()
+        self.logged.update(logged)
+        return out
+
     def training_step(self, batch, batch_idx: int, optimizer_idx: int = 0, zero_grad: bool = True):
+        """reference vitvqgan.py:101-127 (see _training_step_eager).  With engine.use_graphs (ENH_GRAPHS=1 / bench.py --graphs) the loss-module path
+        replays from HIP graphs; the fused pixel + codebook step has its own graph inside the engine (forward_backward_graphed)."""
+        from ... import _C
+        eng = self.engine
+        if eng.use_graphs and _C.TIMER is None and eng.comm is None and not self._fusable_loss() and (optimizer_idx == 0 or hasattr(self.loss, "discriminator")):
+            return self._graphed_training_step(batch, batch_idx, optimizer_idx, zero_grad)
+        return self._training_step_eager(batch, batch_idx, optimizer_idx, zero_grad)
+
+    def _training_step_eager(self, batch, batch_idx: int, optimizer_idx: int = 0, zero_grad: bool = True):
         """reference vitvqgan.py:101-127.  optimizer_idx 0 = autoencoder: forward + backward run fused on the engine
         and the returned loss is detached (the gradients are already in param.grad)."""
         x = self.get_input(batch, self.image_key)

@@ -281,3 +281,48 @@ def test_adaptive_adversarial_weight_with_the_perceptual_term(C, lpips_random_in
     assert gn > 0 and gn == gn
     l1 = m.training_step({"image": x}, 0, 1)
     assert torch.isfinite(l1)
+
+
+def test_graph_replay_of_the_two_optimizer_step_equals_the_eager_sequence(lpips_random_init):
+    """the protocol every shipped config runs (autoencoder step through LPIPS + discriminator, then the discriminator step with the
+    lazy R1 penalty) replayed from HIP graphs — one per (optimizer, host-side variant: R1 or not) — gives the SAME bits as the eager sequence: losses of
+    every step, and both flat parameter buffers after four optimizer rounds (R1 on rounds 0 and 2)."""
+    import warnings
+    import vitvq_oracle as O
+    from enhancing.modules.stage1.vitvqgan import ViTVQ
+    from enhancing.utils.general import AttrDict
+    cfg = O.TINY_CFG
+    loss = {"target": "enhancing.losses.vqperceptual.VQLPIPSWithDiscriminator",
+            "params": dict(loglaplace_weight=0.0, loggaussian_weight=1.0, perceptual_weight=0.1, adversarial_weight=0.1, do_r1_every=2,
+                           disc_params={"size": cfg["image_size"]})}
+    xs = [O.make_images(5 + i, 2, cfg["image_size"]) for i in range(2)]
+
+    def run(graphs: bool):
+        torch.manual_seed(0)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m = ViTVQ("image", cfg["image_size"], cfg["patch_size"], AttrDict.wrap(cfg["encoder"]), AttrDict.wrap(cfg["decoder"]),
+                      AttrDict.wrap(cfg["quantizer"]), AttrDict.wrap(loss))
+        m.load_state_dict({**O.make_params(cfg, seed=11), **{"loss." + k: v for k, v in m.loss.state_dict().items()}}, strict=False)
+        m.train()
+        m.learning_rate = 1e-3
+        opts, _ = m.configure_optimizers()
+        m.engine.use_graphs = graphs
+        losses = []
+        for i in range(4):
+            b = {"image": xs[i % 2]}
+            l0 = m.training_step(b, i, 0); opts[0].step()
+            l1 = m.training_step(b, i, 1); opts[1].step()
+            m.global_step += 1
+            losses.append((l0.clone(), l1.clone(), m.logged["train/g_loss"].clone(), m.logged["train/perceptual_loss"].clone()))
+        torch.cuda.synchronize()
+        if graphs:
+            assert len(m._step_graphs) == 3          # optimizer 0; optimizer 1 with and without R1
+        return losses, m.engine.store.p.clone(), m.loss.disc_store(m.engine.device).p.clone()
+
+    le, pe, de = run(False)
+    lg, pg, dg = run(True)
+    for i, (a, b) in enumerate(zip(le, lg)):
+        assert all(torch.equal(u, v) for u, v in zip(a, b)), (i, [float(u) for u in a], [float(v) for v in b])
+    assert torch.equal(pe, pg) and torch.equal(de, dg)
+    assert float(le[0][0]) != float(le[3][0])
