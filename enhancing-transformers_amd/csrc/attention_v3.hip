@@ -17,9 +17,12 @@
 // The vector segment is cut to what the exponentials need (as attention_v2.hip): q arrives pre-scaled by scale * log2(e) and -m_ref rides in the MFMA C
 // operand, so a score is exponentiated straight from the accumulator; m_ref is a REFERENCE maximum that is only raised (O, l rescaled, a wave-uniform
 // branch) when a row's tile maximum exceeds it by more than 2^8 — on the first tile and then almost never.
-// LDS: K and V each in a 2-slot ring of 8-KiB tiles (32 KiB).  K(i+1) and V(i) are read in half-steps 2i+1 (A) and 2i+2 (B); group A writes K(i+1) in its
-// vector segment 2i (from registers loaded one period earlier), group B writes V(i+1) in its vector segment 2i+1: every slot is rewritten at least one
-// barrier after its last reader and one barrier before its first.
+// LDS: K and V each in a 2-slot ring of 8-KiB tiles (32 KiB).  The matrix segment touches no memory: its sixteen operand fragments (V(i), K(i+1)) are
+// fetched in the VECTOR segment in front of it (half-step 2i for group A, 2i+1 for B), so nothing in it waits for LDS (the first version read them in
+// the matrix segment itself and ran 13 % slower than the four-wave kernel: with one wave per SIMD in that segment nobody covers a fragment's latency).
+// Group A writes K(i+2) in its vector segment 2i (from registers loaded one period earlier) into the slot whose tile K(i) was last fetched in half-step
+// 2i-1; group B writes V(i+1) in half-step 2i+1 into the slot of V(i-1), last fetched in 2i-1: every slot is rewritten at least one barrier after its
+// last reader and read at least one barrier after its writer.
 // Workgroup = 256 queries of one (image, head); needs N % 256 == 0 (the launcher falls back to the four-wave kernel otherwise).
 #include "attention_common.h"
 
@@ -38,33 +41,55 @@
 #define A3_PIN16(x) asm volatile("" : "+v"(x))
 #define A3_PIN4(x) do { u32x4 u_ = __builtin_bit_cast(u32x4, (x)); asm volatile("" : "+v"(u_)); (x) = __builtin_bit_cast(s16x8, u_); } while (0)
 
-// matrix segment: O += V^T P (8 MFMAs, skipped for the segment in front of tile 0) and the next tile's scores S = K Q^T + (-m_ref) (8 MFMAs)
-template <bool PV, bool SNEXT, bool PRE>
-__device__ __forceinline__ void a3_matrix(const unsigned char* kbuf, const unsigned char* vbuf, int lane, const s16x8 (&qf)[4], const s16x8 (&p)[4],
-                                          const f32x16& negm, f32x16 (&o)[2], f32x16 (&s)[2]) {
+// fragments of the NEXT matrix segment, read in the vector segment in front of it (the tiles they come from were written at least one barrier earlier):
+// V^T of tile i for O += V^T P(i), K rows of tile i+1 for S(i+1) — 16 fragments, 64 registers; the matrix segment itself touches no memory
+template <bool KNEXT>
+__device__ __forceinline__ void a3_fetch(const unsigned char* kbuf, const unsigned char* vbuf, int lane, s16x8 (&vf)[4][2], s16x8 (&kf)[4][2]) {
   const int l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int db = 0; db < 2; ++db) vf[i][db] = att_frag_tr(vbuf, (i >> 1) * 32 + 16 * (i & 1), db, lane);
+  if (KNEXT) {
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) kf[ds][kb] = att_frag_row(kbuf, kb * 32, ds, l31, hi);
+  }
+}
+__device__ __forceinline__ void a3_fetch_k(const unsigned char* kbuf, int lane, s16x8 (&kf)[4][2]) {
+  const int l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int ds = 0; ds < 4; ++ds)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) kf[ds][kb] = att_frag_row(kbuf, kb * 32, ds, l31, hi);
+}
+
+// matrix segment: O += V^T P (8 MFMAs, skipped for the segment in front of tile 0) and the next tile's scores S = K Q^T + (-m_ref) (8 MFMAs), all operands
+// in registers: sixteen MFMAs back to back
+template <bool PV, bool SNEXT, bool PRE>
+__device__ __forceinline__ void a3_matrix(const s16x8 (&vf)[4][2], const s16x8 (&kf)[4][2], const s16x8 (&qf)[4], const s16x8 (&p)[4], const f32x16& negm,
+                                          f32x16 (&o)[2], f32x16 (&s)[2]) {
   if (PV) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {          // P slice i = keys 16 i .. 16 i + 15 of the tile
+    for (int i = 0; i < 4; ++i)            // P slice i = keys 16 i .. 16 i + 15 of the tile
 #pragma unroll
-      for (int db = 0; db < 2; ++db) o[db] = MFMA32(att_frag_tr(vbuf, (i >> 1) * 32 + 16 * (i & 1), db, lane), p[i], o[db]);
-    }
+      for (int db = 0; db < 2; ++db) o[db] = MFMA32(vf[i][db], p[i], o[db]);
   }
   if (SNEXT) {
 #pragma unroll
     for (int ds = 0; ds < 4; ++ds)
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {      // the two 32-key accumulators alternate: no MFMA waits for the one issued just before it
-        const s16x8 kf = att_frag_row(kbuf, kb * 32, ds, l31, hi);
         if (ds == 0) {
-          if (PRE) s[kb] = MFMA32(kf, qf[ds], negm);
+          if (PRE) s[kb] = MFMA32(kf[ds][kb], qf[ds], negm);
           else {
             f32x16 z;
 #pragma unroll
             for (int r = 0; r < 16; ++r) z[r] = 0.f;
-            s[kb] = MFMA32(kf, qf[ds], z);
+            s[kb] = MFMA32(kf[ds][kb], qf[ds], z);
           }
-        } else s[kb] = MFMA32(kf, qf[ds], s[kb]);
+        } else s[kb] = MFMA32(kf[ds][kb], qf[ds], s[kb]);
       }
   }
 }
@@ -140,39 +165,53 @@ __global__ __launch_bounds__(512, 2) void attn_fwd3_kernel(const uint16_t* __res
   s16x8 qf[4];
 #pragma unroll
   for (int ds = 0; ds < 4; ++ds) qf[ds] = *reinterpret_cast<const s16x8*>(Qp + (int64_t)(q0 + l31) * RS + ds * 16 + hi * 8);
+  // staging: group A keeps K two tiles ahead of the softmax (K(i+2) goes to LDS in vector segment i), group B keeps V one tile ahead — so that in
+  // vector segment i BOTH operands of the following matrix segment (K(i+1), V(i)) are already in LDS and their fragments can be fetched there
+  const int ahead = grp == 0 ? 2 : 1;
   u32x4 rs[2];
   att_gload(rs, Sp, RS, 0, tg);                      // tile 0 of this group's operand -> slot 0
   att_sstore(rs, sbuf[0], tg);
-  if (nt > 1) att_gload(rs, Sp, RS, 64, tg);         // tile 1 stays in registers until the group's first vector segment
+  if (grp == 0 && nt > 1) {                          // K(1) -> slot 1
+    att_gload(rs, Sp, RS, 64, tg);
+    att_sstore(rs, sbuf[1], tg);
+  }
+  if (ahead < nt) att_gload(rs, Sp, RS, ahead * 64, tg);      // K(2) / V(1) stay in registers until the group's first vector segment
 #pragma unroll
   for (int ds = 0; ds < 4; ++ds) att_pin(qf[ds]);
 
   f32x16 o[2], s[2], negm;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; negm[r] = 0.f; s[0][r] = 0.f; s[1][r] = 0.f; }
-  s16x8 p[4];
+  s16x8 p[4], vf[4][2], kf[4][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) p[i] = (s16x8){0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 4; ++i) {
+    p[i] = (s16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    vf[i][0] = p[i]; vf[i][1] = p[i]; kf[i][0] = p[i]; kf[i][1] = p[i];
+  }
   float m_ref = 0.f, l_part = 0.f;
-  A3_BARRIER();                                        // K(0), V(0) are in LDS
+  A3_BARRIER();                                        // K(0), K(1), V(0) are in LDS
   // Both groups run the SAME instruction stream  [ vector(i) | barrier | matrix(i) | barrier ]  — group B one barrier behind group A (its lead-in barrier
   // here, group A's trailing one after the loop), which is what puts the partners of a SIMD in antiphase.  No group-dependent branch inside the loop:
   // with one, the compiler merged the two variants through register copies of the in-flight tile prefetch and waited for it in the matrix segment.
-  a3_matrix<false, true, PRE>(smem[0][0], smem[1][0], lane, qf, p, negm, o, s);      // S(0), both groups at once (the only un-phased segment)
+  a3_fetch_k(smem[0][0], lane, kf);
+  a3_matrix<false, true, PRE>(vf, kf, qf, p, negm, o, s);      // S(0), both groups at once (the only un-phased segment)
   A3_PIN16(s[0]); A3_PIN16(s[1]);
+  A3_BARRIER();                                        // everybody has read K(0): its slot may take K(2)
   if (grp == 1) A3_BARRIER();
   for (int i = 0; i < nt; ++i) {
     const int cur = i & 1, nxt = cur ^ 1;
-    // ---- vector segment: softmax of tile i; this group's operand tile i+1 goes from registers to LDS, tile i+2 is requested ----
+    // ---- vector segment: the fragments of the matrix segment that follows (V(i), K(i+1): written at least one barrier ago), the softmax of tile i,
+    //      this group's staged tile from registers to LDS, the next one requested ----
+    a3_fetch<true>(smem[0][nxt], smem[1][cur], lane, vf, kf);       // (last tile: the K slot holds an old tile and the scores made from it are never used —
+                                                                    //  cheaper than a second code variant whose register assignment the loop has to reconcile)
     a3_softmax<PRE>(i == 0, sl2, s, p, negm, m_ref, l_part, o);
-    if (i + 1 < nt) att_sstore(rs, sbuf[nxt], tg);
-    if (i + 2 < nt) att_gload(rs, Sp, RS, (i + 2) * 64, tg);
+    if (i + ahead < nt) att_sstore(rs, sbuf[(i + ahead) & 1], tg);
+    if (i + ahead + 1 < nt) att_gload(rs, Sp, RS, (i + ahead + 1) * 64, tg);
     A3_PIN4(p[0]); A3_PIN4(p[1]); A3_PIN4(p[2]); A3_PIN4(p[3]);      // (pure arithmetic otherwise sinks to its first use: into the matrix segment)
     A3_PIN1(l_part); A3_PIN1(m_ref); A3_PIN16(negm); A3_PIN16(o[0]); A3_PIN16(o[1]);
     A3_BARRIER();
-    // ---- matrix segment: O += V(i)^T P(i), S(i+1) = K(i+1) Q^T - m_ref ----
-    if (i + 1 < nt) a3_matrix<true, true, PRE>(smem[0][nxt], smem[1][cur], lane, qf, p, negm, o, s);
-    else a3_matrix<true, false, PRE>(smem[0][nxt], smem[1][cur], lane, qf, p, negm, o, s);
+    // ---- matrix segment: O += V(i)^T P(i), S(i+1) = K(i+1) Q^T - m_ref: sixteen MFMAs on registers ----
+    a3_matrix<true, true, PRE>(vf, kf, qf, p, negm, o, s);
     A3_PIN16(o[0]); A3_PIN16(o[1]); A3_PIN16(s[0]); A3_PIN16(s[1]);
     A3_BARRIER();
   }
