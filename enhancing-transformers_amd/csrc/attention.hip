@@ -281,20 +281,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
 void attn_fwd2_launch(const uint16_t* qkv, int B, int N, int H, float scale_log2, uint16_t* out, float* lse, bool ones, bool pre, dim3 grid, hipStream_t s);
 // round-4 eight-wave antiphase forward (attention_v3.hip); needs N % 256 == 0
 void attn_fwd3_launch(const uint16_t* qkv, int B, int N, int H, float scale_log2, uint16_t* out, float* lse, bool pre, hipStream_t s);
+void attn_bwd_dkv3_launch(const uint16_t* qkv, const uint16_t* d_o, const float* lse, const float* delta, int B, int N, int H, float kscale, uint16_t* dqkv,
+                          hipStream_t s);
 void attn_bwd_dq2_launch(const uint16_t* qkv, const uint16_t* o, const uint16_t* d_o, const float* lse, float* delta, int B, int N, int H, float scale,
                          float scale_log2, uint16_t* dqkv, bool pre, dim3 grid, hipStream_t s);
 
 // kernel family per pass (explicit state behind an explicit call, as enh_gemm_set_kernel); 0 = the library's choice:
 //   forward: 1 round-2 kernel | 2 pipelined, row sums on the matrix pipe | 3 pipelined, vector row sums | 4 eight waves in antiphase (round 4)
 //   dQ     : 1 round-2 kernel | 2 pipelined (attention_v2.hip)           | 3 round-2 skeleton with -delta (and, pre-scaled q, -lse) as MFMA C operands
-//   dK/dV  : 1 round-2 kernel | 2 round-2 skeleton with -delta (and, pre-scaled q, -lse) as MFMA C operands
+//   dK/dV  : 1 round-2 kernel | 2 round-2 skeleton with -delta (and, pre-scaled q, -lse) as MFMA C operands | 3 eight waves in antiphase (round 4; pre-scaled q
+//            and N % 256 == 0, else family 2)
 static int g_att_fwd = 0, g_att_dq = 0, g_att_dkv = 0;
 #define ATT_DEFAULT_FWD 1
 #define ATT_DEFAULT_DQ 1
 #define ATT_DEFAULT_DKV 2
 
 extern "C" int enh_attention_set_kernel(int fwd, int dq, int dkv) {
-  ENH_REQUIRE(fwd >= 0 && fwd <= 4 && dq >= 0 && dq <= 3 && dkv >= 0 && dkv <= 2, ENH_E_BADARG, "enh_attention_set_kernel: fwd in 0..4, dq in 0..3, dkv in 0..2");
+  ENH_REQUIRE(fwd >= 0 && fwd <= 4 && dq >= 0 && dq <= 3 && dkv >= 0 && dkv <= 3, ENH_E_BADARG, "enh_attention_set_kernel: fwd in 0..4, dq in 0..3, dkv in 0..3");
   g_att_fwd = fwd; g_att_dq = dq; g_att_dkv = dkv;
   return ENH_OK;
 }
@@ -331,12 +334,15 @@ extern "C" int enh_attention_backward(const enh_bf16* qkv, const enh_bf16* out, 
   // dK is formed from the q tile as stored: with pre-scaled q' = q * scale * log2e the factor is scale / (scale * log2e) = ln 2.
   const float kscale = pre ? ATT_LN2 : scale;
   // (either dQ kernel also writes delta_ws = rowsum(dO * O) for the dK/dV kernel that follows)
-  const int fq = g_att_dq ? g_att_dq : ATT_DEFAULT_DQ, fk = g_att_dkv ? g_att_dkv : ATT_DEFAULT_DKV;
+  const int fq = g_att_dq ? g_att_dq : ATT_DEFAULT_DQ;
+  int fk = g_att_dkv ? g_att_dkv : ATT_DEFAULT_DKV;
+  if (fk == 3 && (!pre || N % 256 != 0)) fk = 2;
   if (fq == 1) attn_bwd_dq_kernel<0><<<grid, 256, 0, s>>>(qkv, out, dout, lse, delta_ws, B, N, H, scale, sl2, dqkv);
   else if (fq == 2) attn_bwd_dq2_launch(qkv, out, dout, lse, delta_ws, B, N, H, scale, sl2, dqkv, pre, grid, s);
   else if (pre) attn_bwd_dq_kernel<2><<<grid, 256, 0, s>>>(qkv, out, dout, lse, delta_ws, B, N, H, scale, sl2, dqkv);
   else attn_bwd_dq_kernel<1><<<grid, 256, 0, s>>>(qkv, out, dout, lse, delta_ws, B, N, H, scale, sl2, dqkv);
-  if (fk == 1) attn_bwd_dkv_kernel<false, false><<<grid, 256, 0, s>>>(qkv, dout, lse, delta_ws, B, N, H, kscale, sl2, dqkv);
+  if (fk == 3) attn_bwd_dkv3_launch(qkv, dout, lse, delta_ws, B, N, H, kscale, dqkv, s);
+  else if (fk == 1) attn_bwd_dkv_kernel<false, false><<<grid, 256, 0, s>>>(qkv, dout, lse, delta_ws, B, N, H, kscale, sl2, dqkv);
   else if (pre) attn_bwd_dkv_kernel<true, true><<<grid, 256, 0, s>>>(qkv, dout, lse, delta_ws, B, N, H, kscale, sl2, dqkv);
   else attn_bwd_dkv_kernel<true, false><<<grid, 256, 0, s>>>(qkv, dout, lse, delta_ws, B, N, H, kscale, sl2, dqkv);
   return enh_check_launch("enh_attention_backward");

@@ -237,3 +237,164 @@ void attn_fwd3_launch(const uint16_t* qkv, int B, int N, int H, float scale_log2
   if (pre) attn_fwd3_kernel<true><<<grid, 512, 0, s>>>(qkv, B, N, H, scale_log2, out, lse);
   else attn_fwd3_kernel<false><<<grid, 512, 0, s>>>(qkv, B, N, H, scale_log2, out, lse);
 }
+
+// =================================================================================================
+// backward: dK, dV — the same antiphase structure.  Workgroup = 256 keys of one (image, head): eight waves x 32 keys, K / V fragments of the wave's keys in
+// registers for the whole sweep; Q / dO stream through LDS in 32-QUERY blocks (three-slot rings of 4-KiB tiles), and a wave alternates
+//     vector segment i :  P = exp2(S(i)) , dS = P o dP(i) , both packed to bf16                                  [16 exponentials, 16 products, 16 packs]
+//     matrix segment i :  dV += dO(i)^T P , dK += Q(i)^T dS  (8 MFMAs) ; S(i+1) = Q(i+1) K^T - lse , dP(i+1) = dO(i+1) V^T - delta  (8 MFMAs)
+// with its SIMD partner half a period behind.  The four-wave kernel of attention.hip runs this work at two waves per SIMD and takes, per wave and 64-query
+// tile, the SUM of its matrix time (32 MFMAs = 1024 clk) and its vector time (~1100 clk): 4400 wave cycles measured (profiles/r03_attention_lab.txt §3).
+// 32-query phases (instead of the 64-query tiles of the other kernels) keep the scores that cross a barrier at 32 registers per product.
+// Pre-scaled q only (the products are log2-domain scores; -lse and -delta ride in the MFMA C operand): the launcher keeps the four-wave kernel otherwise.
+// Staging: group A writes Q(i+1) and the statistics of block i+1 in its vector segment i (needed from the matrix segment that follows it), group B writes
+// dO(i+2) in its vector segment i; with three slots per ring no slot is rewritten before the barrier after its last reader.
+// =================================================================================================
+#define A3Q_TILE_BYTES 4096   // 32 queries x 64 d, bf16
+// one 32-row tile through 256 threads: 16 B per thread
+__device__ __forceinline__ u32x4 a3q_gload(const uint16_t* __restrict__ base, int64_t rs, int row0, int tg) {
+  const int c = tg & 7, r = tg >> 3;
+  return *reinterpret_cast<const u32x4*>(base + (int64_t)(row0 + r) * rs + c * 8);
+}
+__device__ __forceinline__ void a3q_sstore(const u32x4& v, unsigned char* tile, int tg) {
+  *reinterpret_cast<u32x4*>(tile + att_off(tg >> 3, tg & 7)) = v;
+}
+
+__global__ __launch_bounds__(512, 2) void attn_bwd_dkv3_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ d_o, const float* __restrict__ lse,
+                                                               const float* __restrict__ delta, int B, int N, int H, float kscale, uint16_t* __restrict__ dqkv) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2][3][A3Q_TILE_BYTES];   // [Q | dO][slot]
+  __shared__ __attribute__((aligned(16))) float s_stat[3][2][32];                     // [slot][-lse * log2e | -delta]
+  int blk, head;
+  if (!att_block_coords(N / 256, B * H, blk, head)) return;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int grp = wave >> 2, tg = t & 255;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int b = head / H, h = head - b * H;
+  const int key0 = blk * 256 + wave * 32;
+  const int64_t RS = (int64_t)3 * H * ATT_D, OS = (int64_t)H * ATT_D;
+  const uint16_t* Qp = qkv + (int64_t)b * N * RS + h * ATT_D;
+  const uint16_t* Kp = Qp + H * ATT_D;
+  const uint16_t* Vp = Kp + H * ATT_D;
+  const uint16_t* dOp = d_o + (int64_t)b * N * OS + h * ATT_D;
+  const float* lsep = lse + ((int64_t)b * H + h) * N;
+  const float* delp = delta + ((int64_t)b * H + h) * N;
+  // this group's staged operand: A streams Q (row stride RS) and the statistics, B streams dO (row stride OS)
+  const uint16_t* Sp = grp == 0 ? Qp : dOp;
+  const int64_t Ss = grp == 0 ? RS : OS;
+  unsigned char(*sbuf)[A3Q_TILE_BYTES] = smem[grp];
+  const int ahead = grp == 0 ? 1 : 2;
+  const int nt = N / 32;
+  // statistics: threads 0-31 of group A fetch lse (stored as -lse * log2e), 32-63 delta (stored negated)
+  const bool stat_thr = grp == 0 && tg < 64;
+  const float* statp = (tg & 32) ? delp : lsep;
+  const float stat_mul = (tg & 32) ? -1.0f : -1.4426950408889634f;
+
+  s16x8 kf[4], vf[4];
+#pragma unroll
+  for (int ds = 0; ds < 4; ++ds) {
+    kf[ds] = *reinterpret_cast<const s16x8*>(Kp + (int64_t)(key0 + l31) * RS + ds * 16 + hi * 8);
+    vf[ds] = *reinterpret_cast<const s16x8*>(Vp + (int64_t)(key0 + l31) * RS + ds * 16 + hi * 8);
+  }
+  // prologue: Q(0), dO(0), dO(1), stat(0) -> LDS; Q(1) + stat(1) / dO(2) stay in registers for the first vector segment
+  u32x4 rs = a3q_gload(Sp, Ss, 0, tg);
+  a3q_sstore(rs, sbuf[0], tg);
+  float rstat = 0.f;
+  if (stat_thr) s_stat[0][tg >> 5][tg & 31] = statp[tg & 31] * stat_mul;
+  if (grp == 1 && nt > 1) {
+    rs = a3q_gload(Sp, Ss, 32, tg);
+    a3q_sstore(rs, sbuf[1], tg);
+  }
+  if (ahead < nt) {
+    rs = a3q_gload(Sp, Ss, ahead * 32, tg);
+    if (stat_thr) rstat = statp[ahead * 32 + (tg & 31)];
+  }
+#pragma unroll
+  for (int ds = 0; ds < 4; ++ds) { att_pin(kf[ds]); att_pin(vf[ds]); }
+
+  f32x16 dk[2], dv[2], s, dp;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dk[0][r] = 0.f; dk[1][r] = 0.f; dv[0][r] = 0.f; dv[1][r] = 0.f; }
+  s16x8 pa[2], dsa[2];
+  pa[0] = (s16x8){0, 0, 0, 0, 0, 0, 0, 0}; pa[1] = pa[0]; dsa[0] = pa[0]; dsa[1] = pa[0];
+  A3_BARRIER();
+
+  // scores of block `slot`: S = Q K^T + (-lse), dP = dO V^T + (-delta); this lane's 16 query rows are 8 g4 + 4 hi + 0..3
+#define A3Q_SCORES(SLOT)                                                                                   \
+  do {                                                                                                     \
+    _Pragma("unroll") for (int g4 = 0; g4 < 4; ++g4) {                                                     \
+      const f32x4 l4 = *reinterpret_cast<const f32x4*>(&s_stat[SLOT][0][8 * g4 + 4 * hi]);                 \
+      const f32x4 d4 = *reinterpret_cast<const f32x4*>(&s_stat[SLOT][1][8 * g4 + 4 * hi]);                 \
+      _Pragma("unroll") for (int k = 0; k < 4; ++k) { s[g4 * 4 + k] = l4[k]; dp[g4 * 4 + k] = d4[k]; }     \
+    }                                                                                                      \
+    _Pragma("unroll") for (int ds = 0; ds < 4; ++ds) {                                                     \
+      s = MFMA32(att_frag_row(smem[0][SLOT], 0, ds, l31, hi), kf[ds], s);                                  \
+      dp = MFMA32(att_frag_row(smem[1][SLOT], 0, ds, l31, hi), vf[ds], dp);                                \
+    }                                                                                                      \
+  } while (0)
+
+  A3Q_SCORES(0);                                        // block 0, both groups at once (the only un-phased segment)
+  A3_PIN16(s); A3_PIN16(dp);
+  if (grp == 1) A3_BARRIER();
+  int cur = 0;                                          // slot of block i
+  for (int i = 0; i < nt; ++i) {
+    const int nxt = cur == 2 ? 0 : cur + 1;
+    const int stg = grp == 0 ? nxt : (nxt == 2 ? 0 : nxt + 1);      // slot of block i + ahead
+    // ---- vector segment: P and dS of block i, packed; this group's staged block from registers to LDS, the next one requested ----
+    {
+      float pv[16], dsv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        pv[r] = __builtin_amdgcn_exp2f(s[r]);
+        dsv[r] = pv[r] * dp[r];                        // (the factor of dS is applied once to the finished dK)
+      }
+#pragma unroll
+      for (int c2 = 0; c2 < 2; ++c2) { pa[c2] = pack8_bf16(&pv[c2 * 8]); dsa[c2] = pack8_bf16(&dsv[c2 * 8]); }
+    }
+    if (i + ahead < nt) {
+      a3q_sstore(rs, sbuf[stg], tg);
+      if (stat_thr) s_stat[stg][tg >> 5][tg & 31] = rstat * stat_mul;
+    }
+    if (i + ahead + 1 < nt) {
+      rs = a3q_gload(Sp, Ss, (i + ahead + 1) * 32, tg);
+      if (stat_thr) rstat = statp[(i + ahead + 1) * 32 + (tg & 31)];
+    }
+    A3_PIN4(pa[0]); A3_PIN4(pa[1]); A3_PIN4(dsa[0]); A3_PIN4(dsa[1]);
+    A3_BARRIER();
+    // ---- matrix segment: dV += dO(i)^T P, dK += Q(i)^T dS; then the scores of block i+1 (the last block computes unused ones from an old slot) ----
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        dv[db] = MFMA32(att_frag_tr(smem[1][cur], 16 * c2, db, lane), pa[c2], dv[db]);
+        dk[db] = MFMA32(att_frag_tr(smem[0][cur], 16 * c2, db, lane), dsa[c2], dk[db]);
+      }
+    A3Q_SCORES(nxt);
+    A3_PIN16(dv[0]); A3_PIN16(dv[1]); A3_PIN16(dk[0]); A3_PIN16(dk[1]); A3_PIN16(s); A3_PIN16(dp);
+    A3_BARRIER();
+    cur = nxt;
+  }
+  if (grp == 0) A3_BARRIER();
+#undef A3Q_SCORES
+
+  // D^T[d][key]: lane (key = key0 + l31, hi) holds d = db*32 + 8*(r>>2) + 4*hi + (r&3)
+  uint16_t* dkp = dqkv + ((int64_t)b * N + key0 + l31) * RS + H * ATT_D + h * ATT_D;
+  uint16_t* dvp = dkp + H * ATT_D;
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int d0 = db * 32 + 8 * g4 + 4 * hi;
+      const u32x2 wk = {pack_bf16x2(dk[db][g4 * 4 + 0] * kscale, dk[db][g4 * 4 + 1] * kscale), pack_bf16x2(dk[db][g4 * 4 + 2] * kscale, dk[db][g4 * 4 + 3] * kscale)};
+      const u32x2 wv = {pack_bf16x2(dv[db][g4 * 4 + 0], dv[db][g4 * 4 + 1]), pack_bf16x2(dv[db][g4 * 4 + 2], dv[db][g4 * 4 + 3])};
+      *reinterpret_cast<u32x2*>(dkp + d0) = wk;
+      *reinterpret_cast<u32x2*>(dvp + d0) = wv;
+    }
+}
+
+void attn_bwd_dkv3_launch(const uint16_t* qkv, const uint16_t* d_o, const float* lse, const float* delta, int B, int N, int H, float kscale, uint16_t* dqkv,
+                          hipStream_t s) {
+  const int64_t nblk = N / 256, heads = (int64_t)B * H;
+  const dim3 grid((unsigned)(((heads + 7) / 8) * 8 * nblk));
+  attn_bwd_dkv3_kernel<<<grid, 512, 0, s>>>(qkv, d_o, lse, delta, B, N, H, kscale, dqkv);
+}
