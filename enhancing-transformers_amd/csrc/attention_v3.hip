@@ -247,8 +247,8 @@ void attn_fwd3_launch(const uint16_t* qkv, int B, int N, int H, float scale_log2
 // tile, the SUM of its matrix time (32 MFMAs = 1024 clk) and its vector time (~1100 clk): 4400 wave cycles measured (profiles/r03_attention_lab.txt §3).
 // 32-query phases (instead of the 64-query tiles of the other kernels) keep the scores that cross a barrier at 32 registers per product.
 // Pre-scaled q only (the products are log2-domain scores; -lse and -delta ride in the MFMA C operand): the launcher keeps the four-wave kernel otherwise.
-// Staging: group A writes Q(i+1) and the statistics of block i+1 in its vector segment i (needed from the matrix segment that follows it), group B writes
-// dO(i+2) in its vector segment i; with three slots per ring no slot is rewritten before the barrier after its last reader.
+// Staging: group A writes Q(i+2) and the statistics of block i+2, group B writes dO(i+2), each in its vector segment i, into the slot of block i-1, whose
+// last readers were the vector segments i-1; three slots per ring.
 // =================================================================================================
 #define A3Q_TILE_BYTES 4096   // 32 queries x 64 d, bf16
 // one 32-row tile through 256 threads: 16 B per thread
@@ -279,11 +279,13 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv3_kernel(const uint16_t* _
   const uint16_t* dOp = d_o + (int64_t)b * N * OS + h * ATT_D;
   const float* lsep = lse + ((int64_t)b * H + h) * N;
   const float* delp = delta + ((int64_t)b * H + h) * N;
-  // this group's staged operand: A streams Q (row stride RS) and the statistics, B streams dO (row stride OS)
+  // this group's staged operand: A streams Q (row stride RS) and the statistics, B streams dO (row stride OS); both keep their operand TWO blocks ahead
+  // (block i+2 goes to LDS in vector segment i), so that in vector segment i every fragment of the matrix segment that follows — the transposed
+  // fragments of block i and the row fragments and statistics of block i+1 — is already in LDS and is fetched THERE: the matrix segment is sixteen MFMAs on
+  // registers.  (Fetched inside the matrix segment they cost it their LDS latency with nobody to cover it: 1.0 ms instead of 0.89 for the four-wave kernel.)
   const uint16_t* Sp = grp == 0 ? Qp : dOp;
   const int64_t Ss = grp == 0 ? RS : OS;
   unsigned char(*sbuf)[A3Q_TILE_BYTES] = smem[grp];
-  const int ahead = grp == 0 ? 1 : 2;
   const int nt = N / 32;
   // statistics: threads 0-31 of group A fetch lse (stored as -lse * log2e), 32-63 delta (stored negated)
   const bool stat_thr = grp == 0 && tg < 64;
@@ -296,18 +298,19 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv3_kernel(const uint16_t* _
     kf[ds] = *reinterpret_cast<const s16x8*>(Kp + (int64_t)(key0 + l31) * RS + ds * 16 + hi * 8);
     vf[ds] = *reinterpret_cast<const s16x8*>(Vp + (int64_t)(key0 + l31) * RS + ds * 16 + hi * 8);
   }
-  // prologue: Q(0), dO(0), dO(1), stat(0) -> LDS; Q(1) + stat(1) / dO(2) stay in registers for the first vector segment
+  // prologue: blocks 0 and 1 of both operands (+ statistics) -> LDS; block 2 stays in registers for the first vector segment
   u32x4 rs = a3q_gload(Sp, Ss, 0, tg);
   a3q_sstore(rs, sbuf[0], tg);
   float rstat = 0.f;
   if (stat_thr) s_stat[0][tg >> 5][tg & 31] = statp[tg & 31] * stat_mul;
-  if (grp == 1 && nt > 1) {
+  if (nt > 1) {
     rs = a3q_gload(Sp, Ss, 32, tg);
     a3q_sstore(rs, sbuf[1], tg);
+    if (stat_thr) s_stat[1][tg >> 5][tg & 31] = statp[32 + (tg & 31)] * stat_mul;
   }
-  if (ahead < nt) {
-    rs = a3q_gload(Sp, Ss, ahead * 32, tg);
-    if (stat_thr) rstat = statp[ahead * 32 + (tg & 31)];
+  if (nt > 2) {
+    rs = a3q_gload(Sp, Ss, 64, tg);
+    if (stat_thr) rstat = statp[64 + (tg & 31)];
   }
 #pragma unroll
   for (int ds = 0; ds < 4; ++ds) { att_pin(kf[ds]); att_pin(vf[ds]); }
@@ -315,32 +318,54 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv3_kernel(const uint16_t* _
   f32x16 dk[2], dv[2], s, dp;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { dk[0][r] = 0.f; dk[1][r] = 0.f; dv[0][r] = 0.f; dv[1][r] = 0.f; }
-  s16x8 pa[2], dsa[2];
+  s16x8 pa[2], dsa[2], qt[2][2], dt[2][2], qr[4], dr[4];      // packed P / dS ; transposed fragments of Q / dO (block i) ; row fragments (block i+1)
   pa[0] = (s16x8){0, 0, 0, 0, 0, 0, 0, 0}; pa[1] = pa[0]; dsa[0] = pa[0]; dsa[1] = pa[0];
   A3_BARRIER();
 
-  // scores of block `slot`: S = Q K^T + (-lse), dP = dO V^T + (-delta); this lane's 16 query rows are 8 g4 + 4 hi + 0..3
-#define A3Q_SCORES(SLOT)                                                                                   \
+  // statistics of a block into the accumulators (the C operands of its score products): this lane's 16 query rows are 8 g4 + 4 hi + 0..3
+#define A3Q_STATS(SLOT)                                                                                    \
   do {                                                                                                     \
     _Pragma("unroll") for (int g4 = 0; g4 < 4; ++g4) {                                                     \
       const f32x4 l4 = *reinterpret_cast<const f32x4*>(&s_stat[SLOT][0][8 * g4 + 4 * hi]);                 \
       const f32x4 d4 = *reinterpret_cast<const f32x4*>(&s_stat[SLOT][1][8 * g4 + 4 * hi]);                 \
       _Pragma("unroll") for (int k = 0; k < 4; ++k) { s[g4 * 4 + k] = l4[k]; dp[g4 * 4 + k] = d4[k]; }     \
     }                                                                                                      \
+  } while (0)
+#define A3Q_ROWFRAGS(SLOT)                                                                                 \
+  do {                                                                                                     \
     _Pragma("unroll") for (int ds = 0; ds < 4; ++ds) {                                                     \
-      s = MFMA32(att_frag_row(smem[0][SLOT], 0, ds, l31, hi), kf[ds], s);                                  \
-      dp = MFMA32(att_frag_row(smem[1][SLOT], 0, ds, l31, hi), vf[ds], dp);                                \
+      qr[ds] = att_frag_row(smem[0][SLOT], 0, ds, l31, hi);                                                \
+      dr[ds] = att_frag_row(smem[1][SLOT], 0, ds, l31, hi);                                                \
+    }                                                                                                      \
+  } while (0)
+  // S = Q K^T + (-lse), dP = dO V^T + (-delta)
+#define A3Q_SCORES()                                                                                       \
+  do {                                                                                                     \
+    _Pragma("unroll") for (int ds = 0; ds < 4; ++ds) {                                                     \
+      s = MFMA32(qr[ds], kf[ds], s);                                                                       \
+      dp = MFMA32(dr[ds], vf[ds], dp);                                                                     \
     }                                                                                                      \
   } while (0)
 
-  A3Q_SCORES(0);                                        // block 0, both groups at once (the only un-phased segment)
+  A3Q_STATS(0);
+  A3Q_ROWFRAGS(0);
+  A3Q_SCORES();                                         // block 0, both groups at once (the only un-phased segment)
   A3_PIN16(s); A3_PIN16(dp);
   if (grp == 1) A3_BARRIER();
   int cur = 0;                                          // slot of block i
   for (int i = 0; i < nt; ++i) {
     const int nxt = cur == 2 ? 0 : cur + 1;
-    const int stg = grp == 0 ? nxt : (nxt == 2 ? 0 : nxt + 1);      // slot of block i + ahead
-    // ---- vector segment: P and dS of block i, packed; this group's staged block from registers to LDS, the next one requested ----
+    const int stg = nxt == 2 ? 0 : nxt + 1;             // slot of block i + 2
+    // ---- vector segment: P and dS of block i, packed; the operand fragments of the matrix segment that follows; this group's staged block from
+    //      registers to LDS, the next one requested ----
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        dt[c2][db] = att_frag_tr(smem[1][cur], 16 * c2, db, lane);
+        qt[c2][db] = att_frag_tr(smem[0][cur], 16 * c2, db, lane);
+      }
+    A3Q_ROWFRAGS(nxt);                                  // (last block: an old slot — the scores made from it are never used)
     {
       float pv[16], dsv[16];
 #pragma unroll
@@ -351,30 +376,34 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv3_kernel(const uint16_t* _
 #pragma unroll
       for (int c2 = 0; c2 < 2; ++c2) { pa[c2] = pack8_bf16(&pv[c2 * 8]); dsa[c2] = pack8_bf16(&dsv[c2 * 8]); }
     }
-    if (i + ahead < nt) {
+    A3_PIN4(pa[0]); A3_PIN4(pa[1]); A3_PIN4(dsa[0]); A3_PIN4(dsa[1]);
+    A3Q_STATS(nxt);                                     // s, dp are free again: the C operands of block i+1's products
+    if (i + 2 < nt) {
       a3q_sstore(rs, sbuf[stg], tg);
       if (stat_thr) s_stat[stg][tg >> 5][tg & 31] = rstat * stat_mul;
     }
-    if (i + ahead + 1 < nt) {
-      rs = a3q_gload(Sp, Ss, (i + ahead + 1) * 32, tg);
-      if (stat_thr) rstat = statp[(i + ahead + 1) * 32 + (tg & 31)];
+    if (i + 3 < nt) {
+      rs = a3q_gload(Sp, Ss, (i + 3) * 32, tg);
+      if (stat_thr) rstat = statp[(i + 3) * 32 + (tg & 31)];
     }
-    A3_PIN4(pa[0]); A3_PIN4(pa[1]); A3_PIN4(dsa[0]); A3_PIN4(dsa[1]);
+    A3_PIN16(s); A3_PIN16(dp);
     A3_BARRIER();
-    // ---- matrix segment: dV += dO(i)^T P, dK += Q(i)^T dS; then the scores of block i+1 (the last block computes unused ones from an old slot) ----
+    // ---- matrix segment, registers only: dV += dO(i)^T P, dK += Q(i)^T dS, then the scores of block i+1 ----
 #pragma unroll
     for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
       for (int db = 0; db < 2; ++db) {
-        dv[db] = MFMA32(att_frag_tr(smem[1][cur], 16 * c2, db, lane), pa[c2], dv[db]);
-        dk[db] = MFMA32(att_frag_tr(smem[0][cur], 16 * c2, db, lane), dsa[c2], dk[db]);
+        dv[db] = MFMA32(dt[c2][db], pa[c2], dv[db]);
+        dk[db] = MFMA32(qt[c2][db], dsa[c2], dk[db]);
       }
-    A3Q_SCORES(nxt);
+    A3Q_SCORES();
     A3_PIN16(dv[0]); A3_PIN16(dv[1]); A3_PIN16(dk[0]); A3_PIN16(dk[1]); A3_PIN16(s); A3_PIN16(dp);
     A3_BARRIER();
     cur = nxt;
   }
   if (grp == 0) A3_BARRIER();
+#undef A3Q_STATS
+#undef A3Q_ROWFRAGS
 #undef A3Q_SCORES
 
   // D^T[d][key]: lane (key = key0 + l31, hi) holds d = db*32 + 8*(r>>2) + 4*hi + (r&3)
