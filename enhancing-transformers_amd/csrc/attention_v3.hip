@@ -37,6 +37,25 @@
     asm volatile("" ::: "memory");           \
   } while (0)
 
+
+// Which of the two groups a wave joins is decided by WHERE the hardware put it: the two waves that share a SIMD must be in different groups, or the
+// antiphase is between SIMDs instead of inside each (measured with the static rule "waves 0-3 / 4-7": every half-step took 2 x 16 MFMAs — both
+// waves of a SIMD were in their matrix segment together, profiles/r04_attention_lab.txt).  Each wave reads its SIMD id (HW_ID bits 5:4) and takes a
+// ticket from a per-SIMD LDS counter: ticket 0 -> group A, 1 -> group B, rank inside the group = SIMD id.  If the placement is not two waves on each
+// of four SIMDs the static rule is used (same results, no antiphase).
+__device__ __forceinline__ void a3_join_groups(int* s_cnt /* [4] LDS, zeroed here */, int t, int wave, int& grp, int& rank) {
+  if (t < 4) s_cnt[t] = 0;
+  __syncthreads();
+  const int simd = (int)__builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11));      // HW_REG_HW_ID, offset 4, size 2
+  int ticket = 0;
+  if ((t & 63) == 0) ticket = atomicAdd(&s_cnt[simd], 1);
+  ticket = __builtin_amdgcn_readfirstlane(ticket);
+  __syncthreads();
+  const bool ok = s_cnt[0] == 2 && s_cnt[1] == 2 && s_cnt[2] == 2 && s_cnt[3] == 2;
+  grp = ok ? ticket : wave >> 2;
+  rank = ok ? simd : wave & 3;
+}
+
 #define A3_PIN1(x) asm volatile("" : "+v"(x))
 #define A3_PIN16(x) asm volatile("" : "+v"(x))
 #define A3_PIN4(x) do { u32x4 u_ = __builtin_bit_cast(u32x4, (x)); asm volatile("" : "+v"(u_)); (x) = __builtin_bit_cast(s16x8, u_); } while (0)
@@ -150,7 +169,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd3_kernel(const uint16_t* __res
   if (!att_block_coords(N / 256, B * H, blk, head)) return;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int grp = wave >> 2, tg = t & 255;
+  __shared__ int s_cnt[4];
+  int grp, rank;
+  a3_join_groups(s_cnt, t, wave, grp, rank);
+  const int tg = rank * 64 + lane;
   const int l31 = lane & 31, hi = lane >> 5;
   const int b = head / H, h = head - b * H;
   const int q0 = blk * 256 + wave * 32;
@@ -268,7 +290,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv3_kernel(const uint16_t* _
   if (!att_block_coords(N / 256, B * H, blk, head)) return;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int grp = wave >> 2, tg = t & 255;
+  __shared__ int s_cnt[4];
+  int grp, rank;
+  a3_join_groups(s_cnt, t, wave, grp, rank);
+  const int tg = rank * 64 + lane;
   const int l31 = lane & 31, hi = lane >> 5;
   const int b = head / H, h = head - b * H;
   const int key0 = blk * 256 + wave * 32;

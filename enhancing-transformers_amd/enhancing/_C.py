@@ -50,6 +50,7 @@ SIGNATURES = {
     "enh_set_cu_budget": (_i32, [_i32]),
     "enh_get_cu_budget": (_i32, []),
     "enh_debug_occupy_cus": (_i32, [_i32, _f32, _vp]),
+    "enh_debug_wave_simd_map": (_i32, [_vp, _vp]),
     "enh_gemm_bf16_variant": (_c.c_char_p, [_i32, _i32, _i64, _i64, _i64]),
     "enh_gemm_bf16_variant_mode": (_c.c_char_p, [_i32, _i32, _i64, _i64, _i64, _i32]),
     "enh_gemm_bf16_dtanh_colsum_workspace_bytes": (_c.c_size_t, [_i32, _i64, _i64, _i64]),
@@ -379,6 +380,14 @@ def occupy_cus(n_wg: int, ms: float, stream=None) -> None:
     """measurement aid: hold n_wg CUs for ms milliseconds on `stream` (a torch stream; default: the current one)"""
     st = ctypes.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
     _check(lib().enh_debug_occupy_cus(int(n_wg), float(ms), st), "enh_debug_occupy_cus")
+
+
+def wave_simd_map():
+    """SIMD ids of the eight waves of the first and of the last workgroup of a chip-filling 512-thread launch -> list of 16 ints"""
+    out = torch.full((16,), -1, dtype=torch.int32, device="cuda")
+    _check(lib().enh_debug_wave_simd_map(_p(out, torch.int32, "out"), _stream()), "enh_debug_wave_simd_map")
+    torch.cuda.synchronize()
+    return out.tolist()
 
 
 def _epi_mode_label(accumulate, have_ws, f32, bf16, bias, act, res) -> int:

@@ -173,6 +173,9 @@ int enh_get_cu_budget(void);
 /* Measurement aid: holds n_wg CUs (one workgroup each, the CU's whole LDS) for ms milliseconds (clamped to 2000) on `stream` — the stand-in for a
  * collective's kernel in the one-GPU contention experiment (tools/comm_contention.py). */
 int enh_debug_occupy_cus(int n_wg, float ms, void* stream);
+/* Measurement aid: out16[w] = SIMD id the hardware gave wave w of the first (w < 8) and of the last (8 <= w < 16) 512-thread workgroup of a chip-filling
+ * grid — the placement rule the eight-wave antiphase attention kernels depend on (profiles/r04_attention_lab.txt). */
+int enh_debug_wave_simd_map(int* out16, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused attention — Attention.forward layers.py:122-132 without materialising the N x N matrix
