@@ -161,9 +161,11 @@ __device__ __forceinline__ void a3_softmax(bool first, float sl2, f32x16 (&s)[2]
   for (int i = 0; i < 4; ++i) p[i] = pack8_bf16(&e[i * 8]);
 }
 
-template <bool PRE>
+// TRACE (measurement aid, enh_debug_attention_fwd3_trace): waves 0 and 4 of workgroup 0 record s_memtime at the four edges of every period
+// (vector segment start | at the first barrier | released | at the second barrier) into trace[wave >> 2][i][4]
+template <bool PRE, bool TRACE>
 __global__ __launch_bounds__(512, 2) void attn_fwd3_kernel(const uint16_t* __restrict__ qkv, int B, int N, int H, float sl2, uint16_t* __restrict__ out,
-                                                           float* __restrict__ lse) {
+                                                           float* __restrict__ lse, unsigned long long* __restrict__ trace) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][ATT_TILE_BYTES];  // [K | V][slot]
   int blk, head;
   if (!att_block_coords(N / 256, B * H, blk, head)) return;
@@ -220,8 +222,11 @@ __global__ __launch_bounds__(512, 2) void attn_fwd3_kernel(const uint16_t* __res
   A3_PIN16(s[0]); A3_PIN16(s[1]);
   A3_BARRIER();                                        // everybody has read K(0): its slot may take K(2)
   if (grp == 1) A3_BARRIER();
+  const bool tr_on = TRACE && blockIdx.x == 0 && lane == 0 && (wave & 3) == 0;
+#define A3_STAMP(K) do { if (TRACE && tr_on) trace[((wave >> 2) * nt + i) * 4 + (K)] = __builtin_amdgcn_s_memtime(); } while (0)
   for (int i = 0; i < nt; ++i) {
     const int cur = i & 1, nxt = cur ^ 1;
+    A3_STAMP(0);
     // ---- vector segment: the fragments of the matrix segment that follows (V(i), K(i+1): written at least one barrier ago), the softmax of tile i,
     //      this group's staged tile from registers to LDS, the next one requested ----
     a3_fetch<true>(smem[0][nxt], smem[1][cur], lane, vf, kf);       // (last tile: the K slot holds an old tile and the scores made from it are never used —
@@ -231,12 +236,16 @@ __global__ __launch_bounds__(512, 2) void attn_fwd3_kernel(const uint16_t* __res
     if (i + ahead + 1 < nt) att_gload(rs, Sp, RS, (i + ahead + 1) * 64, tg);
     A3_PIN4(p[0]); A3_PIN4(p[1]); A3_PIN4(p[2]); A3_PIN4(p[3]);      // (pure arithmetic otherwise sinks to its first use: into the matrix segment)
     A3_PIN1(l_part); A3_PIN1(m_ref); A3_PIN16(negm); A3_PIN16(o[0]); A3_PIN16(o[1]);
+    A3_STAMP(1);
     A3_BARRIER();
+    A3_STAMP(2);
     // ---- matrix segment: O += V(i)^T P(i), S(i+1) = K(i+1) Q^T - m_ref: sixteen MFMAs on registers ----
     a3_matrix<true, true, PRE>(vf, kf, qf, p, negm, o, s);
     A3_PIN16(o[0]); A3_PIN16(o[1]); A3_PIN16(s[0]); A3_PIN16(s[1]);
+    A3_STAMP(3);
     A3_BARRIER();
   }
+#undef A3_STAMP
   if (grp == 0) A3_BARRIER();
 
   const float l = xhalf_sum(l_part);
@@ -256,8 +265,16 @@ __global__ __launch_bounds__(512, 2) void attn_fwd3_kernel(const uint16_t* __res
 void attn_fwd3_launch(const uint16_t* qkv, int B, int N, int H, float scale_log2, uint16_t* out, float* lse, bool pre, hipStream_t s) {
   const int64_t nblk = N / 256, heads = (int64_t)B * H;
   const dim3 grid((unsigned)(((heads + 7) / 8) * 8 * nblk));
-  if (pre) attn_fwd3_kernel<true><<<grid, 512, 0, s>>>(qkv, B, N, H, scale_log2, out, lse);
-  else attn_fwd3_kernel<false><<<grid, 512, 0, s>>>(qkv, B, N, H, scale_log2, out, lse);
+  if (pre) attn_fwd3_kernel<true, false><<<grid, 512, 0, s>>>(qkv, B, N, H, scale_log2, out, lse, nullptr);
+  else attn_fwd3_kernel<false, false><<<grid, 512, 0, s>>>(qkv, B, N, H, scale_log2, out, lse, nullptr);
+}
+
+extern "C" int enh_debug_attention_fwd3_trace(const enh_bf16* qkv, int B, int N, int H, enh_bf16* out, float* lse, unsigned long long* trace, void* stream) {
+  ENH_REQUIRE(qkv && out && lse && trace && N % 256 == 0, ENH_E_BADARG, "enh_debug_attention_fwd3_trace: bad arguments");
+  const int64_t nblk = N / 256, heads = (int64_t)B * H;
+  const dim3 grid((unsigned)(((heads + 7) / 8) * 8 * nblk));
+  attn_fwd3_kernel<true, true><<<grid, 512, 0, (hipStream_t)stream>>>(qkv, B, N, H, 1.0f, out, lse, trace);
+  return enh_check_launch("enh_debug_attention_fwd3_trace");
 }
 
 // =================================================================================================

@@ -51,6 +51,7 @@ SIGNATURES = {
     "enh_get_cu_budget": (_i32, []),
     "enh_debug_occupy_cus": (_i32, [_i32, _f32, _vp]),
     "enh_debug_wave_simd_map": (_i32, [_vp, _vp]),
+    "enh_debug_attention_fwd3_trace": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "enh_gemm_bf16_variant": (_c.c_char_p, [_i32, _i32, _i64, _i64, _i64]),
     "enh_gemm_bf16_variant_mode": (_c.c_char_p, [_i32, _i32, _i64, _i64, _i64, _i32]),
     "enh_gemm_bf16_dtanh_colsum_workspace_bytes": (_c.c_size_t, [_i32, _i64, _i64, _i64]),

@@ -176,6 +176,9 @@ int enh_debug_occupy_cus(int n_wg, float ms, void* stream);
 /* Measurement aid: out16[w] = SIMD id the hardware gave wave w of the first (w < 8) and of the last (8 <= w < 16) 512-thread workgroup of a chip-filling
  * grid — the placement rule the eight-wave antiphase attention kernels depend on (profiles/r04_attention_lab.txt). */
 int enh_debug_wave_simd_map(int* out16, void* stream);
+/* Measurement aid: the eight-wave antiphase forward (pre-scaled q) with s_memtime stamps of waves 0 and 4 of workgroup 0 at the four edges of every
+ * period -> trace[2][N / 64][4] (vector segment start | arrival at the first barrier | release | arrival at the second barrier) */
+int enh_debug_attention_fwd3_trace(const enh_bf16* qkv, int B, int N, int H, enh_bf16* out, float* lse, unsigned long long* trace, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused attention — Attention.forward layers.py:122-132 without materialising the N x N matrix
