@@ -277,18 +277,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
 // =================================================================================================
 // C ABI
 // =================================================================================================
-// round-3 software-pipelined kernels (attention_v2.hip)
-void attn_fwd2_launch(const uint16_t* qkv, int B, int N, int H, float scale_log2, uint16_t* out, float* lse, bool ones, bool pre, dim3 grid, hipStream_t s);
 // round-4 eight-wave antiphase forward (attention_v3.hip); needs N % 256 == 0
 void attn_fwd3_launch(const uint16_t* qkv, int B, int N, int H, float scale_log2, uint16_t* out, float* lse, bool pre, hipStream_t s);
 void attn_bwd_dkv3_launch(const uint16_t* qkv, const uint16_t* d_o, const float* lse, const float* delta, int B, int N, int H, float kscale, uint16_t* dqkv,
                           hipStream_t s);
-void attn_bwd_dq2_launch(const uint16_t* qkv, const uint16_t* o, const uint16_t* d_o, const float* lse, float* delta, int B, int N, int H, float scale,
-                         float scale_log2, uint16_t* dqkv, bool pre, dim3 grid, hipStream_t s);
 
 // kernel family per pass (explicit state behind an explicit call, as enh_gemm_set_kernel); 0 = the library's choice:
-//   forward: 1 round-2 kernel | 2 pipelined, row sums on the matrix pipe | 3 pipelined, vector row sums | 4 eight waves in antiphase (round 4)
-//   dQ     : 1 round-2 kernel | 2 pipelined (attention_v2.hip)           | 3 round-2 skeleton with -delta (and, pre-scaled q, -lse) as MFMA C operands
+//   forward: 1 round-2 kernel | 4 eight waves in antiphase (round 4)      (2, 3: the software-pipelined round-3 kernels — measured slower, removed in round 4)
+//   dQ     : 1 round-2 kernel | 3 round-2 skeleton with -delta (and, pre-scaled q, -lse) as MFMA C operands      (2: removed with them)
 //   dK/dV  : 1 round-2 kernel | 2 round-2 skeleton with -delta (and, pre-scaled q, -lse) as MFMA C operands | 3 eight waves in antiphase (round 4; pre-scaled q
 //            and N % 256 == 0, else family 2)
 static int g_att_fwd = 0, g_att_dq = 0, g_att_dkv = 0;
@@ -297,7 +293,8 @@ static int g_att_fwd = 0, g_att_dq = 0, g_att_dkv = 0;
 #define ATT_DEFAULT_DKV 2
 
 extern "C" int enh_attention_set_kernel(int fwd, int dq, int dkv) {
-  ENH_REQUIRE(fwd >= 0 && fwd <= 4 && dq >= 0 && dq <= 3 && dkv >= 0 && dkv <= 3, ENH_E_BADARG, "enh_attention_set_kernel: fwd in 0..4, dq in 0..3, dkv in 0..3");
+  ENH_REQUIRE((fwd == 0 || fwd == 1 || fwd == 4) && (dq == 0 || dq == 1 || dq == 3) && dkv >= 0 && dkv <= 3, ENH_E_BADARG,
+              "enh_attention_set_kernel: fwd in {0, 1, 4}, dq in {0, 1, 3}, dkv in 0..3");
   g_att_fwd = fwd; g_att_dq = dq; g_att_dkv = dkv;
   return ENH_OK;
 }
@@ -315,8 +312,7 @@ extern "C" int enh_attention_forward(const enh_bf16* qkv, int B, int N, int H, f
   if (fam == 4 && N % 256 != 0) fam = 1;                         // the eight-wave kernel owns 256 queries per workgroup
   const float sl2 = q_prescaled ? 1.0f : scale * ATT_LOG2E;       // pre-scaled q: the products are log2-domain scores already
   if (fam == 4) attn_fwd3_launch(qkv, B, N, H, sl2, out, lse, q_prescaled != 0, (hipStream_t)stream);
-  else if (fam == 1) attn_fwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(qkv, B, N, H, sl2, out, lse);
-  else attn_fwd2_launch(qkv, B, N, H, sl2, out, lse, fam == 2, q_prescaled != 0, grid, (hipStream_t)stream);
+  else attn_fwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(qkv, B, N, H, sl2, out, lse);
   return enh_check_launch("enh_attention_forward");
 }
 
@@ -338,7 +334,6 @@ extern "C" int enh_attention_backward(const enh_bf16* qkv, const enh_bf16* out, 
   int fk = g_att_dkv ? g_att_dkv : ATT_DEFAULT_DKV;
   if (fk == 3 && (!pre || N % 256 != 0)) fk = 2;
   if (fq == 1) attn_bwd_dq_kernel<0><<<grid, 256, 0, s>>>(qkv, out, dout, lse, delta_ws, B, N, H, scale, sl2, dqkv);
-  else if (fq == 2) attn_bwd_dq2_launch(qkv, out, dout, lse, delta_ws, B, N, H, scale, sl2, dqkv, pre, grid, s);
   else if (pre) attn_bwd_dq_kernel<2><<<grid, 256, 0, s>>>(qkv, out, dout, lse, delta_ws, B, N, H, scale, sl2, dqkv);
   else attn_bwd_dq_kernel<1><<<grid, 256, 0, s>>>(qkv, out, dout, lse, delta_ws, B, N, H, scale, sl2, dqkv);
   if (fk == 3) attn_bwd_dkv3_launch(qkv, dout, lse, delta_ws, B, N, H, kscale, dqkv, s);

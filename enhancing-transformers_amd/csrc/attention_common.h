@@ -150,29 +150,39 @@ __device__ __forceinline__ void attn_fwd_exact(const uint16_t* __restrict__ qkv,
       for (int ds = 0; ds < 4; ++ds) s[kb] = MFMA32(att_frag_row(kt_, kb * 32, ds, l31, hi), qf[ds], s[kb]);
     }
     // ---- online softmax for this lane's query column ----
-    float mx = s[0][0];
+    // Round 4 (the kernel runs at the speed of its VECTOR instruction stream, profiles/r04_attention_lab.txt): the row maximum through v_max3 (16
+    // instructions instead of 32 v_max + canonicalisations) and one v_permlane32_swap instead of an LDS round trip; and the running maximum is a
+    // REFERENCE that is raised — O and l rescaled, a wave-uniform branch — only on the first tile and when some row's tile maximum exceeds it by more
+    // than 2^8: the 32 multiplies of O per tile are gone in all but a handful of tiles (numerators stay below 2^8; bf16's relative precision does not
+    // depend on that scale, lse = m + log2(l) is exact either way; cdna_hip_programming.md T13: no product is pending across the rescale here).
+    float mx = max3(s[0][0], s[0][1], s[0][2]);
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+    for (int r = 3; r < 15; r += 2) mx = max3(mx, s[0][r], s[0][r + 1]);
+    mx = max3(mx, s[0][15], s[1][0]);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx * scale_log2);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
+    for (int r = 1; r < 15; r += 2) mx = max3(mx, s[1][r], s[1][r + 1]);
+    mx = xhalf_max(__builtin_fmaxf(mx, s[1][15]));
+    const float mt = mx * scale_log2;
+    if (kt == 0 || __builtin_amdgcn_ballot_w64(mt - m_run > 8.0f) != 0) {
+      const float m_new = fmaxf(m_run, mt);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      l_part *= alpha;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+    }
     float p[2][16];
     float psum = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        p[kb][r] = __builtin_amdgcn_exp2f(s[kb][r] * scale_log2 - m_new);
+        p[kb][r] = __builtin_amdgcn_exp2f(s[kb][r] * scale_log2 - m_run);
         psum += p[kb][r];
       }
-    l_part = l_part * alpha + psum;
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+    l_part += psum;
     // ---- O^T[d][q] += V^T P^T ----
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)

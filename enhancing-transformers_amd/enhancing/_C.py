@@ -138,7 +138,7 @@ def lib():
         if sched:
             if sched not in ("static", "dynamic") or L.enh_gemm_set_scheduler(int(sched == "dynamic")) != 0:
                 raise RuntimeError(f"ENH_GEMM_SCHEDULER={sched!r}: expected static | dynamic")
-        att = os.environ.get("ENH_ATTN_KERNEL")       # "fwd,dq,dkv" families, e.g. "2,2,1" (0 = library default, 1 = round-2 kernels, 2 = pipelined)
+        att = os.environ.get("ENH_ATTN_KERNEL")       # "fwd,dq,dkv" families, e.g. "4,1,3" (0 = library default; include/enh_hip.h enh_attention_set_kernel)
         if att:
             f, q, k = (int(x) for x in att.split(","))
             if L.enh_attention_set_kernel(f, q, k) != 0:

@@ -194,11 +194,12 @@ int enh_debug_attention_fwd3_trace(const enh_bf16* qkv, int B, int N, int H, enh
 int enh_attention_forward(const enh_bf16* qkv, int B, int N, int H, float scale, int q_prescaled, enh_bf16* out, float* lse,
                           void* stream);
 /* kernel family per pass for A/B measurements (explicit library state, like enh_gemm_set_kernel), 0 = the library's choice:
- *   fwd: 1 round-2 kernel, 2 software-pipelined with row sums on the matrix pipe, 3 software-pipelined with vector row sums (csrc/attention_v2.hip),
- *        4 eight waves per workgroup in two groups in antiphase — one wave of a SIMD in its matrix segment while its partner runs the softmax
- *        (csrc/attention_v3.hip; N % 256 == 0, otherwise family 1 serves the call)
- *   dq : 1 round-2 kernel, 2 software-pipelined, 3 round-2 skeleton with -delta (-lse too when q is pre-scaled) as MFMA C operands
- *   dkv: 1 round-2 kernel, 2 round-2 skeleton with -delta (-lse too when q is pre-scaled) as MFMA C operands
+ *   fwd: 1 four-wave kernel (round 2), 4 eight waves per workgroup in two groups in antiphase — one wave of a SIMD in its matrix segment while its
+ *        partner runs the softmax (csrc/attention_v3.hip; N % 256 == 0, otherwise family 1 serves the call)
+ *   dq : 1 four-wave kernel (round 2), 3 the same skeleton with -delta (-lse too when q is pre-scaled) as MFMA C operands
+ *   dkv: 1 four-wave kernel (round 2), 2 the same skeleton with -delta (-lse too when q is pre-scaled) as MFMA C operands [default],
+ *        3 eight waves in antiphase (pre-scaled q and N % 256 == 0, otherwise family 2)
+ * (fwd 2 / 3 and dq 2 were the software-pipelined round-3 kernels: measured slower, removed in round 4.)
  * Same results up to rounding: every family passes the same parity tests. */
 int enh_attention_set_kernel(int fwd, int dq, int dkv);
 /* dqkv [B,N,3*H*64] bf16 ; delta_ws [B,H,N] f32 scratch */
