@@ -138,6 +138,7 @@ def lib():
         if sched:
             if sched not in ("static", "dynamic") or L.enh_gemm_set_scheduler(int(sched == "dynamic")) != 0:
                 raise RuntimeError(f"ENH_GEMM_SCHEDULER={sched!r}: expected static | dynamic")
+            _DYN_SCHEDULE[0] = sched == "dynamic"
         att = os.environ.get("ENH_ATTN_KERNEL")       # "fwd,dq,dkv" families, e.g. "4,1,3" (0 = library default; include/enh_hip.h enh_attention_set_kernel)
         if att:
             f, q, k = (int(x) for x in att.split(","))
@@ -328,9 +329,12 @@ def gemm(a, b, M: int, N: int, K: int, trans_a: bool = False, trans_b: bool = Fa
         # (a position-table residual, res_rows != M, is not the persistent kernel's case: ask with the generic mode)
         fam = lib().enh_gemm_bf16_variant_mode(int(trans_a), int(trans_b), M, N, K, 0 if (res is not None and res_rows != M) else mode).decode()
         targs = f"{'true' if trans_a else 'false'}, {'true' if trans_b else 'false'}"
-        if fam == "gemm_bf16_w256r_kernel":   # template <TB, EPI>: A is never transposed there
-            targs = f"{'true' if trans_b else 'false'}, {mode}"
-        elif fam in ("gemm_bf16_w256_kernel", "gemm_bf16_w256p_kernel"):   # the epilogue mode is a template parameter (gemm.hip epi_mode(), mirrored here for the label only)
+        dyn = "true" if _DYN_SCHEDULE[0] else "false"      # the persistent kernels' last template argument: the tile schedule (gemm.hip DYN)
+        if fam == "gemm_bf16_w256r_kernel":   # template <TB, EPI, DYN>: A is never transposed there
+            targs = f"{'true' if trans_b else 'false'}, {mode}, {dyn}"
+        elif fam == "gemm_bf16_w256p_kernel":
+            targs += f", {mode}, {dyn}"
+        elif fam == "gemm_bf16_w256_kernel":   # the epilogue mode is a template parameter (gemm.hip epi_mode(), mirrored here for the label only)
             targs += f", {mode}"
         TIMER.run(f"{fam}<{targs}>", 2.0 * M * N * K, lambda: _check(lib().enh_gemm_bf16_ws(*args), "enh_gemm_bf16"))
 
@@ -347,7 +351,9 @@ def gemm_dtanh_colsum(a, b, M: int, N: int, K: int, aux, out_bf16, colsum_out, t
         call()
     else:   # labelled with the GEMM kernel's symbol (the partial-row second pass and, off the tile grid, the column-sum kernel ride along)
         fam = lib().enh_gemm_bf16_variant_mode(0, int(trans_b), M, N, K, 3).decode()
-        TIMER.run(f"{fam}<false, {'true' if trans_b else 'false'}" + (", 3>" if "w256" in fam else ">"), 2.0 * M * N * K, call)
+        dyn = ", true>" if _DYN_SCHEDULE[0] else ", false>"
+        TIMER.run(f"{fam}<false, {'true' if trans_b else 'false'}" + ((", 3" + (dyn if fam == "gemm_bf16_w256p_kernel" else ">")) if "w256" in fam else ">"),
+                  2.0 * M * N * K, call)
 
 
 def set_cu_budget(n: int) -> None:
@@ -373,8 +379,12 @@ def device_cus() -> int:
 _DEVICE_CUS = [None]
 
 
+_DYN_SCHEDULE = [True]      # mirrors the library's default (enh_gemm_set_scheduler), for timing labels only
+
+
 def gemm_set_scheduler(dynamic: bool) -> None:
     _check(lib().enh_gemm_set_scheduler(int(bool(dynamic))), "enh_gemm_set_scheduler")
+    _DYN_SCHEDULE[0] = bool(dynamic)
 
 
 def occupy_cus(n_wg: int, ms: float, stream=None) -> None:
