@@ -244,51 +244,69 @@ __global__ void vq_loss_finalize_kernel(const float* __restrict__ partials, int 
 // codebook gradient, deterministic (round 4).  dE[k] = sum over the (token, depth) entries that picked code k of their contribution vector — a
 // scatter-add whose natural forms (per-token atomics; the LDS hash + one global atomic per distinct code of rounds 1-3) add in an order that changes
 // from run to run.  Here the backward kernel only WRITES each entry's vector and code (entry e = depth * M + token), and the sum is an "owner scans"
-// reduction with a fixed order: a workgroup owns 32 consecutive codes and one of 8 token slices; it walks its slice's codes in ascending entry order
-// (256 per step, hits compacted in order by ballot), and each half-wave adds the vectors of ITS 4 codes (code mod 8 = half-wave id) one column per
-// lane, in that order; the 8 slice partials of a code are then added in slice order.  No sort, no float atomics: the same bits on every run, which is
-// what a diff of two data-parallel runs needs (quantizers.py:85-90 is the reference's autograd scatter).  A code that attracts
-// every token makes one half-wave walk its whole slice (n / 8 entries) — the pathological bound; with the ~30 hot codes of an untrained model the
-// pass takes tens of microseconds.
+// reduction with a fixed order: a workgroup owns 32 consecutive codes and one of 16 token slices; it walks its slice's codes in ascending entry order
+// (256 per step, hits compacted in order by ballot); hit q of a step goes to half-wave q mod 8, which adds its vector (one column per lane) into ITS copy
+// of the 32 x 32 accumulator in LDS; the eight copies and then the 16 slice partials of a code are added in a fixed order.  No sort, no float atomics:
+// the same bits on every run, which is what a diff of two data-parallel runs needs (quantizers.py:85-90 is the reference's autograd
+// scatter).  Usage collapse is the stress case (an untrained model uses a handful of codes): all hits of a slice then belong to one workgroup, whose eight
+// half-waves share them (128-way parallel over the launch) with four loads in flight each.
 // ---------------------------------------------------------------------------------------------
 #define VQ_CPW 32   // codes per workgroup
-#define VQ_RS 8     // token slices
+#define VQ_RS 16    // token slices
 __global__ __launch_bounds__(256) void vq_de_partial_kernel(const int* __restrict__ codes, const float* __restrict__ contrib, int64_t n, int K,
                                                             float* __restrict__ part) {
   __shared__ int s_list[256];
   __shared__ int s_wc[4];
+  __shared__ float s_acc[8][VQ_CPW][VQ_D];       // [half-wave][code][column]: each half-wave adds into its own copy (32 KiB)
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, grp = t >> 5, gl = t & 31;
   const int cb = blockIdx.x * VQ_CPW, slice = blockIdx.y;
   const int64_t per = ((n + (int64_t)VQ_RS * 256 - 1) / ((int64_t)VQ_RS * 256)) * 256;
   const int64_t e0 = (int64_t)slice * per, e1 = e0 + per < n ? e0 + per : n;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;    // codes cb + grp + 8 c, column gl
+#pragma unroll
+  for (int k = 0; k < 8 * VQ_CPW * VQ_D / 256; ++k) (&s_acc[0][0][0])[t + 256 * k] = 0.f;
   for (int64_t base = e0; base < e1; base += 256) {
     const int64_t e = base + t;
     const unsigned lc = e < e1 ? (unsigned)(codes[e] - cb) : 0xffffffffu;
     const bool hit = lc < (unsigned)VQ_CPW;
     const unsigned long long m = __ballot(hit);
     if (lane == 0) s_wc[wave] = __popcll(m);
-    __syncthreads();
+    __syncthreads();                                   // (also orders the zero-fill / the previous chunk's list reads before this chunk's list writes)
     int off = 0, total = 0;
 #pragma unroll
     for (int w = 0; w < 4; ++w) { const int c = s_wc[w]; if (w < wave) off += c; total += c; }
     if (hit) s_list[off + __popcll(m & ((1ull << lane) - 1ull))] = t | ((int)lc << 8);
     __syncthreads();
-    for (int q = 0; q < total; ++q) {
-      const int item = s_list[q], lcq = item >> 8;
-      if ((lcq & 7) == grp) {
-        const float v = contrib[(size_t)(base + (item & 255)) * VQ_D + gl];
-        const int c = lcq >> 3;
-        if (c == 0) a0 += v; else if (c == 1) a1 += v; else if (c == 2) a2 += v; else a3 += v;
-      }
-    }
-    __syncthreads();
-  }
-  const float acc[4] = {a0, a1, a2, a3};
+    // hit q of the chunk (ascending entry order) belongs to half-wave q mod 8; four hits per trip so that their vector loads are in flight together
+    // (a code that attracts every token — an untrained model has a handful of codes in use — makes this loop the whole kernel: one load per trip
+    // cost 4.7 ms per launch at 131 072 tokens on 6 codes)
+    for (int q0 = grp; q0 < total; q0 += 32) {
+      float v[4];
+      int c[4];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const int code = cb + grp + 8 * c;
-    if (code < K) part[((size_t)slice * K + code) * VQ_D + gl] = acc[c];
+      for (int u = 0; u < 4; ++u) {
+        const int q = q0 + 8 * u;
+        c[u] = -1;
+        v[u] = 0.f;
+        if (q < total) {
+          const int item = s_list[q];
+          c[u] = item >> 8;
+          v[u] = contrib[(size_t)(base + (item & 255)) * VQ_D + gl];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (c[u] >= 0) s_acc[grp][c[u]][gl] += v[u];
+    }
+  }
+  __syncthreads();
+  // the eight half-wave copies of a code are added in a fixed order
+#pragma unroll
+  for (int k = 0; k < VQ_CPW * VQ_D / 256; ++k) {
+    const int idx = t + 256 * k, c = idx >> 5, col = idx & 31;
+    float a = s_acc[0][c][col];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) a += s_acc[g][c][col];
+    if (cb + c < K) part[((size_t)slice * K + cb + c) * VQ_D + col] = a;
   }
 }
 __global__ __launch_bounds__(256) void vq_de_finalize_kernel(const float* __restrict__ part, int K, float* __restrict__ dE) {
