@@ -167,8 +167,10 @@ def parity_mode_block(model, eng, cfg, batches, B, lr, dev):
             eng.forward_backward(x, w_l1=0.0, w_l2=1.0, codebook_weight=1.0)
             eng.optimizer_step(lr)
         out["train_images_per_s"]["x3_encoder_forward"] = rate(tstep, B, 3)
+        eng.decoder_precision = "x3"
+        out["train_images_per_s"]["x3_whole_forward"] = rate(tstep, B, 2)
     finally:
-        eng.encoder_precision = "bf16"
+        eng.encoder_precision = eng.decoder_precision = "bf16"
     # parity of the two encoders against the fp32 oracle (the reference's arithmetic on the host), same weights, 2 images
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
     P = {k: v.detach().float().cpu() for k, v in model.state_dict().items() if not k.startswith("loss.")}

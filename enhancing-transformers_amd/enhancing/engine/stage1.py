@@ -346,7 +346,8 @@ class _DecodeFn(torch.autograd.Function):
     def forward(ctx, engine, quant, anchor):
         st = engine._split_st
         B, io = st["B"], engine._io_bufs(st["B"])
-        engine.decode_train(st, quant.detach().reshape(B * engine.n_tok, engine.ed).to(dtype=engine.adt).contiguous())
+        q32 = quant.detach().reshape(B * engine.n_tok, engine.ed).to(dtype=F32).contiguous()
+        engine.decode_train(st, q32.to(dtype=engine.adt), zq32=q32)
         _C.unpatchify_loss(st["pix"], None, B, engine.C, engine.size, engine.size, engine.patch, 0.0, 0.0, io["xrec"], None, None)
         ctx.engine, ctx.st, ctx.qshape = engine, st, quant.shape
         return io["xrec"].clone()
@@ -364,13 +365,15 @@ class Stage1Engine:
     """Binds a ``ViTVQ`` module tree to the HIP schedule on one device."""
 
     def __init__(self, model: nn.Module, device: Optional[torch.device] = None, precision: Optional[str] = None,
-                 encoder_precision: Optional[str] = None, codes_precision: Optional[str] = None) -> None:
+                 encoder_precision: Optional[str] = None, codes_precision: Optional[str] = None, decoder_precision: Optional[str] = None) -> None:
         """precision: "bf16" (product path: bf16 MFMA operands, fp32 accumulation / residual stream / master weights) or "fp32" (exact
         mode for parity runs: every operand fp32, vector-ALU kernels); default from ENH_PRECISION, else "bf16".
         Within the bf16 product path the ENCODER forward (patch embedding .. pre_quant, the part that decides the codes) can run on split-bf16
         ("x3") operands — three MFMA passes, ~1e-5 relative, codes equal to the fp32 reference's up to its own near-ties (csrc/x3.hip):
           encoder_precision  "bf16" | "x3": training / reconstruct / forward (ENH_ENCODER_PRECISION, default "bf16": the measured headline path)
-          codes_precision    "bf16" | "x3": encode_codes, i.e. the tokens stage 2 consumes (ENH_CODES_PRECISION, default "x3")"""
+          codes_precision    "bf16" | "x3": encode_codes, i.e. the tokens stage 2 consumes (ENH_CODES_PRECISION, default "x3")
+          decoder_precision  "bf16" | "x3": post_quant .. to_pixel of training / reconstruct / decode (ENH_DECODER_PRECISION, default "bf16"); with both towers
+                             on x3 the whole forward — codes, reconstruction, losses — is within ~1e-5 of the fp32 reference (the backward stays bf16)"""
         import os
         precision = precision or os.environ.get("ENH_PRECISION", "bf16")
         if precision not in ("bf16", "fp32"):
@@ -378,7 +381,8 @@ class Stage1Engine:
         self.precision = precision
         self.encoder_precision = encoder_precision or os.environ.get("ENH_ENCODER_PRECISION", "bf16")
         self.codes_precision = codes_precision or os.environ.get("ENH_CODES_PRECISION", "x3")
-        for name, v in (("encoder_precision", self.encoder_precision), ("codes_precision", self.codes_precision)):
+        self.decoder_precision = decoder_precision or os.environ.get("ENH_DECODER_PRECISION", "bf16")
+        for name, v in (("encoder_precision", self.encoder_precision), ("codes_precision", self.codes_precision), ("decoder_precision", self.decoder_precision)):
             if v not in ("bf16", "x3"):
                 raise ValueError(f"{name} must be 'bf16' or 'x3', got {v!r}")
         self.adt = BF16 if precision == "bf16" else F32
@@ -444,11 +448,18 @@ class Stage1Engine:
                 X["wpre"] = torch.empty(self.ed, 3 * self.enc.dim, dtype=BF16, device=self.device)
             _C.split3(s.w["encoder.to_patch_embedding.0.weight"].view(self.enc.dim, self.pd), X["wpe"], order=1)
             _C.split3(s.w["pre_quant.weight"], X["wpre"], order=1)
+            if "wpost" not in X:
+                X["wpost"] = torch.empty(self.dec.dim, 3 * self.ed, dtype=BF16, device=self.device)
+                X["wpix"] = torch.empty(self.pd, 3 * self.dec.dim, dtype=BF16, device=self.device)
+            _C.split3(s.w["post_quant.weight"], X["wpost"], order=1)
+            # to_pixel's weight is stored [K = dim][N = C*p*p] (ConvTranspose2d): the K-concatenated operand is built from its transpose
+            _C.split3(s.w["decoder.to_pixel.1.weight"].view(self.dec.dim, self.pd).t().contiguous(), X["wpix"], order=1)
             X["version"] = s.version
         if B not in X["io"]:
             M = B * self.n_tok
-            X["io"][B] = dict(patches32=torch.empty(M, self.pd, dtype=F32, device=self.device), patches3=torch.empty(M, 3 * self.pd, dtype=BF16, device=self.device))
-        return dict(wpe=X["wpe"], wpre=X["wpre"], **X["io"][B])
+            X["io"][B] = dict(patches32=torch.empty(M, self.pd, dtype=F32, device=self.device), patches3=torch.empty(M, 3 * self.pd, dtype=BF16, device=self.device),
+                              zq3=torch.empty(M, 3 * self.ed, dtype=BF16, device=self.device))
+        return dict(wpe=X["wpe"], wpre=X["wpre"], wpost=X["wpost"], wpix=X["wpix"], **X["io"][B])
 
     def _encode_tokens(self, img: torch.Tensor, save: bool, want_f32: bool = False, x3: bool = False) -> dict:
         """patch-embed GEMM (+bias +pos table) -> encoder tower.  reference layers.py:177-182.  x3: on split-bf16 operands (product path only)."""
@@ -476,14 +487,23 @@ class Stage1Engine:
             _C.mm(eb["xf16"], s.wa["pre_quant.weight"], B * self.n_tok, self.ed, self.enc.dim, io["h"], bias=s.w["pre_quant.bias"])
         return io["h"]
 
-    def _decode_tokens(self, zq16: torch.Tensor, B: int, save: bool) -> torch.Tensor:
-        """post_quant (+bias +pos table) -> decoder tower -> to_pixel GEMM.  reference vitvqgan.py:68-72, layers.py:209-214"""
+    def _decode_tokens(self, zq16: torch.Tensor, B: int, save: bool, zq32: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """post_quant (+bias +pos table) -> decoder tower -> to_pixel GEMM.  reference vitvqgan.py:68-72, layers.py:209-214.  zq32 (the quantized tokens
+        in f32) selects the x3 decoder: every product from split-bf16 operands (product path only)."""
         s, io, M = self.store, self._io_bufs(B), B * self.n_tok
+        pp = self.patch * self.patch
+        io["bias_pix"].view(self.C, pp).copy_(s.w["decoder.to_pixel.1.bias"].view(self.C, 1).expand(self.C, pp))
+        if zq32 is not None and self.precision == "bf16":
+            X = self._x3_io(B)
+            _C.split3(zq32, X["zq3"])
+            _C.mm(X["zq3"], X["wpost"], M, self.dec.dim, 3 * self.ed, self.dec.input_buffer(B, save), bias=s.w["post_quant.bias"],
+                  res=s.w["decoder.de_pos_embedding"].view(self.n_tok, self.dec.dim), res_rows=self.n_tok)
+            b = self.dec.forward_x3(B, save)
+            _C.mm(b["xf3"], X["wpix"], M, self.pd, 3 * self.dec.dim, io["pix"], bias=io["bias_pix"])
+            return io["pix"]
         _C.mm(zq16, s.wa["post_quant.weight"], M, self.dec.dim, self.ed, self.dec.input_buffer(B, save), bias=s.w["post_quant.bias"],
               res=s.w["decoder.de_pos_embedding"].view(self.n_tok, self.dec.dim), res_rows=self.n_tok)
         b = self.dec.forward(B, save)
-        pp = self.patch * self.patch
-        io["bias_pix"].view(self.C, pp).copy_(s.w["decoder.to_pixel.1.bias"].view(self.C, 1).expand(self.C, pp))
         wpix16 = s.wa["decoder.to_pixel.1.weight"].view(self.dec.dim, self.pd)  # stored [K][N]
         _C.mm(b["xf16"], wpix16, M, self.pd, self.dec.dim, io["pix"], trans_b=True, bias=io["bias_pix"])
         return io["pix"]
@@ -511,7 +531,7 @@ class Stage1Engine:
         exact = self.precision != "bf16"
         zq, zq16, idx, qloss = _C.vq_forward(h, self.store.w["quantizer.embedding.weight"], float(self.q.beta), self.q.depth, self.q.use_norm,
                                              want_bf16=not exact)
-        pix = self._decode_tokens(zq if exact else zq16, B, save=False)
+        pix = self._decode_tokens(zq if exact else zq16, B, save=False, zq32=zq if self.decoder_precision == "x3" else None)
         _C.unpatchify_loss(pix, None, B, self.C, self.size, self.size, self.patch, 0.0, 0.0, io["xrec"], None, None)
         idx = idx.view(B, self.n_tok, self.q.depth) if self.q.use_residual else idx.view(B, self.n_tok)
         return io["xrec"].clone(), qloss.view(()).clone(), idx
@@ -522,8 +542,8 @@ class Stage1Engine:
         self._invalidate_saved()
         B = quant.shape[0]
         io = self._io_bufs(B)
-        zq16 = quant.reshape(B * self.n_tok, self.ed).to(device=self.device, dtype=self.adt).contiguous()
-        pix = self._decode_tokens(zq16, B, save=False)
+        zq32 = quant.reshape(B * self.n_tok, self.ed).to(device=self.device, dtype=F32).contiguous()
+        pix = self._decode_tokens(zq32.to(self.adt), B, save=False, zq32=zq32 if self.decoder_precision == "x3" else None)
         _C.unpatchify_loss(pix, None, B, self.C, self.size, self.size, self.patch, 0.0, 0.0, io["xrec"], None, None)
         return io["xrec"].clone()
 
@@ -559,9 +579,10 @@ class Stage1Engine:
         self._fwd_serial = getattr(self, "_fwd_serial", 0) + 1
         return dict(img=img, B=B, eb=eb, h=h, serial=self._fwd_serial)
 
-    def decode_train(self, st: dict, zq16: torch.Tensor) -> dict:
-        """second half: post_quant + decoder + to_pixel from the quantized tokens [M, embed_dim] (operand dtype of this precision mode), saved"""
-        st.update(zq16=zq16, pix=self._decode_tokens(zq16, st["B"], save=True))
+    def decode_train(self, st: dict, zq16: torch.Tensor, zq32: Optional[torch.Tensor] = None) -> dict:
+        """second half: post_quant + decoder + to_pixel from the quantized tokens [M, embed_dim] (operand dtype of this precision mode), saved; zq32: the same
+        tokens in f32 for the x3 decoder (decoder_precision)"""
+        st.update(zq16=zq16, pix=self._decode_tokens(zq16, st["B"], save=True, zq32=zq32 if self.decoder_precision == "x3" else None))
         return st
 
     def forward_train(self, img: torch.Tensor) -> dict:
@@ -572,7 +593,7 @@ class Stage1Engine:
         exact = self.precision != "bf16"
         zq, zq16, idx, qloss = _C.vq_forward(st["h"], E, float(self.q.beta), self.q.depth, self.q.use_norm, want_bf16=not exact)
         st.update(idx=idx, qloss=qloss)
-        return self.decode_train(st, zq if exact else zq16)
+        return self.decode_train(st, zq if exact else zq16, zq32=zq)
 
     def _check_serial(self, st: dict) -> None:
         if st["serial"] != self._fwd_serial:
@@ -730,9 +751,12 @@ class Stage1Engine:
         _C.adamw_step(s.p, s.g, s.m, s.v, s.p16 if self.precision == "bf16" else None, s.step_count, lr, betas[0], betas[1], eps, weight_decay,
                       grad_scale)
         s.refresh_operands()      # operands derived from the masters (the towers' pre-scaled q | k | v weights): 24 small launches at base
-        if self.encoder_precision == "x3" and self.precision == "bf16":
+        if "x3" in (self.encoder_precision, self.decoder_precision) and self.precision == "bf16":
             # the x3 weight images are otherwise rebuilt lazily by the next x3 forward — which a HIP-graph replay never runs on the host
-            self.enc.x3_weights()
+            if self.encoder_precision == "x3":
+                self.enc.x3_weights()
+            if self.decoder_precision == "x3":
+                self.dec.x3_weights()
             for B in list(self.__dict__.get("_x3", {}).get("io", {})):
                 self._x3_io(B)
 

@@ -54,6 +54,7 @@ class ViTVQ(nn.Module):
         # defaults (ENH_ENCODER_PRECISION / "bf16" for training and reconstruction; ENH_CODES_PRECISION / "x3" for encode_codes)
         self.encoder_precision = None
         self.codes_precision = None
+        self.decoder_precision = None     # "bf16" | "x3": post_quant .. to_pixel forward (None -> ENH_DECODER_PRECISION / "bf16")
 
         if path is not None:
             self.init_from_ckpt(path, ignore_keys)
@@ -63,7 +64,8 @@ class ViTVQ(nn.Module):
     def engine(self):
         if self._engine is None:
             from ...engine.stage1 import Stage1Engine
-            self._engine = Stage1Engine(self, precision=self.precision, encoder_precision=self.encoder_precision, codes_precision=self.codes_precision)
+            self._engine = Stage1Engine(self, precision=self.precision, encoder_precision=self.encoder_precision, codes_precision=self.codes_precision,
+                                        decoder_precision=self.decoder_precision)
         return self._engine
 
     @property
@@ -196,18 +198,26 @@ class ViTVQ(nn.Module):
             sb = {self.image_key: static_x}
             stores = [eng.store] + ([self.loss.disc_store(eng.device)] if hasattr(self.loss, "discriminator") else [])
             saved = [st.g.clone() for st in stores]            # the warm-up passes must not leak into an accumulation window
+            # Operand images DERIVED from the parameters on the host side of the eager code (the discriminator's packed convolution weights, cached
+            # between optimizer steps: losses/op/conv_nhwc.py) must be rebuilt INSIDE every graph: a graph that found the cache warm would read, on every
+            # replay, the image of the weights as they were at capture (caught by the bit-identity test in the full suite: optimizer 1's no-R1 graph,
+            # captured in a step whose optimizer-0 pass was already a replay).  So the cache is dropped before the warm-up, before the capture and after it.
+            from ...losses.op.conv_nhwc import invalidate_packed_weights
             cur, side = torch.cuda.current_stream(), torch.cuda.Stream()
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 for _ in range(2):
+                    invalidate_packed_weights()
                     self._training_step_eager(sb, batch_idx, optimizer_idx, zero_grad)
             cur.wait_stream(side)
             for st, g0 in zip(stores, saved):
                 st.g.copy_(g0)
             before = dict(self.logged)
+            invalidate_packed_weights()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 out = self._training_step_eager(sb, batch_idx, optimizer_idx, zero_grad)
+            invalidate_packed_weights()       # (what the capture cached lives in the graph's memory pool and is rewritten by every replay)
             for st, g0 in zip(stores, saved):
                 st.g.copy_(g0)
             logged = {k: v for k, v in self.logged.items() if k not in before or before[k] is not v}
