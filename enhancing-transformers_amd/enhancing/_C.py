@@ -312,10 +312,13 @@ def gemm(a, b, M: int, N: int, K: int, trans_a: bool = False, trans_b: bool = Fa
     ldb = b.stride(0) if ldb is None else ldb
     out = out_f32 if out_f32 is not None else out_bf16
     ldc = out.stride(0) if ldc is None else ldc
-    # split-K weight gradients: partial slabs in a caller-owned workspace + a fixed-order second pass (deterministic; no f32 atomics)
+    # split-K calls (weight gradients; also any accumulate-into-f32 call with a long K and few tiles, e.g. the discriminator's 8192 -> 512 linear at a
+    # small batch): partial slabs in a caller-owned workspace + a fixed-order second pass — deterministic, no f32 atomics.  (Until round 4 only the
+    # weight-gradient layout got the workspace; the other layouts fell back to atomics and made the discriminator's forward differ by an ulp from call
+    # to call — found by the graph-replay bit-identity test.)
     ws, ws_bytes = None, 0
-    if accumulate and trans_a and trans_b and out_f32 is not None and out_bf16 is None and bias is None and res is None and act == ACT_NONE and ldc == N:
-        ws_bytes = lib().enh_gemm_bf16_workspace_bytes(1, 1, M, N, K)
+    if accumulate and out_f32 is not None and out_bf16 is None and bias is None and res is None and act == ACT_NONE and ldc == N:
+        ws_bytes = lib().enh_gemm_bf16_workspace_bytes(int(trans_a), int(trans_b), M, N, K)
         if ws_bytes:
             ws = _gemm_workspace(a.device, ws_bytes)
     args = (_p(a, BF16, "A"), lda, int(trans_a), _p(b, BF16, "B"), ldb, int(trans_b), M, N, K, _p(bias, F32, "bias"),

@@ -394,6 +394,27 @@ def test_gemm_wgrad_splitk_two_pass_is_deterministic(C):
     assert rel(runs[0], ref + base.double()) <= 1e-5
 
 
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+def test_split_k_accumulate_is_bit_reproducible_in_every_layout(C, ta, tb):
+    """an accumulate-into-f32 call whose few tiles cannot fill the chip is split along K — with the binding's workspace as partial slabs + a fixed-order second
+    pass in EVERY operand layout (until round 4 only the weight-gradient layout: the discriminator's 8192 -> 512 linear at a small batch summed its K
+    slices with f32 atomics and its output differed by an ulp from call to call)."""
+    g = torch.Generator().manual_seed(9)
+    M, N, K = 8, 512, 8192
+    A, B = _mk((K, M) if ta else (M, K), g, 0.5), _mk((K, N) if tb else (N, K), g, 0.1)
+    a, b = A.to(torch.bfloat16).cuda(), B.to(torch.bfloat16).cuda()
+    assert C.lib().enh_gemm_bf16_workspace_bytes(int(ta), int(tb), M, N, K) > 0      # the shape IS split
+    outs = []
+    for _ in range(12):
+        o = torch.zeros(M, N, device="cuda")
+        C.gemm(a, b, M, N, K, trans_a=ta, trans_b=tb, accumulate=True, out_f32=o)
+        outs.append(o)
+    torch.cuda.synchronize()
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    ref = (A.double().t() if ta else A.double()) @ (B.double() if tb else B.double().t())
+    assert rel(outs[0], ref) <= F32_TOL
+
+
 def test_gemm_rejects_bad_shapes(C):
     a = torch.zeros(8, 12, dtype=torch.bfloat16, device="cuda")
     o = torch.zeros(8, 8, device="cuda")
