@@ -45,3 +45,16 @@ extern "C" int enh_set_cu_budget(int n_cus) {
   return ENH_OK;
 }
 extern "C" int enh_get_cu_budget(void) { return enh_cu_budget(); }
+
+// Zero fill as a KERNEL.  hipMemsetAsync inside the library is not graph-safe on this stack: a captured 2-KiB memset node re-executed only half of its range
+// on replay (found by the graph-replay bit-identity test of the two-optimizer step: garbage in half of a bias gradient from the second replay on;
+// reproduced in isolation with tools/graph_probe2.py).  Every "out = 0 before the atomics / partial sums" of the library goes through this.
+__global__ __launch_bounds__(256) void enh_zero_f32_kernel(float* __restrict__ p, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0.f;
+}
+int enh_zero_f32_launch(float* p, int64_t n, hipStream_t s) {
+  if (n <= 0) return ENH_OK;
+  enh_zero_f32_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, s>>>(p, n);
+  return enh_check_launch("enh_zero_f32");
+}

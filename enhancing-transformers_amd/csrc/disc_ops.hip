@@ -166,8 +166,8 @@ extern "C" int enh_channel_sum_f32(const float* x, int B, int C, int64_t inner, 
   ENH_REQUIRE(x && out && B > 0 && C > 0 && inner > 0, ENH_E_BADARG, "enh_channel_sum_f32: bad argument");
   hipStream_t s = (hipStream_t)stream;
   if (!accumulate) {
-    hipError_t e = hipMemsetAsync(out, 0, (size_t)C * sizeof(float), s);
-    if (e != hipSuccess) { enh_set_error("enh_channel_sum_f32: memset failed"); return ENH_E_HIP_BASE - (int)e; }
+    const int rc = enh_zero_f32_launch(out, C, s);
+    if (rc) return rc;
   }
   int64_t chunk = (inner + 63) / 64;               // up to 64 slices of the inner axis per (batch, channel) row ...
   if (chunk < 4096) chunk = 4096;                   // ... but never less than 16 KiB of work per workgroup

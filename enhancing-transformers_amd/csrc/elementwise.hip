@@ -242,8 +242,8 @@ static int colsum_bf16_impl(const enh_bf16* x, int64_t M, int64_t N, int64_t ldx
   ENH_REQUIRE(M > 0 && N > 0 && N % 2 == 0 && ldx % 2 == 0, ENH_E_SHAPE, "enh_colsum_bf16: N and ldx must be even");
   hipStream_t s = (hipStream_t)stream;
   if (!accumulate && !part) {
-    hipError_t e = hipMemsetAsync(out, 0, (size_t)N * sizeof(float), s);
-    if (e != hipSuccess) { enh_set_error("enh_colsum_bf16: memset failed: %s", hipGetErrorString(e)); return ENH_E_HIP_BASE - (int)e; }
+    const int rc = enh_zero_f32_launch(out, N, s);
+    if (rc) return rc;
   }
   const int64_t chunks = colsum_chunks(M);
   const int64_t rows_per_block = (M + chunks - 1) / chunks;

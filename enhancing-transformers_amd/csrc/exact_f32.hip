@@ -254,7 +254,7 @@ extern "C" int enh_attention_backward_f32(const float* qkv, const float* out, co
 extern "C" int enh_colsum_f32(const float* x, int64_t M, int64_t N, int64_t ldx, float* out, int accumulate, void* stream) {
   ENH_REQUIRE(x && out && M > 0 && N > 0, ENH_E_BADARG, "enh_colsum_f32: bad argument");
   hipStream_t s = (hipStream_t)stream;
-  if (!accumulate) (void)hipMemsetAsync(out, 0, (size_t)N * sizeof(float), s);
+  if (!accumulate) { const int rc = enh_zero_f32_launch(out, N, s); if (rc) return rc; }
   int64_t chunks = (M + 1023) / 1024;
   if (chunks > 128) chunks = 128;
   const int64_t rpb = (M + chunks - 1) / chunks;
