@@ -1,4 +1,4 @@
-"""debug aid: two training sequences of the two-optimizer protocol from the same seed, snapshot after every training_step / optimizer step: first difference?"""
+"""Two training sequences of the two-optimizer protocol from the same seed, snapshot after every training_step / optimizer step: first difference?"""
 import os, sys, warnings
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in ("enhancing-transformers_amd", "oracle", "tests"):

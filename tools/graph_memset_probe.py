@@ -1,3 +1,6 @@
+"""Reproduces the ROCm graph-capture defect the library works around (csrc/common.cpp enh_zero_f32_launch): a hipMemsetAsync node captured inside a library call
+re-executes only part of its range on replay.  With the fill kernel every replay equals the eager call; with hipMemsetAsync half of the 512 channel sums were
+garbage from the second replay on (profiles/r04_graph_replay_findings.txt)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "enhancing-transformers_amd"))
