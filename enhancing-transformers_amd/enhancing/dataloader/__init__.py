@@ -72,7 +72,7 @@ class DataModuleFromConfig:
             sampler = DistributedSampler(ds, num_replicas=self.world, rank=self.rank, shuffle=shuffle)
             self._samplers[key] = sampler
         loader = DataLoader(ds, batch_size=self.batch_size, num_workers=workers, shuffle=shuffle and sampler is None, sampler=sampler,
-                            collate_fn=_collate_for(ds))
+                            collate_fn=_collate_for(ds), pin_memory=bool(getattr(ds, "device_transform", False)) and torch.cuda.is_available())
         if getattr(ds, "device_transform", False):       # crop + flip + ToTensor run on the GPU (imagenet.DeviceTransform)
             from .imagenet import DeviceTransform
             return _Mapped(loader, DeviceTransform(ds.resolution, resize=ds._resize_arg() if hasattr(ds, "_resize_arg") else None))

@@ -69,6 +69,17 @@ def build_tables(in_sizes: Sequence[Tuple[int, int]], out_sizes: Sequence[Tuple[
     return (torch.tensor(meta, dtype=torch.int32), torch.from_numpy(np.concatenate(bnd).astype(np.int32)), torch.from_numpy(np.concatenate(wts).astype(np.int32)))
 
 
+def resize_with_tables_u8(src: torch.Tensor, meta: torch.Tensor, bounds: torch.Tensor, weights: torch.Tensor, out_sizes: torch.Tensor) -> torch.Tensor:
+    """the device half of resize_batch_u8 for tables that were built elsewhere (collate_u8 in a DataLoader worker): three asynchronous copies
+    (from pinned memory when the loader pins) and the kernel; `out_sizes` int32 [B, 2] = (h_out, w_out) stays on the host"""
+    from .. import _C
+    dev = src.device
+    HD, WD = (int(v) for v in out_sizes.max(dim=0).values.tolist())
+    dst = torch.zeros(src.shape[0], HD, WD, 3, dtype=torch.uint8, device=dev)
+    _C.resize_u8(src, meta.to(dev, non_blocking=True), bounds.to(dev, non_blocking=True), weights.to(dev, non_blocking=True), dst)
+    return dst
+
+
 def resize_batch_u8(src: torch.Tensor, in_sizes: Sequence[Tuple[int, int]], size) -> Tuple[torch.Tensor, List[Tuple[int, int]]]:
     """src uint8 [B, HS, WS, 3] on the device (image b occupies the top-left h_in x w_in corner of its slot) -> (uint8 [B, HD, WD, 3] with image b resized
     into the top-left corner of its slot, [(h_out, w_out)])"""

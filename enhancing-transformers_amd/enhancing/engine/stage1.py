@@ -140,6 +140,9 @@ class _Tower:
         # rounding, so that the attention kernels see log2-domain logits and feed -max / -lse through the MFMA C operand (include/enh_hip.h
         # enh_attention_forward, q_prescaled).  The BACKWARD GEMMs keep the plain shadow: the attention backward returns the gradient with respect to the
         # unscaled q, so neither the input gradient nor the weight gradient needs a correction.  Rebuilt whenever the masters change (store hook).
+        # Known asymmetry: forward operand / alpha and the backward operand bf16(W_q) are two separate roundings of the same master, so they differ by
+        # up to one bf16 ulp (2^-7 relative worst case, 2^-9 rms) — the size of the rounding either already carries against the master; bounded in
+        # tests/test_ops_gpu.py::test_head_scaled_cast_and_the_forward_backward_operand_gap.  x3 and fp32 modes use the unscaled operand both ways.
         self.q_prescaled = store.precision == "bf16" and os.environ.get("ENH_ATTN_PRESCALE", "1") != "0"
         self.wqkv_fwd: List[torch.Tensor] = []
         if self.q_prescaled:

@@ -409,6 +409,46 @@ def test_device_transform_paths_equal_the_host_path(tmp_path, monkeypatch):
             assert torch.equal(a["image"], c["image"]) and torch.equal(a["class"], c["class"]), split
 
 
+def test_resize_tables_are_built_by_the_collate_and_outliers_can_be_prereduced(tmp_path):
+    """device_resize batches leave collate_u8 (i.e. the DataLoader worker) with the enh_resize_u8 tables already built — identical to what the consumer
+    would build — so DeviceTransform only copies them.  host_prereduce=k bounds the slot of a decoded outlier: shorter side lands in [k, 2k); images
+    below 2k are untouched (bit-identical samples)."""
+    import numpy as np
+    from PIL import Image
+    from enhancing.dataloader.imagenet import ImageNetTrain, collate_u8
+    from enhancing.dataloader.resize import build_tables, output_size
+    rng = np.random.default_rng(3)
+    d = tmp_path / "train" / "a"
+    d.mkdir(parents=True)
+    sizes = [(50, 70), (45, 33), (400, 610)]                        # (h, w); the last one is the "outlier"
+    for k, (h, w) in enumerate(sizes):
+        Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(d / f"i{k}.png")
+    ds = ImageNetTrain(str(tmp_path), resolution=32, device_resize=True)
+    np.random.seed(0)
+    samples = [ds[i] for i in range(3)]
+    batch = collate_u8(samples)
+    assert batch["in_size"].tolist() == [list(s) for s in sizes] and tuple(batch["pixels_u8"].shape) == (3, 400, 610, 3)
+    outs = []
+    for h, w in sizes:
+        wo, ho = output_size(w, h, 32)
+        outs.append((ho, wo))
+    assert batch["out_size"].tolist() == [list(o) for o in outs]
+    meta, bnd, wts = build_tables(sizes, outs)
+    assert torch.equal(batch["resize_meta"], meta) and torch.equal(batch["resize_bounds"], bnd) and torch.equal(batch["resize_weights"], wts)
+    assert batch["resize_meta"].dtype == torch.int32 and batch["resize_bounds"].dtype == torch.int32 and batch["resize_weights"].dtype == torch.int32
+
+    capped = ImageNetTrain(str(tmp_path), resolution=32, device_resize=True, host_prereduce=64)
+    np.random.seed(0)
+    csamples = [capped[i] for i in range(3)]
+    for a, b in zip(samples[:2], csamples[:2]):                     # below 2k: untouched, same random draws
+        assert torch.equal(a["pixels_u8"], b["pixels_u8"]) and torch.equal(a["window"], b["window"])
+    h, w = csamples[2]["in_size"].tolist()
+    assert 64 <= min(h, w) < 128 and tuple(collate_u8(csamples)["pixels_u8"].shape[1:3]) == (h, w)
+    ref = np.asarray(Image.open(d / "i2.png").convert("RGB").reduce(400 // 64))
+    assert np.array_equal(csamples[2]["pixels_u8"].numpy(), ref)
+    assert csamples[2]["out_size"].tolist() == [32, int(32 * w / h)]
+
+
 def test_image_logger_and_setup_callbacks(tmp_path, monkeypatch):
     """reference utils/callback.py:21-141 + general.py:43-60: frequency rule (every batch_frequency batches and the early 2, 4, ... steps), max_images,
     clamp, file naming, torchvision's grid geometry; the Trainer calls the Lightning hook names"""

@@ -599,6 +599,28 @@ def test_gemm_suite_under_each_kernel_family(sel, symbol):
     assert r.returncode == 0, r.stdout[-3000:]
 
 
+def test_head_scaled_cast_and_the_forward_backward_operand_gap(C):
+    """to_qkv's FORWARD operand is bf16(alpha * W_q) (one rounding of the master, engine/stage1.py _Tower.refresh_qkv_operands) while the backward GEMMs
+    read bf16(W_q): two roundings of the same fp32 number, so forward operand / alpha and backward operand differ by at most one bf16 ulp of W_q
+    (relative 2^-7 worst case, 2^-9 rms) — the same size as the bf16 rounding each of them already carries against the master.  The cast itself is
+    bit-exact against torch's round-to-nearest-even."""
+    torch.manual_seed(5)
+    inner, dim, alpha = 512, 768, 0.125 * 1.4426950408889634
+    w = torch.randn(3 * inner, dim, device="cuda") * 0.02
+    y = torch.empty(3 * inner, dim, dtype=torch.bfloat16, device="cuda")
+    C.cast_bf16_head_scaled(w, y, inner * dim, alpha)
+    torch.cuda.synchronize()
+    expect = w.clone()
+    expect[:inner] *= np.float32(alpha)
+    assert torch.equal(y, expect.to(torch.bfloat16))
+    plain = w.to(torch.bfloat16).float()
+    fwd_q = y[:inner].float() / np.float32(alpha)
+    gap = (fwd_q - plain[:inner]).abs() / plain[:inner].abs().clamp_min(1e-30)
+    assert float(gap.max()) <= 2.0 ** -7 and float(gap.pow(2).mean().sqrt()) <= 2.0 ** -8
+    master_gap = (plain[:inner] - w[:inner]).abs() / w[:inner].abs().clamp_min(1e-30)      # what either operand already carries against the master
+    assert float(gap.pow(2).mean().sqrt()) <= 2.0 * float(master_gap.pow(2).mean().sqrt())
+
+
 def test_crop_flip_u8_device_transform():
     """enh_crop_flip_u8 (device-side crop + flip + ToTensor of the input pipeline, reference dataloader/imagenet.py:30-36) is bit-identical to the host path"""
     import numpy as np
