@@ -353,6 +353,239 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_glds_kernel(const ConvArgs 
   conv_epilogue(args, acc, m0, n0, wm, wn, lg, l16, smem + wave * 8192);   // the stages are free: no LDS read follows the loop's last barrier
 }
 
+// =================================================================================================
+// "w256" form of the convolution (round 4): the dense w256 main loop (gemm.hip gemm_bf16_w256_kernel — 256-row tile, FOUR waves of 128 x 32*NJ, one wave per
+// SIMD, v_mfma_f32_32x32x16_bf16, two 64-KiB LDS slots, one barrier per 64-deep K stage, one fragment read per MFMA and one global_load_lds per one or two
+// MFMAs) fed by the gather of conv_igemm_glds_kernel: C % 64 == 0, so a K stage lies inside ONE tap and a staged row is "pixel offset + a tap offset that is
+// uniform for the wave"; lanes whose tap falls outside the image read the zero page.  Waves 0, 1 stage the two 128-pixel halves of the A tile, waves 2, 3 the
+// weights; BOTH run the same instruction stream — a staging lane keeps, per 1-KiB piece u, an element offset and a packed (y, x), and the wave keeps
+// (dy, dx, tap offset) in scalar registers (weights: y = x = dy = dx = 0, the offset advances by 64) — so the pointer of a piece costs ~10 vector
+// instructions in the MFMA slot where it is issued and no divergence.
+//   NJ = 4: 256 x 256 tile, the dense kernel's LDS image [A0 | A1 | B0 | B1].     NJ = 2: 256 x 128 tile for N = 128 layers: [A0 | A1 | B0 | - ], wave tile
+//   128 x 64, waves 2 and 3 stage half of B0 each (8 pieces per stage), 8 MFMAs and 6 fragment reads per k16 step.
+// Output: dense rows leave through a wave-private LDS tile as whole row segments; strided rows (stride-2 input gradient) as 8-byte pieces.
+// =================================================================================================
+#define CW_SLOT (4 * G_TILE_BYTES)
+#define CW_LDS_BYTES (2 * CW_SLOT + 2048)
+
+__device__ __forceinline__ void conv_epi_value(const ConvArgs& args, float (&v)[4], const float4& b4, const uint2& ax, const uint2& ad) {
+  const uint32_t d0 = ad.x, d1 = ad.y;
+  const float e0 = bf16_bits_to_f32((uint16_t)(d0 & 0xffffu)), e1 = bf16_bits_to_f32((uint16_t)(d0 >> 16));
+  const float e2 = bf16_bits_to_f32((uint16_t)(d1 & 0xffffu)), e3 = bf16_bits_to_f32((uint16_t)(d1 >> 16));
+  if (args.mode == 0) {
+    v[0] = fmaxf(v[0] + b4.x, 0.f); v[1] = fmaxf(v[1] + b4.y, 0.f); v[2] = fmaxf(v[2] + b4.z, 0.f); v[3] = fmaxf(v[3] + b4.w, 0.f);
+  } else if (args.mode == 1) {
+    const uint32_t a0 = ax.x, a1 = ax.y;
+    v[0] = (a0 & 0x7fffu) && !(a0 & 0x8000u) ? v[0] + e0 : 0.f;
+    v[1] = ((a0 >> 16) & 0x7fffu) && !(a0 >> 31) ? v[1] + e1 : 0.f;
+    v[2] = (a1 & 0x7fffu) && !(a1 & 0x8000u) ? v[2] + e2 : 0.f;
+    v[3] = ((a1 >> 16) & 0x7fffu) && !(a1 >> 31) ? v[3] + e3 : 0.f;
+  } else if (args.mode == 3) {
+    v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = (v[r] > 0.f ? v[r] : v[r] * args.p0) * args.p1;
+  } else if (args.mode == 4) {
+    v[0] += args.p0 * e0; v[1] += args.p0 * e1; v[2] += args.p0 * e2; v[3] += args.p0 * e3;
+  }
+}
+
+// accumulator layout of the swapped 32x32 MFMA: acc[i][j][r] = C[mw + i*32 + (lane&31)][nw + j*32 + 8*(r>>2) + 4*(lane>>5) + (r&3)]
+template <int NJ>
+__device__ __forceinline__ void conv_epilogue32(const ConvArgs& args, f32x16 (&acc)[4][NJ], int64_t mw, int64_t nw, int lane, float* wave_bias, unsigned char* stage) {
+  const enh_conv_geom& g = args.g;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const bool dense = g.os == 1 && g.HO == g.Hm && g.WO == g.Wm && g.oph == 0 && g.opw == 0;
+  const bool has_bias = (args.mode == 0 || args.mode == 3) && args.bias;
+  if (lane < NJ * 8) {
+    const float4 bv = has_bias ? *reinterpret_cast<const float4*>(args.bias + nw + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(wave_bias + lane * 4) = bv;
+  }
+  const bool want_aux = args.mode == 1, want_add = (args.mode == 1 || args.mode == 4) && args.add;
+  __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's last fragment reads are done
+  __builtin_amdgcn_s_barrier();         // ... and everybody else's: `stage` overlays the K slots
+  constexpr int CH = 4 * NJ;            // 16-byte chunks per staged row (32*NJ columns of bf16)
+  constexpr int RPP = 64 / CH;          // rows per read-back pass
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t m = mw + i * 32 + l31;
+    const int64_t orow = m < args.M ? (dense ? m : conv_out_pixel(g, m)) * g.N : -1;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      uint2 ax[4], ad[4];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int64_t n = nw + j * 32 + 8 * g4 + 4 * hi;
+        ax[g4] = make_uint2(0u, 0u); ad[g4] = make_uint2(0u, 0u);
+        if (orow >= 0) {
+          if (want_aux) ax[g4] = *reinterpret_cast<const uint2*>(args.aux + orow + n);
+          if (want_add) ad[g4] = *reinterpret_cast<const uint2*>(args.add + orow + n);
+        }
+      }
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        float v[4] = {acc_read(acc[i][j][g4 * 4 + 0]), acc_read(acc[i][j][g4 * 4 + 1]), acc_read(acc[i][j][g4 * 4 + 2]), acc_read(acc[i][j][g4 * 4 + 3])};
+        const float4 b4 = *reinterpret_cast<const float4*>(wave_bias + j * 32 + 8 * g4 + 4 * hi);
+        conv_epi_value(args, v, b4, ax[g4], ad[g4]);
+        const u32x2 o_ = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        if (dense) *reinterpret_cast<u32x2*>(stage + l31 * (CH * 16) + (((j * 4 + g4) ^ (l31 & (CH - 1))) << 4) + hi * 8) = o_;
+        else if (orow >= 0) *reinterpret_cast<u32x2*>(args.out + orow + nw + j * 32 + 8 * g4 + 4 * hi) = o_;
+      }
+    }
+    if (dense) {
+#pragma unroll
+      for (int p = 0; p < 32 / RPP; ++p) {
+        const int row = p * RPP + lane / CH, c = lane % CH;
+        const u32x4 w = *reinterpret_cast<const u32x4*>(stage + row * (CH * 16) + ((c ^ (row & (CH - 1))) << 4));
+        const int64_t mm = mw + i * 32 + row;
+        if (mm < args.M) *reinterpret_cast<u32x4*>(args.out + mm * g.N + nw + c * 8) = w;
+      }
+    }
+  }
+}
+
+template <int NJ>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_igemm_w256_kernel(const ConvArgs args) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2 slots][A0 | A1 | B0 | B1] + bias strips
+  const enh_conv_geom& g = args.g;
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int bid_ = xcd_contiguous((int)blockIdx.x, args.nbm * args.nbn);
+  const int tile_m = bid_ % args.nbm, tile_n = bid_ / args.nbm;
+  const int64_t m0 = (int64_t)tile_m * 256, n0 = (int64_t)tile_n * (64 * NJ);
+  const int nst = (int)(args.K / G_BK);   // >= 2 (launcher)
+
+  // ---- staging state -----------------------------------------------------------------------------------------------------------
+  const bool stage_a = wave < 2;                                   // wave-uniform
+  const int sub = (NJ == 4 || stage_a) ? wave : 2;                 // which 16-KiB sub-tile of a slot this wave fills
+  const int slab0 = (NJ == 2 && wave == 3) ? 8 : 0;                // ... and from which 1-KiB slab on
+  unsigned char* const my_sub = smem + sub * G_TILE_BYTES + slab0 * 1024;
+  const uint16_t* const gbase = stage_a ? args.X : args.Wt;
+  const uint16_t* const zero = reinterpret_cast<const uint16_t*>(g_conv_zero_page);
+  int rowoff[16], pyx[16];
+  {
+    // pixel (b, y, x) of this lane's row of piece 0 by one 32-bit division; the rows of pieces 1..15 are 8 pixels further each
+    const unsigned hw = (unsigned)g.Hm * (unsigned)g.Wm;
+    const unsigned row0 = (unsigned)m0 + wave * 128 + slab0 * 8 + (lane >> 3);
+    unsigned pb = row0 / hw, prem = row0 - pb * hw;
+    unsigned py_ = prem / (unsigned)g.Wm, px_ = prem - py_ * (unsigned)g.Wm;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int r = (slab0 + u) * 8 + (lane >> 3), pc = lane & 7;    // row of the sub-tile, physical chunk ; logical chunk of the row image:
+      const int c = pc ^ ((r >> 1) & 7);
+      if (stage_a) {
+        const bool exists = (int64_t)m0 + wave * 128 + r < args.M;
+        rowoff[u] = exists ? (int)(((pb * g.Hs + py_ * g.gs) * g.Ws + px_ * g.gs) * g.C) + c * 8 : 0;
+        pyx[u] = exists ? (int)(((py_ * g.gs) << 16) | (px_ * g.gs)) : 0x40004000;   // every tap of a row that does not exist falls outside the image
+        px_ += 8;
+        while (px_ >= (unsigned)g.Wm) { px_ -= (unsigned)g.Wm; ++py_; }
+        while (py_ >= (unsigned)g.Hm) { py_ -= (unsigned)g.Hm; ++pb; }
+      } else {
+        rowoff[u] = (int)((n0 + (NJ == 4 ? (wave - 2) * 128 : 0) + r) * args.K) + c * 8;
+        pyx[u] = 0;
+      }
+    }
+  }
+  // scalar tap state of the stage the NEXT request belongs to
+  int s_ch = 0, s_jx = 0, s_jy = 0;
+  int s_dy = stage_a ? g.oy0 : 0, s_dx = stage_a ? g.ox0 : 0;
+  int s_off = stage_a ? (s_dy * g.Ws + s_dx) * g.C : 0;
+  const unsigned lim_y = stage_a ? (unsigned)g.Hs : 1u, lim_x = stage_a ? (unsigned)g.Ws : 1u;
+#define CW_ADVANCE()                                                                                                              \
+  do {                                                                                                                            \
+    if (stage_a) {                                                                                                                \
+      s_ch += G_BK;                                                                                                               \
+      if (s_ch == g.C) { s_ch = 0; if (++s_jx == g.ntx) { s_jx = 0; ++s_jy; } s_dy = g.oy0 + s_jy * g.sty; s_dx = g.ox0 + s_jx * g.stx; } \
+      s_off = (s_dy * g.Ws + s_dx) * g.C + s_ch;                                                                                  \
+    } else s_off += G_BK;                                                                                                         \
+  } while (0)
+#define CW_ISSUE_ONE(SLOT, U)                                                                                                     \
+  do {                                                                                                                            \
+    if (NJ == 4 || (U) < 8 || stage_a) {                                                                                          \
+      const unsigned sy_ = (unsigned)((pyx[U] >> 16) + s_dy), sx_ = (unsigned)((pyx[U] & 0xffff) + s_dx);                         \
+      const uint16_t* p_ = (sy_ < lim_y && sx_ < lim_x) ? gbase + (rowoff[U] + s_off) : zero;                                     \
+      __builtin_amdgcn_global_load_lds((const GLB_AS void*)p_, (LDS_AS void*)(my_sub + (SLOT) * CW_SLOT + (U) * 1024), 16, 0, 0);  \
+    }                                                                                                                             \
+  } while (0)
+#define CW_READ_ONE(FA, FB, SLOT, S, U)                                                                                           \
+  do {                                                                                                                            \
+    if ((U) < 4) FA[(U) & 3] = frag32<false>(smem + (SLOT) * CW_SLOT + wm * G_TILE_BYTES, ((U) & 3) * 32, S, lane);               \
+    else FB[(U) & 3] = frag32<false>(smem + (SLOT) * CW_SLOT + (NJ == 4 ? (2 + wn) * G_TILE_BYTES : 2 * G_TILE_BYTES), (NJ == 4 ? 0 : wn * 64) + ((U) & 3) * 32, S, lane); \
+  } while (0)
+#define CW_MM(Q, FA, FB)                                                                                                          \
+  acc[(Q) / NJ][(Q) % NJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, FB[(Q) % NJ]), __builtin_bit_cast(bf16x8, FA[(Q) / NJ]), acc[(Q) / NJ][(Q) % NJ], 0, 0, 0)
+#define CW_FENCE() __builtin_amdgcn_sched_barrier(0)
+  // one k16 step: 4*NJ MFMAs on (FA, FB); under the first 4 + NJ MFMAs one fragment read each (k-step RS of slot RSLOT into RA / RB); 8 staging requests
+  // (pieces G0 .. G0+7 into slot GSLOT) spread evenly over the MFMAs
+#define CW_KSTEP(FA, FB, RA, RB, RSLOT, RS, DO_READ, GSLOT, G0, DO_ISSUE)                                                         \
+  do {                                                                                                                            \
+    CW_FENCE();                                                                                                                   \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4 * NJ; ++q_) {                                                                       \
+      CW_MM(q_, FA, FB);                                                                                                          \
+      if ((DO_READ) && q_ < 4 + NJ) { CW_READ_ONE(RA, RB, RSLOT, RS, q_); }                                                       \
+      if ((DO_ISSUE) && (NJ == 2 || (q_ & 1))) { CW_ISSUE_ONE(GSLOT, (G0) + (NJ == 2 ? q_ : (q_ >> 1))); }                        \
+      CW_FENCE();                                                                                                                 \
+    }                                                                                                                             \
+  } while (0)
+
+  f32x16 acc[4][NJ];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  s16x8 fa0[4], fb0[4], fa1[4], fb1[4];
+
+  // prologue: stage 0 -> slot 0 completely; pieces 0-7 of stage 1 -> slot 1 (pieces 8-15 follow under the first k-step)
+#pragma unroll
+  for (int u = 0; u < 16; ++u) CW_ISSUE_ONE(0, u);
+  CW_ADVANCE();
+#pragma unroll
+  for (int u = 0; u < 8; ++u) CW_ISSUE_ONE(1, u);
+  __builtin_amdgcn_s_waitcnt(0x0F78);   // vmcnt(8): stage 0 landed (a wave that stages 8 pieces per stage issued exactly 8 after them as well)
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int u = 0; u < 4 + NJ; ++u) CW_READ_ONE(fa0, fb0, 0, 0, u);
+  CW_FENCE();
+
+  // invariant at the top of iteration j: the tap state is at stage j+1, whose pieces 0-7 are already requested into slot (j+1)&1
+  int j = 0;
+  for (; j + 2 < nst; ++j) {
+    const int slot = j & 1;
+    CW_KSTEP(fa0, fb0, fa1, fb1, slot, 1, true, slot ^ 1, 8, true);      // + pieces 8-15 of stage j+1
+    CW_ADVANCE();
+    CW_KSTEP(fa1, fb1, fa0, fb0, slot, 2, true, 0, 0, false);
+    CW_KSTEP(fa0, fb0, fa1, fb1, slot, 3, true, 0, 0, false);
+    __builtin_amdgcn_s_waitcnt(0x0070);    // vmcnt(0): stage j+1 landed (nothing newer outstanding) ; lgkmcnt(0): this slot is read out
+    __builtin_amdgcn_s_barrier();
+    CW_FENCE();
+    CW_KSTEP(fa1, fb1, fa0, fb0, slot ^ 1, 0, true, slot, 0, true);      // + pieces 0-7 of stage j+2 into the slot just vacated
+  }
+  {  // tail: stages nst-2 and nst-1
+    const int slot = j & 1;
+    CW_KSTEP(fa0, fb0, fa1, fb1, slot, 1, true, slot ^ 1, 8, true);      // + pieces 8-15 of stage nst-1
+    CW_KSTEP(fa1, fb1, fa0, fb0, slot, 2, true, 0, 0, false);
+    CW_KSTEP(fa0, fb0, fa1, fb1, slot, 3, true, 0, 0, false);
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    __builtin_amdgcn_s_barrier();
+    CW_FENCE();
+    CW_KSTEP(fa1, fb1, fa0, fb0, slot ^ 1, 0, true, 0, 0, false);
+    CW_KSTEP(fa0, fb0, fa1, fb1, slot ^ 1, 1, true, 0, 0, false);
+    CW_KSTEP(fa1, fb1, fa0, fb0, slot ^ 1, 2, true, 0, 0, false);
+    CW_KSTEP(fa0, fb0, fa1, fb1, slot ^ 1, 3, true, 0, 0, false);
+    CW_KSTEP(fa1, fb1, fa0, fb0, 0, 0, false, 0, 0, false);
+  }
+#undef CW_ADVANCE
+#undef CW_ISSUE_ONE
+#undef CW_READ_ONE
+#undef CW_MM
+#undef CW_KSTEP
+#undef CW_FENCE
+  conv_epilogue32<NJ>(args, acc, m0 + wm * 128, n0 + wn * (32 * NJ), lane, reinterpret_cast<float*>(smem + 2 * CW_SLOT) + wave * 128, smem + wave * 8192);
+}
+
 static int conv_geom_check(const enh_conv_geom* g, const char* who) {
   ENH_REQUIRE(g, ENH_E_BADARG, "%s: geometry is NULL", who);
   ENH_REQUIRE(g->B > 0 && g->Hs > 0 && g->Ws > 0 && g->Hm > 0 && g->Wm > 0 && g->HO > 0 && g->WO > 0, ENH_E_BADARG, "%s: non-positive size", who);
@@ -363,17 +596,39 @@ static int conv_geom_check(const enh_conv_geom* g, const char* who) {
   return ENH_OK;
 }
 
-static int g_conv_variant = 0;   // 0 = per-shape choice, 1 = register-staged kernel everywhere (A/B measurements; explicit state like enh_gemm_set_kernel)
+// 0 = per-shape choice, 1 = register-staged kernel everywhere, 2 = no 256-row kernel (the round-2 choice), 3 = the 256-row kernel wherever the shape allows
+// it, however few tiles (A/B measurements and tests; explicit state like enh_gemm_set_kernel)
+static int g_conv_variant = 0;
 extern "C" int enh_conv_set_kernel(int variant) {
-  ENH_REQUIRE(variant == 0 || variant == 1, ENH_E_BADARG, "enh_conv_set_kernel: variant must be 0 (auto) or 1 (register-staged)");
+  ENH_REQUIRE(variant >= 0 && variant <= 3, ENH_E_BADARG, "enh_conv_set_kernel: variant must be 0 (auto), 1 (register-staged), 2 (128-row kernels), 3 (256-row kernel wherever possible)");
   g_conv_variant = variant;
   return ENH_OK;
+}
+
+// the 256-row kernel: whole K stages inside one tap, whole N tiles, 32-bit element offsets, (y, x) in 14 bits each; 0 = not applicable, else NJ
+static int conv_w256_nj(const ConvArgs& a) {
+  const enh_conv_geom& g = a.g;
+  if (g_conv_variant == 1 || g_conv_variant == 2) return 0;
+  if (g.C % G_BK != 0 || a.K < 4 * G_BK || g.N % 128 != 0) return 0;
+  if (a.M >= (1ll << 31) - 512 || (int64_t)g.B * g.Hs * g.Ws * g.C >= (1ll << 31) || (int64_t)g.N * a.K >= (1ll << 31) || g.Hs > 16000 || g.Ws > 16000) return 0;
+  if ((int64_t)(g.Hm - 1) * g.gs > 16000 || (int64_t)(g.Wm - 1) * g.gs > 16000) return 0;
+  const int nj = g.N % 256 == 0 ? 4 : 2;
+  if (g_conv_variant == 3) return nj;
+  // per-shape choice (B = 16 layer table, profiles/r04_conv_layers.txt): 256 x 256 tiles with dense output rows win 1.2-1.4x (760 -> 930, 764 -> 1052 TF/s);
+  // the 256 x 128 form loses to the 128 x 128 kernel (614 -> 513: same LDS traffic per MFMA, half the workgroups in flight), and so do the parity
+  // classes of a stride-2 input gradient (1-4 taps: two to eight K stages per tile, the deeper prologue is not amortised: 408 -> 326)
+  const bool dense = g.os == 1 && g.HO == g.Hm && g.WO == g.Wm && g.oph == 0 && g.opw == 0;
+  if (nj != 4 || !dense) return 0;
+  const int64_t tiles = ((a.M + 255) / 256) * (g.N / 256);
+  return tiles >= enh_device_cus() ? nj : 0;   // below one tile per CU the 128-row kernels (four times the workgroups, two per CU) fill the chip better
 }
 
 static void conv_lds_attr_once() {
   static const bool attr_set = [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_glds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G_TILE_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G_TILE_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_w256_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_w256_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS_BYTES);
     return true;
   }();
   (void)attr_set;
@@ -393,7 +648,12 @@ extern "C" int enh_conv_nhwc_bf16(const enh_bf16* src, const enh_bf16* wt, const
   a.nbm = (int)((a.M + G_BM - 1) / G_BM); a.nbn = (g->N + G_BN - 1) / G_BN;
   ENH_REQUIRE((int64_t)a.nbm * a.nbn < (1ll << 30), ENH_E_SHAPE, "enh_conv_nhwc_bf16: grid too large");
   conv_lds_attr_once();
-  if (g->C % G_BK == 0 && a.K >= 2 * G_BK && g_conv_variant != 1)
+  const int nj = conv_w256_nj(a);
+  if (nj) {
+    a.nbm = (int)((a.M + 255) / 256); a.nbn = g->N / (64 * nj);
+    if (nj == 4) conv_igemm_w256_kernel<4><<<dim3((unsigned)(a.nbm * a.nbn)), 256, CW_LDS_BYTES, (hipStream_t)stream>>>(a);
+    else conv_igemm_w256_kernel<2><<<dim3((unsigned)(a.nbm * a.nbn)), 256, CW_LDS_BYTES, (hipStream_t)stream>>>(a);
+  } else if (g->C % G_BK == 0 && a.K >= 2 * G_BK && g_conv_variant != 1)
     conv_igemm_glds_kernel<<<dim3((unsigned)(a.nbm * a.nbn)), 256, 4 * G_TILE_BYTES, (hipStream_t)stream>>>(a);
   else
     conv_igemm_kernel<<<dim3((unsigned)(a.nbm * a.nbn)), 256, 4 * G_TILE_BYTES, (hipStream_t)stream>>>(a);

@@ -248,7 +248,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_pipe2_kernel(const GemmArgs 
 #define G4_BM 256
 #define G4_BN 256
 #define G4_STAGE_BYTES (4 * G_TILE_BYTES)
-__device__ __forceinline__ int lds_kmaj2_off(int k, int q) { return k * 256 + ((q ^ (((k & 3) << 1) | ((k >> 2) & 1))) << 5); }
 
 template <bool TR>
 __device__ __forceinline__ const uint16_t* glds_src_ptr2(const uint16_t* __restrict__ P, int64_t ld, int64_t x0, int64_t X,
@@ -260,26 +259,6 @@ __device__ __forceinline__ const uint16_t* glds_src_ptr2(const uint16_t* __restr
   if (col > X - 8) col = X - 8;
   return P + (k_begin + k) * ld + col;
 }
-// 32x32x16 operand fragment: index = base + (lane & 31), k = s*16 + (lane>>5)*8 + 0..7
-template <bool TR>
-__device__ __forceinline__ s16x8 frag32(const unsigned char* tile, int base, int s, int lane) {
-  const int l31 = lane & 31, hi = lane >> 5;
-  if (!TR) {
-    return *reinterpret_cast<const s16x8*>(tile + lds_row_off(base + l31, s * 2 + hi));
-  } else {
-    const int G = lane >> 4, s16 = lane & 15;
-    const int kr = s * 16 + hi * 8 + (s16 >> 2);
-    const int q = (base >> 4) + (G & 1);
-    typedef __attribute__((ext_vector_type(2))) unsigned long long u64x2;
-    u64x2 o;
-    unsigned long long lo, up;
-    lds_tr_read_b64_asm(lo, tile + lds_kmaj2_off(kr, q) + (s16 & 3) * 8);
-    lds_tr_read_b64_asm(up, tile + lds_kmaj2_off(kr + 4, q) + (s16 & 3) * 8);
-    o[0] = lo; o[1] = up;
-    return __builtin_bit_cast(s16x8, o);
-  }
-}
-
 // epilogue for the swapped 32x32 accumulator layout: acc[i][j][r] = C[mw + i*32 + (lane&31)][nw + j*32 + 8*(r>>2) + 4*(lane>>5) + (r&3)]
 template <int MODE, int NJ, bool BOUNDS>
 __device__ __forceinline__ void gemm_epilogue32_loops(const GemmArgs& args, f32x16 (&acc)[4][NJ], int64_t mw, int64_t nw, int lane, int split, float* wave_bias,
@@ -630,11 +609,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 // accumulator -> vector register AT THIS POINT of the instruction stream (the register allocator otherwise copies all 256 accumulators out at the top
 // of the epilogue: 256 live registers, spills, and scratch reloads are vector-memory operations that wait on the next tile's requests)
-__device__ __forceinline__ float acc_read(float a) {
-  float x;
-  asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(a));
-  return x;
-}
+// (acc_read: gemm_tiles.h)
 
 template <int MODE>
 __device__ __forceinline__ void gemm_epilogue_p(const GemmArgs& args, f32x16 (&acc)[4][4], int64_t mw, int64_t nw, int lane_in, float* wave_bias, unsigned char* st,

@@ -20,6 +20,38 @@
 __device__ __forceinline__ int lds_row_off(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
 __device__ __forceinline__ int lds_kmaj_off(int k, int q) { return k * 256 + ((q ^ ((k & 3) | (((k >> 3) & 1) << 2))) << 5); }
 
+// ---- 32x32x16 fragments of the 256 x 256 kernels (gemm.hip w256 family, conv_igemm.hip conv_igemm_w256_kernel) ------------------------------
+// second contraction-major image ("kmaj2": chunk q ^ (2*(k&3) | (k>>2)&1)): keeps the 32-column transpose reads of this fragment shape conflict-free
+__device__ __forceinline__ int lds_kmaj2_off(int k, int q) { return k * 256 + ((q ^ (((k & 3) << 1) | ((k >> 2) & 1))) << 5); }
+// 32x32x16 operand fragment: index = base + (lane & 31), k = s*16 + (lane>>5)*8 + 0..7
+template <bool TR>
+__device__ __forceinline__ s16x8 frag32(const unsigned char* tile, int base, int s, int lane) {
+  const int l31 = lane & 31, hi = lane >> 5;
+  if (!TR) {
+    return *reinterpret_cast<const s16x8*>(tile + lds_row_off(base + l31, s * 2 + hi));
+  } else {
+    const int G = lane >> 4, s16 = lane & 15;
+    const int kr = s * 16 + hi * 8 + (s16 >> 2);
+    const int q = (base >> 4) + (G & 1);
+    typedef __attribute__((ext_vector_type(2))) unsigned long long u64x2;
+    u64x2 o;
+    unsigned long long lo, up;
+    lds_tr_read_b64_asm(lo, tile + lds_kmaj2_off(kr, q) + (s16 & 3) * 8);
+    lds_tr_read_b64_asm(up, tile + lds_kmaj2_off(kr + 4, q) + (s16 & 3) * 8);
+    o[0] = lo; o[1] = up;
+    return __builtin_bit_cast(s16x8, o);
+  }
+}
+
+
+// accumulator -> vector register AT THIS POINT of the instruction stream (left to the register allocator, an epilogue over 256 accumulators copies all of
+// them out at its top: 256 live registers and spills)
+__device__ __forceinline__ float acc_read(float a) {
+  float x;
+  asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(a));
+  return x;
+}
+
 struct GemmArgs {
   const uint16_t* A; int64_t lda;
   const uint16_t* B; int64_t ldb;

@@ -144,8 +144,10 @@ def lib():
             f, q, k = (int(x) for x in att.split(","))
             if L.enh_attention_set_kernel(f, q, k) != 0:
                 raise RuntimeError(L.enh_last_error().decode())
-        if os.environ.get("ENH_CONV_KERNEL") == "reg" and L.enh_conv_set_kernel(1) != 0:      # A/B: register-staged convolution kernel everywhere
-            raise RuntimeError(L.enh_last_error().decode())
+        conv = os.environ.get("ENH_CONV_KERNEL")      # A/B: "reg" register-staged everywhere | "t128" no 256-row kernels | "t256" 256-row wherever the shape allows
+        if conv:
+            if conv not in CONV_KERNELS or L.enh_conv_set_kernel(CONV_KERNELS[conv]) != 0:
+                raise RuntimeError(f"ENH_CONV_KERNEL={conv!r}: expected one of {sorted(CONV_KERNELS)}")
     return _LIB
 
 
@@ -383,6 +385,14 @@ _DEVICE_CUS = [None]
 
 
 _DYN_SCHEDULE = [True]      # mirrors the library's default (enh_gemm_set_scheduler), for timing labels only
+
+
+CONV_KERNELS = {"auto": 0, "reg": 1, "t128": 2, "t256": 3}
+
+
+def conv_set_kernel(name: str) -> None:
+    """kernel family of the implicit-GEMM convolutions (enh_conv_set_kernel / enh_conv_wgrad_set_kernel are one switch here): auto | reg | t128 | t256"""
+    _check(lib().enh_conv_set_kernel(CONV_KERNELS[name]), "enh_conv_set_kernel")
 
 
 def gemm_set_scheduler(dynamic: bool) -> None:

@@ -322,8 +322,10 @@ typedef struct enh_conv_geom {
  *   mode 4: acc + p0 * add[o,n]                     (StyleBlock's (out + skip) / sqrt(2), layers.py:262, folded into the skip convolution) */
 int enh_conv_nhwc_bf16(const enh_bf16* src, const enh_bf16* wt, const enh_conv_geom* g, int mode, const float* bias, const enh_bf16* aux,
                        const enh_bf16* add, float p0, float p1, enh_bf16* out, void* stream);
-/* kernel choice of enh_conv_nhwc_bf16 for A/B measurements (explicit library state, like enh_gemm_set_kernel): 0 = per shape (LDS-DMA kernel when
- * C % 64 == 0, register-staged otherwise), 1 = register-staged everywhere */
+/* kernel choice of enh_conv_nhwc_bf16 / enh_conv_wgrad_nhwc_bf16 for A/B measurements (explicit library state, like enh_gemm_set_kernel):
+ * 0 = per shape (256-row tiles when C % 64 == 0, N % 128 == 0, at least four K stages and one tile per CU; else the 128 x 128 LDS-DMA kernel when
+ * C % 64 == 0; else register-staged), 1 = register-staged everywhere, 2 = never the 256-row kernels (the round-2 choice), 3 = the 256-row kernels
+ * wherever the shape allows them, however few tiles */
 int enh_conv_set_kernel(int variant);
 /* dw[n][tap*C + c] = sum over pixels (b,y,x) of dy[b,y,x,n] * src[b, y*gs + oy0 + jy*sty, x*gs + ox0 + jx*stx, c]   (f32, overwritten).
  * The pixel axis is split over the grid; partial slabs go to `ws` (enh_conv_wgrad_workspace_bytes) and are added in a fixed order. */

@@ -23,6 +23,16 @@ def ops():
     return conv_nhwc
 
 
+@pytest.fixture(params=["auto", "t256"])
+def family(request):
+    """kernel family of the implicit-GEMM convolutions: the per-shape choice, and the 256-row kernels wherever the shape allows them (at test sizes the
+    per-shape choice never picks them: fewer tiles than CUs)"""
+    from enhancing import _C
+    _C.conv_set_kernel(request.param)
+    yield request.param
+    _C.conv_set_kernel("auto")
+
+
 def _nhwc(x_nchw):
     return x_nchw.permute(0, 2, 3, 1).contiguous()
 
@@ -35,11 +45,14 @@ def _nchw(x_nhwc):
 CASES = [(2, 16, 16, 3, 128, 1, 1, 0), (2, 16, 20, 64, 128, 3, 1, 1), (3, 17, 17, 64, 136, 3, 2, 0), (2, 15, 15, 40, 64, 1, 2, 0),
          (8, 4, 4, 513, 512, 3, 1, 1), (1, 70, 66, 24, 72, 3, 1, 1), (1, 35, 35, 96, 128, 3, 2, 0), (2, 33, 33, 128, 256, 3, 2, 0),
          # geometries the discriminator never uses: padded stride 2, stride 3 (nine parity classes), a 5 x 5 kernel
-         (2, 10, 8, 24, 64, 3, 2, 1), (1, 11, 10, 16, 32, 3, 3, 1), (2, 6, 6, 8, 16, 5, 2, 2), (2, 12, 12, 64, 64, 3, 2, 1)]
+         (2, 10, 8, 24, 64, 3, 2, 1), (1, 11, 10, 16, 32, 3, 3, 1), (2, 6, 6, 8, 16, 5, 2, 2), (2, 12, 12, 64, 64, 3, 2, 1),
+         # shapes the 256-row kernels take (C % 64 == 0, N % 128 == 0): 256 x 256 and 256 x 128 tiles, ragged last row tile, two column tiles, rows shorter
+         # than the 8-pixel staging step, padded stride 2 (strided output rows in the input gradient)
+         (2, 24, 24, 128, 256, 3, 1, 1), (1, 20, 12, 256, 512, 3, 1, 1), (5, 6, 5, 128, 128, 3, 1, 1), (2, 19, 18, 128, 256, 3, 2, 1)]
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,k,s,p", CASES)
-def test_conv_forward_dgrad_wgrad(ops, B, H, W, Cin, Cout, k, s, p):
+def test_conv_forward_dgrad_wgrad(ops, family, B, H, W, Cin, Cout, k, s, p):
     g = torch.Generator().manual_seed(Cin * 7 + Cout)
     Cp = ops.pad8(Cin)
     x = bf16r(torch.randn(B, Cin, H, W, generator=g))
@@ -68,8 +81,8 @@ def test_conv_forward_dgrad_wgrad(ops, B, H, W, Cin, Cout, k, s, p):
         assert not gx[:, Cin:].abs().sum().item()           # gradient of the zero padding channels: zero rows of the transposed weights
 
 
-@pytest.mark.parametrize("B,H,W,Cin,Cout,k,s,p", [(2, 16, 16, 64, 128, 3, 1, 1), (2, 17, 17, 32, 64, 3, 2, 0), (2, 15, 15, 32, 64, 1, 2, 0)])
-def test_fused_epilogues_and_second_order(ops, B, H, W, Cin, Cout, k, s, p):
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,s,p", [(2, 16, 16, 64, 128, 3, 1, 1), (2, 17, 17, 32, 64, 3, 2, 0), (2, 15, 15, 32, 64, 1, 2, 0), (2, 17, 17, 128, 256, 3, 2, 0)])
+def test_fused_epilogues_and_second_order(ops, family, B, H, W, Cin, Cout, k, s, p):
     """conv + bias + leaky-ReLU and conv + residual merge in one kernel: values, first derivatives, and the R1-style second-order term
     d/d(w, bias) of |d out / d x|^2 (differentiates THROUGH _Dgrad and _Gate) against torch autograd on the same operands"""
     from enhancing.losses.op import conv2d_gradfix

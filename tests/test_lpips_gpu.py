@@ -25,8 +25,17 @@ def _nchw(x):     # [B,H,W,C] bf16 device -> [B,C,H,W] f32 host
     return x.float().cpu().permute(0, 3, 1, 2).contiguous()
 
 
+@pytest.mark.parametrize("family", ["auto", "t256"])
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 16, 16, 64, 64), (1, 8, 24, 128, 256), (3, 4, 4, 512, 512), (2, 32, 32, 64, 128)])
-def test_conv3x3_implicit_gemm_all_modes(C, B, H, W, Cin, Cout):
+def test_conv3x3_implicit_gemm_all_modes(C, family, B, H, W, Cin, Cout):
+    C.conv_set_kernel(family)       # t256: the 256-row kernels wherever C % 64 == 0 and N % 128 == 0 (the per-shape choice needs one tile per CU)
+    try:
+        _conv3x3_all_modes(C, B, H, W, Cin, Cout)
+    finally:
+        C.conv_set_kernel("auto")
+
+
+def _conv3x3_all_modes(C, B, H, W, Cin, Cout):
     g = torch.Generator().manual_seed(B + H + Cin)
     x = bf16r(torch.randn(B, Cin, H, W, generator=g))
     w = bf16r(torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5)

@@ -1,5 +1,5 @@
 """Per-layer timing of the discriminator's implicit-GEMM convolutions (forward / input gradient / weight gradient) at the real layer shapes.
-Usage (GPU box): python tools/conv_bench.py [batch]"""
+Usage (GPU box): python tools/conv_bench.py [batch] [auto|reg|t128|t256]"""
 import os
 import sys
 
@@ -10,6 +10,9 @@ sys.path.insert(0, os.path.join(ROOT, "enhancing-transformers_amd"))
 from enhancing.losses.op import conv_nhwc as cn  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+if len(sys.argv) > 2:
+    cn._C.conv_set_kernel(sys.argv[2])
+    print(f"kernel family: {sys.argv[2]}")
 # H, Cin, Cout, k, stride, pad (input spatial size H x H)
 LAYERS = [(256, 8, 128, 1, 1, 0), (256, 128, 128, 3, 1, 1), (257, 128, 256, 3, 2, 0), (255, 128, 256, 1, 2, 0), (128, 256, 256, 3, 1, 1),
           (129, 256, 512, 3, 2, 0), (64, 512, 512, 3, 1, 1), (65, 512, 512, 3, 2, 0), (32, 512, 512, 3, 1, 1), (16, 512, 512, 3, 1, 1)]
