@@ -775,6 +775,165 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_igemm_kernel(const ConvWgra
   gemm_epilogue(args.e, acc, m0, n0, wm, wn, lg, l16, split);
 }
 
+// =================================================================================================
+// "w256" form of the weight gradient (round 4): the dense split-K weight-gradient kernel (gemm_bf16_w256_kernel<true, true, EPI_WS>: both operands
+// contraction-major in the "kmaj2" LDS image, transpose reads, 256 x 256 tile, one wave per SIMD) with the gathered operand fetched by global_load_lds.
+// The contraction runs over pixels; a 64-pixel K stage of a grid whose width is a multiple of 64 lies inside ONE image row, and a 128-column sub-tile of
+// (tap, channel) with C % 128 == 0 inside ONE tap — so the wave that stages a B sub-tile keeps (image, row, first column, validity of the source row, base
+// pointer) in SCALAR registers, and a lane keeps two 32-bit offsets: per 1-KiB piece the pointer is "scalar base + lane offset", the horizontal padding
+// a single unsigned compare, lanes outside the image read the zero page.  Waves 0, 1 stage dy (a plain matrix) through the same instruction stream.
+// Split over the pixel axis; partial slabs to the workspace, added in a fixed order by splitk_reduce_kernel (deterministic).
+// =================================================================================================
+template <bool BOUNDS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_wgrad_w256_kernel(const ConvWgradArgs args) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2 slots][A0 | A1 | B0 | B1]
+  const enh_conv_geom& g = args.g;
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nwg = args.e.nbm * args.e.nbn;
+  const int lin = xcd_contiguous((int)blockIdx.x, nwg * args.e.splits);   // all tiles of one pixel slice on one XCD: they re-read the same pixels
+  const int split = lin / nwg, bid = lin - split * nwg;
+  const int tile_m = bid % args.e.nbm, tile_n = bid / args.e.nbm;
+  const int64_t m0 = (int64_t)tile_m * 256, n0 = (int64_t)tile_n * 256;
+  const int64_t k_begin = (int64_t)split * args.e.k_per_split;
+  int64_t k_end = k_begin + args.e.k_per_split;
+  if (k_end > args.e.K) k_end = args.e.K;
+  const int nst = (int)((k_end - k_begin) / G_BK);   // >= 2 (launcher)
+
+  // ---- staging state: pointer of piece u = s_base + (u odd ? voff_o : voff_e) + (u >> 1) * step2, valid iff s_ok && vx0 + u * vxstep + s_x < lim ----
+  const bool stage_a = wave < 2;                                   // wave-uniform
+  const int l4 = lane >> 4, pp = lane & 15;
+  const int col_e = (((pp >> 1) ^ (l4 << 1)) << 4) + (pp & 1) * 8;        // kmaj2 image, k-row 4u + l4: chunk q ^ (2 * (k & 3) | (k >> 2) & 1)
+  const int col_o = (((pp >> 1) ^ ((l4 << 1) | 1)) << 4) + (pp & 1) * 8;
+  const uint16_t* const zero = reinterpret_cast<const uint16_t*>(g_conv_zero_page);
+  int voff_e, voff_o, step2;
+  unsigned vx0, vxstep, lim, s_x;
+  bool s_ok;
+  const uint16_t* s_base;
+  int s_b = 0, s_y = 0, s_x0 = 0, dy_ = 0, dx_ = 0, ch0 = 0;
+  bool sub_ok = true;
+  if (stage_a) {
+    const int ld = g.N;
+    voff_e = l4 * ld + col_e; voff_o = (4 + l4) * ld + col_o; step2 = 8 * ld;
+    vx0 = 0u; vxstep = 0u; lim = 1u; s_x = 0u; s_ok = true;
+    s_base = args.DY + k_begin * ld + m0 + wave * 128;
+  } else {
+    const int64_t nb = n0 + (wave - 2) * 128;
+    sub_ok = nb < args.e.N;
+    const int tap = sub_ok ? (int)(nb / g.C) : 0;
+    ch0 = sub_ok ? (int)(nb - (int64_t)tap * g.C) : 0;
+    const int jy = tap / g.ntx, jx = tap - jy * g.ntx;
+    dy_ = g.oy0 + jy * g.sty; dx_ = g.ox0 + jx * g.stx;
+    const int pix = g.gs * g.C;
+    voff_e = l4 * pix + col_e; voff_o = (4 + l4) * pix + col_o; step2 = 8 * pix;
+    vx0 = (unsigned)(l4 * g.gs); vxstep = (unsigned)(4 * g.gs); lim = (unsigned)g.Ws;
+    const int64_t hw = (int64_t)g.Hm * g.Wm;
+    s_b = (int)(k_begin / hw);
+    const int rem = (int)(k_begin - (int64_t)s_b * hw);
+    s_y = rem / g.Wm; s_x0 = rem - s_y * g.Wm;
+    const int sy = s_y * g.gs + dy_;
+    s_ok = sub_ok && (unsigned)sy < (unsigned)g.Hs;
+    s_x = (unsigned)(s_x0 * g.gs + dx_);
+    s_base = args.X + (((int64_t)s_b * g.Hs + sy) * g.Ws + (int64_t)s_x0 * g.gs + dx_) * g.C + ch0;
+  }
+  unsigned char* const my_sub = smem + wave * G_TILE_BYTES;
+#define WW_ADVANCE()                                                                                                              \
+  do {                                                                                                                            \
+    if (stage_a) s_base += (int64_t)G_BK * g.N;                                                                                   \
+    else {                                                                                                                        \
+      s_x0 += G_BK;                                                                                                               \
+      if (s_x0 == g.Wm) { s_x0 = 0; if (++s_y == g.Hm) { s_y = 0; ++s_b; } }                                                      \
+      const int sy_ = s_y * g.gs + dy_;                                                                                           \
+      s_ok = sub_ok && (unsigned)sy_ < (unsigned)g.Hs;                                                                            \
+      s_x = (unsigned)(s_x0 * g.gs + dx_);                                                                                        \
+      s_base = args.X + (((int64_t)s_b * g.Hs + sy_) * g.Ws + (int64_t)s_x0 * g.gs + dx_) * g.C + ch0;                            \
+    }                                                                                                                             \
+  } while (0)
+#define WW_ISSUE_ONE(SLOT, U)                                                                                                     \
+  do {                                                                                                                            \
+    const unsigned vx_ = vx0 + (unsigned)(U) * vxstep + s_x;                                                                      \
+    const uint16_t* p_ = (s_ok && vx_ < lim) ? s_base + ((((U) & 1) ? voff_o : voff_e) + ((U) >> 1) * step2) : zero;              \
+    __builtin_amdgcn_global_load_lds((const GLB_AS void*)p_, (LDS_AS void*)(my_sub + (SLOT) * CW_SLOT + (U) * 1024), 16, 0, 0);    \
+  } while (0)
+#define WW_READ_ONE(FA, FB, SLOT, S, U)                                                                                           \
+  do {                                                                                                                            \
+    if ((U) < 4) FA[(U) & 3] = frag32<true>(smem + (SLOT) * CW_SLOT + wm * G_TILE_BYTES, ((U) & 3) * 32, S, lane);                \
+    else FB[(U) & 3] = frag32<true>(smem + (SLOT) * CW_SLOT + (2 + wn) * G_TILE_BYTES, ((U) & 3) * 32, S, lane);                  \
+  } while (0)
+#define WW_MM(Q, FA, FB)                                                                                                          \
+  acc[(Q) >> 2][(Q) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, FB[(Q) & 3]), __builtin_bit_cast(bf16x8, FA[(Q) >> 2]), acc[(Q) >> 2][(Q) & 3], 0, 0, 0)
+#define WW_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define WW_KSTEP(FA, FB, RA, RB, RSLOT, RS, DO_READ, GSLOT, G0, DO_ISSUE)                                                         \
+  do {                                                                                                                            \
+    __builtin_amdgcn_s_waitcnt(0xC07F); /* the asm transpose reads are invisible to the compiler's wait-count pass */               \
+    WW_FENCE();                                                                                                                   \
+    _Pragma("unroll") for (int q_ = 0; q_ < 16; ++q_) {                                                                           \
+      WW_MM(q_, FA, FB);                                                                                                          \
+      if ((DO_READ) && q_ < 8) { WW_READ_ONE(RA, RB, RSLOT, RS, q_); }                                                            \
+      if ((DO_ISSUE) && (q_ & 1)) { WW_ISSUE_ONE(GSLOT, (G0) + (q_ >> 1)); }                                                      \
+      WW_FENCE();                                                                                                                 \
+    }                                                                                                                             \
+  } while (0)
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  s16x8 fa0[4], fb0[4], fa1[4], fb1[4];
+
+#pragma unroll
+  for (int u = 0; u < 16; ++u) WW_ISSUE_ONE(0, u);
+  WW_ADVANCE();
+#pragma unroll
+  for (int u = 0; u < 8; ++u) WW_ISSUE_ONE(1, u);
+  __builtin_amdgcn_s_waitcnt(0x0F78);   // vmcnt(8): stage 0 landed
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int u = 0; u < 8; ++u) WW_READ_ONE(fa0, fb0, 0, 0, u);
+  WW_FENCE();
+
+  // invariant at the top of iteration j: the staging state is at stage j+1, whose pieces 0-7 are already requested into slot (j+1)&1
+  int j = 0;
+  for (; j + 2 < nst; ++j) {
+    const int slot = j & 1;
+    WW_KSTEP(fa0, fb0, fa1, fb1, slot, 1, true, slot ^ 1, 8, true);      // + pieces 8-15 of stage j+1
+    WW_ADVANCE();
+    WW_KSTEP(fa1, fb1, fa0, fb0, slot, 2, true, 0, 0, false);
+    WW_KSTEP(fa0, fb0, fa1, fb1, slot, 3, true, 0, 0, false);
+    __builtin_amdgcn_s_waitcnt(0x0070);    // vmcnt(0): stage j+1 landed ; lgkmcnt(0): this slot is read out
+    __builtin_amdgcn_s_barrier();
+    WW_FENCE();
+    WW_KSTEP(fa1, fb1, fa0, fb0, slot ^ 1, 0, true, slot, 0, true);      // + pieces 0-7 of stage j+2 into the slot just vacated
+  }
+  {  // tail: stages nst-2 and nst-1
+    const int slot = j & 1;
+    WW_KSTEP(fa0, fb0, fa1, fb1, slot, 1, true, slot ^ 1, 8, true);      // + pieces 8-15 of stage nst-1
+    WW_KSTEP(fa1, fb1, fa0, fb0, slot, 2, true, 0, 0, false);
+    WW_KSTEP(fa0, fb0, fa1, fb1, slot, 3, true, 0, 0, false);
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    __builtin_amdgcn_s_barrier();
+    WW_FENCE();
+    WW_KSTEP(fa1, fb1, fa0, fb0, slot ^ 1, 0, true, 0, 0, false);
+    WW_KSTEP(fa0, fb0, fa1, fb1, slot ^ 1, 1, true, 0, 0, false);
+    WW_KSTEP(fa1, fb1, fa0, fb0, slot ^ 1, 2, true, 0, 0, false);
+    WW_KSTEP(fa0, fb0, fa1, fb1, slot ^ 1, 3, true, 0, 0, false);
+    WW_KSTEP(fa1, fb1, fa0, fb0, 0, 0, false, 0, 0, false);
+  }
+#undef WW_ADVANCE
+#undef WW_ISSUE_ONE
+#undef WW_READ_ONE
+#undef WW_MM
+#undef WW_KSTEP
+#undef WW_FENCE
+  gemm_epilogue32_loops<EPI_WS, 4, BOUNDS>(args.e, acc, m0 + wm * 128, n0 + wn * 128, lane, split, reinterpret_cast<float*>(smem + 2 * CW_SLOT) + wave * 128,
+                                           smem + wave * 8192, smem + wave * 16384);
+}
+
 struct WgradPlan { int splits; int64_t k_per_split; };
 static WgradPlan conv_wgrad_plan(int64_t M, int64_t N, int64_t K) {
   const int64_t tiles = ((M + G_BM - 1) / G_BM) * ((N + G_BN - 1) / G_BN);
@@ -787,11 +946,38 @@ static WgradPlan conv_wgrad_plan(int64_t M, int64_t N, int64_t K) {
   return {(int)splits, per};
 }
 
+// the 256-row kernel's plan: one workgroup per CU, the pixel axis cut so that tiles x slices just fills the CU budget; {0, 0} = not applicable
+static WgradPlan conv_wgrad_w256_plan(const enh_conv_geom& g, int64_t M, int64_t N, int64_t K, int cus) {
+  const WgradPlan none = {0, 0};
+  if (g_conv_variant == 1 || g_conv_variant == 2) return none;
+  if (M % 256 != 0 || g.C % 128 != 0 || g.Wm % G_BK != 0 || K % G_BK != 0 || g.ntx <= 0 || g.nty <= 0) return none;
+  if ((int64_t)g.B * g.Hs * g.Ws * g.C >= (1ll << 31) || K >= (1ll << 31) || (int64_t)g.gs * g.C * 64 >= (1 << 30) || (int64_t)g.N * 64 >= (1 << 30)) return none;
+  const int64_t tiles = (M / 256) * ((N + 255) / 256), stages = K / G_BK;
+  int64_t splits = cus / tiles;
+  if (splits > stages / 8) splits = stages / 8;         // at least 8 K stages per slice
+  if (splits < 2) return none;                          // (the epilogue instantiated for this kernel is the workspace one)
+  const int64_t per = ((stages + splits - 1) / splits) * G_BK;
+  splits = (K + per - 1) / per;
+  if (splits < 2 || K - (splits - 1) * per < 2 * G_BK) return none;
+  return {(int)splits, per};
+}
+
+static void conv_wgrad_dims(const enh_conv_geom* g, int64_t& M, int64_t& N, int64_t& K) {
+  M = g->N; N = (int64_t)g->nty * g->ntx * g->C; K = (int64_t)g->B * g->Hm * g->Wm;
+}
+
+// sized for whichever kernel family and CU budget is selected LATER as well (enh_conv_set_kernel / enh_set_cu_budget may change between the query and the call)
 extern "C" size_t enh_conv_wgrad_workspace_bytes(const enh_conv_geom* g) {
   if (!g || g->N <= 0 || g->C <= 0) return 0;
-  const int64_t M = g->N, N = (int64_t)g->nty * g->ntx * g->C, K = (int64_t)g->B * g->Hm * g->Wm;
+  int64_t M, N, K;
+  conv_wgrad_dims(g, M, N, K);
   const WgradPlan p = conv_wgrad_plan(M, N, K);
-  return p.splits > 1 ? (size_t)p.splits * M * N * sizeof(float) : 0;
+  const int keep = g_conv_variant;
+  g_conv_variant = 0;
+  const WgradPlan q = conv_wgrad_w256_plan(*g, M, N, K, enh_device_cus());
+  g_conv_variant = keep;
+  const int splits = p.splits > q.splits ? p.splits : q.splits;
+  return splits > 1 ? (size_t)splits * M * N * sizeof(float) : 0;
 }
 
 extern "C" int enh_conv_wgrad_nhwc_bf16(const enh_bf16* src, const enh_bf16* dy, const enh_conv_geom* g, float* dw, void* ws, size_t ws_bytes, void* stream) {
@@ -806,12 +992,12 @@ extern "C" int enh_conv_wgrad_nhwc_bf16(const enh_bf16* src, const enh_bf16* dy,
   a.X = src; a.DY = dy; a.g = gg;
   GemmArgs& e = a.e;
   e.A = nullptr; e.lda = 0; e.B = nullptr; e.ldb = 0;
-  e.M = g->N; e.N = (int64_t)g->nty * g->ntx * g->C; e.K = (int64_t)g->B * g->Hm * g->Wm;
-  const WgradPlan p = conv_wgrad_plan(e.M, e.N, e.K);
+  conv_wgrad_dims(g, e.M, e.N, e.K);
+  const WgradPlan big = conv_wgrad_w256_plan(gg, e.M, e.N, e.K, enh_cu_budget());
+  const WgradPlan p = big.splits ? big : conv_wgrad_plan(e.M, e.N, e.K);
   e.k_per_split = p.k_per_split; e.splits = p.splits;
   e.bias = nullptr; e.act = ENH_ACT_NONE; e.aux = nullptr; e.ldaux = 0; e.res = nullptr; e.ldres = 0; e.res_rows = 0;
   e.c_bf16 = nullptr; e.c_f32 = dw; e.ldc = e.N; e.ws = nullptr; e.accumulate = 0;
-  e.nbm = (int)((e.M + G_BM - 1) / G_BM); e.nbn = (int)((e.N + G_BN - 1) / G_BN);
   const int64_t MN = e.M * e.N;
   if (p.splits > 1) {
     ENH_REQUIRE(ws && ws_bytes >= (size_t)p.splits * MN * sizeof(float), ENH_E_WORKSPACE, "enh_conv_wgrad_nhwc_bf16: workspace too small (%zu < %zu bytes)",
@@ -820,11 +1006,21 @@ extern "C" int enh_conv_wgrad_nhwc_bf16(const enh_bf16* src, const enh_bf16* dy,
   }
   static const bool attr_set = [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_igemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G_TILE_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_w256_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_w256_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS_BYTES);
     return true;
   }();
   (void)attr_set;
   hipStream_t s = (hipStream_t)stream;
-  conv_wgrad_igemm_kernel<<<dim3((unsigned)(e.nbm * e.nbn * p.splits)), 256, 4 * G_TILE_BYTES, s>>>(a);
+  if (big.splits) {
+    e.nbm = (int)(e.M / 256); e.nbn = (int)((e.N + 255) / 256);
+    const dim3 grid((unsigned)(e.nbm * e.nbn * p.splits));
+    if (e.N % 256 == 0) conv_wgrad_w256_kernel<false><<<grid, 256, CW_LDS_BYTES, s>>>(a);
+    else conv_wgrad_w256_kernel<true><<<grid, 256, CW_LDS_BYTES, s>>>(a);
+  } else {
+    e.nbm = (int)((e.M + G_BM - 1) / G_BM); e.nbn = (int)((e.N + G_BN - 1) / G_BN);
+    conv_wgrad_igemm_kernel<<<dim3((unsigned)(e.nbm * e.nbn * p.splits)), 256, 4 * G_TILE_BYTES, s>>>(a);
+  }
   if (p.splits > 1) splitk_reduce_kernel<<<dim3((unsigned)((MN / 4 + 255) / 256)), 256, 0, s>>>(e.ws, p.splits, MN, e.N, dw, e.N, 0);
   return enh_check_launch("enh_conv_wgrad_nhwc_bf16");
 }

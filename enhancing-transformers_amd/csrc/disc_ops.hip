@@ -263,12 +263,120 @@ __global__ __launch_bounds__(256) void blur_nhwc_kernel(const uint16_t* __restri
     if (ox0 + o < Wo) *reinterpret_cast<u32x4*>(out + ((b * Ho + oy) * (int64_t)Wo + ox0 + o) * C + c8 * 8) = pack8(acc[o]);
 }
 
+// The 4 x 4 case (every Blur of the discriminator) as a column march: one thread = 8 channels x 2 output columns x a strip of RS output rows.  Each input
+// row of the strip is loaded ONCE (5 16-byte loads, requested one row ahead) and unpacked once; it contributes to the up to four output rows that are in
+// flight (a ring of accumulators whose slot is a compile-time constant: the march is unrolled in groups of four rows).  16 loads per output (4 per output
+// with the one-row kernel's 4-column reuse) become 2.5 * (RS + 3) / RS.  A given output receives its 16 products in the same order as in
+// blur_nhwc_kernel (rows ascending, columns ascending), so the two kernels agree bit for bit.
+// Lab (B = 16, 256^2 x 128 / 128^2 x 256 / 64^2 x 512, profiles/r04_conv_layers.txt): one-row kernel 245 / 123 / 65 us; this form 117 / 60 / 35 us
+// (4.6 TB/s of input + output); 4 columns per thread 153 / 86 / 49 (282 registers: one wave per SIMD; 285 when forced to two waves, it spills);
+// loads issued unconditionally from clamped addresses and masked instead of predicated: 130 / 64 / 38; 1 column per thread at three waves: 321.
+template <int RS>
+__global__ __launch_bounds__(256, 2) void blur4x4_nhwc_kernel(const uint16_t* __restrict__ x, const float* __restrict__ kernel, uint16_t* __restrict__ out,
+                                                              int B, int H, int W, int C, int Ho, int Wo, int pad_y0, int pad_x0, int flip) {
+  static_assert((RS + 3) % 4 == 0, "the march runs in groups of four input rows");
+  constexpr int NC = 2;
+  float w[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[i][j] = flip ? kernel[i * 4 + j] : kernel[(3 - i) * 4 + (3 - j)];
+  const int c8n = C >> 3, wq = (Wo + NC - 1) / NC, ns = (Ho + RS - 1) / RS;
+  const int64_t total = (int64_t)B * ns * wq * c8n;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int c8 = (int)(idx % c8n);
+  int64_t q = idx / c8n;
+  const int xq = (int)(q % wq); q /= wq;
+  const int st = (int)(q % ns);
+  const int64_t b = q / ns;
+  const int ox0 = xq * NC, oy0 = st * RS;
+  const uint16_t* xb = x + b * H * (int64_t)W * C + c8 * 8;
+  uint16_t* ob = out + b * Ho * (int64_t)Wo * C + c8 * 8;
+  int coff[NC + 3];        // element offset of input column jj inside a row, -1 outside the image
+#pragma unroll
+  for (int jj = 0; jj < NC + 3; ++jj) {
+    const int ix = ox0 + jj - pad_x0;
+    coff[jj] = (ix >= 0 && ix < W) ? ix * C : -1;
+  }
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  auto load_row = [&](int t, u32x4 (&r)[NC + 3]) {
+    const int iy = oy0 + t - pad_y0;
+    const bool rok = iy >= 0 && iy < H && t < RS + 3;
+    const uint16_t* row = xb + (int64_t)(rok ? iy : 0) * W * C;
+#pragma unroll
+    for (int jj = 0; jj < NC + 3; ++jj) r[jj] = (rok && coff[jj] >= 0) ? *reinterpret_cast<const u32x4*>(row + coff[jj]) : zero4;
+  };
+  float acc[4][NC][8];   // [ring slot = output row & 3][output column][channel]
+#pragma unroll
+  for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+    for (int o = 0; o < NC; ++o)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[s_][o][k] = 0.f;
+  u32x4 cur[NC + 3], nxt[NC + 3];
+  load_row(0, cur);
+  for (int t4 = 0; t4 < RS + 3; t4 += 4) {
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+      const int t = t4 + tt;                       // input row oy0 - pad_y0 + t feeds output rows oy0 + t - i, i = 0..3 (ring slot (tt - i) & 3)
+      load_row(t + 1, nxt);
+#pragma unroll
+      for (int jj = 0; jj < NC + 3; ++jj) {
+        float f[8];
+        unpack8(cur[jj], f);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int o = 0; o < NC; ++o) {
+            const int j = jj - o;
+            if (j >= 0 && j < 4) {
+#pragma unroll
+              for (int k = 0; k < 8; ++k) acc[(tt - i) & 3][o][k] += w[i][j] * f[k];
+            }
+          }
+      }
+      // output row oy0 + t - 3 is complete (its i = 3 term was this row): store it and hand its slot to output row oy0 + t + 1
+      const int orow = t - 3;
+      if (orow >= 0 && orow < RS && oy0 + orow < Ho) {
+        uint16_t* dst = ob + (int64_t)(oy0 + orow) * Wo * C + (int64_t)ox0 * C;
+#pragma unroll
+        for (int o = 0; o < NC; ++o)
+          if (ox0 + o < Wo) *reinterpret_cast<u32x4*>(dst + (int64_t)o * C) = pack8(acc[(tt - 3) & 3][o]);
+      }
+#pragma unroll
+      for (int o = 0; o < NC; ++o)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[(tt - 3) & 3][o][k] = 0.f;
+#pragma unroll
+      for (int jj = 0; jj < NC + 3; ++jj) cur[jj] = nxt[jj];
+    }
+  }
+}
+
+static int g_blur_variant = 0;   // 0 = per shape, 1 = the one-row kernel everywhere (A/B, tests)
+extern "C" int enh_blur_set_kernel(int variant) {
+  ENH_REQUIRE(variant == 0 || variant == 1, ENH_E_BADARG, "enh_blur_set_kernel: variant must be 0 (auto) or 1 (one-row kernel)");
+  g_blur_variant = variant;
+  return ENH_OK;
+}
+
 extern "C" int enh_blur_nhwc_bf16(const enh_bf16* x, const float* kernel, int B, int H, int W, int C, int kh, int kw, int pad_y0, int pad_y1, int pad_x0,
                                   int pad_x1, int flip, enh_bf16* out, void* stream) {
   ENH_REQUIRE(x && kernel && out && B > 0 && H > 0 && W > 0, ENH_E_BADARG, "enh_blur_nhwc_bf16: bad argument");
   ENH_REQUIRE(C > 0 && C % 8 == 0 && kh > 0 && kw > 0 && kh * kw <= 64, ENH_E_SHAPE, "enh_blur_nhwc_bf16: C must be a multiple of 8 and the kernel at most 64 taps");
   const int Ho = H + pad_y0 + pad_y1 - kh + 1, Wo = W + pad_x0 + pad_x1 - kw + 1;
   ENH_REQUIRE(Ho > 0 && Wo > 0, ENH_E_SHAPE, "enh_blur_nhwc_bf16: empty output");
+  if (kh == 4 && kw == 4 && g_blur_variant == 0 && (int64_t)W * C < (1ll << 31)) {
+    // strips of 13 rows when that still gives every CU several workgroups, else 5
+    const int64_t cols = (int64_t)B * ((Wo + 1) / 2) * (C / 8);
+    const int64_t t13 = cols * ((Ho + 12) / 13), t5 = cols * ((Ho + 4) / 5);
+    if (t13 >= 256ll * 256 * 4)
+      blur4x4_nhwc_kernel<13><<<dim3((unsigned)((t13 + 255) / 256)), 256, 0, (hipStream_t)stream>>>(x, kernel, out, B, H, W, C, Ho, Wo, pad_y0, pad_x0, flip);
+    else
+      blur4x4_nhwc_kernel<5><<<dim3((unsigned)((t5 + 255) / 256)), 256, 0, (hipStream_t)stream>>>(x, kernel, out, B, H, W, C, Ho, Wo, pad_y0, pad_x0, flip);
+    return enh_check_launch("enh_blur_nhwc_bf16");
+  }
   const int64_t total = (int64_t)B * Ho * ((Wo + 3) / 4) * (C / 8);
   blur_nhwc_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, (hipStream_t)stream>>>(x, kernel, out, B, H, W, C, Ho, Wo, kh, kw, pad_y0, pad_x0, flip);
   return enh_check_launch("enh_blur_nhwc_bf16");

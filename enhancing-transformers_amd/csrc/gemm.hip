@@ -24,9 +24,6 @@
 #include "common.h"
 
 #include "gemm_tiles.h"
-#ifndef W2_LDS_STORE
-#define W2_LDS_STORE 1   // lab switch: bf16 outputs through an LDS transpose (whole-row 16-byte stores) vs 8-byte stores straight from the accumulator layout
-#endif
 
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs args) {
@@ -259,176 +256,7 @@ __device__ __forceinline__ const uint16_t* glds_src_ptr2(const uint16_t* __restr
   if (col > X - 8) col = X - 8;
   return P + (k_begin + k) * ld + col;
 }
-// epilogue for the swapped 32x32 accumulator layout: acc[i][j][r] = C[mw + i*32 + (lane&31)][nw + j*32 + 8*(r>>2) + 4*(lane>>5) + (r&3)]
-template <int MODE, int NJ, bool BOUNDS>
-__device__ __forceinline__ void gemm_epilogue32_loops(const GemmArgs& args, f32x16 (&acc)[4][NJ], int64_t mw, int64_t nw, int lane, int split, float* wave_bias,
-                                                      unsigned char* stage, unsigned char* stage32) {
-  const int l31 = lane & 31, hi = lane >> 5;
-  // Row-blocks whose inputs (saved tanh output / residual / old C) are requested TOGETHER before the first is consumed.  With one wave per SIMD every
-  // group costs one full memory round trip (~2-4 us under load) during which nothing else runs, so the group is made as large as the registers allow:
-  // the accumulators live in AGPRs and the K loop's fragment registers are dead here.  8 bytes per element group: all four row-blocks (128 VGPRs);
-  // 16 bytes (f32 residual): two.
-  constexpr int GI = MODE == EPI_BF16_DTANH ? 4 : (MODE == EPI_F32_BIAS_RES ? 2 : 1);
-  if (MODE == EPI_GENERIC) {   // runtime-flag mode: one row-block at a time, the bias fetched where it is used (the round-1 code shape: no spills)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int64_t m = mw + i * 32 + l31;
-      if (BOUNDS && m >= args.M) continue;
-      EpiIn in[NJ][4];
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          const int64_t n = nw + j * 32 + 8 * g4 + 4 * hi;
-          if (!BOUNDS || n < args.N) in[j][g4] = epi_load<MODE>(args, m, n);
-        }
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          const int64_t n = nw + j * 32 + 8 * g4 + 4 * hi;
-          if (BOUNDS && n >= args.N) continue;
-          float v[4] = {acc[i][j][g4 * 4 + 0], acc[i][j][g4 * 4 + 1], acc[i][j][g4 * 4 + 2], acc[i][j][g4 * 4 + 3]};
-          epi4<MODE>(args, v, in[j][g4], epi_bias<MODE>(args, n), m, n, split);
-        }
-      }
-    }
-    return;
-  }
-  // The bias of the wave's NJ*32 columns goes through a wave-private LDS strip: fetched once and BEFORE any store (see epi_bias), and read back with
-  // ds_read_b128 — LDS traffic is counted by lgkmcnt, so unlike a global load it can be waited for without waiting for the stores in flight, and
-  // it costs no registers across the row-blocks.
-  constexpr bool HAS_BIAS = MODE == EPI_BF16_BIAS_TANH || MODE == EPI_F32_BIAS_RES;
-  if (HAS_BIAS && lane < NJ * 8) {
-    const int64_t n = nw + lane * 4;
-    const float4 bv = (!BOUNDS || n < args.N) ? *reinterpret_cast<const float4*>(args.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-    *reinterpret_cast<float4*>(wave_bias + lane * 4) = bv;
-  }
-#if W2_LDS_STORE
-  // bf16 outputs leave through a wave-private 8-KiB LDS tile: per lane the accumulator layout only offers 8-byte pieces 256 B apart (a wave store
-  // touches 32 rows x 16 B; a pure fill kernel writes HBM at 7.4 TB/s, this pattern at 3.1-3.9), so each 32 x 128 block is transposed through LDS
-  // (XOR-swizzled 16-byte chunks: the 8-byte writes and the 16-byte reads are both conflict-free) and leaves as 16 bytes per lane, whole 256-byte row
-  // segments per instruction.  `stage` overlays the K loop's slots: one barrier first.
-  constexpr bool STAGED = (MODE == EPI_BF16 || MODE == EPI_BF16_BIAS_TANH || MODE == EPI_BF16_DTANH) && NJ == 4 && !BOUNDS;
-  if (STAGED) {
-    EpiIn in[GI][NJ][4];
-    if (MODE == EPI_BF16_DTANH) {
-#pragma unroll
-      for (int ii = 0; ii < GI; ++ii)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-          for (int g4 = 0; g4 < 4; ++g4) in[ii][j][g4] = epi_load<MODE>(args, mw + ii * 32 + l31, nw + j * 32 + 8 * g4 + 4 * hi);
-    }
-    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's last fragment reads are done
-    __builtin_amdgcn_s_barrier();         // ... and so are everybody else's: the slots may be overwritten
-    const int rrow = lane >> 4, rc16 = lane & 15;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          float v[4] = {acc[i][j][g4 * 4 + 0], acc[i][j][g4 * 4 + 1], acc[i][j][g4 * 4 + 2], acc[i][j][g4 * 4 + 3]};
-          const float4 b4 = HAS_BIAS ? *reinterpret_cast<const float4*>(wave_bias + j * 32 + 8 * g4 + 4 * hi) : make_float4(0.f, 0.f, 0.f, 0.f);
-          epi_value<MODE>(args, v, in[MODE == EPI_BF16_DTANH ? i : 0][j][g4], b4, nw + j * 32 + 8 * g4 + 4 * hi);
-          const u32x2 o_ = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-          *reinterpret_cast<u32x2*>(stage + l31 * 256 + (((j * 4 + g4) ^ (l31 & 15)) << 4) + hi * 8) = o_;
-        }
-#pragma unroll
-      for (int p = 0; p < 8; ++p) {
-        const int row = p * 4 + rrow;
-        const u32x4 w = *reinterpret_cast<const u32x4*>(stage + row * 256 + ((rc16 ^ (row & 15)) << 4));
-        *reinterpret_cast<u32x4*>(args.c_bf16 + (mw + i * 32 + row) * args.ldc + nw + rc16 * 8) = w;
-      }
-    }
-    return;
-  }
-  // f32 outputs (C, or a split-K partial slab): the same transpose with a 16-KiB tile per wave — the accumulator layout gives 16 bytes per lane 512 B
-  // apart (32 rows x 32 B per instruction); through LDS a store instruction covers two whole 512-byte row segments
-  constexpr bool STAGED32 = (MODE == EPI_F32_BIAS_RES || MODE == EPI_F32 || MODE == EPI_WS) && NJ == 4 && !BOUNDS;
-  if (STAGED32) {
-    unsigned char* st32 = stage32;   // 16 KiB per wave
-    float* dst = MODE == EPI_WS ? args.ws + ((int64_t)split * args.M + mw) * args.N + nw : args.c_f32 + mw * args.ldc + nw;
-    const int64_t ldd = MODE == EPI_WS ? args.N : args.ldc;
-    const int rrow = lane >> 5, rc = lane & 31;
-    bool synced = false;
-    constexpr int GS = 1;   // row-blocks of residual requested together in this form (two = 128 registers on top of the read-back temporaries: spills)
-#pragma unroll
-    for (int i0 = 0; i0 < 4; i0 += GS) {
-      EpiIn in[GS][NJ][4];
-      if (MODE == EPI_F32_BIAS_RES) {
-#pragma unroll
-        for (int ii = 0; ii < GS; ++ii)
-#pragma unroll
-          for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) in[ii][j][g4] = epi_load<MODE>(args, mw + (i0 + ii) * 32 + l31, nw + j * 32 + 8 * g4 + 4 * hi);
-      }
-      if (!synced) {
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_s_barrier();
-        synced = true;
-      }
-#pragma unroll
-      for (int ii = 0; ii < GS; ++ii) {
-        const int i = i0 + ii;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-          for (int g4 = 0; g4 < 4; ++g4) {
-            float v[4] = {acc[i][j][g4 * 4 + 0], acc[i][j][g4 * 4 + 1], acc[i][j][g4 * 4 + 2], acc[i][j][g4 * 4 + 3]};
-            const float4 b4 = HAS_BIAS ? *reinterpret_cast<const float4*>(wave_bias + j * 32 + 8 * g4 + 4 * hi) : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (MODE != EPI_WS) epi_value<MODE>(args, v, in[ii][j][g4], b4, nw + j * 32 + 8 * g4 + 4 * hi);
-            const f32x4 o_ = {v[0], v[1], v[2], v[3]};
-            *reinterpret_cast<f32x4*>(st32 + l31 * 512 + (((j * 8 + g4 * 2 + hi) ^ l31) << 4)) = o_;
-          }
-#pragma unroll
-        for (int p = 0; p < 16; ++p) {
-          const int row = p * 2 + rrow;
-          const f32x4 w = *reinterpret_cast<const f32x4*>(st32 + row * 512 + ((rc ^ row) << 4));
-          *reinterpret_cast<f32x4*>(dst + (int64_t)(i * 32 + row) * ldd + rc * 4) = w;
-          if ((p & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four read / store pairs in flight at a time: hoisting all 16 reads costs 64 registers
-        }
-      }
-    }
-    return;
-  }
-#endif
-#pragma unroll
-  for (int i0 = 0; i0 < 4; i0 += GI) {
-    EpiIn in[GI][NJ][4];
-#pragma unroll
-    for (int ii = 0; ii < GI; ++ii) {
-      const int64_t m = mw + (i0 + ii) * 32 + l31;
-      if (BOUNDS && m >= args.M) continue;
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          const int64_t n = nw + j * 32 + 8 * g4 + 4 * hi;
-          if (!BOUNDS || n < args.N) in[ii][j][g4] = epi_load<MODE>(args, m, n);
-        }
-    }
-#pragma unroll
-    for (int ii = 0; ii < GI; ++ii) {
-      const int i = i0 + ii;
-      const int64_t m = mw + i * 32 + l31;
-      if (BOUNDS && m >= args.M) continue;
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          const int64_t n = nw + j * 32 + 8 * g4 + 4 * hi;
-          if (BOUNDS && n >= args.N) continue;
-          float v[4] = {acc[i][j][g4 * 4 + 0], acc[i][j][g4 * 4 + 1], acc[i][j][g4 * 4 + 2], acc[i][j][g4 * 4 + 3]};
-          const float4 b4 = HAS_BIAS ? *reinterpret_cast<const float4*>(wave_bias + j * 32 + 8 * g4 + 4 * hi) : make_float4(0.f, 0.f, 0.f, 0.f);
-          epi4<MODE>(args, v, in[ii][j][g4], b4, m, n, split);
-        }
-      }
-    }
-  }
-}
+// (gemm_epilogue32_loops, the epilogue of the swapped 32x32 accumulator layout: gemm_tiles.h)
 
 // =================================================================================================
 // "w256": 256 x 256 x 64 workgroup tile, FOUR waves (2 x 2) of 128 x 128 — one wave per SIMD, 256 accumulator registers (AGPRs) + ~170 VGPRs.

@@ -80,6 +80,7 @@ SIGNATURES = {
     "enh_conv_wgrad_nhwc_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "enh_conv_pack_weight": (_i32, [_vp, _i32, _i32, _i32, _f32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "enh_conv_unpack_wgrad": (_i32, [_vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),
+    "enh_blur_set_kernel": (_i32, [_i32]),
     "enh_blur_nhwc_bf16": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "enh_lrelu_gate_bf16": (_i32, [_vp, _vp, _i64, _f32, _f32, _vp, _vp]),
     "enh_img_to_nhwc8": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
@@ -647,6 +648,11 @@ def blur_nhwc(x, kernel, pad0: int, pad1: int, flip: bool):
     _check(lib().enh_blur_nhwc_bf16(_p(x, BF16, "x"), _p(kernel, F32, "kernel"), B, H, W, C, kh, kw, pad0, pad1, pad0, pad1, int(flip), _p(out), _stream()),
            "enh_blur_nhwc_bf16")
     return out
+
+
+def blur_set_kernel(variant: int) -> None:
+    """0 = per shape (the row-marching 4 x 4 kernel where it applies), 1 = the one-row kernel everywhere (A/B, tests)"""
+    _check(lib().enh_blur_set_kernel(int(variant)), "enh_blur_set_kernel")
 
 
 def lrelu_gate(g, ref, slope: float, scale: float):

@@ -340,6 +340,9 @@ int enh_conv_unpack_wgrad(const float* dwp, int Cout, int Cin, int cin_padded, i
 /* Blur (layers.py:140-160 -> upfirdn2d with unit up / down): out[b,oy,ox,c] = sum_{i,j} w(i,j) x[b, oy+i-pad_y0, ox+j-pad_x0, c] with
  * w(i,j) = kernel[kh-1-i][kw-1-j] (flip = 0, upfirdn2d's convention) or kernel[i][j] (flip = 1, the adjoint); out is [B, H+pad_y0+pad_y1-kh+1, W+..., C];
  * pads may be negative (crop) */
+/* kernel choice of enh_blur_nhwc_bf16 (explicit library state): 0 = per shape (4 x 4 filters: the row-marching kernel, bit-identical results),
+ * 1 = the one-row kernel everywhere */
+int enh_blur_set_kernel(int variant);
 int enh_blur_nhwc_bf16(const enh_bf16* x, const float* kernel, int B, int H, int W, int C, int kh, int kw, int pad_y0, int pad_y1, int pad_x0,
                        int pad_x1, int flip, enh_bf16* out, void* stream);
 /* y = g * (ref > 0 ? 1 : slope) * scale — the first / second derivative of FusedLeakyReLU through its saved output (fused_act.py:21-45);

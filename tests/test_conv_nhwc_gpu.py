@@ -48,7 +48,9 @@ CASES = [(2, 16, 16, 3, 128, 1, 1, 0), (2, 16, 20, 64, 128, 3, 1, 1), (3, 17, 17
          (2, 10, 8, 24, 64, 3, 2, 1), (1, 11, 10, 16, 32, 3, 3, 1), (2, 6, 6, 8, 16, 5, 2, 2), (2, 12, 12, 64, 64, 3, 2, 1),
          # shapes the 256-row kernels take (C % 64 == 0, N % 128 == 0): 256 x 256 and 256 x 128 tiles, ragged last row tile, two column tiles, rows shorter
          # than the 8-pixel staging step, padded stride 2 (strided output rows in the input gradient)
-         (2, 24, 24, 128, 256, 3, 1, 1), (1, 20, 12, 256, 512, 3, 1, 1), (5, 6, 5, 128, 128, 3, 1, 1), (2, 19, 18, 128, 256, 3, 2, 1)]
+         (2, 24, 24, 128, 256, 3, 1, 1), (1, 20, 12, 256, 512, 3, 1, 1), (5, 6, 5, 128, 128, 3, 1, 1), (2, 19, 18, 128, 256, 3, 2, 1),
+         # ... and the 256-row weight gradient (grid width % 64 == 0, C % 128 == 0, Cout % 256 == 0, >= 16 K stages): ragged and whole column tiles, stride 2
+         (2, 8, 64, 128, 256, 3, 1, 1), (3, 8, 64, 256, 256, 3, 1, 1), (2, 17, 129, 128, 256, 3, 2, 0)]
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,k,s,p", CASES)
@@ -141,6 +143,25 @@ def test_blur_and_its_adjoint(ops, shape, pad):
     y.backward(_nhwc(gy).to(BF).cuda())
     assert rel(_nchw(y.float()), yr) <= 1.25 * bf16_floor(yr.detach())
     assert rel(_nchw(xd.grad.float()), xr.grad) <= 1.25 * bf16_floor(xr.grad)
+
+
+@pytest.mark.parametrize("shape,pad", [((2, 32, 32, 16), (2, 2)), ((3, 17, 23, 40), (1, 1)), ((1, 258, 257, 8), (2, 2)), ((2, 5, 9, 64), (2, 1)), ((16, 67, 66, 128), (2, 2)),
+                                       ((1, 3, 2, 8), (2, 2))])
+def test_marching_blur_equals_the_one_row_kernel_bit_for_bit(ops, shape, pad):
+    """the 4 x 4 Blur as a column march (one load per input element and strip instead of four) adds every output's 16 products in the order of the
+    one-row kernel: identical bits, for both flip conventions, ragged strips / column groups and padding on every side"""
+    from enhancing import _C
+    g = torch.Generator().manual_seed(11)
+    kern = torch.rand(4, 4, generator=g).cuda()
+    x = torch.randn(*shape, generator=g).to(BF).cuda()
+    for flip in (False, True):
+        _C.blur_set_kernel(1)
+        try:
+            ref = _C.blur_nhwc(x, kern, pad[0], pad[1], flip)
+        finally:
+            _C.blur_set_kernel(0)
+        got = _C.blur_nhwc(x, kern, pad[0], pad[1], flip)
+        assert got.shape == ref.shape and torch.equal(got, ref), (shape, pad, flip, (got.float() - ref.float()).abs().max().item())
 
 
 def test_elementwise_pieces(ops):

@@ -44,7 +44,10 @@ for H, Cin, Cout, k, s, p in LAYERS:
 kern = torch.tensor([1., 3., 3., 1.], device="cuda")
 kern = kern[None] * kern[:, None]
 kern = kern / kern.sum()
-for H, C in ((256, 128), (128, 256), (64, 512)):
-    x = torch.randn(B, H, H, C, device="cuda").to(torch.bfloat16)
-    t = timeit(lambda: cn._C.blur_nhwc(x, kern, 2, 2, False))
-    print(f"blur {H}^2 x {C}: {t*1e3:7.1f} us  {2*x.numel()*2/t/1e6:6.0f} GB/s")
+for variant in (1, 0):
+    cn._C.blur_set_kernel(variant)
+    for H, C in ((256, 128), (128, 256), (64, 512)):
+        x = torch.randn(B, H, H, C, device="cuda").to(torch.bfloat16)
+        t = timeit(lambda: cn._C.blur_nhwc(x, kern, 2, 2, False))
+        print(f"blur variant {variant} {H}^2 x {C}: {t*1e3:7.1f} us  {2*x.numel()*2/t/1e6:6.0f} GB/s")
+cn._C.blur_set_kernel(0)
