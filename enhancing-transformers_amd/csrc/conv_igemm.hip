@@ -23,6 +23,12 @@
 // 4 waves of 64 x 64 (v_mfma_f32_16x16x32_bf16), 2 workgroups per CU.  C and N multiples of 8; any grid size.
 #include "gemm_tiles.h"
 
+// conv_pointwise.hip: the dense 1 x 1 geometries with an 8-channel side (the discriminator's first layer) as streaming kernels
+int conv_pointwise_forward(const uint16_t* src, const uint16_t* wt, const enh_conv_geom& g, int mode, const float* bias, float p0, float p1, uint16_t* out,
+                           hipStream_t stream);
+int conv_pointwise_wgrad_slabs(const enh_conv_geom& g);
+void conv_pointwise_wgrad(const uint16_t* src, const uint16_t* dy, const enh_conv_geom& g, float* ws, float* dw, hipStream_t stream);
+
 struct ConvArgs {
   const uint16_t* X; const uint16_t* Wt;
   enh_conv_geom g;
@@ -354,15 +360,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_glds_kernel(const ConvArgs 
 }
 
 // =================================================================================================
-// "w256" form of the convolution (round 4): the dense w256 main loop (gemm.hip gemm_bf16_w256_kernel — 256-row tile, FOUR waves of 128 x 32*NJ, one wave per
-// SIMD, v_mfma_f32_32x32x16_bf16, two 64-KiB LDS slots, one barrier per 64-deep K stage, one fragment read per MFMA and one global_load_lds per one or two
+// "w256" form of the convolution (round 4): the dense w256 main loop (gemm.hip gemm_bf16_w256_kernel — 256 x 256 tile, FOUR waves of 128 x 128, one wave per
+// SIMD, v_mfma_f32_32x32x16_bf16, two 64-KiB LDS slots, one barrier per 64-deep K stage, one fragment read per MFMA and one global_load_lds per two
 // MFMAs) fed by the gather of conv_igemm_glds_kernel: C % 64 == 0, so a K stage lies inside ONE tap and a staged row is "pixel offset + a tap offset that is
 // uniform for the wave"; lanes whose tap falls outside the image read the zero page.  Waves 0, 1 stage the two 128-pixel halves of the A tile, waves 2, 3 the
 // weights; BOTH run the same instruction stream — a staging lane keeps, per 1-KiB piece u, an element offset and a packed (y, x), and the wave keeps
 // (dy, dx, tap offset) in scalar registers (weights: y = x = dy = dx = 0, the offset advances by 64) — so the pointer of a piece costs ~10 vector
 // instructions in the MFMA slot where it is issued and no divergence.
-//   NJ = 4: 256 x 256 tile, the dense kernel's LDS image [A0 | A1 | B0 | B1].     NJ = 2: 256 x 128 tile for N = 128 layers: [A0 | A1 | B0 | - ], wave tile
-//   128 x 64, waves 2 and 3 stage half of B0 each (8 pieces per stage), 8 MFMAs and 6 fragment reads per k16 step.
+// LDS image per slot: the dense kernel's [A0 | A1 | B0 | B1].  N % 256 == 0; other multiples of 128 run conv_igemm_w512_kernel below.
 // Output: dense rows leave through a wave-private LDS tile as whole row segments; strided rows (stride-2 input gradient) as 8-byte pieces.
 // =================================================================================================
 #define CW_SLOT (4 * G_TILE_BYTES)
@@ -396,13 +401,11 @@ __device__ __forceinline__ void conv_epilogue32(const ConvArgs& args, f32x16 (&a
   const int l31 = lane & 31, hi = lane >> 5;
   const bool dense = g.os == 1 && g.HO == g.Hm && g.WO == g.Wm && g.oph == 0 && g.opw == 0;
   const bool has_bias = (args.mode == 0 || args.mode == 3) && args.bias;
-  if (lane < NJ * 8) {
-    const float4 bv = has_bias ? *reinterpret_cast<const float4*>(args.bias + nw + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    *reinterpret_cast<float4*>(wave_bias + lane * 4) = bv;
-  }
+  const float4 bv = (lane < NJ * 8 && has_bias) ? *reinterpret_cast<const float4*>(args.bias + nw + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
   const bool want_aux = args.mode == 1, want_add = (args.mode == 1 || args.mode == 4) && args.add;
   __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's last fragment reads are done
-  __builtin_amdgcn_s_barrier();         // ... and everybody else's: `stage` overlays the K slots
+  __builtin_amdgcn_s_barrier();         // ... and everybody else's: `stage` (and, in the 512-row kernel, the bias strip) overlay the K slots
+  if (lane < NJ * 8) *reinterpret_cast<float4*>(wave_bias + lane * 4) = bv;
   constexpr int CH = 4 * NJ;            // 16-byte chunks per staged row (32*NJ columns of bf16)
   constexpr int RPP = 64 / CH;          // rows per read-back pass
 #pragma unroll
@@ -457,10 +460,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int nst = (int)(args.K / G_BK);   // >= 2 (launcher)
 
   // ---- staging state -----------------------------------------------------------------------------------------------------------
+  static_assert(NJ == 4, "256 x 256 tiles");
   const bool stage_a = wave < 2;                                   // wave-uniform
-  const int sub = (NJ == 4 || stage_a) ? wave : 2;                 // which 16-KiB sub-tile of a slot this wave fills
-  const int slab0 = (NJ == 2 && wave == 3) ? 8 : 0;                // ... and from which 1-KiB slab on
-  unsigned char* const my_sub = smem + sub * G_TILE_BYTES + slab0 * 1024;
+  constexpr int slab0 = 0;
+  unsigned char* const my_sub = smem + wave * G_TILE_BYTES;        // the 16-KiB sub-tile of a slot this wave fills
   const uint16_t* const gbase = stage_a ? args.X : args.Wt;
   const uint16_t* const zero = reinterpret_cast<const uint16_t*>(g_conv_zero_page);
   int rowoff[16], pyx[16];
@@ -482,7 +485,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         while (px_ >= (unsigned)g.Wm) { px_ -= (unsigned)g.Wm; ++py_; }
         while (py_ >= (unsigned)g.Hm) { py_ -= (unsigned)g.Hm; ++pb; }
       } else {
-        rowoff[u] = (int)((n0 + (NJ == 4 ? (wave - 2) * 128 : 0) + r) * args.K) + c * 8;
+        rowoff[u] = (int)((n0 + (wave - 2) * 128 + r) * args.K) + c * 8;
         pyx[u] = 0;
       }
     }
@@ -502,7 +505,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   } while (0)
 #define CW_ISSUE_ONE(SLOT, U)                                                                                                     \
   do {                                                                                                                            \
-    if (NJ == 4 || (U) < 8 || stage_a) {                                                                                          \
+    {                                                                                                                             \
       const unsigned sy_ = (unsigned)((pyx[U] >> 16) + s_dy), sx_ = (unsigned)((pyx[U] & 0xffff) + s_dx);                         \
       const uint16_t* p_ = (sy_ < lim_y && sx_ < lim_x) ? gbase + (rowoff[U] + s_off) : zero;                                     \
       __builtin_amdgcn_global_load_lds((const GLB_AS void*)p_, (LDS_AS void*)(my_sub + (SLOT) * CW_SLOT + (U) * 1024), 16, 0, 0);  \
@@ -511,20 +514,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define CW_READ_ONE(FA, FB, SLOT, S, U)                                                                                           \
   do {                                                                                                                            \
     if ((U) < 4) FA[(U) & 3] = frag32<false>(smem + (SLOT) * CW_SLOT + wm * G_TILE_BYTES, ((U) & 3) * 32, S, lane);               \
-    else FB[(U) & 3] = frag32<false>(smem + (SLOT) * CW_SLOT + (NJ == 4 ? (2 + wn) * G_TILE_BYTES : 2 * G_TILE_BYTES), (NJ == 4 ? 0 : wn * 64) + ((U) & 3) * 32, S, lane); \
+    else FB[(U) & 3] = frag32<false>(smem + (SLOT) * CW_SLOT + (2 + wn) * G_TILE_BYTES, ((U) & 3) * 32, S, lane);                 \
   } while (0)
 #define CW_MM(Q, FA, FB)                                                                                                          \
   acc[(Q) / NJ][(Q) % NJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, FB[(Q) % NJ]), __builtin_bit_cast(bf16x8, FA[(Q) / NJ]), acc[(Q) / NJ][(Q) % NJ], 0, 0, 0)
 #define CW_FENCE() __builtin_amdgcn_sched_barrier(0)
-  // one k16 step: 4*NJ MFMAs on (FA, FB); under the first 4 + NJ MFMAs one fragment read each (k-step RS of slot RSLOT into RA / RB); 8 staging requests
-  // (pieces G0 .. G0+7 into slot GSLOT) spread evenly over the MFMAs
+  // one k16 step: 16 MFMAs on (FA, FB); under the first 8 one fragment read each (k-step RS of slot RSLOT into RA / RB); 8 staging requests (pieces
+  // G0 .. G0+7 into slot GSLOT) under the odd MFMAs
 #define CW_KSTEP(FA, FB, RA, RB, RSLOT, RS, DO_READ, GSLOT, G0, DO_ISSUE)                                                         \
   do {                                                                                                                            \
     CW_FENCE();                                                                                                                   \
     _Pragma("unroll") for (int q_ = 0; q_ < 4 * NJ; ++q_) {                                                                       \
       CW_MM(q_, FA, FB);                                                                                                          \
       if ((DO_READ) && q_ < 4 + NJ) { CW_READ_ONE(RA, RB, RSLOT, RS, q_); }                                                       \
-      if ((DO_ISSUE) && (NJ == 2 || (q_ & 1))) { CW_ISSUE_ONE(GSLOT, (G0) + (NJ == 2 ? q_ : (q_ >> 1))); }                        \
+      if ((DO_ISSUE) && (q_ & 1)) { CW_ISSUE_ONE(GSLOT, (G0) + (q_ >> 1)); }                                                      \
       CW_FENCE();                                                                                                                 \
     }                                                                                                                             \
   } while (0)
@@ -544,7 +547,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   CW_ADVANCE();
 #pragma unroll
   for (int u = 0; u < 8; ++u) CW_ISSUE_ONE(1, u);
-  __builtin_amdgcn_s_waitcnt(0x0F78);   // vmcnt(8): stage 0 landed (a wave that stages 8 pieces per stage issued exactly 8 after them as well)
+  __builtin_amdgcn_s_waitcnt(0x0F78);   // vmcnt(8): stage 0 landed
   __builtin_amdgcn_s_barrier();
 #pragma unroll
   for (int u = 0; u < 4 + NJ; ++u) CW_READ_ONE(fa0, fb0, 0, 0, u);
@@ -586,6 +589,157 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   conv_epilogue32<NJ>(args, acc, m0 + wm * 128, n0 + wn * (32 * NJ), lane, reinterpret_cast<float*>(smem + 2 * CW_SLOT) + wave * 128, smem + wave * 8192);
 }
 
+// =================================================================================================
+// "w512": the same main loop for N = 128 layers (the discriminator's 128 -> 128 convolution at 256^2 and its input gradient — the largest single layer).
+// 512 x 128 tile, the four waves stacked along M (each 128 x 128: the accumulators, fragment reads and MFMA count per wave are those of the 256 x 256
+// kernel), so each wave owns the 128-pixel A sub-tile it multiplies and the ONE 16-KiB weight sub-tile is shared by all four.  LDS image per slot
+// [A0 | A1 | A2 | A3 | B0] = 80 KiB, two slots = the CU's whole 160 KiB; every wave stages its own pixels (16 pieces per K stage) and a quarter of the
+// weights (4 pieces): 10 requests under the 16 MFMAs of each of the two k16 steps that carry requests.  The epilogue's staging tiles and bias strips
+// overlay the slots.  (A 256 x 128 tile with 128 x 64 waves was built first and lost to the 128 x 128 kernel: 614 -> 513 TF/s — half the workgroups
+// in flight and 1.5x the LDS traffic per MFMA; profiles/r04_conv_layers.txt.)
+// =================================================================================================
+#define CX_SLOT (5 * G_TILE_BYTES)
+#define CX_LDS_BYTES (2 * CX_SLOT)
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_igemm_w512_kernel(const ConvArgs args) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2 slots][A0 | A1 | A2 | A3 | B0]
+  const enh_conv_geom& g = args.g;
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int bid_ = xcd_contiguous((int)blockIdx.x, args.nbm * args.nbn);
+  const int tile_m = bid_ % args.nbm, tile_n = bid_ / args.nbm;
+  const int64_t m0 = (int64_t)tile_m * 512, n0 = (int64_t)tile_n * 128;
+  const int nst = (int)(args.K / G_BK);   // >= 2 (launcher)
+
+  // ---- staging state: 16 pieces of this wave's pixels (offset + packed (y, x) each), 4 pieces of the weights -------------------------
+  const uint16_t* const zero = reinterpret_cast<const uint16_t*>(g_conv_zero_page);
+  int rowoff[16], pyx[16], boff[4];
+  {
+    const unsigned hw = (unsigned)g.Hm * (unsigned)g.Wm;
+    const unsigned row0 = (unsigned)m0 + wave * 128 + (lane >> 3);
+    unsigned pb = row0 / hw, prem = row0 - pb * hw;
+    unsigned py_ = prem / (unsigned)g.Wm, px_ = prem - py_ * (unsigned)g.Wm;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int r = u * 8 + (lane >> 3), pc = lane & 7;
+      const int c = pc ^ ((r >> 1) & 7);
+      const bool exists = (int64_t)m0 + wave * 128 + r < args.M;
+      rowoff[u] = exists ? (int)(((pb * g.Hs + py_ * g.gs) * g.Ws + px_ * g.gs) * g.C) + c * 8 : 0;
+      pyx[u] = exists ? (int)(((py_ * g.gs) << 16) | (px_ * g.gs)) : 0x40004000;   // every tap of a row that does not exist falls outside the image
+      px_ += 8;
+      while (px_ >= (unsigned)g.Wm) { px_ -= (unsigned)g.Wm; ++py_; }
+      while (py_ >= (unsigned)g.Hm) { py_ -= (unsigned)g.Hm; ++pb; }
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int r = (wave * 4 + v) * 8 + (lane >> 3), pc = lane & 7;
+      const int c = pc ^ ((r >> 1) & 7);
+      boff[v] = (int)((n0 + r) * args.K) + c * 8;
+    }
+  }
+  unsigned char* const my_a = smem + wave * G_TILE_BYTES;
+  unsigned char* const my_b = smem + 4 * G_TILE_BYTES + wave * 4096;
+  int s_ch = 0, s_jx = 0, s_jy = 0, s_k = 0;
+  int s_dy = g.oy0, s_dx = g.ox0;
+  int s_off = (s_dy * g.Ws + s_dx) * g.C;
+#define CX_ADVANCE()                                                                                                              \
+  do {                                                                                                                            \
+    s_k += G_BK; s_ch += G_BK;                                                                                                    \
+    if (s_ch == g.C) { s_ch = 0; if (++s_jx == g.ntx) { s_jx = 0; ++s_jy; } s_dy = g.oy0 + s_jy * g.sty; s_dx = g.ox0 + s_jx * g.stx; } \
+    s_off = (s_dy * g.Ws + s_dx) * g.C + s_ch;                                                                                    \
+  } while (0)
+#define CX_ISSUE_A(SLOT, U)                                                                                                       \
+  do {                                                                                                                            \
+    const unsigned sy_ = (unsigned)((pyx[U] >> 16) + s_dy), sx_ = (unsigned)((pyx[U] & 0xffff) + s_dx);                           \
+    const uint16_t* p_ = (sy_ < (unsigned)g.Hs && sx_ < (unsigned)g.Ws) ? args.X + (rowoff[U] + s_off) : zero;                    \
+    __builtin_amdgcn_global_load_lds((const GLB_AS void*)p_, (LDS_AS void*)(my_a + (SLOT) * CX_SLOT + (U) * 1024), 16, 0, 0);     \
+  } while (0)
+#define CX_ISSUE_B(SLOT, V)                                                                                                       \
+  __builtin_amdgcn_global_load_lds((const GLB_AS void*)(args.Wt + (boff[V] + s_k)), (LDS_AS void*)(my_b + (SLOT) * CX_SLOT + (V) * 1024), 16, 0, 0)
+#define CX_READ_ONE(FA, FB, SLOT, S, U)                                                                                           \
+  do {                                                                                                                            \
+    if ((U) < 4) FA[(U) & 3] = frag32<false>(smem + (SLOT) * CX_SLOT + wave * G_TILE_BYTES, ((U) & 3) * 32, S, lane);             \
+    else FB[(U) & 3] = frag32<false>(smem + (SLOT) * CX_SLOT + 4 * G_TILE_BYTES, ((U) & 3) * 32, S, lane);                        \
+  } while (0)
+#define CX_MM(Q, FA, FB)                                                                                                          \
+  acc[(Q) >> 2][(Q) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, FB[(Q) & 3]), __builtin_bit_cast(bf16x8, FA[(Q) >> 2]), acc[(Q) >> 2][(Q) & 3], 0, 0, 0)
+#define CX_FENCE() __builtin_amdgcn_sched_barrier(0)
+  // one k16 step: 16 MFMAs; under the first 8 one fragment read each; HALF = 0 / 1: requests of the first / second half of a stage (A pieces 8*HALF..+7 under
+  // the odd MFMAs, weight pieces 2*HALF, +1 under MFMAs 4 and 10)
+#define CX_KSTEP(FA, FB, RA, RB, RSLOT, RS, DO_READ, GSLOT, HALF, DO_ISSUE)                                                       \
+  do {                                                                                                                            \
+    CX_FENCE();                                                                                                                   \
+    _Pragma("unroll") for (int q_ = 0; q_ < 16; ++q_) {                                                                           \
+      CX_MM(q_, FA, FB);                                                                                                          \
+      if ((DO_READ) && q_ < 8) { CX_READ_ONE(RA, RB, RSLOT, RS, q_); }                                                            \
+      if ((DO_ISSUE) && (q_ & 1)) { CX_ISSUE_A(GSLOT, (HALF) * 8 + (q_ >> 1)); }                                                  \
+      if ((DO_ISSUE) && (q_ == 4 || q_ == 10)) { CX_ISSUE_B(GSLOT, (HALF) * 2 + (q_ == 10)); }                                    \
+      CX_FENCE();                                                                                                                 \
+    }                                                                                                                             \
+  } while (0)
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  s16x8 fa0[4], fb0[4], fa1[4], fb1[4];
+
+  // prologue: stage 0 -> slot 0 completely; the first half of stage 1 -> slot 1
+#pragma unroll
+  for (int u = 0; u < 16; ++u) CX_ISSUE_A(0, u);
+#pragma unroll
+  for (int v = 0; v < 4; ++v) CX_ISSUE_B(0, v);
+  CX_ADVANCE();
+#pragma unroll
+  for (int u = 0; u < 8; ++u) CX_ISSUE_A(1, u);
+  CX_ISSUE_B(1, 0); CX_ISSUE_B(1, 1);
+  __builtin_amdgcn_s_waitcnt(0x0F7A);   // vmcnt(10): stage 0 landed
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int u = 0; u < 8; ++u) CX_READ_ONE(fa0, fb0, 0, 0, u);
+  CX_FENCE();
+
+  // invariant at the top of iteration j: the tap state is at stage j+1, whose first half is already requested into slot (j+1)&1
+  int j = 0;
+  for (; j + 2 < nst; ++j) {
+    const int slot = j & 1;
+    CX_KSTEP(fa0, fb0, fa1, fb1, slot, 1, true, slot ^ 1, 1, true);      // + second half of stage j+1
+    CX_ADVANCE();
+    CX_KSTEP(fa1, fb1, fa0, fb0, slot, 2, true, 0, 0, false);
+    CX_KSTEP(fa0, fb0, fa1, fb1, slot, 3, true, 0, 0, false);
+    __builtin_amdgcn_s_waitcnt(0x0070);    // vmcnt(0): stage j+1 landed (nothing newer outstanding) ; lgkmcnt(0): this slot is read out
+    __builtin_amdgcn_s_barrier();
+    CX_FENCE();
+    CX_KSTEP(fa1, fb1, fa0, fb0, slot ^ 1, 0, true, slot, 0, true);      // + first half of stage j+2 into the slot just vacated
+  }
+  {  // tail: stages nst-2 and nst-1
+    const int slot = j & 1;
+    CX_KSTEP(fa0, fb0, fa1, fb1, slot, 1, true, slot ^ 1, 1, true);      // + second half of stage nst-1
+    CX_KSTEP(fa1, fb1, fa0, fb0, slot, 2, true, 0, 0, false);
+    CX_KSTEP(fa0, fb0, fa1, fb1, slot, 3, true, 0, 0, false);
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    __builtin_amdgcn_s_barrier();
+    CX_FENCE();
+    CX_KSTEP(fa1, fb1, fa0, fb0, slot ^ 1, 0, true, 0, 0, false);
+    CX_KSTEP(fa0, fb0, fa1, fb1, slot ^ 1, 1, true, 0, 0, false);
+    CX_KSTEP(fa1, fb1, fa0, fb0, slot ^ 1, 2, true, 0, 0, false);
+    CX_KSTEP(fa0, fb0, fa1, fb1, slot ^ 1, 3, true, 0, 0, false);
+    CX_KSTEP(fa1, fb1, fa0, fb0, 0, 0, false, 0, 0, false);
+  }
+#undef CX_ADVANCE
+#undef CX_ISSUE_A
+#undef CX_ISSUE_B
+#undef CX_READ_ONE
+#undef CX_MM
+#undef CX_KSTEP
+#undef CX_FENCE
+  conv_epilogue32<4>(args, acc, m0 + wave * 128, n0, lane, reinterpret_cast<float*>(smem + 32768) + wave * 128, smem + wave * 8192);
+}
+
 static int conv_geom_check(const enh_conv_geom* g, const char* who) {
   ENH_REQUIRE(g, ENH_E_BADARG, "%s: geometry is NULL", who);
   ENH_REQUIRE(g->B > 0 && g->Hs > 0 && g->Ws > 0 && g->Hm > 0 && g->Wm > 0 && g->HO > 0 && g->WO > 0, ENH_E_BADARG, "%s: non-positive size", who);
@@ -605,21 +759,21 @@ extern "C" int enh_conv_set_kernel(int variant) {
   return ENH_OK;
 }
 
-// the 256-row kernel: whole K stages inside one tap, whole N tiles, 32-bit element offsets, (y, x) in 14 bits each; 0 = not applicable, else NJ
+// the 256 / 512-row kernels: whole K stages inside one tap, whole N tiles, 32-bit element offsets, (y, x) in 14 bits each.
+// 0 = not applicable, 4 = 256 x 256 tiles (N % 256 == 0), 5 = 512 x 128 tiles (other multiples of 128)
 static int conv_w256_nj(const ConvArgs& a) {
   const enh_conv_geom& g = a.g;
   if (g_conv_variant == 1 || g_conv_variant == 2) return 0;
   if (g.C % G_BK != 0 || a.K < 4 * G_BK || g.N % 128 != 0) return 0;
-  if (a.M >= (1ll << 31) - 512 || (int64_t)g.B * g.Hs * g.Ws * g.C >= (1ll << 31) || (int64_t)g.N * a.K >= (1ll << 31) || g.Hs > 16000 || g.Ws > 16000) return 0;
+  if (a.M >= (1ll << 31) - 1024 || (int64_t)g.B * g.Hs * g.Ws * g.C >= (1ll << 31) || (int64_t)g.N * a.K >= (1ll << 31) || g.Hs > 16000 || g.Ws > 16000) return 0;
   if ((int64_t)(g.Hm - 1) * g.gs > 16000 || (int64_t)(g.Wm - 1) * g.gs > 16000) return 0;
-  const int nj = g.N % 256 == 0 ? 4 : 2;
+  const int nj = g.N % 256 == 0 ? 4 : 5;
   if (g_conv_variant == 3) return nj;
-  // per-shape choice (B = 16 layer table, profiles/r04_conv_layers.txt): 256 x 256 tiles with dense output rows win 1.2-1.4x (760 -> 930, 764 -> 1052 TF/s);
-  // the 256 x 128 form loses to the 128 x 128 kernel (614 -> 513: same LDS traffic per MFMA, half the workgroups in flight), and so do the parity
-  // classes of a stride-2 input gradient (1-4 taps: two to eight K stages per tile, the deeper prologue is not amortised: 408 -> 326)
+  // per-shape choice (B = 16 layer table, profiles/r04_conv_layers.txt): with dense output rows the large tiles win 1.2-1.4x (760 -> 930, 764 -> 1052 TF/s);
+  // the parity classes of a stride-2 input gradient (1-4 taps: two to eight K stages per tile) do not amortise the deeper prologue (408 -> 326)
   const bool dense = g.os == 1 && g.HO == g.Hm && g.WO == g.Wm && g.oph == 0 && g.opw == 0;
-  if (nj != 4 || !dense) return 0;
-  const int64_t tiles = ((a.M + 255) / 256) * (g.N / 256);
+  if (!dense) return 0;
+  const int64_t tiles = nj == 4 ? ((a.M + 255) / 256) * (g.N / 256) : ((a.M + 511) / 512) * (g.N / 128);
   return tiles >= enh_device_cus() ? nj : 0;   // below one tile per CU the 128-row kernels (four times the workgroups, two per CU) fill the chip better
 }
 
@@ -628,7 +782,7 @@ static void conv_lds_attr_once() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_glds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G_TILE_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G_TILE_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_w256_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_w256_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_w512_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CX_LDS_BYTES);
     return true;
   }();
   (void)attr_set;
@@ -641,6 +795,7 @@ extern "C" int enh_conv_nhwc_bf16(const enh_bf16* src, const enh_bf16* wt, const
   if (rc != ENH_OK) return rc;
   ENH_REQUIRE(mode >= 0 && mode <= 4, ENH_E_BADARG, "enh_conv_nhwc_bf16: mode must be 0..4");
   ENH_REQUIRE((mode != 0 || bias) && (mode != 1 || aux) && (mode != 4 || add), ENH_E_BADARG, "enh_conv_nhwc_bf16: mode 0 needs bias, mode 1 aux, mode 4 add");
+  if (g_conv_variant == 0 && conv_pointwise_forward(src, wt, *g, mode, bias, p0, p1, out, (hipStream_t)stream)) return enh_check_launch("enh_conv_nhwc_bf16");
   ConvArgs a;
   a.X = src; a.Wt = wt; a.g = *g;
   a.M = (int64_t)g->B * g->Hm * g->Wm; a.K = (int64_t)g->nty * g->ntx * g->C;
@@ -650,9 +805,13 @@ extern "C" int enh_conv_nhwc_bf16(const enh_bf16* src, const enh_bf16* wt, const
   conv_lds_attr_once();
   const int nj = conv_w256_nj(a);
   if (nj) {
-    a.nbm = (int)((a.M + 255) / 256); a.nbn = g->N / (64 * nj);
-    if (nj == 4) conv_igemm_w256_kernel<4><<<dim3((unsigned)(a.nbm * a.nbn)), 256, CW_LDS_BYTES, (hipStream_t)stream>>>(a);
-    else conv_igemm_w256_kernel<2><<<dim3((unsigned)(a.nbm * a.nbn)), 256, CW_LDS_BYTES, (hipStream_t)stream>>>(a);
+    if (nj == 4) {
+      a.nbm = (int)((a.M + 255) / 256); a.nbn = g->N / 256;
+      conv_igemm_w256_kernel<4><<<dim3((unsigned)(a.nbm * a.nbn)), 256, CW_LDS_BYTES, (hipStream_t)stream>>>(a);
+    } else {
+      a.nbm = (int)((a.M + 511) / 512); a.nbn = g->N / 128;
+      conv_igemm_w512_kernel<<<dim3((unsigned)(a.nbm * a.nbn)), 256, CX_LDS_BYTES, (hipStream_t)stream>>>(a);
+    }
   } else if (g->C % G_BK == 0 && a.K >= 2 * G_BK && g_conv_variant != 1)
     conv_igemm_glds_kernel<<<dim3((unsigned)(a.nbm * a.nbn)), 256, 4 * G_TILE_BYTES, (hipStream_t)stream>>>(a);
   else
@@ -976,7 +1135,9 @@ extern "C" size_t enh_conv_wgrad_workspace_bytes(const enh_conv_geom* g) {
   g_conv_variant = 0;
   const WgradPlan q = conv_wgrad_w256_plan(*g, M, N, K, enh_device_cus());
   g_conv_variant = keep;
-  const int splits = p.splits > q.splits ? p.splits : q.splits;
+  int splits = p.splits > q.splits ? p.splits : q.splits;
+  const int pw = conv_pointwise_wgrad_slabs(*g);
+  if (pw > splits) splits = pw;
   return splits > 1 ? (size_t)splits * M * N * sizeof(float) : 0;
 }
 
@@ -988,6 +1149,14 @@ extern "C" int enh_conv_wgrad_nhwc_bf16(const enh_bf16* src, const enh_bf16* dy,
   if (rc != ENH_OK) return rc;
   ENH_REQUIRE(g->nty > 0 && g->ntx > 0, ENH_E_SHAPE, "enh_conv_wgrad_nhwc_bf16: empty tap grid");
   ENH_REQUIRE((int64_t)g->B * g->Hm * g->Wm < (1ll << 31) && (int64_t)g->B * g->Hs * g->Ws < (1ll << 31), ENH_E_SHAPE, "enh_conv_wgrad_nhwc_bf16: more than 2^31 pixels");
+  const int pw_slabs = g_conv_variant == 0 ? conv_pointwise_wgrad_slabs(gg) : 0;
+  if (pw_slabs > 0) {
+    const int64_t MN = (int64_t)g->N * 8;
+    ENH_REQUIRE(pw_slabs == 1 || (ws && ws_bytes >= (size_t)pw_slabs * MN * sizeof(float)), ENH_E_WORKSPACE, "enh_conv_wgrad_nhwc_bf16: workspace too small (%zu < %zu bytes)",
+                ws_bytes, (size_t)pw_slabs * MN * sizeof(float));
+    conv_pointwise_wgrad(src, dy, gg, (float*)ws, dw, (hipStream_t)stream);
+    return enh_check_launch("enh_conv_wgrad_nhwc_bf16");
+  }
   ConvWgradArgs a;
   a.X = src; a.DY = dy; a.g = gg;
   GemmArgs& e = a.e;

@@ -42,7 +42,8 @@ def _nchw(x_nhwc):
 
 
 # B, H, W, Cin (real), Cout, k, stride, pad   — the discriminator's layer shapes in small, plus ragged sizes / padded channels
-CASES = [(2, 16, 16, 3, 128, 1, 1, 0), (2, 16, 20, 64, 128, 3, 1, 1), (3, 17, 17, 64, 136, 3, 2, 0), (2, 15, 15, 40, 64, 1, 2, 0),
+CASES = [(2, 16, 16, 3, 128, 1, 1, 0), (3, 7, 9, 5, 64, 1, 1, 0), (1, 40, 33, 8, 16, 1, 1, 0),   # the 8-channel pointwise kernels (conv_pointwise.hip)
+         (2, 16, 20, 64, 128, 3, 1, 1), (3, 17, 17, 64, 136, 3, 2, 0), (2, 15, 15, 40, 64, 1, 2, 0),
          (8, 4, 4, 513, 512, 3, 1, 1), (1, 70, 66, 24, 72, 3, 1, 1), (1, 35, 35, 96, 128, 3, 2, 0), (2, 33, 33, 128, 256, 3, 2, 0),
          # geometries the discriminator never uses: padded stride 2, stride 3 (nine parity classes), a 5 x 5 kernel
          (2, 10, 8, 24, 64, 3, 2, 1), (1, 11, 10, 16, 32, 3, 3, 1), (2, 6, 6, 8, 16, 5, 2, 2), (2, 12, 12, 64, 64, 3, 2, 1),
