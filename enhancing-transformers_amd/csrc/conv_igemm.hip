@@ -36,6 +36,7 @@ struct ConvArgs {
   const float* bias; int mode; const uint16_t* aux; const uint16_t* add; float p0, p1;
   uint16_t* out;
   int nbm, nbn;
+  float* ws; int splits, st_per_split;   // split over the K stages (small grids): partial slabs [split][M][N] f32, finished by conv_splitk_finish_kernel
 };
 
 // Workgroup b runs on XCD b % 8 (private 4 MiB L2 each): hand every XCD a CONTIGUOUS run of the linear tile order, so that the vertical halo of
@@ -52,6 +53,28 @@ __device__ __forceinline__ int64_t conv_out_pixel(const enh_conv_geom& g, int64_
   const int64_t b = m / hw, rem = m - b * hw;
   const int y = (int)(rem / g.Wm), x = (int)(rem - (int64_t)y * g.Wm);
   return (b * g.HO + (int64_t)y * g.os + g.oph) * g.WO + (int64_t)x * g.os + g.opw;
+}
+
+// the five epilogue modes on four consecutive output columns (bias b4, saved activation ax, addend ad as they were loaded)
+__device__ __forceinline__ void conv_epi_value(const ConvArgs& args, float (&v)[4], const float4& b4, const uint2& ax, const uint2& ad) {
+  const uint32_t d0 = ad.x, d1 = ad.y;
+  const float e0 = bf16_bits_to_f32((uint16_t)(d0 & 0xffffu)), e1 = bf16_bits_to_f32((uint16_t)(d0 >> 16));
+  const float e2 = bf16_bits_to_f32((uint16_t)(d1 & 0xffffu)), e3 = bf16_bits_to_f32((uint16_t)(d1 >> 16));
+  if (args.mode == 0) {
+    v[0] = fmaxf(v[0] + b4.x, 0.f); v[1] = fmaxf(v[1] + b4.y, 0.f); v[2] = fmaxf(v[2] + b4.z, 0.f); v[3] = fmaxf(v[3] + b4.w, 0.f);
+  } else if (args.mode == 1) {
+    const uint32_t a0 = ax.x, a1 = ax.y;
+    v[0] = (a0 & 0x7fffu) && !(a0 & 0x8000u) ? v[0] + e0 : 0.f;
+    v[1] = ((a0 >> 16) & 0x7fffu) && !(a0 >> 31) ? v[1] + e1 : 0.f;
+    v[2] = (a1 & 0x7fffu) && !(a1 & 0x8000u) ? v[2] + e2 : 0.f;
+    v[3] = ((a1 >> 16) & 0x7fffu) && !(a1 >> 31) ? v[3] + e3 : 0.f;
+  } else if (args.mode == 3) {
+    v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = (v[r] > 0.f ? v[r] : v[r] * args.p0) * args.p1;
+  } else if (args.mode == 4) {
+    v[0] += args.p0 * e0; v[1] += args.p0 * e1; v[2] += args.p0 * e2; v[3] += args.p0 * e3;
+  }
 }
 
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& args, f32x4 (&acc)[4][4], int64_t m0, int64_t n0, int wm, int wn, int lg, int l16,
@@ -247,10 +270,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_glds_kernel(const ConvArgs 
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int l16 = lane & 15, lg = lane >> 4;
-  const int bid_ = xcd_contiguous((int)blockIdx.x, args.nbm * args.nbn);
+  const int ntile = args.nbm * args.nbn;
+  const int lin_ = xcd_contiguous((int)blockIdx.x, ntile * args.splits);
+  const int split = lin_ / ntile, bid_ = lin_ - split * ntile;
   const int tile_m = bid_ % args.nbm, tile_n = bid_ / args.nbm;
   const int64_t m0 = (int64_t)tile_m * G_BM, n0 = (int64_t)tile_n * G_BN;
-  const int nk = (int)(args.K / G_BK);
+  const int ks0 = split * args.st_per_split;                 // this workgroup's K stages: [ks0, ks0 + nk)
+  const int nk_all = (int)(args.K / G_BK);
+  const int nk = nk_all - ks0 < args.st_per_split ? nk_all - ks0 : args.st_per_split;
 
   // A operand: slab i of this wave = rows (wave*4 + i)*8 + (lane>>3), physical chunk lane&7 holding logical chunk c = pc ^ ((r>>1)&7) (gemm_tiles.h row image)
   int py[4], px[4], coff[4];
@@ -270,12 +297,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_glds_kernel(const ConvArgs 
     } else { py[i] = -(1 << 28); px[i] = -(1 << 28); pb[i] = 0; }
     int64_t co = n0 + r;                       // B operand (weights [N][K]): rows beyond N are clamped, their products land in columns that are never stored
     if (co > g.N - 1) co = g.N - 1;
-    bsrc[i] = args.Wt + co * args.K + c * 8;
+    bsrc[i] = args.Wt + co * args.K + (int64_t)ks0 * G_BK + c * 8;
   }
   const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_conv_zero_page);
-  // source pointers of K step `ks` (uniform tap) for the four A slabs
+  // source pointers of K step `ks` of this workgroup (uniform tap) for the four A slabs
   auto a_ptrs = [&](int ks, const uint16_t* (&ap)[4]) {
-    const int k0 = ks * G_BK;
+    const int k0 = (ks0 + ks) * G_BK;
     const int tap = k0 / g.C, ch0 = k0 - tap * g.C;
     const int jy = tap / g.ntx, jx = tap - jy * g.ntx;
     const int dy = g.oy0 + jy * g.sty, dx = g.ox0 + jx * g.stx;
@@ -356,7 +383,44 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_glds_kernel(const ConvArgs 
   }
 #undef CG_LOAD
 #undef CG_READ
+  if (args.ws) {   // split over K: the f32 partial tile goes to this split's slab as it lies in the accumulators (16 bytes per lane)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t m = m0 + wm * 64 + i * 16 + l16;
+      if (m >= args.M) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t n = n0 + wn * 64 + j * 16 + lg * 4;
+        if (n < g.N) *reinterpret_cast<f32x4*>(args.ws + ((int64_t)split * args.M + m) * g.N + n) = acc[i][j];
+      }
+    }
+    return;
+  }
   conv_epilogue(args, acc, m0, n0, wm, wn, lg, l16, smem + wave * 8192);   // the stages are free: no LDS read follows the loop's last barrier
+}
+
+// second pass of a split convolution: out[o, n..n+3] = epilogue( sum over the slabs in ascending order ) — one thread per four columns
+__global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const ConvArgs args) {
+  const enh_conv_geom& g = args.g;
+  const int n4 = g.N >> 2;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= args.M * n4) return;
+  const int64_t m = idx / n4;
+  const int n = (int)(idx - m * n4) * 4;
+  f32x4 a = *reinterpret_cast<const f32x4*>(args.ws + m * g.N + n);
+  for (int s_ = 1; s_ < args.splits; ++s_) {
+    const f32x4 b = *reinterpret_cast<const f32x4*>(args.ws + ((int64_t)s_ * args.M + m) * g.N + n);
+    a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
+  }
+  const bool dense = g.os == 1 && g.HO == g.Hm && g.WO == g.Wm && g.oph == 0 && g.opw == 0;
+  const int64_t orow = (dense ? m : conv_out_pixel(g, m)) * g.N;
+  float v[4] = {a[0], a[1], a[2], a[3]};
+  const float4 b4 = ((args.mode == 0 || args.mode == 3) && args.bias) ? *reinterpret_cast<const float4*>(args.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const uint2 ax = args.mode == 1 ? *reinterpret_cast<const uint2*>(args.aux + orow + n) : make_uint2(0u, 0u);
+  const uint2 ad = ((args.mode == 1 || args.mode == 4) && args.add) ? *reinterpret_cast<const uint2*>(args.add + orow + n) : make_uint2(0u, 0u);
+  conv_epi_value(args, v, b4, ax, ad);
+  const u32x2 o_ = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+  *reinterpret_cast<u32x2*>(args.out + orow + n) = o_;
 }
 
 // =================================================================================================
@@ -372,27 +436,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_glds_kernel(const ConvArgs 
 // =================================================================================================
 #define CW_SLOT (4 * G_TILE_BYTES)
 #define CW_LDS_BYTES (2 * CW_SLOT + 2048)
-
-__device__ __forceinline__ void conv_epi_value(const ConvArgs& args, float (&v)[4], const float4& b4, const uint2& ax, const uint2& ad) {
-  const uint32_t d0 = ad.x, d1 = ad.y;
-  const float e0 = bf16_bits_to_f32((uint16_t)(d0 & 0xffffu)), e1 = bf16_bits_to_f32((uint16_t)(d0 >> 16));
-  const float e2 = bf16_bits_to_f32((uint16_t)(d1 & 0xffffu)), e3 = bf16_bits_to_f32((uint16_t)(d1 >> 16));
-  if (args.mode == 0) {
-    v[0] = fmaxf(v[0] + b4.x, 0.f); v[1] = fmaxf(v[1] + b4.y, 0.f); v[2] = fmaxf(v[2] + b4.z, 0.f); v[3] = fmaxf(v[3] + b4.w, 0.f);
-  } else if (args.mode == 1) {
-    const uint32_t a0 = ax.x, a1 = ax.y;
-    v[0] = (a0 & 0x7fffu) && !(a0 & 0x8000u) ? v[0] + e0 : 0.f;
-    v[1] = ((a0 >> 16) & 0x7fffu) && !(a0 >> 31) ? v[1] + e1 : 0.f;
-    v[2] = (a1 & 0x7fffu) && !(a1 & 0x8000u) ? v[2] + e2 : 0.f;
-    v[3] = ((a1 >> 16) & 0x7fffu) && !(a1 >> 31) ? v[3] + e3 : 0.f;
-  } else if (args.mode == 3) {
-    v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = (v[r] > 0.f ? v[r] : v[r] * args.p0) * args.p1;
-  } else if (args.mode == 4) {
-    v[0] += args.p0 * e0; v[1] += args.p0 * e1; v[2] += args.p0 * e2; v[3] += args.p0 * e3;
-  }
-}
 
 // accumulator layout of the swapped 32x32 MFMA: acc[i][j][r] = C[mw + i*32 + (lane&31)][nw + j*32 + 8*(r>>2) + 4*(lane>>5) + (r&3)]
 template <int NJ>
@@ -788,8 +831,52 @@ static void conv_lds_attr_once() {
   (void)attr_set;
 }
 
+// Small grids (the <= 16^2 layers at 16 images: 128 tiles of a 72-stage K loop on 256 CUs) are split over the K stages so that every CU has two
+// workgroups; {1, all} = not split.  Only the LDS-DMA 128 x 128 kernel has the split form.
+struct ConvSplit { int splits, st_per_split; };
+static ConvSplit conv_split_plan(const enh_conv_geom& g, int64_t M, int64_t K) {
+  const int nst = (int)(K / G_BK);
+  const ConvSplit none = {1, nst};
+  if (g_conv_variant != 0 || g.C % G_BK != 0 || nst < 16 || g.N % 4 != 0) return none;   // (the A/B families run their own kernels unsplit)
+  const int64_t tiles = ((M + G_BM - 1) / G_BM) * ((g.N + G_BN - 1) / G_BN);
+  const int cus = enh_device_cus();
+  if (tiles * 2 > cus) return none;                        // at least half a round of workgroups already
+  int splits = (int)((2 * cus) / tiles);
+  if (splits > 8) splits = 8;
+  if (splits > nst / 4) splits = nst / 4;                   // at least four stages per slice
+  if (splits < 2) return none;
+  const int per = (nst + splits - 1) / splits;
+  splits = (nst + per - 1) / per;
+  if (nst - (splits - 1) * per < 2) return none;            // the pipelined K loop wants two stages
+  return {splits, per};
+}
+
+extern "C" size_t enh_conv_workspace_bytes(const enh_conv_geom* g) {
+  if (!g || g->N <= 0 || g->C <= 0) return 0;
+  const int64_t M = (int64_t)g->B * g->Hm * g->Wm, K = (int64_t)g->nty * g->ntx * g->C;
+  const int keep = g_conv_variant;
+  g_conv_variant = 0;                                       // sized for the per-shape choice whatever family is selected now
+  const ConvSplit sp = conv_split_plan(*g, M, K);
+  g_conv_variant = keep;
+  return sp.splits > 1 ? (size_t)sp.splits * M * g->N * sizeof(float) : 0;
+}
+
+static int conv_nhwc_impl(const enh_bf16* src, const enh_bf16* wt, const enh_conv_geom* g, int mode, const float* bias, const enh_bf16* aux,
+                          const enh_bf16* add, float p0, float p1, enh_bf16* out, void* ws, size_t ws_bytes, void* stream);
+
 extern "C" int enh_conv_nhwc_bf16(const enh_bf16* src, const enh_bf16* wt, const enh_conv_geom* g, int mode, const float* bias, const enh_bf16* aux,
                                   const enh_bf16* add, float p0, float p1, enh_bf16* out, void* stream) {
+  return conv_nhwc_impl(src, wt, g, mode, bias, aux, add, p0, p1, out, nullptr, 0, stream);
+}
+
+// the same with a caller-provided workspace (enh_conv_workspace_bytes): small grids are then split over the contraction
+extern "C" int enh_conv_nhwc_bf16_ws(const enh_bf16* src, const enh_bf16* wt, const enh_conv_geom* g, int mode, const float* bias, const enh_bf16* aux,
+                                     const enh_bf16* add, float p0, float p1, enh_bf16* out, void* ws, size_t ws_bytes, void* stream) {
+  return conv_nhwc_impl(src, wt, g, mode, bias, aux, add, p0, p1, out, ws, ws_bytes, stream);
+}
+
+static int conv_nhwc_impl(const enh_bf16* src, const enh_bf16* wt, const enh_conv_geom* g, int mode, const float* bias, const enh_bf16* aux,
+                          const enh_bf16* add, float p0, float p1, enh_bf16* out, void* ws, size_t ws_bytes, void* stream) {
   ENH_REQUIRE(src && wt && out, ENH_E_BADARG, "enh_conv_nhwc_bf16: bad argument");
   const int rc = conv_geom_check(g, "enh_conv_nhwc_bf16");
   if (rc != ENH_OK) return rc;
@@ -801,8 +888,16 @@ extern "C" int enh_conv_nhwc_bf16(const enh_bf16* src, const enh_bf16* wt, const
   a.M = (int64_t)g->B * g->Hm * g->Wm; a.K = (int64_t)g->nty * g->ntx * g->C;
   a.bias = bias; a.mode = mode; a.aux = aux; a.add = add; a.p0 = p0; a.p1 = p1; a.out = out;
   a.nbm = (int)((a.M + G_BM - 1) / G_BM); a.nbn = (g->N + G_BN - 1) / G_BN;
+  a.ws = nullptr; a.splits = 1; a.st_per_split = (int)(a.K / G_BK);
   ENH_REQUIRE((int64_t)a.nbm * a.nbn < (1ll << 30), ENH_E_SHAPE, "enh_conv_nhwc_bf16: grid too large");
   conv_lds_attr_once();
+  const ConvSplit sp = ws ? conv_split_plan(*g, a.M, a.K) : ConvSplit{1, 0};
+  if (sp.splits > 1 && ws_bytes >= (size_t)sp.splits * a.M * g->N * sizeof(float)) {
+    a.ws = (float*)ws; a.splits = sp.splits; a.st_per_split = sp.st_per_split;
+    conv_igemm_glds_kernel<<<dim3((unsigned)(a.nbm * a.nbn * a.splits)), 256, 4 * G_TILE_BYTES, (hipStream_t)stream>>>(a);
+    conv_splitk_finish_kernel<<<dim3((unsigned)((a.M * (g->N / 4) + 255) / 256)), 256, 0, (hipStream_t)stream>>>(a);
+    return enh_check_launch("enh_conv_nhwc_bf16");
+  }
   const int nj = conv_w256_nj(a);
   if (nj) {
     if (nj == 4) {

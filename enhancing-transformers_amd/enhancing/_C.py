@@ -75,6 +75,8 @@ SIGNATURES = {
     "enh_im2col_bf16": (_i32, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp]),
     "enh_col2im_f32": (_i32, [_vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _i64, _vp]),
     "enh_conv_nhwc_bf16": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _f32, _f32, _vp, _vp]),
+    "enh_conv_nhwc_bf16_ws": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _sz, _vp]),
+    "enh_conv_workspace_bytes": (_sz, [_vp]),
     "enh_conv_set_kernel": (_i32, [_i32]),
     "enh_conv_wgrad_workspace_bytes": (_sz, [_vp]),
     "enh_conv_wgrad_nhwc_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -605,9 +607,11 @@ def conv_nhwc(src, wt, geom, mode: int, bias=None, aux=None, add=None, p0: float
     if out is None:
         out = torch.empty(g.B, g.HO, g.WO, g.N, dtype=BF16, device=src.device)
     work = 2.0 * g.B * g.Hm * g.Wm * g.N * g.nty * g.ntx * g.C
+    nb = lib().enh_conv_workspace_bytes(ctypes.byref(g))       # > 0: a small grid that the library splits over the contraction
+    ws = _gemm_workspace(src.device, nb) if nb else None
     _timed("conv_igemm_kernel", work,
-           lambda: _check(lib().enh_conv_nhwc_bf16(_p(src, BF16, "src"), _p(wt, BF16, "wt"), ctypes.byref(g), mode, _p(bias, F32, "bias"), _p(aux, BF16, "aux"),
-                                                   _p(add, BF16, "add"), p0, p1, _p(out, BF16, "out"), _stream()), "enh_conv_nhwc_bf16"))
+           lambda: _check(lib().enh_conv_nhwc_bf16_ws(_p(src, BF16, "src"), _p(wt, BF16, "wt"), ctypes.byref(g), mode, _p(bias, F32, "bias"), _p(aux, BF16, "aux"),
+                                                      _p(add, BF16, "add"), p0, p1, _p(out, BF16, "out"), _p(ws), nb, _stream()), "enh_conv_nhwc_bf16_ws"))
     return out
 
 

@@ -322,6 +322,12 @@ typedef struct enh_conv_geom {
  *   mode 4: acc + p0 * add[o,n]                     (StyleBlock's (out + skip) / sqrt(2), layers.py:262, folded into the skip convolution) */
 int enh_conv_nhwc_bf16(const enh_bf16* src, const enh_bf16* wt, const enh_conv_geom* g, int mode, const float* bias, const enh_bf16* aux,
                        const enh_bf16* add, float p0, float p1, enh_bf16* out, void* stream);
+/* The same with a caller-provided workspace of enh_conv_workspace_bytes(g) bytes (0 = none needed): grids of less than half a round of workgroups
+ * (the <= 16^2 layers at 16 images) are then split over the contraction — f32 partial slabs, added in ascending order by a second kernel that
+ * applies the epilogue (deterministic).  ws == NULL or too small: not split. */
+size_t enh_conv_workspace_bytes(const enh_conv_geom* g);
+int enh_conv_nhwc_bf16_ws(const enh_bf16* src, const enh_bf16* wt, const enh_conv_geom* g, int mode, const float* bias, const enh_bf16* aux,
+                          const enh_bf16* add, float p0, float p1, enh_bf16* out, void* ws, size_t ws_bytes, void* stream);
 /* kernel choice of enh_conv_nhwc_bf16 / enh_conv_wgrad_nhwc_bf16 for A/B measurements (explicit library state, like enh_gemm_set_kernel):
  * 0 = per shape (256-row tiles when C % 64 == 0, N % 128 == 0, at least four K stages and one tile per CU; else the 128 x 128 LDS-DMA kernel when
  * C % 64 == 0; else register-staged), 1 = register-staged everywhere, 2 = never the 256-row kernels (the round-2 choice), 3 = the 256-row kernels
