@@ -87,17 +87,19 @@ class EqualConv2d(nn.Module):
             out = out + self.bias.view(-1, 1, 1, 1)
         return out
 
-    def forward_nhwc(self, x: torch.Tensor, act: Optional[FusedLeakyReLU] = None, add: Optional[torch.Tensor] = None, alpha: float = 1.0) -> torch.Tensor:
-        """x [B,H,W,Cp] bf16.  act: the FusedLeakyReLU that follows (fused into the kernel's epilogue); add / alpha: returns
-        alpha * (conv(x) + add) — the residual merge of a StyleBlock, with alpha folded into the weights"""
+    def forward_nhwc(self, x: torch.Tensor, act: Optional[FusedLeakyReLU] = None, add: Optional[torch.Tensor] = None, alpha: float = 1.0,
+                     gain: float = 1.0, add_scaled: bool = False) -> torch.Tensor:
+        """x [B,H,W,Cp] bf16.  act: the FusedLeakyReLU that follows (fused into the kernel's epilogue; `gain` multiplies its output gain); add / alpha:
+        returns alpha * (conv(x) + add) — the residual merge of a StyleBlock, with alpha folded into the weights; add_scaled: `add` already carries
+        the factor alpha (its producer took it as `gain`), so it enters with weight 1 and its gradient needs no scaling pass"""
         if act is not None:
             if self.bias is not None or add is not None:
                 raise RuntimeError("EqualConv2d.forward_nhwc: an activated convolution carries its bias in the activation and takes no residual")
-            return conv_nhwc.conv_bias_lrelu(x, self.weight, act.bias, self.scale, self.stride, self.padding, act.negative_slope, act.scale)
+            return conv_nhwc.conv_bias_lrelu(x, self.weight, act.bias, self.scale, self.stride, self.padding, act.negative_slope, act.scale * gain)
         if add is not None:
             if self.bias is not None:
                 raise RuntimeError("EqualConv2d.forward_nhwc: the residual merge is only fused into a bias-free convolution")
-            return conv_nhwc.conv_add(x, self.weight, add, self.scale * alpha, self.stride, self.padding, alpha)
+            return conv_nhwc.conv_add(x, self.weight, add, self.scale * alpha, self.stride, self.padding, 1.0 if add_scaled else alpha)
         out = conv_nhwc.conv(x, self.weight, self.scale * alpha, self.stride, self.padding)
         return out if self.bias is None else out + (alpha * self.bias).to(out.dtype)
 
@@ -141,12 +143,12 @@ class ConvLayer(nn.Sequential):
             layers.append(FusedLeakyReLU(out_channel, bias=bias))
         super().__init__(*layers)
 
-    def forward_nhwc(self, x: torch.Tensor, add: Optional[torch.Tensor] = None, alpha: float = 1.0) -> torch.Tensor:
+    def forward_nhwc(self, x: torch.Tensor, add: Optional[torch.Tensor] = None, alpha: float = 1.0, gain: float = 1.0, add_scaled: bool = False) -> torch.Tensor:
         mods = list(self)
         if isinstance(mods[0], Blur):
             x, mods = mods[0].forward_nhwc(x), mods[1:]
         act = mods[1] if len(mods) > 1 else None
-        return mods[0].forward_nhwc(x, act=act, add=add, alpha=alpha)
+        return mods[0].forward_nhwc(x, act=act, add=add, alpha=alpha, gain=gain, add_scaled=add_scaled)
 
     def forward_cm(self, x: torch.Tensor, layout: str = "cm") -> torch.Tensor:
         for m in self:
@@ -167,8 +169,11 @@ class StyleBlock(nn.Module):
         self.skip = ConvLayer(in_channel, out_channel, 1, downsample=True, activate=False, bias=False)
 
     def forward_nhwc(self, x: torch.Tensor) -> torch.Tensor:
-        out = self.conv2.forward_nhwc(self.conv1.forward_nhwc(x))
-        return self.skip.forward_nhwc(x, add=out, alpha=1 / sqrt(2))      # (out + skip(x)) / sqrt(2) in the skip convolution's epilogue
+        # (out + skip(x)) / sqrt(2): the factor on `out` rides in conv2's activation gain (sqrt(2) / sqrt(2) = 1: one multiply less per element, and the
+        # backward pass has no scaling pass over d(out)), the one on skip(x) in the skip convolution's weights; the sum is taken in that kernel's epilogue
+        alpha = 1 / sqrt(2)
+        out = self.conv2.forward_nhwc(self.conv1.forward_nhwc(x), gain=alpha)
+        return self.skip.forward_nhwc(x, add=out, alpha=alpha, add_scaled=True)
 
     def forward_cm(self, x: torch.Tensor) -> torch.Tensor:
         out = self.conv2.forward_cm(self.conv1.forward_cm(x))

@@ -233,7 +233,7 @@ class _ConvAdd(Function):
         g = g.contiguous()
         dx = _Dgrad.apply(g, w, scale, stride, pad, x.shape[1], x.shape[2], x.shape[3]) if ctx.needs_input_grad[0] else None
         dw = _Wgrad.apply(x, g, scale, stride, pad, w.shape[2], w.shape[1]) if ctx.needs_input_grad[1] and not _no_wgrad() else None
-        dadd = _Gate.apply(g, None, 1.0, alpha) if ctx.needs_input_grad[2] else None
+        dadd = (g if alpha == 1.0 else _Gate.apply(g, None, 1.0, alpha)) if ctx.needs_input_grad[2] else None
         return dx, dw, dadd, None, None, None, None
 
 

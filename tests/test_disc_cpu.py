@@ -40,9 +40,23 @@ def test_discriminator_wiring_first_and_second_order(monkeypatch, B, lowering):
     import disc_oracle as O
     import hip_emulation
     hip_emulation.install(monkeypatch, exact=True)
+    from enhancing import _C
     from enhancing.losses.layers import StyleDiscriminator
     from enhancing.losses.op import conv2d_gradfix
-    torch.manual_seed(B)
+    # The igemm path folds the residual merge's 1/sqrt(2) into conv2's activation gain (one rounding where the reference has two), which moves later
+    # pre-activations by an ulp; a leaky-ReLU gate whose pre-activation lies within ~1e-7 of zero then flips and the comparison "to rounding" is off
+    # by that one gate (seen with seed 8: |pre-activation| 5e-10, one gate of 65536).  The stand-in records the smallest |activation| it produced and
+    # the test asserts the margin, so a seed is only accepted if no such near-tie exists.
+    margin = [float("inf")]
+    inner = _C.conv_nhwc
+
+    def conv_nhwc_recording(src, wt, geom, mode, **kw):
+        out = inner(src, wt, geom, mode, **kw)
+        if mode == 3:
+            margin[0] = min(margin[0], float(out.detach().abs().min()))
+        return out
+    monkeypatch.setattr(_C, "conv_nhwc", conv_nhwc_recording)
+    torch.manual_seed(B + 20 if lowering == "igemm" else B)
     D = StyleDiscriminator(size=16, lowering=lowering)
     with torch.no_grad():
         for n, p in D.named_parameters():
@@ -59,6 +73,7 @@ def test_discriminator_wiring_first_and_second_order(monkeypatch, B, lowering):
     y2 = O.discriminator(sd, x2, 16)
     g2, = torch.autograd.grad(y2.sum(), x2, create_graph=True)
     (80 * g2.square().sum([1, 2, 3]).mean() + F.softplus(-y2).mean()).backward()
+    assert lowering != "igemm" or margin[0] > 2e-8, margin       # 0.2 x slope x the ~1e-7 an ulp moves a pre-activation
     assert rel(y1, y2) <= 1e-5 and rel(g1, g2) <= 1e-5
     for n, p in D.named_parameters():
         assert rel(p.grad, sd[n].grad) <= 2e-5, n
