@@ -272,7 +272,10 @@ extern "C" int enh_colsum_bf16_ws(const enh_bf16* x, int64_t M, int64_t N, int64
 
 // y[i] = bf16(x[i] * (i < n_scaled ? alpha : 1)): the forward operand of a packed q | k | v projection whose q rows carry the softmax scale (one rounding,
 // from the fp32 master) — include/enh_hip.h enh_attention_forward, q_prescaled
-__global__ void cast_f32_bf16_head_scaled_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, int64_t n, int64_t n_scaled, float alpha) {
+// blockIdx.y = one of `count` equally spaced blocks (the same projection of successive transformer layers in the flat parameter store): one launch for a tower
+__global__ void cast_f32_bf16_head_scaled_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, int64_t n, int64_t n_scaled, float alpha,
+                                                 int64_t x_stride, int64_t y_stride) {
+  x += (int64_t)blockIdx.y * x_stride; y += (int64_t)blockIdx.y * y_stride;
   const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= n) return;
   if (i + 3 < n) {
@@ -287,8 +290,18 @@ __global__ void cast_f32_bf16_head_scaled_kernel(const float* __restrict__ x, ui
 extern "C" int enh_cast_f32_bf16_head_scaled(const float* x, enh_bf16* y, int64_t n, int64_t n_scaled, float alpha, void* stream) {
   ENH_REQUIRE(x && y && n > 0 && n_scaled >= 0 && n_scaled <= n && n_scaled % 4 == 0, ENH_E_BADARG, "enh_cast_f32_bf16_head_scaled: bad argument");
   const int64_t n4 = (n + 3) / 4;
-  cast_f32_bf16_head_scaled_kernel<<<(int)((n4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, y, n, n_scaled, alpha);
+  cast_f32_bf16_head_scaled_kernel<<<(int)((n4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, y, n, n_scaled, alpha, 0, 0);
   return enh_check_launch("enh_cast_f32_bf16_head_scaled");
+}
+
+extern "C" int enh_cast_f32_bf16_head_scaled_strided(const float* x, int64_t x_stride, enh_bf16* y, int64_t y_stride, int64_t n, int64_t n_scaled, float alpha,
+                                                     int count, void* stream) {
+  ENH_REQUIRE(x && y && n > 0 && n_scaled >= 0 && n_scaled <= n && n_scaled % 4 == 0 && count > 0 && count <= 65535, ENH_E_BADARG,
+              "enh_cast_f32_bf16_head_scaled_strided: bad argument");
+  ENH_REQUIRE(x_stride % 4 == 0 && y_stride % 4 == 0 && y_stride >= n, ENH_E_SHAPE, "enh_cast_f32_bf16_head_scaled_strided: strides must be multiples of 4 elements and the outputs disjoint");
+  const int64_t n4 = (n + 3) / 4;
+  cast_f32_bf16_head_scaled_kernel<<<dim3((unsigned)((n4 + 255) / 256), (unsigned)count), 256, 0, (hipStream_t)stream>>>(x, y, n, n_scaled, alpha, x_stride, y_stride);
+  return enh_check_launch("enh_cast_f32_bf16_head_scaled_strided");
 }
 
 extern "C" int enh_cast_f32_bf16(const float* x, enh_bf16* y, int64_t n, void* stream) {

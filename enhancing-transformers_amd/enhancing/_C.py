@@ -66,6 +66,7 @@ SIGNATURES = {
     "enh_colsum_bf16_workspace_bytes": (_sz, [_i64, _i64]),
     "enh_cast_f32_bf16": (_i32, [_vp, _vp, _i64, _vp]),
     "enh_cast_f32_bf16_head_scaled": (_i32, [_vp, _vp, _i64, _i64, _f32, _vp]),
+    "enh_cast_f32_bf16_head_scaled_strided": (_i32, [_vp, _i64, _vp, _i64, _i64, _i64, _f32, _i32, _vp]),
     "enh_crop_flip_u8": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),
     "enh_resize_u8_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "enh_resize_u8": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _sz, _vp]),
@@ -494,6 +495,13 @@ def colsum(x, M: int, N: int, out, accumulate: bool = False):
 def cast_bf16_head_scaled(x, y, n_scaled: int, alpha: float):
     """y = bf16(x * alpha) for the first n_scaled elements, bf16(x) for the rest"""
     _check(lib().enh_cast_f32_bf16_head_scaled(_p(x, F32, "x"), _p(y, BF16, "y"), x.numel(), n_scaled, alpha, _stream()), "enh_cast_f32_bf16_head_scaled")
+
+
+def cast_bf16_head_scaled_strided(x0, x_stride: int, y, n: int, n_scaled: int, alpha: float):
+    """y [count, n] bf16 (contiguous) <- the blocks x0 + b * x_stride (x0: the first block, a view into the flat f32 store), q rows scaled by alpha"""
+    count = y.shape[0]
+    _check(lib().enh_cast_f32_bf16_head_scaled_strided(_p(x0, F32, "x"), x_stride, _p(y, BF16, "y"), y.stride(0), n, n_scaled, alpha, count, _stream()),
+           "enh_cast_f32_bf16_head_scaled_strided")
 
 
 def cast_bf16(x, y):

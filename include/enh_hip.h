@@ -251,6 +251,10 @@ int enh_cast_f32_bf16(const float* x, enh_bf16* y, int64_t n, void* stream);
 /* y[i] = bf16(x[i] * (i < n_scaled ? alpha : 1)), n_scaled % 4 == 0: forward operand of a packed q | k | v projection weight whose leading q rows carry
  * the softmax scale * log2(e) (one rounding from the fp32 master; see enh_attention_forward, q_prescaled) */
 int enh_cast_f32_bf16_head_scaled(const float* x, enh_bf16* y, int64_t n, int64_t n_scaled, float alpha, void* stream);
+/* the same for `count` equally spaced blocks (block b reads x + b*x_stride, writes y + b*y_stride; strides in elements, multiples of 4): the to_qkv weights of
+ * every layer of a tower in one launch */
+int enh_cast_f32_bf16_head_scaled_strided(const float* x, int64_t x_stride, enh_bf16* y, int64_t y_stride, int64_t n, int64_t n_scaled, float alpha,
+                                          int count, void* stream);
 /* torch.optim.AdamW(lr, betas=(0.9,0.99), weight_decay=1e-4) step over one flat buffer (vitvqgan.py:160),
  * also refreshes the bf16 shadow used by the GEMMs.  grad_scale multiplies g first (DDP mean / accumulation). */
 int enh_adamw_step(float* p, const float* g, float* m, float* v, enh_bf16* p_bf16, int64_t n, int step, float lr,

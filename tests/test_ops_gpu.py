@@ -613,6 +613,15 @@ def test_head_scaled_cast_and_the_forward_backward_operand_gap(C):
     expect = w.clone()
     expect[:inner] *= np.float32(alpha)
     assert torch.equal(y, expect.to(torch.bfloat16))
+    # the strided form (every layer of a tower in one launch) writes the same bits
+    store = torch.randn(5 * 3 * inner * dim + 64, device="cuda") * 0.02
+    step = 3 * inner * dim + 16
+    ys = torch.empty(3, 3 * inner, dim, dtype=torch.bfloat16, device="cuda")
+    C.cast_bf16_head_scaled_strided(store[8:8 + 3 * inner * dim], step, ys, 3 * inner * dim, inner * dim, alpha)
+    for b in range(3):
+        one = torch.empty(3 * inner, dim, dtype=torch.bfloat16, device="cuda")
+        C.cast_bf16_head_scaled(store[8 + b * step:8 + b * step + 3 * inner * dim].view(3 * inner, dim), one, inner * dim, alpha)
+        assert torch.equal(ys[b], one)
     plain = w.to(torch.bfloat16).float()
     fwd_q = y[:inner].float() / np.float32(alpha)
     gap = (fwd_q - plain[:inner]).abs() / plain[:inner].abs().clamp_min(1e-30)
