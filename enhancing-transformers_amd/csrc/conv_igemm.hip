@@ -49,10 +49,11 @@ __device__ __forceinline__ int xcd_contiguous(int bid, int nwg) {
 
 // output element offset (in pixels) of GEMM row m
 __device__ __forceinline__ int64_t conv_out_pixel(const enh_conv_geom& g, int64_t m) {
-  const int64_t hw = (int64_t)g.Hm * g.Wm;
-  const int64_t b = m / hw, rem = m - b * hw;
-  const int y = (int)(rem / g.Wm), x = (int)(rem - (int64_t)y * g.Wm);
-  return (b * g.HO + (int64_t)y * g.os + g.oph) * g.WO + (int64_t)x * g.os + g.opw;
+  // 32-bit divisions (the launcher requires fewer than 2^31 GEMM rows): a 64-bit one costs ~5x the instructions, and a strided epilogue does four per lane
+  const unsigned hw = (unsigned)g.Hm * (unsigned)g.Wm, mm = (unsigned)m;
+  const unsigned b = mm / hw, rem = mm - b * hw;
+  const unsigned y = rem / (unsigned)g.Wm, x = rem - y * (unsigned)g.Wm;
+  return ((int64_t)b * g.HO + (int64_t)y * g.os + g.oph) * g.WO + (int64_t)x * g.os + g.opw;
 }
 
 // the five epilogue modes on four consecutive output columns (bias b4, saved activation ax, addend ad as they were loaded)
@@ -184,11 +185,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs args)
   for (int i = 0; i < 4; ++i) {
     const int64_t row = m0 + r0 + 32 * i;
     if (row < args.M) {
-      const int64_t hw = (int64_t)g.Hm * g.Wm;
-      const int64_t b = row / hw, rem = row - b * hw;
-      const int y = (int)(rem / g.Wm), x = (int)(rem - (int64_t)y * g.Wm);
+      const unsigned hw = (unsigned)g.Hm * (unsigned)g.Wm, rr = (unsigned)row;      // < 2^31 rows (launcher): 32-bit divisions
+      const unsigned b = rr / hw, rem = rr - b * hw;
+      const int y = (int)(rem / (unsigned)g.Wm), x = (int)(rem - (unsigned)y * (unsigned)g.Wm);
       py[i] = y * g.gs; px[i] = x * g.gs;
-      pb[i] = b * g.Hs * g.Ws;
+      pb[i] = (int64_t)b * g.Hs * g.Ws;
     } else { py[i] = -(1 << 28); px[i] = -(1 << 28); pb[i] = 0; }   // every tap of an out-of-range row falls outside the image -> zeros
   }
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
@@ -290,10 +291,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_glds_kernel(const ConvArgs 
     coff[i] = c * 8;
     const int64_t row = m0 + r;
     if (row < args.M) {
-      const int64_t hw = (int64_t)g.Hm * g.Wm;
-      const int64_t b = row / hw, rem = row - b * hw;
-      const int y = (int)(rem / g.Wm), x = (int)(rem - (int64_t)y * g.Wm);
-      py[i] = y * g.gs; px[i] = x * g.gs; pb[i] = b * g.Hs * g.Ws;
+      const unsigned hw = (unsigned)g.Hm * (unsigned)g.Wm, rr = (unsigned)row;      // < 2^31 rows (launcher): 32-bit divisions
+      const unsigned b = rr / hw, rem = rr - b * hw;
+      const int y = (int)(rem / (unsigned)g.Wm), x = (int)(rem - (unsigned)y * (unsigned)g.Wm);
+      py[i] = y * g.gs; px[i] = x * g.gs; pb[i] = (int64_t)b * g.Hs * g.Ws;
     } else { py[i] = -(1 << 28); px[i] = -(1 << 28); pb[i] = 0; }
     int64_t co = n0 + r;                       // B operand (weights [N][K]): rows beyond N are clamped, their products land in columns that are never stored
     if (co > g.N - 1) co = g.N - 1;
@@ -889,7 +890,7 @@ static int conv_nhwc_impl(const enh_bf16* src, const enh_bf16* wt, const enh_con
   a.bias = bias; a.mode = mode; a.aux = aux; a.add = add; a.p0 = p0; a.p1 = p1; a.out = out;
   a.nbm = (int)((a.M + G_BM - 1) / G_BM); a.nbn = (g->N + G_BN - 1) / G_BN;
   a.ws = nullptr; a.splits = 1; a.st_per_split = (int)(a.K / G_BK);
-  ENH_REQUIRE((int64_t)a.nbm * a.nbn < (1ll << 30), ENH_E_SHAPE, "enh_conv_nhwc_bf16: grid too large");
+  ENH_REQUIRE((int64_t)a.nbm * a.nbn < (1ll << 30) && a.M < (1ll << 31), ENH_E_SHAPE, "enh_conv_nhwc_bf16: grid too large (2^31 GEMM rows or more)");
   conv_lds_attr_once();
   const ConvSplit sp = ws ? conv_split_plan(*g, a.M, a.K) : ConvSplit{1, 0};
   if (sp.splits > 1 && ws_bytes >= (size_t)sp.splits * a.M * g->N * sizeof(float)) {
