@@ -293,7 +293,10 @@ __device__ __forceinline__ const uint16_t* w256_src(const uint16_t* __restrict__
 
 // EPI: the epilogue mode is a template parameter of THIS kernel (chosen on the host): an in-kernel 8-way switch over unrolled epilogues made the
 // code 10x larger and the whole kernel ~10 % slower (measured, same main loop)
-template <bool TA, bool TB, int EPI>
+// LAB (measurement only, wrong results): 1 = fragments fetched with plain ds_read_b128 from the same tiles (same LDS bytes, no transpose reads),
+// 2 = no fragment reads at all (the loop's MFMA + LDS-DMA ceiling), 3 = neither fragment reads nor staging requests (MFMAs + barriers), 4 = all reads,
+// every second staging request, 5 = all reads, no staging requests
+template <bool TA, bool TB, int EPI, int LAB = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_bf16_w256_kernel(const GemmArgs args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2 slots][A0 | A1 | B0 | B1], 16 KiB each
   const int t = threadIdx.x;
@@ -326,17 +329,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   s16x8 fa0[4], fb0[4], fa1[4], fb1[4];
+  if (LAB == 2 || LAB == 3) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { fa0[u] = (s16x8){1, 1, 1, 1, 1, 1, 1, 1}; fb0[u] = fa0[u]; fa1[u] = fa0[u]; fb1[u] = fa0[u]; }
+  }
 
 #define W2_ISSUE_ONE(SLOT, U)                                                                                                     \
-  __builtin_amdgcn_global_load_lds((const GLB_AS void*)((((U) & 1) ? gsrc_o : gsrc_e) + ((U) >> 1) * pair_step),                  \
-                                   (LDS_AS void*)(my_sub + (SLOT) * W2_SLOT + (U) * 1024), 16, 0, 0)
+  do {                                                                                                                            \
+    if (LAB == 3 || LAB == 5 || (LAB == 4 && ((U) & 1))) break;                                                                   \
+    __builtin_amdgcn_global_load_lds((const GLB_AS void*)((((U) & 1) ? gsrc_o : gsrc_e) + ((U) >> 1) * pair_step),                \
+                                     (LDS_AS void*)(my_sub + (SLOT) * W2_SLOT + (U) * 1024), 16, 0, 0);                           \
+  } while (0)
 #define W2_ADVANCE() do { gsrc_e += stage_step; gsrc_o += stage_step; } while (0)
   // fragment u of k16-step S from slot SLOT: u = 0..3 the wave's A row-blocks, 4..7 its B column-blocks.  Transposed operands are read with the
   // asm transpose read (the compiler's wait-count pass knows nothing about them: explicit lgkmcnt(0) at every k-step boundary below)
 #define W2_READ_ONE(FA, FB, SLOT, S, U)                                                                                           \
   do {                                                                                                                            \
-    if ((U) < 4) FA[(U) & 3] = frag32<TA>(smem + (SLOT) * W2_SLOT + wm * G_TILE_BYTES, ((U) & 3) * 32, S, lane);                  \
-    else FB[(U) & 3] = frag32<TB>(smem + (SLOT) * W2_SLOT + (2 + wn) * G_TILE_BYTES, ((U) & 3) * 32, S, lane);                    \
+    if (LAB == 2 || LAB == 3) break;                                                                                              \
+    if ((U) < 4) FA[(U) & 3] = frag32<TA && LAB == 0>(smem + (SLOT) * W2_SLOT + wm * G_TILE_BYTES, ((U) & 3) * 32, S, lane);      \
+    else FB[(U) & 3] = frag32<TB && LAB == 0>(smem + (SLOT) * W2_SLOT + (2 + wn) * G_TILE_BYTES, ((U) & 3) * 32, S, lane);        \
   } while (0)
 #define W2_MM(Q, FA, FB)                                                                                                          \
   acc[(Q) >> 2][(Q) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, FB[(Q) & 3]), __builtin_bit_cast(bf16x8, FA[(Q) >> 2]), acc[(Q) >> 2][(Q) & 3], 0, 0, 0)
@@ -370,6 +381,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   } while (0)
 
   // prologue: stage 0 -> slot 0 completely; pieces 0-7 of stage 1 -> slot 1 (pieces 8-15 follow under the first k-step)
+  {
 #pragma unroll
   for (int u = 0; u < 16; ++u) W2_ISSUE_ONE(0, u);
   W2_ADVANCE();
@@ -407,6 +419,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     W2_KSTEP(fa1, fb1, fa0, fb0, slot ^ 1, 2, true, 0, 0, false);
     W2_KSTEP(fa0, fb0, fa1, fb1, slot ^ 1, 3, true, 0, 0, false);
     W2_KSTEP(fa1, fb1, fa0, fb0, 0, 0, false, 0, 0, false);
+  }
   }
   gemm_epilogue32_loops<EPI, 4, false>(args, acc, m0 + wm * 128, n0 + wn * 128, lane, split,
                                        reinterpret_cast<float*>(smem + 2 * W2_SLOT) + wave * 128, smem + wave * 8192, smem + wave * 16384);
@@ -621,6 +634,7 @@ __device__ __forceinline__ void tile_claim_retire(unsigned* ctr, unsigned f, int
 
 template <bool TA, bool TB, int EPI, bool DYN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_bf16_w256p_kernel(const GemmArgs args) {
+  constexpr int LAB = 0;   // (the shared K-step macros name the one-tile kernel's laboratory switch)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -763,6 +777,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define W2R_D 2
 template <bool TB, int EPI, bool DYN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_bf16_w256r_kernel(const GemmArgs args) {
+  constexpr int LAB = 0;   // (the shared K-step macros name the one-tile kernel's laboratory switch)
   constexpr bool TA = false;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int t = threadIdx.x;
@@ -991,6 +1006,12 @@ static int cu_budget_rows() { const int b = enh_cu_budget(); return b >= 8 ? (b 
 // gemm_bf16_w256p_kernel).  The counters are library-owned device words (not an allocation): 64 launch slots x 8 queues, used round-robin — a slot is
 // reused 64 persistent launches later, by which time the launch that used it has long retired (they run in stream order on one stream; two streams
 // would have to keep 64 persistent GEMMs in flight to collide).
+static int g_w256_lab = 0;   // enh_debug_gemm_lab: measurement-only forms of the split-K weight-gradient loop (wrong results)
+extern "C" int enh_debug_gemm_lab(int variant) {
+  ENH_REQUIRE(variant >= 0 && variant <= 5, ENH_E_BADARG, "enh_debug_gemm_lab: 0 (off) .. 5");
+  g_w256_lab = variant;
+  return ENH_OK;
+}
 static int g_dyn_schedule = 1;
 __device__ unsigned int g_tile_ctr[64][8];
 extern "C" int enh_gemm_set_scheduler(int dynamic) {
@@ -1168,9 +1189,24 @@ static int gemm_bf16_impl(const enh_bf16* A, int64_t lda, int trans_a, const enh
     }();
     (void)w2_attr;
     const int mode = epi_mode(g);
+    bool lab_launched = false;
+    if (g_w256_lab && trans_a && trans_b && mode == EPI_WS) {   // measurement only (enh_debug_gemm_lab)
+      static const bool lab_attr = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_w256_kernel<true, true, EPI_WS, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W2_SLOT + W2_BIAS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_w256_kernel<true, true, EPI_WS, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W2_SLOT + W2_BIAS_BYTES);
+        return true;
+      }();
+      (void)lab_attr;
+#define W2_LAB_GO(L_) do { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_w256_kernel<true, true, EPI_WS, L_>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W2_SLOT + W2_BIAS_BYTES); \
+                           gemm_bf16_w256_kernel<true, true, EPI_WS, L_><<<grid, 256, 2 * W2_SLOT + W2_BIAS_BYTES, s>>>(g); } while (0)
+      if (g_w256_lab == 1) W2_LAB_GO(1); else if (g_w256_lab == 2) W2_LAB_GO(2); else if (g_w256_lab == 3) W2_LAB_GO(3); else if (g_w256_lab == 4) W2_LAB_GO(4); else if (g_w256_lab == 5) W2_LAB_GO(5);
+#undef W2_LAB_GO
+      lab_launched = true;
+    }
     // (the persistent epilogues use 16-byte accesses everywhere: operands that only meet the API's weaker alignment rules take the one-tile kernel)
     const bool p_aligned = aligned16(c_bf16) && aligned16(aux) && aligned16(res) && aligned16(bias) && (!c_bf16 || ldc % 8 == 0) && (!aux || ldaux % 8 == 0);
-    if (gemm_persistent(pl, trans_a, K, mode) && (!res || res_rows == M) && p_aligned) {
+    if (lab_launched) {
+    } else if (gemm_persistent(pl, trans_a, K, mode) && (!res || res_rows == M) && p_aligned) {
       // persistent form: one workgroup per CU walks the tiles
 #define W2P_ROW(TB_, D_) {nullptr, gemm_bf16_w256p_kernel<false, TB_, EPI_BF16, D_>, gemm_bf16_w256p_kernel<false, TB_, EPI_BF16_BIAS_TANH, D_>, gemm_bf16_w256p_kernel<false, TB_, EPI_BF16_DTANH, D_>, \
                           gemm_bf16_w256p_kernel<false, TB_, EPI_F32_BIAS_RES, D_>, gemm_bf16_w256p_kernel<false, TB_, EPI_F32, D_>, nullptr, nullptr}
