@@ -313,12 +313,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
   // staging: wave w fills sub-tile w of every slot (0, 1: A halves ; 2, 3: B halves): 16 one-KiB slabs per stage, two source patterns
   const bool stage_a = wave < 2;   // wave-uniform
-  const uint16_t* gsrc_e = stage_a ? w256_src<TA>(args.A, args.lda, m0 + wave * 128, k_begin, 0, lane) : w256_src<TB>(args.B, args.ldb, n0 + (wave - 2) * 128, k_begin, 0, lane);
-  const uint16_t* gsrc_o = stage_a ? w256_src<TA>(args.A, args.lda, m0 + wave * 128, k_begin, 1, lane) : w256_src<TB>(args.B, args.ldb, n0 + (wave - 2) * 128, k_begin, 1, lane);
   const bool my_tr = stage_a ? TA : TB;
   const int64_t my_ld = stage_a ? args.lda : args.ldb;
   const int64_t pair_step = (my_tr ? 8 : 16) * my_ld;              // elements between slabs u and u + 2
   const int64_t stage_step = my_tr ? (int64_t)G_BK * my_ld : (int64_t)G_BK;
+  const uint16_t* gsrc_e = stage_a ? w256_src<TA>(args.A, args.lda, m0 + wave * 128, k_begin, 0, lane) : w256_src<TB>(args.B, args.ldb, n0 + (wave - 2) * 128, k_begin, 0, lane);
+  const uint16_t* gsrc_o = stage_a ? w256_src<TA>(args.A, args.lda, m0 + wave * 128, k_begin, 1, lane) : w256_src<TB>(args.B, args.ldb, n0 + (wave - 2) * 128, k_begin, 1, lane);
   unsigned char* const my_sub = smem + wave * G_TILE_BYTES;
 
   f32x16 acc[4][4];
