@@ -296,8 +296,8 @@ __device__ __forceinline__ const uint16_t* w256_src(const uint16_t* __restrict__
 // LAB (measurement only, wrong results): 1 = fragments fetched with plain ds_read_b128 from the same tiles (same LDS bytes, no transpose reads),
 // 2 = no fragment reads at all (the loop's MFMA + LDS-DMA ceiling), 3 = neither fragment reads nor staging requests (MFMAs + barriers), 4 = all reads,
 // every second staging request, 5 = all reads, no staging requests
-template <bool TA, bool TB, int EPI, int LAB = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_bf16_w256_kernel(const GemmArgs args) {
+template <bool TA, bool TB, int EPI, int LAB>
+__device__ __forceinline__ void gemm_bf16_w256_body(const GemmArgs& args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2 slots][A0 | A1 | B0 | B1], 16 KiB each
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -423,6 +423,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
   gemm_epilogue32_loops<EPI, 4, false>(args, acc, m0 + wm * 128, n0 + wn * 128, lane, split,
                                        reinterpret_cast<float*>(smem + 2 * W2_SLOT) + wave * 128, smem + wave * 8192, smem + wave * 16384);
+}
+
+template <bool TA, bool TB, int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_bf16_w256_kernel(const GemmArgs args) {
+  gemm_bf16_w256_body<TA, TB, EPI, 0>(args);
+}
+// the measurement-only forms of the split-K weight-gradient loop (enh_debug_gemm_lab)
+template <int LAB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_bf16_w256_lab_kernel(const GemmArgs args) {
+  gemm_bf16_w256_body<true, true, EPI_WS, LAB>(args);
 }
 
 // =================================================================================================
@@ -1191,14 +1201,8 @@ static int gemm_bf16_impl(const enh_bf16* A, int64_t lda, int trans_a, const enh
     const int mode = epi_mode(g);
     bool lab_launched = false;
     if (g_w256_lab && trans_a && trans_b && mode == EPI_WS) {   // measurement only (enh_debug_gemm_lab)
-      static const bool lab_attr = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_w256_kernel<true, true, EPI_WS, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W2_SLOT + W2_BIAS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_w256_kernel<true, true, EPI_WS, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W2_SLOT + W2_BIAS_BYTES);
-        return true;
-      }();
-      (void)lab_attr;
-#define W2_LAB_GO(L_) do { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_w256_kernel<true, true, EPI_WS, L_>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W2_SLOT + W2_BIAS_BYTES); \
-                           gemm_bf16_w256_kernel<true, true, EPI_WS, L_><<<grid, 256, 2 * W2_SLOT + W2_BIAS_BYTES, s>>>(g); } while (0)
+#define W2_LAB_GO(L_) do { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_w256_lab_kernel<L_>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W2_SLOT + W2_BIAS_BYTES); \
+                           gemm_bf16_w256_lab_kernel<L_><<<grid, 256, 2 * W2_SLOT + W2_BIAS_BYTES, s>>>(g); } while (0)
       if (g_w256_lab == 1) W2_LAB_GO(1); else if (g_w256_lab == 2) W2_LAB_GO(2); else if (g_w256_lab == 3) W2_LAB_GO(3); else if (g_w256_lab == 4) W2_LAB_GO(4); else if (g_w256_lab == 5) W2_LAB_GO(5);
 #undef W2_LAB_GO
       lab_launched = true;
