@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_glds_kernel(const ConvArgs 
     }
   };
 #define CG_LOAD(PTR, BUF, WHICH, I)                                                                                                          \
-  __builtin_amdgcn_global_load_lds((const GLB_AS void*)(PTR), (LDS_AS void*)(smem + (BUF) * (2 * G_TILE_BYTES) + (WHICH) * G_TILE_BYTES + (wave * 4 + (I)) * 1024), 16, 0, 0)
+  __builtin_amdgcn_global_load_lds((const GLB_AS void*)(PTR), (LDS_AS void*)(smem + (BUF) * (2 * G_TILE_BYTES) + (WHICH) * G_TILE_BYTES + (wave * 4 + (I)) * 1024), 16, 0, ENH_GLDS_AUX)
 #define CG_READ(FA, FB, BUF, KS)                                                                                         \
   do {                                                                                                                   \
     const unsigned char* sa_ = smem + (BUF) * (2 * G_TILE_BYTES);                                                        \
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     {                                                                                                                             \
       const unsigned sy_ = (unsigned)((pyx[U] >> 16) + s_dy), sx_ = (unsigned)((pyx[U] & 0xffff) + s_dx);                         \
       const uint16_t* p_ = (sy_ < lim_y && sx_ < lim_x) ? gbase + (rowoff[U] + s_off) : zero;                                     \
-      __builtin_amdgcn_global_load_lds((const GLB_AS void*)p_, (LDS_AS void*)(my_sub + (SLOT) * CW_SLOT + (U) * 1024), 16, 0, 0);  \
+      __builtin_amdgcn_global_load_lds((const GLB_AS void*)p_, (LDS_AS void*)(my_sub + (SLOT) * CW_SLOT + (U) * 1024), 16, 0, ENH_GLDS_AUX);  \
     }                                                                                                                             \
   } while (0)
 #define CW_READ_ONE(FA, FB, SLOT, S, U)                                                                                           \
@@ -697,10 +697,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   do {                                                                                                                            \
     const unsigned sy_ = (unsigned)((pyx[U] >> 16) + s_dy), sx_ = (unsigned)((pyx[U] & 0xffff) + s_dx);                           \
     const uint16_t* p_ = (sy_ < (unsigned)g.Hs && sx_ < (unsigned)g.Ws) ? args.X + (rowoff[U] + s_off) : zero;                    \
-    __builtin_amdgcn_global_load_lds((const GLB_AS void*)p_, (LDS_AS void*)(my_a + (SLOT) * CX_SLOT + (U) * 1024), 16, 0, 0);     \
+    __builtin_amdgcn_global_load_lds((const GLB_AS void*)p_, (LDS_AS void*)(my_a + (SLOT) * CX_SLOT + (U) * 1024), 16, 0, ENH_GLDS_AUX);     \
   } while (0)
 #define CX_ISSUE_B(SLOT, V)                                                                                                       \
-  __builtin_amdgcn_global_load_lds((const GLB_AS void*)(args.Wt + (boff[V] + s_k)), (LDS_AS void*)(my_b + (SLOT) * CX_SLOT + (V) * 1024), 16, 0, 0)
+  __builtin_amdgcn_global_load_lds((const GLB_AS void*)(args.Wt + (boff[V] + s_k)), (LDS_AS void*)(my_b + (SLOT) * CX_SLOT + (V) * 1024), 16, 0, ENH_GLDS_AUX)
 #define CX_READ_ONE(FA, FB, SLOT, S, U)                                                                                           \
   do {                                                                                                                            \
     if ((U) < 4) FA[(U) & 3] = frag32<false>(smem + (SLOT) * CX_SLOT + wave * G_TILE_BYTES, ((U) & 3) * 32, S, lane);             \
@@ -1110,7 +1110,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   do {                                                                                                                            \
     const unsigned vx_ = vx0 + (unsigned)(U) * vxstep + s_x;                                                                      \
     const uint16_t* p_ = (s_ok && vx_ < lim) ? s_base + ((((U) & 1) ? voff_o : voff_e) + ((U) >> 1) * step2) : zero;              \
-    __builtin_amdgcn_global_load_lds((const GLB_AS void*)p_, (LDS_AS void*)(my_sub + (SLOT) * CW_SLOT + (U) * 1024), 16, 0, 0);    \
+    __builtin_amdgcn_global_load_lds((const GLB_AS void*)p_, (LDS_AS void*)(my_sub + (SLOT) * CW_SLOT + (U) * 1024), 16, 0, ENH_GLDS_AUX);    \
   } while (0)
 #define WW_READ_ONE(FA, FB, SLOT, S, U)                                                                                           \
   do {                                                                                                                            \

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_pipe2_kernel(const GemmArgs 
     unsigned char* base_ = smem + (BUF) * (2 * G_TILE_BYTES);                                                            \
     _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                                                   \
       __builtin_amdgcn_global_load_lds((const GLB_AS void*)src[i_],                                                      \
-                                       (LDS_AS void*)(base_ + (i_ >> 2) * G_TILE_BYTES + (wave * 4 + (i_ & 3)) * 1024), 16, 0, 0); \
+                                       (LDS_AS void*)(base_ + (i_ >> 2) * G_TILE_BYTES + (wave * 4 + (i_ & 3)) * 1024), 16, 0, ENH_GLDS_AUX); \
       src[i_] += step[i_];                                                                                               \
     }                                                                                                                    \
   } while (0)
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_pipe2_kernel(const GemmArgs 
         acc[i][jj * 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb1[jj * 2]), __builtin_bit_cast(bf16x8, fa1[i]), acc[i][jj * 2], 0, 0, 0);
         acc[i][jj * 2 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb1[jj * 2 + 1]), __builtin_bit_cast(bf16x8, fa1[i]), acc[i][jj * 2 + 1], 0, 0, 0);
         if (more) {
-          __builtin_amdgcn_global_load_lds((const GLB_AS void*)src[ld], (LDS_AS void*)(nbase + (ld >> 2) * G_TILE_BYTES + (wave * 4 + (ld & 3)) * 1024), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((const GLB_AS void*)src[ld], (LDS_AS void*)(nbase + (ld >> 2) * G_TILE_BYTES + (wave * 4 + (ld & 3)) * 1024), 16, 0, ENH_GLDS_AUX);
           src[ld] += step[ld];
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -338,7 +338,8 @@ __device__ __forceinline__ void gemm_bf16_w256_body(const GemmArgs& args) {
   do {                                                                                                                            \
     if (LAB == 3 || LAB == 5 || (LAB == 4 && ((U) & 1))) break;                                                                   \
     __builtin_amdgcn_global_load_lds((const GLB_AS void*)((((U) & 1) ? gsrc_o : gsrc_e) + ((U) >> 1) * pair_step),                \
-                                     (LDS_AS void*)(my_sub + (SLOT) * W2_SLOT + (U) * 1024), 16, 0, 0);                           \
+                                     (LDS_AS void*)(my_sub + (SLOT) * W2_SLOT + (U) * 1024), 16, 0,                               \
+                                     LAB == 6 ? 1 : (LAB == 7 ? 2 : (LAB == 8 ? 16 : (LAB == 9 ? 17 : ENH_GLDS_AUX)))); /* lab 6-9: sc0 / nt / sc1 / sc0 sc1 */ \
   } while (0)
 #define W2_ADVANCE() do { gsrc_e += stage_step; gsrc_o += stage_step; } while (0)
   // fragment u of k16-step S from slot SLOT: u = 0..3 the wave's A row-blocks, 4..7 its B column-blocks.  Transposed operands are read with the
@@ -842,8 +843,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define W2R_BPTR(U, KOFF) ((((U) & 1) ? gB_o : gB_e) + ((U) >> 1) * pairB + (KOFF))
 #define W2R_A_LOAD(SET, U, KOFF) ra[SET][U] = *reinterpret_cast<const u32x4*>(W2R_APTR(U, KOFF))
 #define W2R_A_WRITE(SLOT, SET, U) *reinterpret_cast<u32x4*>(smem + (SLOT) * W2_SLOT + a_lds + (U) * 1024 + lane * 16) = ra[SET][U]
-#define W2R_A_DMA(SLOT, U, KOFF) __builtin_amdgcn_global_load_lds((const GLB_AS void*)W2R_APTR(U, KOFF), (LDS_AS void*)(smem + (SLOT) * W2_SLOT + a_lds + (U) * 1024), 16, 0, 0)
-#define W2R_B_DMA(SLOT, U, KOFF) __builtin_amdgcn_global_load_lds((const GLB_AS void*)W2R_BPTR(U, KOFF), (LDS_AS void*)(smem + (SLOT) * W2_SLOT + b_lds + (U) * 1024), 16, 0, 0)
+#define W2R_A_DMA(SLOT, U, KOFF) __builtin_amdgcn_global_load_lds((const GLB_AS void*)W2R_APTR(U, KOFF), (LDS_AS void*)(smem + (SLOT) * W2_SLOT + a_lds + (U) * 1024), 16, 0, ENH_GLDS_AUX)
+#define W2R_B_DMA(SLOT, U, KOFF) __builtin_amdgcn_global_load_lds((const GLB_AS void*)W2R_BPTR(U, KOFF), (LDS_AS void*)(smem + (SLOT) * W2_SLOT + b_lds + (U) * 1024), 16, 0, ENH_GLDS_AUX)
   // k16 step 0 of a stage: + fragment reads of k-step 1 ; under every odd MFMA: the A share of the next stage leaves its registers for LDS and the
   // registers are re-used at once for the share three stages further on
 #define W2R_K0(FA, FB, RA, RB, RSLOT, ZERO, WSLOT, SET)                                                                           \
@@ -1018,7 +1019,7 @@ static int cu_budget_rows() { const int b = enh_cu_budget(); return b >= 8 ? (b 
 // would have to keep 64 persistent GEMMs in flight to collide).
 static int g_w256_lab = 0;   // enh_debug_gemm_lab: measurement-only forms of the split-K weight-gradient loop (wrong results)
 extern "C" int enh_debug_gemm_lab(int variant) {
-  ENH_REQUIRE(variant >= 0 && variant <= 5, ENH_E_BADARG, "enh_debug_gemm_lab: 0 (off) .. 5");
+  ENH_REQUIRE(variant >= 0 && variant <= 9, ENH_E_BADARG, "enh_debug_gemm_lab: 0 (off) .. 9");
   g_w256_lab = variant;
   return ENH_OK;
 }
@@ -1203,7 +1204,8 @@ static int gemm_bf16_impl(const enh_bf16* A, int64_t lda, int trans_a, const enh
     if (g_w256_lab && trans_a && trans_b && mode == EPI_WS) {   // measurement only (enh_debug_gemm_lab)
 #define W2_LAB_GO(L_) do { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_w256_lab_kernel<L_>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W2_SLOT + W2_BIAS_BYTES); \
                            gemm_bf16_w256_lab_kernel<L_><<<grid, 256, 2 * W2_SLOT + W2_BIAS_BYTES, s>>>(g); } while (0)
-      if (g_w256_lab == 1) W2_LAB_GO(1); else if (g_w256_lab == 2) W2_LAB_GO(2); else if (g_w256_lab == 3) W2_LAB_GO(3); else if (g_w256_lab == 4) W2_LAB_GO(4); else if (g_w256_lab == 5) W2_LAB_GO(5);
+      if (g_w256_lab == 1) W2_LAB_GO(1); else if (g_w256_lab == 2) W2_LAB_GO(2); else if (g_w256_lab == 3) W2_LAB_GO(3); else if (g_w256_lab == 4) W2_LAB_GO(4); else if (g_w256_lab == 5) W2_LAB_GO(5); else if (g_w256_lab == 6) W2_LAB_GO(6); else if (g_w256_lab == 7) W2_LAB_GO(7); else if (g_w256_lab == 8) W2_LAB_GO(8);
+      else if (g_w256_lab == 9) W2_LAB_GO(9);
 #undef W2_LAB_GO
       lab_launched = true;
     }

@@ -174,7 +174,8 @@ int enh_get_cu_budget(void);
  * collective's kernel in the one-GPU contention experiment (tools/comm_contention.py). */
 /* measurement only (results are WRONG while it is on): the split-K weight-gradient loop with 1 = plain 16-byte fragment reads instead of the
  * transposing ones (same LDS bytes), 2 = no fragment reads, 3 = neither fragment reads nor staging requests (MFMAs + barriers), 4 = every second
- * staging request, 5 = all fragment reads, no staging requests; 0 = off (tools/wgrad_lab.py, profiles/r04_gemm_fill_lab.txt) */
+ * staging request, 5 = all fragment reads, no staging requests, 6 .. 9 = the shipped loop with cache-policy bits sc0 / nt / sc1 / sc0 + sc1 on its
+ * staging requests (correct results); 0 = off (tools/wgrad_lab.py, profiles/r04_gemm_fill_lab.txt) */
 int enh_debug_gemm_lab(int variant);
 int enh_debug_occupy_cus(int n_wg, float ms, void* stream);
 /* Measurement aid: out16[w] = SIMD id the hardware gave wave w of the first (w < 8) and of the last (8 <= w < 16) 512-thread workgroup of a chip-filling

@@ -19,7 +19,7 @@ for name, M, N in (("qkv", 2304, 768), ("out", 768, 768), ("fc1", 3072, 768), ("
     b = torch.randn(K, N, device="cuda").to(torch.bfloat16)      # X  [tokens][in features]
     c = torch.zeros(M, N, device="cuda")
     row = []
-    for lab in (0, 1, 2, 3, 4, 5, 0):
+    for lab in (0, 1, 2, 3, 4, 5, 8, 0):
         _C.lib().enh_debug_gemm_lab(lab)
         t = timeit(lambda: _C.mm(a, b, M, N, K, c, trans_a=True, trans_b=True, accumulate=True))
         row.append(f"lab {lab}: {t*1e3:7.1f} us {2.0*M*N*K/t/1e9:6.0f} TF/s")
