@@ -258,6 +258,14 @@ def main():
                     help="per bucket: one RCCL all-reduce (default) or reduce-scatter + all-gather (SURVEY.md 8e's direct exchange); same sums")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` with no launcher environment re-executes itself under torch.distributed.run, one rank per GPU (as main.py does;
+    # reference main.py:54-57 hands the same job to Lightning's DDP plugin).  Under a launcher (RANK set) WORLD_SIZE must equal --gpus.
+    if args.gpus > 1 and "RANK" not in os.environ:
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", os.environ.get("MASTER_PORT", "29517"), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")))
+
     import torch
     import torch.distributed as dist
     from enhancing import _C
@@ -301,6 +309,9 @@ def main():
         model.train()
         model.learning_rate = lr
         opts, _ = model.configure_optimizers()
+        if world > 1 and len(opts) > 1:       # the discriminator's own DDP: broadcast + bucketed all-reduce behind ITS backward (engine/ddp.py AutogradGradSync)
+            dist.broadcast(opts[1].store.p, 0)
+            opts[1].attach_sync(model.loss.discriminator, compress="bf16" if args.grad_bf16 else None, algo=args.grad_algo)
 
     def step(i):
         if adversarial:   # per optimizer: training_step (forward + backward) then its AdamW step, as Lightning 1.5 drives vitvqgan.py:101-127
@@ -349,6 +360,10 @@ def main():
         # per-rank exposed communication (so that the first real multi-GPU run explains itself) + the bucket accounting the DDP tests insist on
         mine = eng.comm.comm_wait_ms(last=args.steps)
         mine.update(rank=rank, bytes_reduced_per_step=eng.comm.bytes_reduced / max(args.warmup + args.steps, 1), gap_elems=eng.comm.gap_elems)
+        if adversarial and len(opts) > 1 and opts[1].comm is not None:      # the second optimizer's collectives, reported separately
+            dsync = opts[1].comm
+            mine["discriminator"] = dict(dsync.comm_wait_ms(last=args.steps), bytes_reduced_per_step=dsync.bytes_reduced / max(args.warmup + args.steps, 1),
+                                         gap_elems=dsync.gap_elems, n_params=int(dsync.store.g.numel()), n_buckets=len(dsync.buckets))
         allr = [None] * world
         dist.all_gather_object(allr, mine)
         comm_info = {"backend": dist.get_backend(), "algo": args.grad_algo, "comm_cus": args.comm_cus, "bucket_dtype": "bf16" if args.grad_bf16 else "fp32",

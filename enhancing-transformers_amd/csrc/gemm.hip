@@ -1024,6 +1024,15 @@ extern "C" int enh_debug_gemm_lab(int variant) {
   return ENH_OK;
 }
 static int g_dyn_schedule = 1;
+// tile order of the non-split forms (gemm_tile_coords_of).  Default (grp_rows = 0): per shape — 8-row groups, rows fastest (an 8 x 4 patch of tiles in flight
+// per XCD), except long-K problems (K >= 2048: fc2 forward, the qkv / fc1 input gradients), which walk row-major over the tiles (every A panel — 1-1.5 MB
+// there — is fetched by one XCD once): -1 ... -4 % per launch on those, nothing elsewhere (profiles/r05_gemm_landing_lab.txt; results are bit-identical).
+static int g_grp_rows = 0, g_col_fast = 0;
+extern "C" int enh_debug_gemm_order(int grp_rows, int col_fast) {
+  ENH_REQUIRE(grp_rows >= 0 && grp_rows <= 4096 && (col_fast == 0 || col_fast == 1), ENH_E_BADARG, "enh_debug_gemm_order: grp_rows 0 (auto) .. 4096, col_fast 0 | 1");
+  g_grp_rows = grp_rows; g_col_fast = col_fast;
+  return ENH_OK;
+}
 __device__ unsigned int g_tile_ctr[64][8];
 extern "C" int enh_gemm_set_scheduler(int dynamic) {
   ENH_REQUIRE(dynamic == 0 || dynamic == 1, ENH_E_BADARG, "enh_gemm_set_scheduler: 0 (static) or 1 (dynamic)");
@@ -1146,6 +1155,8 @@ static int gemm_bf16_impl(const enh_bf16* A, int64_t lda, int trans_a, const enh
   g.accumulate = accumulate; g.c_f32 = c_f32; g.c_bf16 = c_bf16; g.ldc = ldc; g.ws = nullptr;
   g.colpart = colpart;
   g.tile_ctr = nullptr;
+  if (g_grp_rows > 0) { g.grp_rows = g_grp_rows; g.col_fast = g_col_fast; }
+  else { g.col_fast = K >= 2048 ? 1 : 0; g.grp_rows = g.col_fast ? 4 : 8; }
   g.nbm = (int)((M + bm - 1) / bm);
   g.nbn = (int)((N + bn - 1) / bn);
   const int64_t tiles = (int64_t)g.nbm * g.nbn;

@@ -66,6 +66,8 @@ struct GemmArgs {
   int splits;  // number of K-slices (1 = no split-K; otherwise a multiple of 8)
   float* colpart;  // tanh' mode of the persistent kernel: per-128-row partial column sums of the bf16 result, [M / 128][N] (or null)
   unsigned int* tile_ctr;  // persistent kernels, dynamic schedule: the launch's 8 per-XCD tile counters (zero at launch, reset by the kernel itself)
+  int grp_rows;            // tile order of the non-split forms: row panels per group (8 = the shipped order); col_fast: columns fastest inside a group
+  int col_fast;            // (enh_debug_gemm_order: what the 32 workgroups of an XCD have in flight together is a grp_rows x 32/grp_rows patch, or ~32/nbn rows x nbn)
 };
 
 // global -> registers: one 128 x 64 (row layout) or 64 x 128 (kmaj layout) bf16 operand tile, 4 x 16 B per thread
@@ -295,11 +297,12 @@ __device__ __forceinline__ void gemm_tile_coords_of(const GemmArgs& args, int bl
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, pos = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
   }
-  const int per_group = 8 * args.nbn;
+  const int gr = args.grp_rows;
+  const int per_group = gr * args.nbn;
   const int grp = bid / per_group, within = bid - grp * per_group;
-  const int rows = (args.nbm - grp * 8) < 8 ? (args.nbm - grp * 8) : 8;
-  tile_m = grp * 8 + within % rows;
-  tile_n = within / rows;
+  const int rows = (args.nbm - grp * gr) < gr ? (args.nbm - grp * gr) : gr;
+  if (args.col_fast) { tile_m = grp * gr + within / args.nbn; tile_n = within - (within / args.nbn) * args.nbn; }
+  else { tile_m = grp * gr + within % rows; tile_n = within / rows; }
 }
 __device__ __forceinline__ void gemm_tile_coords(const GemmArgs& args, int& split, int& tile_m, int& tile_n) {
   gemm_tile_coords_of(args, (int)blockIdx.x, split, tile_m, tile_n);

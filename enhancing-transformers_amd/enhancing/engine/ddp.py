@@ -177,6 +177,62 @@ class GradSync:
         return {"host_ms": mean(host), "stream_ms": mean(stream), "steps": len(host), "buckets_per_step": self.buckets_last_step}
 
 
+class AutogradGradSync(GradSync):
+    """The same bucketed, overlapped all-reduce for a store whose gradients are written by a torch AUTOGRAD backward (the StyleGAN discriminator, the
+    second optimizer of reference vitvqgan.py:163-164, whose DDP wrap all-reduces its 115 MB of gradients bucket by bucket behind ITS backward —
+    reference main.py:54-57).  There is no static schedule to announce units, so every parameter gets a post-accumulate-grad hook: the flat buffer is cut
+    into contiguous buckets of >= `min_bucket_elems` elements in REVERSE registration order (the order autograd finishes them: the last layers first) and a
+    bucket is handed to RCCL the moment its last parameter's gradient has been accumulated — while autograd is still differentiating the earlier blocks.
+    `enabled = False` is DDP's no_sync (all but the last micro-batch of an accumulation window); parameters that received no gradient in a step are
+    covered by finish()'s gap pass, as in GradSync."""
+
+    def __init__(self, store, named_params, **kw) -> None:
+        super().__init__(store, **kw)
+        self.enabled = True
+        order = [(n, p) for n, p in named_params if p.requires_grad and n in store.offsets]
+        order.sort(key=lambda np_: store.offsets[np_[0]][0], reverse=True)
+        self.buckets: List[Tuple[int, int]] = []          # [begin, end) of the flat buffer, in firing order
+        self._members: List[int] = []                     # parameters per bucket
+        self._hooks = []
+        hi = None
+        cnt = 0
+        pending = []
+        for i, (n, p) in enumerate(order):
+            off, numel, _ = store.offsets[n]
+            if hi is None:
+                hi = store.g.numel()          # the highest parameter's slice runs to the end of the flat buffer (alignment padding included)
+            pending.append(p)
+            cnt += 1
+            if hi - off >= self.min_bucket or i == len(order) - 1:
+                bid = len(self.buckets)
+                self.buckets.append((off, hi))
+                self._members.append(cnt)
+                for q in pending:
+                    self._hooks.append(q.register_post_accumulate_grad_hook(self._make_hook(bid)))
+                hi, cnt, pending = off, 0, []
+        self._left = list(self._members)
+
+    def _make_hook(self, bid: int):
+        def hook(_param) -> None:
+            if not self.enabled:
+                return
+            self._left[bid] -= 1
+            if self._left[bid] == 0:
+                b, e = self.buckets[bid]
+                self._done.append((b, e))
+                self._reduce(b, e)
+        return hook
+
+    def finish(self) -> None:
+        super().finish()
+        self._left = list(self._members)
+
+    def remove_hooks(self) -> None:
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+
 def init_process_group_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     """torchrun-style rendezvous (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT). -> (rank, local_rank, world)"""
     import os

@@ -29,12 +29,21 @@ class FusedAdamW:
 
 class FlatAdamW:
     """The same fused AdamW launch over any ``ParamStore`` (here: the discriminator's, the second optimizer of reference
-    vitvqgan.py:163-164).  Under DDP the whole flat gradient buffer is averaged with ONE all-reduce right before the step."""
+    vitvqgan.py:163-164).  Under DDP the gradient buckets are all-reduced behind the discriminator's own backward (``attach_sync``: an
+    ``AutogradGradSync`` whose hooks fire as autograd finishes each bucket; ``step`` only waits for what is still in flight) — a process group
+    without an attached sync falls back to ONE blocking all-reduce of the flat buffer right before the step."""
 
     def __init__(self, store, lr: float, betas=(0.9, 0.99), eps: float = 1e-8, weight_decay: float = 1e-4) -> None:
         self.store = store
         self.param_groups = [dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)]
         self.grad_scale = 1.0
+        self.comm = None
+
+    def attach_sync(self, module, **kw):
+        """bucketed asynchronous gradient all-reduce for this store, driven by autograd hooks on `module`'s parameters (engine/ddp.py)"""
+        from .ddp import AutogradGradSync
+        self.comm = AutogradGradSync(self.store, list(module.named_parameters()), **kw)
+        return self.comm
 
     def zero_grad(self, set_to_none: bool = False) -> None:
         self.store.zero_grad()
@@ -44,7 +53,10 @@ class FlatAdamW:
         from .. import _C
         s, g = self.store, self.param_groups[0]
         scale = self.grad_scale
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if self.comm is not None:
+            self.comm.finish()
+            scale /= self.comm.world
+        elif dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(s.g)
             scale /= dist.get_world_size()
         s.step_count += 1

@@ -426,6 +426,7 @@ class Stage1Engine:
         # are active (both record events / issue collectives from the host inside the step).
         self.use_graphs = os.environ.get("ENH_GRAPHS", "0") == "1"
         self._graphs: Dict[tuple, tuple] = {}
+        self.store.operand_hooks.append(self._refresh_x3_operands)
 
     # ---- helpers -----------------------------------------------------------------------------
     def _invalidate_saved(self) -> None:
@@ -761,9 +762,13 @@ class Stage1Engine:
         s.step_count += 1
         _C.adamw_step(s.p, s.g, s.m, s.v, s.p16 if self.precision == "bf16" else None, s.step_count, lr, betas[0], betas[1], eps, weight_decay,
                       grad_scale)
-        s.refresh_operands()      # operands derived from the masters (the towers' pre-scaled q | k | v weights): 24 small launches at base
+        s.refresh_operands()      # operands derived from the masters (the towers' pre-scaled q | k | v weights, the x3 images: _refresh_x3_operands)
+
+    def _refresh_x3_operands(self) -> None:
+        """operand hook of the store (runs after EVERY write to the masters: optimizer_step, and refresh_shadows after a checkpoint load / broadcast — ADVICE
+        r4): with an x3 TRAINING precision the split weight images are rebuilt eagerly.  They are otherwise rebuilt lazily by the next x3 forward — which a
+        HIP-graph replay never runs on the host, so a replay after refresh_shadows() would read the images of the old weights."""
         if "x3" in (self.encoder_precision, self.decoder_precision) and self.precision == "bf16":
-            # the x3 weight images are otherwise rebuilt lazily by the next x3 forward — which a HIP-graph replay never runs on the host
             if self.encoder_precision == "x3":
                 self.enc.x3_weights()
             if self.decoder_precision == "x3":

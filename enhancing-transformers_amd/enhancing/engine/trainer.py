@@ -97,6 +97,7 @@ class Trainer:
         if self.world > 1 and len(opts) > 1:
             import torch.distributed as dist
             dist.broadcast(opts[1].store.p, 0)
+            opts[1].attach_sync(model.loss.discriminator)      # bucketed all-reduce behind the discriminator's autograd backward
         t0, seen = time.time(), 0
         self._hook("on_pretrain_routine_start", model)
         for epoch in range(self.max_epochs):
@@ -111,6 +112,9 @@ class Trainer:
                 last = (batch_idx + 1) % self.accum == 0 or (n_batches is not None and batch_idx + 1 == n_batches)
                 # Lightning 1.5 order: per optimizer, training_step -> backward -> step, so the discriminator step sees the updated autoencoder
                 eng.sync_grads = last   # accumulate locally, all-reduce the window's sum once (what DDP's no_sync gives Lightning)
+                for o in opts[1:]:
+                    if getattr(o, "comm", None) is not None:
+                        o.comm.enabled = last
                 for oi, o in enumerate(opts):
                     model.training_step(batch, batch_idx, oi, zero_grad=first)
                     if last:

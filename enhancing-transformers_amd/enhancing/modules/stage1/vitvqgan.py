@@ -363,7 +363,9 @@ class ViTVQGumbel(ViTVQ):
     def training_step(self, batch, batch_idx: int, optimizer_idx: int = 0, zero_grad: bool = True):
         if self.temperature_scheduler:
             self.quantizer.temperature = self.temperature_scheduler(self.global_step)
-        loss = super().training_step(batch, batch_idx, optimizer_idx, zero_grad)
+        # always the eager sequence: the Gumbel temperature is a HOST scalar read inside the step (gumbel_softmax(tau=...)), a captured HIP graph would
+        # replay the capture-time tau while the logged 'temperature' keeps annealing; the quantizer is plain torch between the two HIP halves
+        loss = self._training_step_eager(batch, batch_idx, optimizer_idx, zero_grad)
         if optimizer_idx == 0:
             self.log("temperature", self.quantizer.temperature)
         return loss

@@ -36,7 +36,7 @@ extern "C" {
 typedef uint16_t enh_bf16; /* raw bfloat16 bits */
 
 const char* enh_last_error(void);
-#define ENH_ABI_VERSION 9   /* bumped whenever a signature below changes; the bindings check it at load */
+#define ENH_ABI_VERSION 10  /* bumped whenever a signature below changes; the bindings check it at load */
 int enh_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -177,6 +177,11 @@ int enh_get_cu_budget(void);
  * staging request, 5 = all fragment reads, no staging requests, 6 .. 9 = the shipped loop with cache-policy bits sc0 / nt / sc1 / sc0 + sc1 on its
  * staging requests (correct results); 0 = off (tools/wgrad_lab.py, profiles/r04_gemm_fill_lab.txt) */
 int enh_debug_gemm_lab(int variant);
+/* Measurement aid (results unchanged): tile order of the forward / input-gradient GEMMs — `grp_rows` row panels per group (8, rows fastest: the 32
+ * workgroups of an XCD have an 8 x 4 patch of tiles in flight), col_fast = 1: columns fastest inside a group (a few rows x ALL column tiles in flight:
+ * every A panel is fetched by one XCD once).  grp_rows = 0: the library's per-shape default (col_fast for K >= 2048).  tools/gemm_ld_lab.py,
+ * profiles/r05_gemm_landing_lab.txt */
+int enh_debug_gemm_order(int grp_rows, int col_fast);
 int enh_debug_occupy_cus(int n_wg, float ms, void* stream);
 /* Measurement aid: out16[w] = SIMD id the hardware gave wave w of the first (w < 8) and of the last (8 <= w < 16) 512-thread workgroup of a chip-filling
  * grid — the placement rule the eight-wave antiphase attention kernels depend on (profiles/r04_attention_lab.txt). */

@@ -67,3 +67,35 @@ def test_vitvq_gumbel_training_step_vs_oracle(monkeypatch):
         xr, _ = m(x)
     assert rec.shape == xr.shape == x.shape
     assert rel(rec, xr) <= 1e-2          # eval mode quantises hard: decode(codes) is the model's own reconstruction
+
+
+def test_gumbel_temperature_anneals_under_graph_replay_mode(monkeypatch):
+    """with engine.use_graphs the loss-module path replays from HIP graphs; the Gumbel temperature is a host scalar inside the step, so
+    ViTVQGumbel must not take that path — the step's loss has to follow the scheduled temperature, and no step graph may be captured."""
+    import vitvq_oracle as O
+    from enhancing.modules.stage1.vitvqgan import ViTVQGumbel
+    from enhancing.utils.general import AttrDict
+    monkeypatch.setattr(torch.nn.functional, "gumbel_softmax", _noiseless)
+    cfg = O.TINY_CFG
+    P = O.make_params(cfg, seed=11)
+    x = O.make_images(5, 2, cfg["image_size"])
+    loss = {"target": "enhancing.losses.vqperceptual.VQLPIPS",
+            "params": dict(codebook_weight=0.5, loglaplace_weight=0.0, loggaussian_weight=1.0, perceptual_weight=0.0)}
+    qcfg = dict(embed_dim=32, n_embed=512, temp_init=0.9)
+
+    def run(temps, graphs):
+        m = ViTVQGumbel("image", cfg["image_size"], cfg["patch_size"], AttrDict.wrap(cfg["encoder"]), AttrDict.wrap(cfg["decoder"]), AttrDict.wrap(qcfg),
+                        AttrDict.wrap(loss))
+        m.load_state_dict(P, strict=True)
+        m.train()
+        m.engine.use_graphs = graphs
+        it = iter(temps)
+        m.temperature_scheduler = lambda step: next(it)
+        out = [float(m.training_step({"image": x}, i, 0)) for i in range(len(temps))]
+        torch.cuda.synchronize()
+        return out, m
+    eager, _ = run([0.9, 0.9, 0.2], graphs=False)
+    replay, m = run([0.9, 0.9, 0.2], graphs=True)
+    assert replay == eager, (replay, eager)                   # same weights every step (no optimizer step): the loss is a function of tau alone
+    assert eager[0] == eager[1] and eager[2] != eager[1]      # ... and it moved when tau did
+    assert not m.__dict__.get("_step_graphs")

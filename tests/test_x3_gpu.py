@@ -262,3 +262,37 @@ def test_full_x3_forward_reconstruction_and_loss_vs_fp32_oracle():
         xr, ql = mt(xt)
     print(f"  tiny vs REFERENCE golden: xrec rel {rel(xr, torch.from_numpy(g['xrec'])):.2e}, qloss {ql.item():.7f} vs {float(g['qloss']):.7f}")
     assert rel(xr, torch.from_numpy(g["xrec"])) <= 5e-5 and abs(ql.item() - float(g["qloss"])) <= 1e-5 * abs(float(g["qloss"]))
+
+
+def test_x3_graph_replay_after_refresh_shadows_reads_the_new_weights():
+    """the split weight images of an x3 TRAINING precision are rebuilt on the host side of the step; a HIP-graph replay never runs that
+    code, so every write to the masters — optimizer_step AND refresh_shadows (checkpoint load, broadcast) — must rebuild them eagerly."""
+    import vitvq_oracle as O
+    from enhancing.modules.stage1.vitvqgan import ViTVQ
+    from enhancing.utils.general import AttrDict
+    cfg = O.TINY_CFG
+    P = O.make_params(cfg, seed=11)
+    x = O.make_images(5, 2, cfg["image_size"]).cuda()
+    loss = {"target": "enhancing.losses.vqperceptual.VQLPIPS",
+            "params": dict(codebook_weight=1.0, loglaplace_weight=0.0, loggaussian_weight=1.0, perceptual_weight=0.0)}
+
+    def build():
+        m = ViTVQ("image", cfg["image_size"], cfg["patch_size"], AttrDict.wrap(cfg["encoder"]), AttrDict.wrap(cfg["decoder"]), AttrDict.wrap(cfg["quantizer"]),
+                  AttrDict.wrap(loss))
+        m.load_state_dict(P)
+        e = m.engine
+        e.encoder_precision = e.decoder_precision = "x3"
+        return m, e
+    m, e = build()
+    e.use_graphs = True
+    a = float(e.forward_backward_graphed(x)["loss"])              # captures (weights W0)
+    with torch.no_grad():
+        e.store.p.mul_(1.05)                                      # an external write to the masters ...
+    e.store.refresh_shadows()                                     # ... announced the documented way
+    b = float(e.forward_backward_graphed(x)["loss"])              # replay: must see W1 in EVERY operand image, the split ones included
+    m2, e2 = build()
+    with torch.no_grad():
+        e2.store.p.mul_(1.05)
+    e2.store.refresh_shadows()
+    ref = float(e2.forward_backward(x)["loss"])                   # eager, same weights
+    assert a != b and b == ref, (a, b, ref)
