@@ -471,8 +471,9 @@ __device__ __forceinline__ void gemm_epilogue_p(const GemmArgs& args, f32x16 (&a
   int lane = lane_in;
   asm volatile("" : "+v"(lane));
   const int l31 = lane & 31, hi = lane >> 5;
-  constexpr bool HAS_BIAS = MODE == EPI_BF16_BIAS_TANH || MODE == EPI_F32_BIAS_RES;
-  constexpr bool OUT16 = MODE == EPI_BF16 || MODE == EPI_BF16_BIAS_TANH || MODE == EPI_BF16_DTANH;
+  constexpr bool HAS_BIAS = MODE == EPI_BF16_BIAS_TANH || MODE == EPI_F32_BIAS_RES || MODE == EPI_BF16_TANH_SPLIT;
+  constexpr bool SPLIT = MODE == EPI_BF16_SPLIT || MODE == EPI_BF16_TANH_SPLIT;   // x3 producers: hi = bf16(v) and lo = bf16(v - hi) planes (csrc/x3.hip split2 / split3, fused)
+  constexpr bool OUT16 = MODE == EPI_BF16 || MODE == EPI_BF16_BIAS_TANH || MODE == EPI_BF16_DTANH || SPLIT;
   // the tile's bias values were requested by the caller a K loop ago (bias4, lanes 0-31): requested here, the wait for them would also be a wait for
   // the next tile's operand requests, which are older (vmcnt retires in order)
   if (HAS_BIAS && lane < 32) *reinterpret_cast<float4*>(wave_bias + lane * 4) = bias4;
@@ -512,6 +513,7 @@ __device__ __forceinline__ void gemm_epilogue_p(const GemmArgs& args, f32x16 (&a
 #pragma unroll
           for (int c = 0; c < 8; ++c) hq[(b + 1) & 1][c] = *reinterpret_cast<const uint2*>(at + l31 * 128 + ((c ^ wsw) << 4) + hi * 8);
         }
+        u32x2 lo_[SPLIT ? 8 : 1];   // SPLIT: the block's lo plane, parked in registers while the hi plane goes through the store tile
 #pragma unroll
         for (int j2 = 0; j2 < 2; ++j2)
 #pragma unroll
@@ -524,12 +526,43 @@ __device__ __forceinline__ void gemm_epilogue_p(const GemmArgs& args, f32x16 (&a
             epi_value<MODE>(args, v, in, b4, nw + j * 32 + 8 * g4 + 4 * hi);
             const u32x2 o_ = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
             *reinterpret_cast<u32x2*>(st + l31 * 128 + (((j2 * 4 + g4) ^ wsw) << 4) + hi * 8) = o_;
+            if (SPLIT) {   // lo = bf16(v - float(hi)), the definition of csrc/x3.hip (bitwise: the subtraction is exact in f32)
+              const float l0 = v[0] - __builtin_bit_cast(float, o_.x << 16), l1 = v[1] - __builtin_bit_cast(float, o_.x & 0xffff0000u);
+              const float l2 = v[2] - __builtin_bit_cast(float, o_.y << 16), l3 = v[3] - __builtin_bit_cast(float, o_.y & 0xffff0000u);
+              lo_[j2 * 4 + g4] = (u32x2){pack_bf16x2(l0, l1), pack_bf16x2(l2, l3)};
+            }
           }
         u32x4 w[4];
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
           const int row = p * 8 + rrow;
           w[p] = *reinterpret_cast<const u32x4*>(st + row * 128 + ((rc ^ ((row >> 1) & 7)) << 4));
+        }
+        if (SPLIT) {   // the lo plane through the same tile (a wave's LDS operations execute in order: these writes follow the reads above)
+          u32x4 wl[4];
+#pragma unroll
+          for (int c = 0; c < 8; ++c) *reinterpret_cast<u32x2*>(st + l31 * 128 + ((c ^ wsw) << 4) + hi * 8) = lo_[c];
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            const int row = p * 8 + rrow;
+            wl[p] = *reinterpret_cast<const u32x4*>(st + row * 128 + ((rc ^ ((row >> 1) & 7)) << 4));
+          }
+          const unsigned lo_off = (unsigned)rrow * (unsigned)args.ldlo + (unsigned)rc * 8u;
+#pragma unroll
+          for (int p = 0; p < 4; ++p)
+            *reinterpret_cast<u32x4*>(args.clo + ((mw + i * 32 + p * 8) * args.ldlo + nw + jh * 64) + lo_off) = wl[p];
+          if (args.c2) {     // (wave-uniform) the second / third copy of the hi plane: the x3 row [hi | lo | hi] and the plane the backward reads
+            const unsigned o2 = (unsigned)rrow * (unsigned)args.ldc2 + (unsigned)rc * 8u;
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+              *reinterpret_cast<u32x4*>(args.c2 + ((mw + i * 32 + p * 8) * args.ldc2 + nw + jh * 64) + o2) = w[p];
+          }
+          if (args.c3) {
+            const unsigned o3 = (unsigned)rrow * (unsigned)args.ldc3 + (unsigned)rc * 8u;
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+              *reinterpret_cast<u32x4*>(args.c3 + ((mw + i * 32 + p * 8) * args.ldc3 + nw + jh * 64) + o3) = w[p];
+          }
         }
 #pragma unroll
         for (int p = 0; p < 4; ++p)
@@ -739,7 +772,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       W2_KSTEP(fa1, fb1, fa0, fb0, par ^ 1, 0, true, par, 0, true);      // + pieces 0-7 of stage 2
     }
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);   // this tile's bias, for the epilogue's LDS strip: requested now, consumed a K loop later
-    if ((EPI == EPI_BF16_BIAS_TANH || EPI == EPI_F32_BIAS_RES) && lane < 32) bias4 = *reinterpret_cast<const float4*>(args.bias + n0 + wn * 128 + lane * 4);
+    if ((EPI == EPI_BF16_BIAS_TANH || EPI == EPI_F32_BIAS_RES || EPI == EPI_BF16_TANH_SPLIT) && lane < 32) bias4 = *reinterpret_cast<const float4*>(args.bias + n0 + wn * 128 + lane * 4);
     for (int j = 1; j < nst; ++j) {
       const int slot = par ^ (j & 1);
       W2_KSTEP(fa0, fb0, fa1, fb1, slot, 1, true, slot ^ 1, 8, true);      // + pieces 8-15 of stage j+1
@@ -944,7 +977,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     unsigned fnext = 0;
     if (DYN && t == 0) fnext = tile_claim(ctr);
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);   // this tile's bias, for the epilogue's LDS strip: requested now, consumed a K loop later
-    if ((EPI == EPI_BF16_BIAS_TANH || EPI == EPI_F32_BIAS_RES) && lane < 32) bias4 = *reinterpret_cast<const float4*>(args.bias + n0 + wn * 128 + lane * 4);
+    if ((EPI == EPI_BF16_BIAS_TANH || EPI == EPI_F32_BIAS_RES || EPI == EPI_BF16_TANH_SPLIT) && lane < 32) bias4 = *reinterpret_cast<const float4*>(args.bias + n0 + wn * 128 + lane * 4);
     if (DYN) {
       W2R_STAGE(false, 0, 0x0078, do { if (t == 0) { tile_claim_retire(ctr, fnext, ntiles, xcd); lds_store_u32(s_next, fnext); } __builtin_amdgcn_s_waitcnt(0xC07F); } while (0));
       vnext = xcd + 8 * (int)lds_load_u32_sync(s_next);
@@ -1154,6 +1187,7 @@ static int gemm_bf16_impl(const enh_bf16* A, int64_t lda, int trans_a, const enh
   g.bias = bias; g.act = act; g.aux = aux; g.ldaux = ldaux; g.res = res; g.ldres = ldres; g.res_rows = res_rows;
   g.accumulate = accumulate; g.c_f32 = c_f32; g.c_bf16 = c_bf16; g.ldc = ldc; g.ws = nullptr;
   g.colpart = colpart;
+  g.c2 = g.c3 = g.clo = nullptr; g.ldc2 = g.ldc3 = g.ldlo = 0;
   g.tile_ctr = nullptr;
   if (g_grp_rows > 0) { g.grp_rows = g_grp_rows; g.col_fast = g_col_fast; }
   else { g.col_fast = K >= 2048 ? 1 : 0; g.grp_rows = g.col_fast ? 4 : 8; }
@@ -1206,7 +1240,7 @@ static int gemm_bf16_impl(const enh_bf16* A, int64_t lda, int trans_a, const enh
     static const bool w2_attr = [] {
       for (int l = 0; l < 4; ++l)
         for (int e = 0; e < EPI_NMODES; ++e)
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(table[l][e]), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W2_SLOT + W2_BIAS_BYTES);
+          if (table[l][e]) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(table[l][e]), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W2_SLOT + W2_BIAS_BYTES);
       return true;
     }();
     (void)w2_attr;
@@ -1311,4 +1345,57 @@ extern "C" int enh_gemm_bf16(const enh_bf16* A, int64_t lda, int trans_a, const 
                              float* c_f32, enh_bf16* c_bf16, int64_t ldc, void* stream) {
   return enh_gemm_bf16_ws(A, lda, trans_a, B, ldb, trans_b, M, N, K, bias, act, aux, ldaux, res, ldres, res_rows, accumulate, c_f32, c_bf16, ldc,
                           nullptr, 0, stream);
+}
+
+// ---- x3 producers fused (round 5) ------------------------------------------------------------------------------------------------------------
+// v = A B^T (+ bias, tanh) is never written: the persistent kernel's epilogue leaves hi = bf16(v) and lo = bf16(v - hi) directly — what the x3 forward did
+// with an f32 [M][N] round trip and csrc/x3.hip's split2 / split3 kernels (2.4 GB per qkv projection, 5.6 GB per fc1 at the base config, B = 128).
+// hi goes to `hi` and, where non-null, `hi2` / `hi3` (the x3 A-operand row [hi | lo | hi] needs it twice, the backward's arena once more); lo to `lo`.
+// Served where the persistent 256 x 256 kernel serves (enh_gemm_bf16_split_fused); the caller otherwise keeps the two-call form.
+static bool gemm_split_plan_ok(int64_t M, int64_t N, int64_t K) {
+  if (g_kernel_override == 0 || g_kernel_override == 3 || g_kernel_override == 7) return false;
+  const GemmPlan pl = gemm_plan(0, 0, M, N, K, false);
+  return pl.family == 7 && pl.splits == 1 && K / G_BK >= 3 && M % 256 == 0 && N % 256 == 0;
+}
+extern "C" int enh_gemm_bf16_split_fused(int64_t M, int64_t N, int64_t K) { return gemm_split_plan_ok(M, N, K) ? 1 : 0; }
+
+extern "C" int enh_gemm_bf16_split(const enh_bf16* A, int64_t lda, const enh_bf16* B, int64_t ldb, int64_t M, int64_t N, int64_t K, const float* bias, int act,
+                                   enh_bf16* hi, int64_t ldhi, enh_bf16* lo, int64_t ldlo, enh_bf16* hi2, int64_t ldhi2, enh_bf16* hi3, int64_t ldhi3,
+                                   void* stream) {
+  ENH_REQUIRE(A && B && hi && lo, ENH_E_BADARG, "enh_gemm_bf16_split: null pointer");
+  ENH_REQUIRE(gemm_split_plan_ok(M, N, K), ENH_E_SHAPE, "enh_gemm_bf16_split: M=%lld N=%lld K=%lld is not served by the persistent 256 x 256 kernel (ask enh_gemm_bf16_split_fused)",
+              (long long)M, (long long)N, (long long)K);
+  ENH_REQUIRE((act == ENH_ACT_NONE && !bias) || (act == ENH_ACT_TANH && bias), ENH_E_BADARG, "enh_gemm_bf16_split: plain (no bias) or bias + tanh");
+  ENH_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldhi % 8 == 0 && ldlo % 8 == 0 && (!hi2 || ldhi2 % 8 == 0) && (!hi3 || ldhi3 % 8 == 0) && aligned16(A) && aligned16(B) &&
+              aligned16(hi) && aligned16(lo) && aligned16(hi2) && aligned16(hi3) && aligned16(bias), ENH_E_SHAPE, "enh_gemm_bf16_split: 16-byte alignment / ld %% 8");
+  GemmArgs g;
+  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.M = M; g.N = N; g.K = K;
+  g.bias = bias; g.act = act; g.aux = nullptr; g.ldaux = 0; g.res = nullptr; g.ldres = 0; g.res_rows = 0;
+  g.accumulate = 0; g.c_f32 = nullptr; g.c_bf16 = hi; g.ldc = ldhi; g.ws = nullptr; g.colpart = nullptr;
+  g.c2 = hi2; g.ldc2 = ldhi2; g.c3 = hi3; g.ldc3 = ldhi3; g.clo = lo; g.ldlo = ldlo;
+  g.tile_ctr = nullptr;
+  if (g_grp_rows > 0) { g.grp_rows = g_grp_rows; g.col_fast = g_col_fast; }
+  else { g.col_fast = K >= 2048 ? 1 : 0; g.grp_rows = g.col_fast ? 4 : 8; }
+  g.nbm = (int)(M / 256); g.nbn = (int)(N / 256);
+  g.k_per_split = K; g.splits = 1;
+  const int64_t tiles = (int64_t)g.nbm * g.nbn;
+  typedef void (*w256_fn)(const GemmArgs);
+  static const w256_fn stable[2][2] = {{gemm_bf16_w256p_kernel<false, false, EPI_BF16_SPLIT, false>, gemm_bf16_w256p_kernel<false, false, EPI_BF16_TANH_SPLIT, false>},
+                                       {gemm_bf16_w256p_kernel<false, false, EPI_BF16_SPLIT, true>, gemm_bf16_w256p_kernel<false, false, EPI_BF16_TANH_SPLIT, true>}};
+  static const bool s_attr = [] {
+    for (int d = 0; d < 2; ++d)
+      for (int e = 0; e < 2; ++e)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stable[d][e]), hipFuncAttributeMaxDynamicSharedMemorySize, W2P_LDS_BYTES);
+    return true;
+  }();
+  (void)s_attr;
+  const int n_cu = cu_budget();
+  const int64_t wgs = tiles < n_cu ? tiles : n_cu;
+  const int dyn = g_dyn_schedule && wgs >= 8 ? 1 : 0;
+  if (dyn) {
+    g.tile_ctr = next_tile_counters();
+    ENH_REQUIRE(g.tile_ctr, ENH_E_BADARG, "enh_gemm_bf16_split: tile counters unavailable");
+  }
+  hipLaunchKernelGGL(stable[dyn][act == ENH_ACT_TANH ? 1 : 0], dim3((unsigned)wgs), dim3(256), (size_t)W2P_LDS_BYTES, (hipStream_t)stream, g);
+  return enh_check_launch("enh_gemm_bf16_split");
 }

@@ -66,6 +66,9 @@ struct GemmArgs {
   int splits;  // number of K-slices (1 = no split-K; otherwise a multiple of 8)
   float* colpart;  // tanh' mode of the persistent kernel: per-128-row partial column sums of the bf16 result, [M / 128][N] (or null)
   unsigned int* tile_ctr;  // persistent kernels, dynamic schedule: the launch's 8 per-XCD tile counters (zero at launch, reset by the kernel itself)
+  // x3 split epilogues of the persistent kernel (EPI_BF16_SPLIT / EPI_BF16_TANH_SPLIT, enh_gemm_bf16_split): the hi plane goes to c_bf16 (ldc) and,
+  // where non-null, to c2 / c3 as well; the lo plane bf16(v - hi) to clo
+  uint16_t* c2; int64_t ldc2; uint16_t* c3; int64_t ldc3; uint16_t* clo; int64_t ldlo;
   int grp_rows;            // tile order of the non-split forms: row panels per group (8 = the shipped order); col_fast: columns fastest inside a group
   int col_fast;            // (enh_debug_gemm_order: what the 32 workgroups of an XCD have in flight together is a grp_rows x 32/grp_rows patch, or ~32/nbn rows x nbn)
 };
@@ -128,7 +131,9 @@ __device__ __forceinline__ s16x8 tile_frag(const unsigned char* tile, int base, 
 // wave per SIMD nothing hides the instruction fetch after each (wave-uniform) branch — the 256 x 256 kernel lost 19 us per tile, more than its
 // K loop at K = 768.  So the combinations the training step uses are compile-time MODES selected once per kernel; anything else takes the
 // generic (branchy) mode.
-enum { EPI_GENERIC = 0, EPI_BF16, EPI_BF16_BIAS_TANH, EPI_BF16_DTANH, EPI_F32_BIAS_RES, EPI_F32, EPI_WS, EPI_ATOMIC, EPI_NMODES };
+enum { EPI_GENERIC = 0, EPI_BF16, EPI_BF16_BIAS_TANH, EPI_BF16_DTANH, EPI_F32_BIAS_RES, EPI_F32, EPI_WS, EPI_ATOMIC,
+       EPI_BF16_SPLIT, EPI_BF16_TANH_SPLIT,   // persistent kernel only, chosen by enh_gemm_bf16_split (never by epi_mode): v | tanh(v + bias) -> hi / lo bf16 planes
+       EPI_NMODES };
 
 __host__ __device__ __forceinline__ int epi_mode(const GemmArgs& a) {
   if (a.accumulate == 3) return EPI_WS;
@@ -175,7 +180,19 @@ __device__ __forceinline__ float4 epi_bias(const GemmArgs& args, int64_t n) {
 template <int MODE>
 __device__ __forceinline__ void epi_value(const GemmArgs& args, float (&v)[4], const EpiIn& in, const float4& b4, int64_t n) {
   constexpr bool G = MODE == EPI_GENERIC;
-  if (MODE == EPI_BF16_BIAS_TANH || MODE == EPI_F32_BIAS_RES) { v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w; }
+  if (MODE == EPI_BF16_BIAS_TANH || MODE == EPI_F32_BIAS_RES || MODE == EPI_BF16_TANH_SPLIT) { v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w; }
+  if (MODE == EPI_BF16_TANH_SPLIT) {
+    // the x3 path keeps ~2^-17 relative per element (hi + lo): 1 - 2 / (exp(2x) + 1) alone loses that below |x| ~ 0.1 (absolute error ~1e-7 against a small
+    // result), so small arguments take the odd series x (1 - x^2/3 + 2 x^4/15 - 17 x^6/315) (next term 62 x^9/2835: < 3e-9 relative at 0.12)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float x = v[r], x2 = x * x;
+      const float t = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+      const float big = 1.f - 2.f * __builtin_amdgcn_rcpf(t + 1.f);
+      const float small = x * (1.f + x2 * (-0.33333333333f + x2 * (0.13333333333f + x2 * -0.05396825397f)));
+      v[r] = x2 < 0.0144f ? small : big;
+    }
+  }
   if (G && args.bias) {
     const float4 bg = *reinterpret_cast<const float4*>(args.bias + n);
     v[0] += bg.x; v[1] += bg.y; v[2] += bg.z; v[3] += bg.w;

@@ -107,13 +107,15 @@ SIGNATURES = {
     "enh_lpips_head_backward": (_i32, [_vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp]),
     "enh_split3_bf16": (_i32, [_vp, _i64, _i64, _i64, _vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp]),
     "enh_split2_bf16": (_i32, [_vp, _i64, _vp, _vp, _vp]),
+    "enh_gemm_bf16_split_fused": (_i32, [_i64, _i64, _i64]),
+    "enh_gemm_bf16_split": (_i32, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     "enh_layernorm_forward_x3": (_i32, [_vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "enh_attention_forward_x3": (_i32, [_vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp]),
     "enh_adamw_step": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
 }
 
 _LIB = None
-ABI_VERSION = 10  # ENH_ABI_VERSION of the include/enh_hip.h these signatures were written against
+ABI_VERSION = 11  # ENH_ABI_VERSION of the include/enh_hip.h these signatures were written against
 
 
 def lib():
@@ -776,6 +778,33 @@ def split3(x, y3, bias=None, act: int = ACT_NONE, order: int = 0, y_hi=None):
 def split2(x, hi, lo):
     _timed("split2_kernel", 8.0 * x.numel(),
            lambda: _check(lib().enh_split2_bf16(_p(x, F32, "x"), x.numel(), _p(hi, BF16, "hi"), _p(lo, BF16, "lo"), _stream()), "enh_split2_bf16"), unit="byte")
+
+
+def gemm_split_fused(M: int, N: int, K: int) -> bool:
+    """does enh_gemm_bf16_split serve this shape (the persistent 256 x 256 kernel)?  Otherwise: mm -> f32, then split2 / split3."""
+    return bool(lib().enh_gemm_bf16_split_fused(M, N, K))
+
+
+def _poff(t: torch.Tensor, elems: int):
+    return ctypes.c_void_p(t.data_ptr() + elems * t.element_size())
+
+
+def gemm_split2(a, b, M: int, N: int, K: int, hi, lo):
+    """hi = bf16(a b^T), lo = bf16(a b^T - hi): mm(...) -> f32 followed by split2, without the f32 round trip (bit-identical)"""
+    _timed("gemm_bf16_w256p_kernel<false, false, 8, %s>" % ("true" if _DYN_SCHEDULE[0] else "false"), 2.0 * M * N * K,
+           lambda: _check(lib().enh_gemm_bf16_split(_p(a, BF16, "A"), a.stride(0), _p(b, BF16, "B"), b.stride(0), M, N, K, None, ACT_NONE,
+                                                    _p(hi, BF16, "hi"), hi.stride(0), _p(lo, BF16, "lo"), lo.stride(0), None, 0, None, 0, _stream()), "enh_gemm_bf16_split"))
+
+
+def gemm_split3_tanh(a, b, M: int, N: int, K: int, bias, y3, y_hi=None):
+    """y3 [M, 3N] = the x3 row [hi | lo | hi] of tanh(a b^T + bias) (+ y_hi [M, N] = the hi plane): mm(...) -> f32 followed by split3(act = tanh), fused"""
+    if not (y3.is_cuda and y3.is_contiguous() and y3.dtype == BF16 and y3.shape[-1] == 3 * N):
+        raise RuntimeError("y3 must be a contiguous bf16 [M, 3N] device tensor")
+    ld3 = y3.stride(0)
+    _timed("gemm_bf16_w256p_kernel<false, false, 9, %s>" % ("true" if _DYN_SCHEDULE[0] else "false"), 2.0 * M * N * K,
+           lambda: _check(lib().enh_gemm_bf16_split(_p(a, BF16, "A"), a.stride(0), _p(b, BF16, "B"), b.stride(0), M, N, K, _p(bias, F32, "bias"), ACT_TANH,
+                                                    _poff(y3, 0), ld3, _poff(y3, N), ld3, _poff(y3, 2 * N), ld3,
+                                                    _p(y_hi, BF16, "y_hi"), y_hi.stride(0) if y_hi is not None else 0, _stream()), "enh_gemm_bf16_split"))
 
 
 def ln_fwd_x3(x, w, b, y3, mean, rstd, y_bf16=None, y_f32=None):

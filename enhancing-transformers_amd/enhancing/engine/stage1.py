@@ -224,17 +224,26 @@ class _Tower:
         except that q is NOT pre-scaled here (recorded in the buffer dict)."""
         s, b, X, W3 = self.s, self.bufs(B, save), self.x3_bufs(B), self.x3_weights()
         M, dim, inner, mlp = B * self.n_tok, self.dim, self.inner, self.mlp
+        fuse = os.environ.get("ENH_X3_FUSED_SPLIT", "1") != "0"      # A/B switch: the round-4 form (GEMM -> f32, split kernel) with 0
+        fused_qkv = fuse and _C.gemm_split_fused(M, 3 * inner, 3 * dim)
+        fused_fc1 = fuse and _C.gemm_split_fused(M, mlp, 3 * dim)
         x = b["x"][0]
         for i, P in enumerate(self.L):
             A, W = b["layers"][i if save else 0], W3[i]
             _C.ln_fwd_x3(x, s.w[P["ln1_w"]], s.w[P["ln1_b"]], X["a3"], A["mean1"], A["rstd1"], y_bf16=A["a1"] if save else None)
-            _C.mm(X["a3"], W["wqkv"], M, 3 * inner, 3 * dim, X["qkv32"])
-            _C.split2(X["qkv32"], A["qkv"], X["qkv_lo"])
+            if fused_qkv:      # hi / lo planes straight from the GEMM's epilogue (no f32 [M, 3 inner] round trip)
+                _C.gemm_split2(X["a3"], W["wqkv"], M, 3 * inner, 3 * dim, A["qkv"], X["qkv_lo"])
+            else:
+                _C.mm(X["a3"], W["wqkv"], M, 3 * inner, 3 * dim, X["qkv32"])
+                _C.split2(X["qkv32"], A["qkv"], X["qkv_lo"])
             _C.attention_forward_x3(A["qkv"], X["qkv_lo"], B, self.n_tok, self.heads, self.scale, X["o3"], A["o"] if save else None, A["lse"])
             _C.mm(X["o3"], W["wout"], M, dim, 3 * inner, A["x_mid"], bias=s.w[P["bout"]], res=x, res_rows=M)
             _C.ln_fwd_x3(A["x_mid"], s.w[P["ln2_w"]], s.w[P["ln2_b"]], X["a3"], A["mean2"], A["rstd2"], y_bf16=A["a2"] if save else None)
-            _C.mm(X["a3"], W["w1"], M, mlp, 3 * dim, X["fc32"])
-            _C.split3(X["fc32"], X["hid3"], bias=s.w[P["b1"]], act=_C.ACT_TANH, y_hi=A["hid"] if save else None)
+            if fused_fc1:
+                _C.gemm_split3_tanh(X["a3"], W["w1"], M, mlp, 3 * dim, s.w[P["b1"]], X["hid3"], A["hid"] if save else None)
+            else:
+                _C.mm(X["a3"], W["w1"], M, mlp, 3 * dim, X["fc32"])
+                _C.split3(X["fc32"], X["hid3"], bias=s.w[P["b1"]], act=_C.ACT_TANH, y_hi=A["hid"] if save else None)
             x_next = b["x"][i + 1] if save else b["x"][(i + 1) & 1]
             _C.mm(X["hid3"], W["w2"], M, dim, 3 * mlp, x_next, bias=s.w[P["b2"]], res=A["x_mid"], res_rows=M)
             x = x_next

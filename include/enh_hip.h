@@ -36,7 +36,7 @@ extern "C" {
 typedef uint16_t enh_bf16; /* raw bfloat16 bits */
 
 const char* enh_last_error(void);
-#define ENH_ABI_VERSION 10  /* bumped whenever a signature below changes; the bindings check it at load */
+#define ENH_ABI_VERSION 11  /* bumped whenever a signature below changes; the bindings check it at load */
 int enh_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -230,6 +230,14 @@ int enh_split3_bf16(const float* x, int64_t ldx, int64_t M, int64_t K, const flo
                     enh_bf16* y_hi, int64_t ldy_hi, void* stream);
 /* hi[i] = bf16(x[i]), lo[i] = bf16(x[i] - hi[i]); n % 8 == 0 (the packed q | k | v projection for enh_attention_forward_x3) */
 int enh_split2_bf16(const float* x, int64_t n, enh_bf16* hi, enh_bf16* lo, void* stream);
+/* The x3 producers fused into the GEMM that computes their input (round 5): v = A B^T (A [M][K'], B [N][K'] row-major, K' = 3K x3 rows) or
+ * v = tanh(A B^T + bias) — reference layers.py:118 (to_qkv) and :99-100 (Linear + Tanh) — leaves hi = bf16(v) in `hi` (and in `hi2`, `hi3` where non-null)
+ * and lo = bf16(v - hi) in `lo` (each [M][N] with its own leading dimension), i.e. enh_gemm_bf16 (f32 out) + enh_split2_bf16 / enh_split3_bf16 without the f32
+ * round trip; plain mode bit-identical to that pair.  act: ENH_ACT_NONE (bias must be null) | ENH_ACT_TANH (bias required).  Served where the persistent
+ * 256 x 256 kernel serves: enh_gemm_bf16_split_fused(M, N, K') == 1 (M, N multiples of 256, enough tiles to fill the chip); ENH_E_SHAPE otherwise. */
+int enh_gemm_bf16_split_fused(int64_t M, int64_t N, int64_t K);
+int enh_gemm_bf16_split(const enh_bf16* A, int64_t lda, const enh_bf16* B, int64_t ldb, int64_t M, int64_t N, int64_t K, const float* bias, int act,
+                        enh_bf16* hi, int64_t ldhi, enh_bf16* lo, int64_t ldlo, enh_bf16* hi2, int64_t ldhi2, enh_bf16* hi3, int64_t ldhi3, void* stream);
 /* enh_layernorm_forward that writes the x3 row y3 [M,3D] (and, optionally, the plain bf16 / f32 outputs); same statistics bits */
 int enh_layernorm_forward_x3(const float* x, const float* w, const float* b, int64_t M, int D, float eps, enh_bf16* y3, enh_bf16* y_bf16,
                              float* y_f32, float* mean, float* rstd, void* stream);

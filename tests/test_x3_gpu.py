@@ -296,3 +296,79 @@ def test_x3_graph_replay_after_refresh_shadows_reads_the_new_weights():
     e2.store.refresh_shadows()
     ref = float(e2.forward_backward(x)["loss"])                   # eager, same weights
     assert a != b and b == ref, (a, b, ref)
+
+
+def test_gemm_split2_is_bitwise_the_gemm_then_split2(C):
+    """round 5: the qkv projection's hi / lo planes straight from the persistent GEMM's epilogue (enh_gemm_bf16_split) == enh_gemm_bf16 (f32 out) followed
+    by enh_split2_bf16, bit for bit (same accumulator, same definition hi = bf16(v), lo = bf16(v - hi)); leading dimensions respected"""
+    torch.manual_seed(5)
+    M, N, K = 8192, 2304, 3 * 768
+    a = (torch.randn(M, K, device="cuda") * 0.5).to(torch.bfloat16)
+    b = (torch.randn(N, K, device="cuda") * 0.05).to(torch.bfloat16)
+    assert C.gemm_split_fused(M, N, K)
+    v = torch.empty(M, N, device="cuda")
+    C.mm(a, b, M, N, K, v)
+    eh = torch.empty(M, N, dtype=torch.bfloat16, device="cuda"); el = torch.empty_like(eh)
+    C.split2(v, eh, el)
+    hi = torch.full((M, N), 7.0, dtype=torch.bfloat16, device="cuda"); lo = torch.full_like(hi, 7.0)
+    C.gemm_split2(a, b, M, N, K, hi, lo)
+    torch.cuda.synchronize()
+    assert torch.equal(hi, eh) and torch.equal(lo, el)
+    assert not C.gemm_split_fused(2048, 768, K)          # too few tiles for the persistent kernel: the caller keeps the two-call form ...
+    with pytest.raises(RuntimeError):
+        C.gemm_split2(a[:2048], b[:768], 2048, 768, K, hi[:2048, :768].contiguous(), lo[:2048, :768].contiguous())     # ... and the entry point refuses
+
+
+def test_gemm_split3_tanh_matches_the_gemm_then_split3(C):
+    """fc1: y3 = [hi | lo | hi] of tanh(a b^T + bias) and the hi plane for the backward, from the GEMM epilogue.  hi + lo is the value to 2^-16 absolute
+    against tanh in f64 (the bound the split3 kernel's own test uses) and agrees with the two-call form to the same level; planes are consistent."""
+    torch.manual_seed(6)
+    M, N, K = 8192, 3072, 3 * 768
+    a = (torch.randn(M, K, device="cuda") * 0.5).to(torch.bfloat16)
+    b = (torch.randn(N, K, device="cuda") * 0.03).to(torch.bfloat16)
+    bias = torch.randn(N, device="cuda") * 0.1
+    assert C.gemm_split_fused(M, N, K)
+    v = torch.empty(M, N, device="cuda")
+    C.mm(a, b, M, N, K, v)
+    ref = torch.tanh((v.double() + bias.double()))
+    e3 = torch.empty(M, 3 * N, dtype=torch.bfloat16, device="cuda")
+    C.split3(v, e3, bias=bias, act=C.ACT_TANH, order=0)
+    y3 = torch.full((M, 3 * N), 7.0, dtype=torch.bfloat16, device="cuda"); yh = torch.full((M, N), 7.0, dtype=torch.bfloat16, device="cuda")
+    C.gemm_split3_tanh(a, b, M, N, K, bias, y3, yh)
+    torch.cuda.synchronize()
+    assert torch.equal(y3[:, :N], y3[:, 2 * N:]) and torch.equal(y3[:, :N], yh)
+    got = y3[:, :N].double() + y3[:, N:2 * N].double()
+    two = e3[:, :N].double() + e3[:, N:2 * N].double()
+    err, err2 = (got - ref).abs().max().item(), (two - ref).abs().max().item()
+    relerr = ((got - ref).abs() / ref.abs().clamp_min(1e-3)).max().item()
+    print(f"fused tanh split: max |hi + lo - tanh| {err:.2e} (two-call form {err2:.2e}), max relative {relerr:.2e}; small-|x| share {(v.abs() < 0.12).float().mean().item():.3f}")
+    assert err <= 2 ** -16 and relerr <= 3e-5
+    # lo really is bf16(value - hi) of the kernel's own value: |value - hi - lo| <= half an ulp of lo
+    assert (y3[:, :N].float() - yh.float()).abs().max().item() == 0.0
+    # without the hi plane for the backward (save = False)
+    y3b = torch.empty_like(y3)
+    C.gemm_split3_tanh(a, b, M, N, K, bias, y3b, None)
+    assert torch.equal(y3b, y3)
+
+
+def test_x3_encode_with_fused_split_epilogues_equals_the_two_call_form(monkeypatch):
+    """the base encoder at 8 images (M = 8192: both fused forms are served): h and codes with ENH_X3_FUSED_SPLIT=1 (default) vs the round-4 form"""
+    from enhancing.modules.stage1.vitvqgan import ViTVQ
+    from enhancing.utils.general import AttrDict
+    import vitvq_oracle as O
+    cfg = dict(BASE)
+    loss = {"target": "enhancing.losses.vqperceptual.VQLPIPS", "params": dict(codebook_weight=1.0, loglaplace_weight=0.0, loggaussian_weight=1.0, perceptual_weight=0.0)}
+    torch.manual_seed(0)
+    m = ViTVQ("image", cfg["image_size"], cfg["patch_size"], AttrDict.wrap(cfg["encoder"]), AttrDict.wrap(cfg["decoder"]), AttrDict.wrap(cfg["quantizer"]), AttrDict.wrap(loss))
+    x = O.make_images(3, 8, 256).cuda()
+    e = m.engine
+    out = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("ENH_X3_FUSED_SPLIT", flag)
+        img = e._check_img(x)
+        h = e._pre_quant(e._encode_tokens(img, save=False, x3=True), 8).clone()
+        out[flag] = (h, e.encode_codes(x, precision="x3").clone())
+    dh = rel(out["1"][0], out["0"][0])
+    same = (out["0"][1] == out["1"][1]).float().mean().item()
+    print(f"x3 encode, fused vs two-call split: h rel diff {dh:.2e}, code agreement {same:.6f}")
+    assert dh <= 2e-5 and same >= 0.9995     # tanh is evaluated by another (equally accurate) formula in the epilogue: fp32 near-ties may move
