@@ -28,6 +28,128 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
   attn_fwd_exact(qkv, B, N, H, scale_log2, out, lse, smem, blk, head);
 }
 
+// Round 5 — the forward for PRE-SCALED q (the training path's convention: the products are log2-domain scores), with the vector stream cut where the
+// round-4 anatomy says the kernel's time is (profiles/r04_attention_lab.txt: it runs at the speed of its vector instructions):
+//   * -m_ref rides in the MFMA C operand of the first S product (a lane owns ONE query column, so -m_ref is a per-lane constant in a 16-register block,
+//     rewritten only when the reference is raised — a handful of tiles per row): the exponential reads the accumulator directly, the 32 multiply-subtracts
+//     per tile are gone (what the dQ / dK/dV kernels do with -lse);
+//   * the row sum runs on float pairs (16 v_pk_add_f32 per tile instead of 32 adds), still exact f32: lse keeps its 5e-8.  (Summing the PACKED bf16
+//     numerators with v_dot2c_f32_bf16 against (1, 1) — also 16 instructions — measured the same time and moved lse to 2e-5: not adopted.)
+// Same skeleton, LDS images and results layout as attn_fwd_exact; the exact running-reference semantics are kept (no fallback path).
+__device__ __forceinline__ float dot2_ones(uint32_t pk, float acc) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, pk), __builtin_bit_cast(bf16x2_t, 0x3f803f80u), acc, false);
+}
+__global__ __launch_bounds__(256, 2) void attn_fwd_pre_kernel(const uint16_t* __restrict__ qkv, int B, int N, int H, uint16_t* __restrict__ out, float* __restrict__ lse) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][ATT_TILE_BYTES];  // [stage][K | V]
+  int blk, head;
+  if (!att_block_coords((N + 127) / 128, B * H, blk, head)) return;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int b = head / H, h = head - b * H;
+  const int q0 = blk * 128 + wave * 32;
+  const int64_t RS = (int64_t)3 * H * ATT_D;
+  const uint16_t* Qp = qkv + (int64_t)b * N * RS + h * ATT_D;
+  const uint16_t* Kp = Qp + H * ATT_D;
+  const uint16_t* Vp = Kp + H * ATT_D;
+  const bool active = q0 < N;
+  const int qrow = active ? q0 + l31 : l31;
+  s16x8 qf[4];
+#pragma unroll
+  for (int ds = 0; ds < 4; ++ds) qf[ds] = *reinterpret_cast<const s16x8*>(Qp + (int64_t)qrow * RS + ds * 16 + hi * 8);
+  f32x16 o[2], negm;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; negm[r] = 0.f; }
+  float m_ref = 0.f;                   // the first tile's scores are taken against 0 and re-based below (kt == 0)
+  f32x2 l2[2] = {{0.f, 0.f}, {0.f, 0.f}};
+
+  const int nt = N / 64;
+  u32x4 rk[2], rv[2];
+  att_gload(rk, Kp, RS, 0, t);
+  att_gload(rv, Vp, RS, 0, t);
+  att_sstore(rk, smem[0][0], t);
+  att_sstore(rv, smem[0][1], t);
+#pragma unroll
+  for (int ds = 0; ds < 4; ++ds) att_pin(qf[ds]);
+  ATT_LOOP_ENTRY();
+  __syncthreads();
+  for (int kt = 0; kt < nt; ++kt) {
+    const int st = kt & 1;
+    if (kt + 1 < nt) {
+      att_gload(rk, Kp, RS, (kt + 1) * 64, t);
+      att_gload(rv, Vp, RS, (kt + 1) * 64, t);
+    }
+    const unsigned char* kt_ = smem[st][0];
+    const unsigned char* vt_ = smem[st][1];
+    f32x16 s[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int ds = 0; ds < 4; ++ds) s[kb] = MFMA32(att_frag_row(kt_, kb * 32, ds, l31, hi), qf[ds], ds == 0 ? negm : s[kb]);   // S^T[key][q] - m_ref[q]
+    // four independent v_max3 chains of depth 4 (one dependent chain of 16 leaves the in-order wave waiting on its own previous instruction)
+    float mq[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const f32x16& sv = s[c >> 1];
+      const int r0 = (c & 1) * 8;
+      mq[c] = max3(sv[r0], sv[r0 + 1], sv[r0 + 2]);
+      mq[c] = max3(mq[c], sv[r0 + 3], sv[r0 + 4]);
+      mq[c] = max3(mq[c], sv[r0 + 5], sv[r0 + 6]);
+    }
+    float mx = max3(mq[0], mq[1], s[0][7]);
+    mx = max3(mx, mq[2], s[0][15]);
+    mx = max3(mx, mq[3], s[1][7]);
+    mx = xhalf_max(__builtin_fmaxf(mx, s[1][15]));       // this tile's row maximum RELATIVE to the reference
+    if (kt == 0 || __builtin_amdgcn_ballot_w64(mx > 8.0f) != 0) {   // wave-uniform: the reference is raised on the first tile and when outgrown by 2^8
+      const float delta = kt == 0 ? mx : __builtin_fmaxf(mx, 0.f);
+      if (kt != 0) {
+        const float alpha = __builtin_amdgcn_exp2f(-delta);
+        l2[0] *= alpha; l2[1] *= alpha;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+      }
+      m_ref += delta;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[0][r] -= delta; s[1][r] -= delta; negm[r] = -m_ref; }
+    }
+    // ---- numerators, packed; row sum of the packed values; O^T[d][q] += V^T P^T ----
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int c2 = 0; c2 < 2; ++c2) {
+        float p8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) p8[j] = __builtin_amdgcn_exp2f(s[kb][c2 * 8 + j]);
+        const u32x4 pk = {pack_bf16x2(p8[0], p8[1]), pack_bf16x2(p8[2], p8[3]), pack_bf16x2(p8[4], p8[5]), pack_bf16x2(p8[6], p8[7])};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) l2[j & 1] += (f32x2){p8[2 * j], p8[2 * j + 1]};      // exact f32 row sum, two lanes of one v_pk_add_f32 (lse stays exact to f32), two chains
+        const s16x8 pb = __builtin_bit_cast(s16x8, pk);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) o[db] = MFMA32(att_frag_tr(vt_, kb * 32 + 16 * c2, db, lane), pb, o[db]);
+      }
+    if (kt + 1 < nt) {
+      att_sstore(rk, smem[st ^ 1][0], t);
+      att_sstore(rv, smem[st ^ 1][1], t);
+    }
+    __syncthreads();
+  }
+  const float l_part = (l2[0][0] + l2[1][0]) + (l2[0][1] + l2[1][1]);
+  const float l = l_part + __shfl_xor(l_part, 32, 64);
+  const float inv = 1.0f / l;
+  if (!active) return;
+  uint16_t* op = out + ((int64_t)b * N + q0 + l31) * (H * ATT_D) + h * ATT_D;
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int d0 = db * 32 + 8 * g4 + 4 * hi;
+      u32x2 w = {pack_bf16x2(o[db][g4 * 4 + 0] * inv, o[db][g4 * 4 + 1] * inv), pack_bf16x2(o[db][g4 * 4 + 2] * inv, o[db][g4 * 4 + 3] * inv)};
+      *reinterpret_cast<u32x2*>(op + d0) = w;
+    }
+  if (hi == 0) lse[((int64_t)b * H + h) * N + q0 + l31] = (m_ref + __builtin_amdgcn_logf(l)) * 0.6931471805599453f;
+}
+
 // =================================================================================================
 // backward: dQ  (same skeleton as forward; K tile is read both as rows and transposed)
 // =================================================================================================
@@ -283,18 +405,19 @@ void attn_bwd_dkv3_launch(const uint16_t* qkv, const uint16_t* d_o, const float*
                           hipStream_t s);
 
 // kernel family per pass (explicit state behind an explicit call, as enh_gemm_set_kernel); 0 = the library's choice:
-//   forward: 1 round-2 kernel | 4 eight waves in antiphase (round 4)      (2, 3: the software-pipelined round-3 kernels — measured slower, removed in round 4)
+//   forward: 1 round-2 kernel | 4 eight waves in antiphase (round 4) | 5 round-2 skeleton with -m_ref as the MFMA C operand and the row sum from the packed
+//            numerators (round 5; pre-scaled q only, else family 1)      (2, 3: the software-pipelined round-3 kernels — measured slower, removed in round 4)
 //   dQ     : 1 round-2 kernel | 3 round-2 skeleton with -delta (and, pre-scaled q, -lse) as MFMA C operands      (2: removed with them)
 //   dK/dV  : 1 round-2 kernel | 2 round-2 skeleton with -delta (and, pre-scaled q, -lse) as MFMA C operands | 3 eight waves in antiphase (round 4; pre-scaled q
 //            and N % 256 == 0, else family 2)
 static int g_att_fwd = 0, g_att_dq = 0, g_att_dkv = 0;
-#define ATT_DEFAULT_FWD 1
+#define ATT_DEFAULT_FWD 5
 #define ATT_DEFAULT_DQ 1
 #define ATT_DEFAULT_DKV 2
 
 extern "C" int enh_attention_set_kernel(int fwd, int dq, int dkv) {
-  ENH_REQUIRE((fwd == 0 || fwd == 1 || fwd == 4) && (dq == 0 || dq == 1 || dq == 3) && dkv >= 0 && dkv <= 3, ENH_E_BADARG,
-              "enh_attention_set_kernel: fwd in {0, 1, 4}, dq in {0, 1, 3}, dkv in 0..3");
+  ENH_REQUIRE((fwd == 0 || fwd == 1 || fwd == 4 || fwd == 5) && (dq == 0 || dq == 1 || dq == 3) && dkv >= 0 && dkv <= 3, ENH_E_BADARG,
+              "enh_attention_set_kernel: fwd in {0, 1, 4, 5}, dq in {0, 1, 3}, dkv in 0..3");
   g_att_fwd = fwd; g_att_dq = dq; g_att_dkv = dkv;
   return ENH_OK;
 }
@@ -310,8 +433,10 @@ extern "C" int enh_attention_forward(const enh_bf16* qkv, int B, int N, int H, f
   const dim3 grid((unsigned)(((heads + 7) / 8) * 8 * nblk));  // 1-D: see att_block_coords
   int fam = g_att_fwd ? g_att_fwd : ATT_DEFAULT_FWD;
   if (fam == 4 && N % 256 != 0) fam = 1;                         // the eight-wave kernel owns 256 queries per workgroup
+  if (fam == 5 && !q_prescaled) fam = 1;                         // -m_ref as a C operand needs log2-domain products
   const float sl2 = q_prescaled ? 1.0f : scale * ATT_LOG2E;       // pre-scaled q: the products are log2-domain scores already
   if (fam == 4) attn_fwd3_launch(qkv, B, N, H, sl2, out, lse, q_prescaled != 0, (hipStream_t)stream);
+  else if (fam == 5) attn_fwd_pre_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(qkv, B, N, H, out, lse);
   else attn_fwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(qkv, B, N, H, sl2, out, lse);
   return enh_check_launch("enh_attention_forward");
 }
