@@ -463,6 +463,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // of the epilogue: 256 live registers, spills, and scratch reloads are vector-memory operations that wait on the next tile's requests)
 // (acc_read: gemm_tiles.h)
 
+// Cache policy of the persistent epilogues' result stores (round 5, tools/r5_cache_policy_ab.sh -> profiles/r05_cache_policy_ab.txt, same-box in-step A/B):
+// with the non-temporal hint on EVERY mode's stores the step gains 0.7 % — all of it in the two modes whose tile also READS a row-contiguous operand
+// (bias + residual f32: 0.433 -> 0.419 ms; tanh': 0.762 -> 0.740 ms), while the plain bf16 / bias + tanh modes lose 0.5 %.  So: nt where it pays.
+// ENH_P_NT_STORE = 1 forces it everywhere, 0 nowhere (lab).  ENH_A_NT (lab): the streamed A operand requested non-temporal — measured slower
+// (qkv forward 0.408 -> 0.424 ms), left off.
+#ifndef ENH_P_NT_STORE
+#define ENH_P_NT_STORE -1
+#endif
+#ifndef ENH_A_NT
+#define ENH_A_NT 0
+#endif
+template <bool NT, typename T>
+__device__ __forceinline__ void p_store(T* ptr, const T& v) {
+  if (NT) __builtin_nontemporal_store(v, ptr); else *ptr = v;
+}
 template <int MODE>
 __device__ __forceinline__ void gemm_epilogue_p(const GemmArgs& args, f32x16 (&acc)[4][4], int64_t mw, int64_t nw, int lane_in, float* wave_bias, unsigned char* st,
                                                 unsigned char* at, const float4& bias4) {
@@ -474,6 +489,7 @@ __device__ __forceinline__ void gemm_epilogue_p(const GemmArgs& args, f32x16 (&a
   constexpr bool HAS_BIAS = MODE == EPI_BF16_BIAS_TANH || MODE == EPI_F32_BIAS_RES || MODE == EPI_BF16_TANH_SPLIT;
   constexpr bool SPLIT = MODE == EPI_BF16_SPLIT || MODE == EPI_BF16_TANH_SPLIT;   // x3 producers: hi = bf16(v) and lo = bf16(v - hi) planes (csrc/x3.hip split2 / split3, fused)
   constexpr bool OUT16 = MODE == EPI_BF16 || MODE == EPI_BF16_BIAS_TANH || MODE == EPI_BF16_DTANH || SPLIT;
+  constexpr bool NT_OUT = ENH_P_NT_STORE < 0 ? (MODE == EPI_F32_BIAS_RES || MODE == EPI_BF16_DTANH) : (ENH_P_NT_STORE != 0);
   // the tile's bias values were requested by the caller a K loop ago (bias4, lanes 0-31): requested here, the wait for them would also be a wait for
   // the next tile's operand requests, which are older (vmcnt retires in order)
   if (HAS_BIAS && lane < 32) *reinterpret_cast<float4*>(wave_bias + lane * 4) = bias4;
@@ -566,7 +582,7 @@ __device__ __forceinline__ void gemm_epilogue_p(const GemmArgs& args, f32x16 (&a
         }
 #pragma unroll
         for (int p = 0; p < 4; ++p)
-          *reinterpret_cast<u32x4*>(args.c_bf16 + ((mw + i * 32 + p * 8) * args.ldc + nw + jh * 64) + out_off) = w[p];   // uniform base + 32-bit lane offset
+          p_store<NT_OUT>(reinterpret_cast<u32x4*>(args.c_bf16 + ((mw + i * 32 + p * 8) * args.ldc + nw + jh * 64) + out_off), w[p]);   // uniform base + 32-bit lane offset
         if (MODE == EPI_BF16_DTANH && args.colpart) {   // column sums of what was just stored (the ROUNDED values): this lane's 8 columns of 4 rows
 #pragma unroll
           for (int p = 0; p < 4; ++p)
@@ -633,7 +649,7 @@ __device__ __forceinline__ void gemm_epilogue_p(const GemmArgs& args, f32x16 (&a
         }
 #pragma unroll
         for (int p = 0; p < 4; ++p)
-          *reinterpret_cast<f32x4*>(dst + ((int64_t)(i * 32 + p * 8) * args.ldc + j * 32) + out_off) = w[p];
+          p_store<NT_OUT>(reinterpret_cast<f32x4*>(dst + ((int64_t)(i * 32 + p * 8) * args.ldc + j * 32) + out_off), w[p]);
         __builtin_amdgcn_sched_barrier(0);
       }
       if (MODE == EPI_F32_BIAS_RES && i + 2 < 4) {
@@ -874,9 +890,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 #define W2R_APTR(U, KOFF) ((((U) & 1) ? gA_o : gA_e) + ((U) >> 1) * pairA + (KOFF))
 #define W2R_BPTR(U, KOFF) ((((U) & 1) ? gB_o : gB_e) + ((U) >> 1) * pairB + (KOFF))
-#define W2R_A_LOAD(SET, U, KOFF) ra[SET][U] = *reinterpret_cast<const u32x4*>(W2R_APTR(U, KOFF))
+#define W2R_A_LOAD(SET, U, KOFF) ra[SET][U] = ENH_A_NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(W2R_APTR(U, KOFF))) : *reinterpret_cast<const u32x4*>(W2R_APTR(U, KOFF))
 #define W2R_A_WRITE(SLOT, SET, U) *reinterpret_cast<u32x4*>(smem + (SLOT) * W2_SLOT + a_lds + (U) * 1024 + lane * 16) = ra[SET][U]
-#define W2R_A_DMA(SLOT, U, KOFF) __builtin_amdgcn_global_load_lds((const GLB_AS void*)W2R_APTR(U, KOFF), (LDS_AS void*)(smem + (SLOT) * W2_SLOT + a_lds + (U) * 1024), 16, 0, ENH_GLDS_AUX)
+#define W2R_A_DMA(SLOT, U, KOFF) __builtin_amdgcn_global_load_lds((const GLB_AS void*)W2R_APTR(U, KOFF), (LDS_AS void*)(smem + (SLOT) * W2_SLOT + a_lds + (U) * 1024), 16, 0, ENH_A_NT ? 2 : ENH_GLDS_AUX)
 #define W2R_B_DMA(SLOT, U, KOFF) __builtin_amdgcn_global_load_lds((const GLB_AS void*)W2R_BPTR(U, KOFF), (LDS_AS void*)(smem + (SLOT) * W2_SLOT + b_lds + (U) * 1024), 16, 0, ENH_GLDS_AUX)
   // k16 step 0 of a stage: + fragment reads of k-step 1 ; under every odd MFMA: the A share of the next stage leaves its registers for LDS and the
   // registers are re-used at once for the share three stages further on
