@@ -62,13 +62,13 @@ __device__ __forceinline__ void att_pin(s16x8& f) {
   asm volatile("" : "+v"(u));
   f = __builtin_bit_cast(s16x8, u);
 }
-// max(a, b, c) in ONE instruction.  fmaxf on MFMA results makes the compiler canonicalise every operand first (v_max_f32 x, x, x: seven instructions
-// for a 4-way maximum, cdna_hip_programming.md "Fused attention" pitfalls); scores are finite products, nothing to canonicalise.
-__device__ __forceinline__ float max3(float a, float b, float c) {
-  float r;
-  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
-}
+// max(a, b, c) in ONE instruction (v_max3_f32).  Written as nested maxima the COMPILER sees: the attention objects are built with -fno-honor-nans, so no
+// operand is canonicalised first (v_max_f32 x, x, x: seven instructions for a 4-way maximum, cdna_hip_programming.md "Fused attention" pitfalls) and the
+// backend fuses the pair into v_max3_f32.  Round 4 used inline asm for this — and inline asm is invisible to the hazard recognizer: the first v_max3
+// behind the S products read the MFMA's destination registers BEFORE the matrix pipe had written them (no s_nop in between), i.e. a stale maximum.  Any
+// reference maximum gives a valid softmax, so every parity test passed; but the result bits changed from launch to launch (tools/attn_det_probe.py,
+// found in round 5 by the graph-replay bit-identity test).  tests/test_isa_lint.py now refuses inline-asm VALU in the attention kernels' hot loops.
+__device__ __forceinline__ float max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 // combine a per-lane value with the other half-wave's (lane ^ 32) through one v_permlane32_swap (no LDS round trip).  Verified semantics
 // (profiles/hw_probe_r01.txt P4): with both operands = v, every lane receives (v[lane & 31], v[(lane & 31) + 32]).
 __device__ __forceinline__ float xhalf_max(float v) {
