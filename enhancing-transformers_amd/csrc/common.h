@@ -9,7 +9,7 @@
 #define GLB_AS __attribute__((address_space(1)))
 // cache-policy bits of the LDS-DMA staging requests.  sc1 (agent scope: no allocation in the CU's vector L1, which no tile ever hits) makes the split-K
 // weight gradient 6.5 % faster IN ISOLATION (tools/wgrad_lab.py: none 535 us, sc0 512-525, sc1 503, sc0 + sc1 503, nt 570, sc1 + nt 552) and changes nothing
-// in the training step (same-box interleaved A/B of two libraries, tools/r4_sc1_ab.sh: 618.4 vs 619.3 images/s, adversarial step 207.3 vs 207.7): inside
+// in the training step (same-box interleaved A/B of two libraries, tools/gpu_session.sh lib-ab; round 4: tools/r4_sc1_ab.sh: 618.4 vs 619.3 images/s, adversarial step 207.3 vs 207.7): inside
 // the step the operands come straight from their producers.  Left at the default.
 #ifdef ENH_GLDS_AUX_OVERRIDE
 #define ENH_GLDS_AUX ENH_GLDS_AUX_OVERRIDE

@@ -463,7 +463,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // of the epilogue: 256 live registers, spills, and scratch reloads are vector-memory operations that wait on the next tile's requests)
 // (acc_read: gemm_tiles.h)
 
-// Cache policy of the persistent epilogues' result stores (round 5, tools/r5_cache_policy_ab.sh -> profiles/r05_cache_policy_ab.txt, same-box in-step A/B):
+// Cache policy of the persistent epilogues' result stores (round 5, tools/gpu_session.sh lib-ab -> profiles/r05_cache_policy_ab.txt, same-box in-step A/B):
 // with the non-temporal hint on EVERY mode's stores the step gains 0.7 % — all of it in the two modes whose tile also READS a row-contiguous operand
 // (bias + residual f32: 0.433 -> 0.419 ms; tanh': 0.762 -> 0.740 ms), while the plain bf16 / bias + tanh modes lose 0.5 %.  So: nt where it pays.
 // ENH_P_NT_STORE = 1 forces it everywhere, 0 nowhere (lab).  ENH_A_NT (lab): the streamed A operand requested non-temporal — measured slower

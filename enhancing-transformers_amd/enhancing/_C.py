@@ -152,6 +152,7 @@ def lib():
             f, q, k = (int(x) for x in att.split(","))
             if L.enh_attention_set_kernel(f, q, k) != 0:
                 raise RuntimeError(L.enh_last_error().decode())
+            _ATT_FAMILY[:] = [f, q, k]
         conv = os.environ.get("ENH_CONV_KERNEL")      # A/B: "reg" register-staged everywhere | "t128" no 256-row kernels | "t256" 256-row wherever the shape allows
         if conv:
             if conv not in CONV_KERNELS or L.enh_conv_set_kernel(CONV_KERNELS[conv]) != 0:
@@ -454,14 +455,21 @@ def _gemm_workspace(device, nbytes: int):
 # ------------------------------------------------------------------------------------------------
 # attention
 # ------------------------------------------------------------------------------------------------
+_ATT_FAMILY = [0, 0, 0]
+
+
 def attention_set_kernel(fwd: int = 0, dq: int = 0, dkv: int = 0) -> None:
     """A/B aid: kernel family per pass (include/enh_hip.h enh_attention_set_kernel)"""
     _check(lib().enh_attention_set_kernel(fwd, dq, dkv), "enh_attention_set_kernel")
+    _ATT_FAMILY[:] = [fwd, dq, dkv]
 
 
 def attention_forward(qkv, B: int, N: int, H: int, scale: float, out, lse, q_prescaled: bool = False):
     """q_prescaled: the q third of qkv holds q * scale * log2(e) (include/enh_hip.h)"""
-    _timed("attn_fwd_kernel", 4.0 * B * H * N * N * 64,
+    # (labelled with the symbol rocprofv3 reports: family 5 — the default — serves pre-scaled q, family 1 everything else; 4 = the antiphase kernels)
+    fam = _ATT_FAMILY[0] or 5
+    name = "attn_fwd3_kernel" if (fam == 4 and N % 256 == 0) else ("attn_fwd_pre_kernel" if (fam == 5 and q_prescaled) else "attn_fwd_kernel")
+    _timed(name, 4.0 * B * H * N * N * 64,
            lambda: _check(lib().enh_attention_forward(_p(qkv, BF16, "qkv"), B, N, H, scale, int(q_prescaled), _p(out, BF16, "out"), _p(lse, F32, "lse"),
                                                       _stream()), "enh_attention_forward"))
 
