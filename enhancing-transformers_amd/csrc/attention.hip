@@ -268,6 +268,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
 // loaded from LDS straight into the accumulator registers (the same four 16-byte reads per block as before, no extra registers), which removes the
 // per-element subtraction (and the scale-and-subtract before the exponential).  kscale: the factor of the finished dK (scale, or ln 2 with PRE).
 template <bool CINIT, bool PRE>
+// (round 5: forcing three waves per SIMD here — __launch_bounds__(256, 3), 168 registers — spills 18 registers into the tile loop and costs +20 % on the backward;
+// four waves on the forward, 38 spills, doubles its time: profiles/r05_attention_lab.txt §5.  The occupancy these kernels have is the one their live set allows.)
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ d_o,
                                                               const float* __restrict__ lse, const float* __restrict__ delta, int B, int N,
                                                               int H, float scale, float scale_log2, uint16_t* __restrict__ dqkv) {
