@@ -1099,6 +1099,12 @@ static unsigned int* next_tile_counters() {
 }
 
 struct GemmPlan { int family, splits; int64_t k_per_split; };
+static int g_force_splits = 0;   // enh_debug_gemm_splits: K slices of the split-K plans (0 = the planner's choice)
+extern "C" int enh_debug_gemm_splits(int splits) {
+  ENH_REQUIRE(splits >= 0 && splits <= 256, ENH_E_BADARG, "enh_debug_gemm_splits: 0 (auto) .. 256");
+  g_force_splits = splits;
+  return ENH_OK;
+}
 
 static GemmPlan gemm_plan(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, bool splittable) {
   const bool k64 = K % G_BK == 0 && (!trans_a || M >= 8) && (!trans_b || N >= 8);
@@ -1109,6 +1115,7 @@ static GemmPlan gemm_plan(int trans_a, int trans_b, int64_t M, int64_t N, int64_
   // 8 stages long (more slices only add partial-sum traffic, a ragged second round costs more: profiles/r01_gemm_ablation.txt)
   auto split_for = [&](int64_t tiles, int64_t slots, int64_t cap) -> int {
     if (!splittable || tiles >= slots / 2 || K < 2048) return 1;
+    if (g_force_splits > 0 && g_force_splits <= ksteps / 2) return g_force_splits;   // enh_debug_gemm_splits (lab)
     int64_t want = slots / tiles;
     if (want > ksteps / 8) want = ksteps / 8;
     if (want > cap) want = cap;

@@ -86,6 +86,7 @@ SIGNATURES = {
     "enh_blur_set_kernel": (_i32, [_i32]),
     "enh_debug_gemm_lab": (_i32, [_i32]),
     "enh_debug_gemm_order": (_i32, [_i32, _i32]),
+    "enh_debug_gemm_splits": (_i32, [_i32]),
     "enh_blur_nhwc_bf16": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "enh_lrelu_gate_bf16": (_i32, [_vp, _vp, _i64, _f32, _f32, _vp, _vp]),
     "enh_img_to_nhwc8": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
@@ -115,7 +116,7 @@ SIGNATURES = {
 }
 
 _LIB = None
-ABI_VERSION = 11  # ENH_ABI_VERSION of the include/enh_hip.h these signatures were written against
+ABI_VERSION = 12  # ENH_ABI_VERSION of the include/enh_hip.h these signatures were written against
 
 
 def lib():

@@ -173,8 +173,16 @@ class LPIPS(nn.Module):
         # loss.perceptual_loss.*), which never calls a child's load_state_dict override
         # weights_loaded only when EVERY tensor of the module arrives (a partial dict under strict=False leaves the missing ones zero), and a random
         # trunk can never arrive: state_dict() of a randomly initialised module omits its tensors (see _drop_random_weights)
-        expected = {prefix + n for n, _ in list(self.named_parameters(remove_duplicate=False)) + list(self.named_buffers(remove_duplicate=False))}
-        if expected and expected <= set(state_dict):
+        # lpips registers the five 1x1 heads twice (`lin{k}` attributes and the `lins` ModuleList): ONE family in the incoming dict fills both (they are
+        # the same Parameters), so either counts as complete (a checkpoint carrying only one family left weights_loaded False although every
+        # tensor had been copied)
+        names = [n for n, _ in list(self.named_parameters(remove_duplicate=False)) + list(self.named_buffers(remove_duplicate=False))]
+        core = {n for n in names if not n.startswith("lins.") and not n.startswith("lin")}
+        fam_attr = {n for n in names if n.startswith("lin") and not n.startswith("lins.")}
+        fam_list = {n for n in names if n.startswith("lins.")}
+        have = set(state_dict)
+        full = lambda fam: bool(fam) and {prefix + n for n in core | fam} <= have
+        if full(fam_attr) or full(fam_list):
             self.weights_loaded, self.random_init = True, False
         self._dev.clear()
         return super()._load_from_state_dict(state_dict, prefix, *a, **k)

@@ -11,7 +11,10 @@
  *     -(1000 + hipError_t).  enh_last_error() gives a thread-local human-readable message.  This mirrors
  *     the reference's native-op precedent, where TORCH_CHECK failures surface as a Python RuntimeError
  *     (enhancing/losses/op/fused_bias_act.cpp:9-15); the Python wrapper raises RuntimeError on rc != 0.
- *   - All functions are stateless and re-entrant (they are called from autograd worker threads too).
+ *   - All functions are stateless and re-entrant (they are called from autograd worker threads too), EXCEPT the explicit library
+ *     state behind the enh_*_set_* / enh_set_cu_budget / enh_debug_* setters (process-global, meant for A/B measurements and for the
+ *     data-parallel driver) and the persistent GEMMs' tile-claim counters, which together with the cached CU count belong to the
+ *     FIRST device the library is used on: one device per process (the deployment model: one process per GPU, torchrun).
  *
  * The reference reaches this path through stock PyTorch ops, not an FFI; each entry
  * below cites the reference lines whose arithmetic it replaces.  Paths are relative to the reference
@@ -36,7 +39,7 @@ extern "C" {
 typedef uint16_t enh_bf16; /* raw bfloat16 bits */
 
 const char* enh_last_error(void);
-#define ENH_ABI_VERSION 11  /* bumped whenever a signature below changes; the bindings check it at load */
+#define ENH_ABI_VERSION 12  /* bumped whenever a signature below changes; the bindings check it at load */
 int enh_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -182,6 +185,9 @@ int enh_debug_gemm_lab(int variant);
  * every A panel is fetched by one XCD once).  grp_rows = 0: the library's per-shape default (col_fast for K >= 2048).  tools/gemm_ld_lab.py,
  * profiles/r05_gemm_landing_lab.txt */
 int enh_debug_gemm_order(int grp_rows, int col_fast);
+/* Measurement aid: force the number of K slices of the split-K plans (weight gradients); 0 = the planner's choice.  With 8 x (tiles per slice)
+ * workgroups every XCD holds whole slices (profiles/r05_gemm_landing_lab.txt §5). */
+int enh_debug_gemm_splits(int splits);
 int enh_debug_occupy_cus(int n_wg, float ms, void* stream);
 /* Measurement aid: out16[w] = SIMD id the hardware gave wave w of the first (w < 8) and of the last (8 <= w < 16) 512-thread workgroup of a chip-filling
  * grid — the placement rule the eight-wave antiphase attention kernels depend on (profiles/r04_attention_lab.txt). */

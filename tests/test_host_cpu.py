@@ -122,6 +122,15 @@ def test_lpips_without_weights_raises_and_parent_load_supplies_them(monkeypatch)
     with torch.no_grad():
         m._conv(2).weight.mul_(2.0)                             # in-place write: version bump -> cache rebuilt
     assert torch.equal(m._device_weights(cpu)["fwd"][2].float(), (after.float() * 2).to(torch.bfloat16).float())
+    # ONE lin-key family is a complete lpips state dict (lin{k} and lins.{k} are the same Parameters) — nested inside a parent checkpoint too
+    for fam_drop in ("lins.", "lin"):
+        P2 = VQLPIPS(perceptual_weight=0.1)
+        one = {"perceptual_loss." + k: v for k, v in real.items()
+               if not (k.startswith("lins.") if fam_drop == "lins." else (k.startswith("lin") and not k.startswith("lins.")))}
+        assert len(one) == len(real) - 5
+        missing = P2.load_state_dict(one, strict=False)
+        assert P2.perceptual_loss.weights_loaded and len(missing.missing_keys) == 5
+        assert torch.equal(P2.perceptual_loss.lin3.model[1].weight, real["lin3.model.1.weight"])
     monkeypatch.setenv("ENH_LPIPS_RANDOM_INIT", "1")
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")

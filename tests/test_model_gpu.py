@@ -82,6 +82,22 @@ def test_decode_codes_roundtrip(tiny):
     assert rel(rec, ref) <= ACT_TOL
 
 
+def test_encode_codes_at_the_forward_precision_equals_the_forward_indices(tiny):
+    """encode_codes defaults to the x3 encoder (the reference's codes), reconstruct / forward / training to the single-pass bf16 encoder (README:
+    the two can differ on fp32 near-ties — ~2 % of tokens at base depth).  Asked for the SAME precision they are one arithmetic: identical indices."""
+    cfg, P, x, m = tiny
+    e = m.engine
+    assert e.codes_precision == "x3" and e.encoder_precision == "bf16"
+    for prec in ("bf16", "x3"):
+        e.encoder_precision = prec
+        try:
+            idx_fwd = e.reconstruct(x)[2]
+            idx_codes = m.encode_codes(x, precision=prec)
+        finally:
+            e.encoder_precision = "bf16"
+        assert torch.equal(idx_fwd.view(-1), idx_codes.view(-1)), prec
+
+
 def test_train_step_gradients_vs_oracle(tiny, golden_dir):
     import vitvq_oracle as O
     cfg, P, x, m = tiny
