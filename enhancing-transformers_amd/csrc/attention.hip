@@ -63,11 +63,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pre_kernel(const uint16_t* __
   f32x2 l2[2] = {{0.f, 0.f}, {0.f, 0.f}};
 
   const int nt = N / 64;
-  u32x4 rk[2], rv[2];
-  att_gload(rk, Kp, RS, 0, t);
-  att_gload(rv, Vp, RS, 0, t);
-  att_sstore(rk, smem[0][0], t);
-  att_sstore(rv, smem[0][1], t);
+  // K / V tiles by LDS-DMA (round 5): no staging registers, no ds_write pass; the next tile is requested at the top of a tile into the stage the last barrier freed
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned ko0 = att_dma_lane_off((int)RS, lane, 0), ko1 = att_dma_lane_off((int)RS, lane, 1);
+  att_dma_tile(Kp, RS, 0, smem[0][0], wave_u, ko0, ko1);
+  att_dma_tile(Vp, RS, 0, smem[0][1], wave_u, ko0, ko1);
 #pragma unroll
   for (int ds = 0; ds < 4; ++ds) att_pin(qf[ds]);
   ATT_LOOP_ENTRY();
@@ -75,11 +75,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pre_kernel(const uint16_t* __
   for (int kt = 0; kt < nt; ++kt) {
     const int st = kt & 1;
     if (kt + 1 < nt) {
-      att_gload(rk, Kp, RS, (kt + 1) * 64, t);
-      att_gload(rv, Vp, RS, (kt + 1) * 64, t);
+      att_dma_tile(Kp, RS, (kt + 1) * 64, smem[st ^ 1][0], wave_u, ko0, ko1);
+      att_dma_tile(Vp, RS, (kt + 1) * 64, smem[st ^ 1][1], wave_u, ko0, ko1);
     }
     const unsigned char* kt_ = smem[st][0];
     const unsigned char* vt_ = smem[st][1];
+    // (Round 5: issuing the tile's fragment reads ahead of their use in a fenced order — all eight K fragments at once, one V fragment behind every S
+    // product, counted lgkmcnt waits instead of the compiler's read / wait(0) / MFMA chains — needs 168 registers (three waves per SIMD instead of four)
+    // and measured no faster than the round-4 kernel; the compiler's serial form at four waves is the fastest of the three: profiles/r05_attention_lab.txt §6.)
     f32x16 s[2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -128,10 +131,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pre_kernel(const uint16_t* __
 #pragma unroll
         for (int db = 0; db < 2; ++db) o[db] = MFMA32(att_frag_tr(vt_, kb * 32 + 16 * c2, db, lane), pb, o[db]);
       }
-    if (kt + 1 < nt) {
-      att_sstore(rk, smem[st ^ 1][0], t);
-      att_sstore(rv, smem[st ^ 1][1], t);
-    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this wave's share of the next tile has landed
     __syncthreads();
   }
   const float l_part = (l2[0][0] + l2[1][0]) + (l2[0][1] + l2[1][1]);
@@ -205,11 +205,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
     for (int r = 0; r < 16; ++r) dq[db][r] = 0.f;
 
   const int nt = N / 64;
-  u32x4 rk[2], rv[2];
-  att_gload(rk, Kp, RS, 0, t);
-  att_gload(rv, Vp, RS, 0, t);
-  att_sstore(rk, smem[0][0], t);
-  att_sstore(rv, smem[0][1], t);
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);      // K / V tiles by LDS-DMA (see attn_fwd_pre_kernel)
+  const unsigned ko0 = att_dma_lane_off((int)RS, lane, 0), ko1 = att_dma_lane_off((int)RS, lane, 1);
+  att_dma_tile(Kp, RS, 0, smem[0][0], wave_u, ko0, ko1);
+  att_dma_tile(Vp, RS, 0, smem[0][1], wave_u, ko0, ko1);
 #pragma unroll
   for (int ds = 0; ds < 4; ++ds) { att_pin(qf[ds]); att_pin(dof[ds]); }
   ATT_LOOP_ENTRY();
@@ -217,8 +216,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
   for (int kt = 0; kt < nt; ++kt) {
     const int st = kt & 1;
     if (kt + 1 < nt) {
-      att_gload(rk, Kp, RS, (kt + 1) * 64, t);
-      att_gload(rv, Vp, RS, (kt + 1) * 64, t);
+      att_dma_tile(Kp, RS, (kt + 1) * 64, smem[st ^ 1][0], wave_u, ko0, ko1);
+      att_dma_tile(Vp, RS, (kt + 1) * 64, smem[st ^ 1][1], wave_u, ko0, ko1);
     }
     const unsigned char* kt_ = smem[st][0];
     const unsigned char* vt_ = smem[st][1];
@@ -243,10 +242,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
         for (int db = 0; db < 2; ++db) dq[db] = MFMA32(att_frag_tr(kt_, kb * 32 + 16 * c2, db, lane), dsb, dq[db]);  // dQ^T[d][q] += K^T dS^T
       }
     }
-    if (kt + 1 < nt) {
-      att_sstore(rk, smem[st ^ 1][0], t);
-      att_sstore(rv, smem[st ^ 1][1], t);
-    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this wave's share of the next tile has landed
     __syncthreads();
   }
   if (!active) return;
@@ -268,9 +264,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
 // loaded from LDS straight into the accumulator registers (the same four 16-byte reads per block as before, no extra registers), which removes the
 // per-element subtraction (and the scale-and-subtract before the exponential).  kscale: the factor of the finished dK (scale, or ln 2 with PRE).
 template <bool CINIT, bool PRE>
+#ifndef ATT_DKV_DMA
+#define ATT_DKV_DMA 1
+#endif
+#ifndef ATT_DKV_OCC
+#define ATT_DKV_OCC 2
+#endif
 // (round 5: forcing three waves per SIMD here — __launch_bounds__(256, 3), 168 registers — spills 18 registers into the tile loop and costs +20 % on the backward;
 // four waves on the forward, 38 spills, doubles its time: profiles/r05_attention_lab.txt §5.  The occupancy these kernels have is the one their live set allows.)
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ d_o,
+__global__ __launch_bounds__(256, ATT_DKV_OCC) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ d_o,
                                                               const float* __restrict__ lse, const float* __restrict__ delta, int B, int N,
                                                               int H, float scale, float scale_log2, uint16_t* __restrict__ dqkv) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][ATT_TILE_BYTES];  // [stage][Q | dO]
@@ -305,18 +307,29 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
     for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
 
   const int nt = N / 64;
+#if ATT_DKV_DMA
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned qo0 = att_dma_lane_off((int)RS, lane, 0), qo1 = att_dma_lane_off((int)RS, lane, 1);
+  const unsigned do0 = att_dma_lane_off((int)OS, lane, 0), do1 = att_dma_lane_off((int)OS, lane, 1);
+  float rstat = 0.f;
+  att_dma_tile(Qp, RS, 0, smem[0][0], wave_u, qo0, qo1);
+  att_dma_tile(dOp, OS, 0, smem[0][1], wave_u, do0, do1);
+#else
   u32x4 rq[2], rd[2];
   float rstat = 0.f;
   att_gload(rq, Qp, RS, 0, t);
   att_gload(rd, dOp, OS, 0, t);
+#endif
   // statistics of the 64 queries of a tile: threads 0-63 fetch lse (kept in the log2 domain), 64-127 delta — through ONE select-addressed load in the
   // straight-line code.  The former `if (t < 64) .. else if (t < 128) ..` put each load in its own divergent block, and the wait-count pass closed
   // that block with s_waitcnt vmcnt(0): every iteration waited for the Q / dO prefetch issued just before it (found in the ISA, round 3).
   const float* statp = ((t & 64) ? delp : lsep) + (t & 63);
   const float stat_mul = (t & 64) ? (CINIT ? -1.0f : 1.0f) : ((CINIT && PRE) ? -1.4426950408889634f : 1.4426950408889634f);   // stored negated where they are C operands
   rstat = statp[0];
+#if !ATT_DKV_DMA
   att_sstore(rq, smem[0][0], t);
   att_sstore(rd, smem[0][1], t);
+#endif
   if (t < 128) s_stat[0][t >> 6][t & 63] = rstat * stat_mul;
 #pragma unroll
   for (int ds = 0; ds < 4; ++ds) { att_pin(kf[ds]); att_pin(vf[ds]); }
@@ -325,8 +338,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
   for (int qt = 0; qt < nt; ++qt) {
     const int st = qt & 1;
     if (qt + 1 < nt) {
+#if ATT_DKV_DMA
+      att_dma_tile(Qp, RS, (qt + 1) * 64, smem[st ^ 1][0], wave_u, qo0, qo1);      // the other stage is free since the barrier that closed tile qt - 1
+      att_dma_tile(dOp, OS, (qt + 1) * 64, smem[st ^ 1][1], wave_u, do0, do1);
+#else
       att_gload(rq, Qp, RS, (qt + 1) * 64, t);
       att_gload(rd, dOp, OS, (qt + 1) * 64, t);
+#endif
       rstat = statp[(qt + 1) * 64];                 // (scaled when it is stored, after the tile's arithmetic: nothing here waits for the load)
     }
     const unsigned char* qt_ = smem[st][0];
@@ -376,10 +394,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const uint16_t* __
       }
     }
     if (qt + 1 < nt) {
+#if !ATT_DKV_DMA
       att_sstore(rq, smem[st ^ 1][0], t);
       att_sstore(rd, smem[st ^ 1][1], t);
+#endif
       if (t < 128) s_stat[st ^ 1][t >> 6][t & 63] = rstat * stat_mul;
     }
+#if ATT_DKV_DMA
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this wave's share of the next tile has landed in LDS
+#endif
     __syncthreads();
   }
   if (!active) return;

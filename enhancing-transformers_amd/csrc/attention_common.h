@@ -27,6 +27,20 @@ __device__ __forceinline__ void att_sstore(const u32x4 (&r)[2], unsigned char* t
 #pragma unroll
   for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(tile + att_off(r0 + 32 * i, c)) = r[i];
 }
+// The same tile image written by LDS-DMA (global_load_lds, 16 B per lane): no staging registers, no ds_write pass.  The LDS destination of a wave
+// instruction is lane-linear (base + lane * 16 B: 8 rows x 128 B), so the swizzle is applied to the lane's SOURCE address: slot p = lane & 7 of row r must
+// receive chunk c = p ^ f(r).  Wave w of the four stages rows 16 w .. 16 w + 15 (two instructions per operand and tile).  The caller waits vmcnt(0) before the
+// barrier that publishes the tile.
+__device__ __forceinline__ unsigned att_dma_lane_off(int rs_elems, int lane, int i) {   // byte offset of this lane's 16 source bytes inside 8-row group i (0 | 1) of a wave's 16 rows
+  const int rr = lane >> 3, p = lane & 7, r = rr + 8 * i;      // f(r) of att_off depends on r & 15 only (bits 1..3), and the wave's row base is a multiple of 16
+  const int c = p ^ ((((r >> 1) & 1) << 2) | ((r >> 2) & 3));
+  return (unsigned)(rr * rs_elems + c * 8) * 2u;
+}
+__device__ __forceinline__ void att_dma_tile(const uint16_t* __restrict__ base, int64_t rs, int row0, unsigned char* tile, int wave, unsigned lane_off0, unsigned lane_off1) {
+  const unsigned char* ub = reinterpret_cast<const unsigned char*>(base + (int64_t)(row0 + wave * 16) * rs);
+  __builtin_amdgcn_global_load_lds((const GLB_AS void*)(ub + lane_off0), (LDS_AS void*)(tile + (wave * 16) * 128), 16, 0, 0);
+  __builtin_amdgcn_global_load_lds((const GLB_AS void*)(ub + (size_t)(unsigned)(8 * (int)rs * 2) + lane_off1), (LDS_AS void*)(tile + (wave * 16 + 8) * 128), 16, 0, 0);
+}
 // 32x32x16 operand fragment, rows = tile rows rb + (lane&31), k = d: ds*16 + hi*8 + 0..7
 __device__ __forceinline__ s16x8 att_frag_row(const unsigned char* tile, int rb, int ds, int l31, int hi) {
   return *reinterpret_cast<const s16x8*>(tile + att_off(rb + l31, ds * 2 + hi));
@@ -82,6 +96,7 @@ __device__ __forceinline__ float xhalf_sum(float v) {
   return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
 }
 
+#define ATT_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
 
 // Workgroup -> (block-within-head, head) mapping.  Hardware places workgroup L on XCD L % 8 (each XCD has a private L2), and the nblk
