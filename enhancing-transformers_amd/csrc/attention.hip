@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pre_kernel(const uint16_t* __
 // the products are already log2-domain scores): -lse enters the S product the same way and the exponential reads the accumulator directly — no
 // vector arithmetic left but exp, the P o dP' multiply and the bf16 packing.  The kernels are vector-ISSUE bound (profiles/r03_attention_lab.txt).
 template <int MODE>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ o, const uint16_t* __restrict__ d_o,
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ o, const uint16_t* __restrict__ d_o,
                                                              const float* __restrict__ lse, float* __restrict__ delta, int B, int N,
                                                              int H, float scale, float scale_log2, uint16_t* __restrict__ dqkv) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][ATT_TILE_BYTES];
@@ -437,7 +437,7 @@ void attn_bwd_dkv3_launch(const uint16_t* qkv, const uint16_t* d_o, const float*
 //            and N % 256 == 0, else family 2)
 static int g_att_fwd = 0, g_att_dq = 0, g_att_dkv = 0;
 #define ATT_DEFAULT_FWD 5
-#define ATT_DEFAULT_DQ 1
+#define ATT_DEFAULT_DQ 3
 #define ATT_DEFAULT_DKV 2
 
 extern "C" int enh_attention_set_kernel(int fwd, int dq, int dkv) {

@@ -213,7 +213,8 @@ int enh_attention_forward(const enh_bf16* qkv, int B, int N, int H, float scale,
  *   fwd: 1 four-wave kernel (round 2), 4 eight waves per workgroup in two groups in antiphase — one wave of a SIMD in its matrix segment while its
  *        partner runs the softmax (csrc/attention_v3.hip; N % 256 == 0, otherwise family 1 serves the call), 5 the four-wave skeleton with the running
  *        reference as the MFMA C operand and the row sum taken from the packed bf16 numerators (round 5; pre-scaled q, otherwise family 1) [default]
- *   dq : 1 four-wave kernel (round 2), 3 the same skeleton with -delta (-lse too when q is pre-scaled) as MFMA C operands
+ *   dq : 1 four-wave kernel (round 2), 3 the same skeleton with -delta (-lse too when q is pre-scaled) as MFMA C operands [default since round 5: with the
+ *        K / V tiles by LDS-DMA it fits three waves per SIMD]
  *   dkv: 1 four-wave kernel (round 2), 2 the same skeleton with -delta (-lse too when q is pre-scaled) as MFMA C operands [default],
  *        3 eight waves in antiphase (pre-scaled q and N % 256 == 0, otherwise family 2)
  * (fwd 2 / 3 and dq 2 were the software-pipelined round-3 kernels: measured slower, removed in round 4.)
