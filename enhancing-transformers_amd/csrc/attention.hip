@@ -424,25 +424,20 @@ __global__ __launch_bounds__(256, ATT_DKV_OCC) void attn_bwd_dkv_kernel(const ui
 // =================================================================================================
 // C ABI
 // =================================================================================================
-// round-4 eight-wave antiphase forward (attention_v3.hip); needs N % 256 == 0
-void attn_fwd3_launch(const uint16_t* qkv, int B, int N, int H, float scale_log2, uint16_t* out, float* lse, bool pre, hipStream_t s);
-void attn_bwd_dkv3_launch(const uint16_t* qkv, const uint16_t* d_o, const float* lse, const float* delta, int B, int N, int H, float kscale, uint16_t* dqkv,
-                          hipStream_t s);
-
 // kernel family per pass (explicit state behind an explicit call, as enh_gemm_set_kernel); 0 = the library's choice:
-//   forward: 1 round-2 kernel | 4 eight waves in antiphase (round 4) | 5 round-2 skeleton with -m_ref as the MFMA C operand and the row sum from the packed
-//            numerators (round 5; pre-scaled q only, else family 1)      (2, 3: the software-pipelined round-3 kernels — measured slower, removed in round 4)
-//   dQ     : 1 round-2 kernel | 3 round-2 skeleton with -delta (and, pre-scaled q, -lse) as MFMA C operands      (2: removed with them)
-//   dK/dV  : 1 round-2 kernel | 2 round-2 skeleton with -delta (and, pre-scaled q, -lse) as MFMA C operands | 3 eight waves in antiphase (round 4; pre-scaled q
-//            and N % 256 == 0, else family 2)
+//   forward: 1 round-2 kernel | 5 round-2 skeleton with -m_ref as the MFMA C operand, packed row sum, K / V by LDS-DMA (round 5; pre-scaled q only, else family 1)
+//   dQ     : 1 round-2 arithmetic | 3 -delta (and, pre-scaled q, -lse) as MFMA C operands
+//   dK/dV  : 1 round-2 arithmetic | 2 -delta (and, pre-scaled q, -lse) as MFMA C operands
+// (forward 2 / 3, dQ 2: the software-pipelined round-3 kernels; forward 4, dK/dV 3: the eight-wave antiphase kernels of round 4 — all measured slower and deleted;
+//  their lab notes stay in profiles/r03_attention_lab.txt, r04_attention_lab.txt.)
 static int g_att_fwd = 0, g_att_dq = 0, g_att_dkv = 0;
 #define ATT_DEFAULT_FWD 5
 #define ATT_DEFAULT_DQ 3
 #define ATT_DEFAULT_DKV 2
 
 extern "C" int enh_attention_set_kernel(int fwd, int dq, int dkv) {
-  ENH_REQUIRE((fwd == 0 || fwd == 1 || fwd == 4 || fwd == 5) && (dq == 0 || dq == 1 || dq == 3) && dkv >= 0 && dkv <= 3, ENH_E_BADARG,
-              "enh_attention_set_kernel: fwd in {0, 1, 4, 5}, dq in {0, 1, 3}, dkv in 0..3");
+  ENH_REQUIRE((fwd == 0 || fwd == 1 || fwd == 5) && (dq == 0 || dq == 1 || dq == 3) && dkv >= 0 && dkv <= 2, ENH_E_BADARG,
+              "enh_attention_set_kernel: fwd in {0, 1, 5}, dq in {0, 1, 3}, dkv in 0..2");
   g_att_fwd = fwd; g_att_dq = dq; g_att_dkv = dkv;
   return ENH_OK;
 }
@@ -457,11 +452,9 @@ extern "C" int enh_attention_forward(const enh_bf16* qkv, int B, int N, int H, f
   const int64_t nblk = (N + 127) / 128, heads = (int64_t)B * H;
   const dim3 grid((unsigned)(((heads + 7) / 8) * 8 * nblk));  // 1-D: see att_block_coords
   int fam = g_att_fwd ? g_att_fwd : ATT_DEFAULT_FWD;
-  if (fam == 4 && N % 256 != 0) fam = 1;                         // the eight-wave kernel owns 256 queries per workgroup
   if (fam == 5 && !q_prescaled) fam = 1;                         // -m_ref as a C operand needs log2-domain products
   const float sl2 = q_prescaled ? 1.0f : scale * ATT_LOG2E;       // pre-scaled q: the products are log2-domain scores already
-  if (fam == 4) attn_fwd3_launch(qkv, B, N, H, sl2, out, lse, q_prescaled != 0, (hipStream_t)stream);
-  else if (fam == 5) attn_fwd_pre_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(qkv, B, N, H, out, lse);
+  if (fam == 5) attn_fwd_pre_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(qkv, B, N, H, out, lse);
   else attn_fwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(qkv, B, N, H, sl2, out, lse);
   return enh_check_launch("enh_attention_forward");
 }
@@ -481,13 +474,11 @@ extern "C" int enh_attention_backward(const enh_bf16* qkv, const enh_bf16* out, 
   const float kscale = pre ? ATT_LN2 : scale;
   // (either dQ kernel also writes delta_ws = rowsum(dO * O) for the dK/dV kernel that follows)
   const int fq = g_att_dq ? g_att_dq : ATT_DEFAULT_DQ;
-  int fk = g_att_dkv ? g_att_dkv : ATT_DEFAULT_DKV;
-  if (fk == 3 && (!pre || N % 256 != 0)) fk = 2;
+  const int fk = g_att_dkv ? g_att_dkv : ATT_DEFAULT_DKV;
   if (fq == 1) attn_bwd_dq_kernel<0><<<grid, 256, 0, s>>>(qkv, out, dout, lse, delta_ws, B, N, H, scale, sl2, dqkv);
   else if (pre) attn_bwd_dq_kernel<2><<<grid, 256, 0, s>>>(qkv, out, dout, lse, delta_ws, B, N, H, scale, sl2, dqkv);
   else attn_bwd_dq_kernel<1><<<grid, 256, 0, s>>>(qkv, out, dout, lse, delta_ws, B, N, H, scale, sl2, dqkv);
-  if (fk == 3) attn_bwd_dkv3_launch(qkv, dout, lse, delta_ws, B, N, H, kscale, dqkv, s);
-  else if (fk == 1) attn_bwd_dkv_kernel<false, false><<<grid, 256, 0, s>>>(qkv, dout, lse, delta_ws, B, N, H, kscale, sl2, dqkv);
+  if (fk == 1) attn_bwd_dkv_kernel<false, false><<<grid, 256, 0, s>>>(qkv, dout, lse, delta_ws, B, N, H, kscale, sl2, dqkv);
   else if (pre) attn_bwd_dkv_kernel<true, true><<<grid, 256, 0, s>>>(qkv, dout, lse, delta_ws, B, N, H, kscale, sl2, dqkv);
   else attn_bwd_dkv_kernel<true, false><<<grid, 256, 0, s>>>(qkv, dout, lse, delta_ws, B, N, H, kscale, sl2, dqkv);
   return enh_check_launch("enh_attention_backward");

@@ -23,18 +23,3 @@ extern "C" int enh_debug_occupy_cus(int n_wg, float ms, void* stream) {
   occupy_cus_kernel<<<dim3((unsigned)n_wg), 256, lds, (hipStream_t)stream>>>((long long)(ms * 1e5f), nullptr);
   return enh_check_launch("enh_debug_occupy_cus");
 }
-
-// Where does the hardware put the eight waves of a 512-thread workgroup?  out[w] = SIMD id (HW_ID bits 5:4) of wave w of workgroup 0 and, behind them,
-// out[8 + w] for the last workgroup of a grid that fills the chip.  The antiphase attention kernels (attention_v3.hip) pair the two waves of a SIMD.
-__global__ __launch_bounds__(512) void wave_simd_map_kernel(int* __restrict__ out) {
-  __shared__ int pad[1024];
-  pad[threadIdx.x] = threadIdx.x;
-  __syncthreads();
-  const int simd = (int)__builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11));
-  if ((threadIdx.x & 63) == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) out[(blockIdx.x == 0 ? 0 : 8) + (threadIdx.x >> 6)] = simd + (pad[threadIdx.x] & 0);
-}
-extern "C" int enh_debug_wave_simd_map(int* out16, void* stream) {
-  ENH_REQUIRE(out16, ENH_E_BADARG, "enh_debug_wave_simd_map: null pointer");
-  wave_simd_map_kernel<<<dim3(1024), 512, 0, (hipStream_t)stream>>>(out16);
-  return enh_check_launch("enh_debug_wave_simd_map");
-}

@@ -50,8 +50,6 @@ SIGNATURES = {
     "enh_set_cu_budget": (_i32, [_i32]),
     "enh_get_cu_budget": (_i32, []),
     "enh_debug_occupy_cus": (_i32, [_i32, _f32, _vp]),
-    "enh_debug_wave_simd_map": (_i32, [_vp, _vp]),
-    "enh_debug_attention_fwd3_trace": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "enh_gemm_bf16_variant": (_c.c_char_p, [_i32, _i32, _i64, _i64, _i64]),
     "enh_gemm_bf16_variant_mode": (_c.c_char_p, [_i32, _i32, _i64, _i64, _i64, _i32]),
     "enh_gemm_bf16_dtanh_colsum_workspace_bytes": (_c.c_size_t, [_i32, _i64, _i64, _i64]),
@@ -116,7 +114,7 @@ SIGNATURES = {
 }
 
 _LIB = None
-ABI_VERSION = 12  # ENH_ABI_VERSION of the include/enh_hip.h these signatures were written against
+ABI_VERSION = 13  # ENH_ABI_VERSION of the include/enh_hip.h these signatures were written against
 
 
 def lib():
@@ -148,7 +146,7 @@ def lib():
             if sched not in ("static", "dynamic") or L.enh_gemm_set_scheduler(int(sched == "dynamic")) != 0:
                 raise RuntimeError(f"ENH_GEMM_SCHEDULER={sched!r}: expected static | dynamic")
             _DYN_SCHEDULE[0] = sched == "dynamic"
-        att = os.environ.get("ENH_ATTN_KERNEL")       # "fwd,dq,dkv" families, e.g. "4,1,3" (0 = library default; include/enh_hip.h enh_attention_set_kernel)
+        att = os.environ.get("ENH_ATTN_KERNEL")       # "fwd,dq,dkv" families, e.g. "1,1,1" (0 = library default; include/enh_hip.h enh_attention_set_kernel)
         if att:
             f, q, k = (int(x) for x in att.split(","))
             if L.enh_attention_set_kernel(f, q, k) != 0:
@@ -416,14 +414,6 @@ def occupy_cus(n_wg: int, ms: float, stream=None) -> None:
     _check(lib().enh_debug_occupy_cus(int(n_wg), float(ms), st), "enh_debug_occupy_cus")
 
 
-def wave_simd_map():
-    """SIMD ids of the eight waves of the first and of the last workgroup of a chip-filling 512-thread launch -> list of 16 ints"""
-    out = torch.full((16,), -1, dtype=torch.int32, device="cuda")
-    _check(lib().enh_debug_wave_simd_map(_p(out, torch.int32, "out"), _stream()), "enh_debug_wave_simd_map")
-    torch.cuda.synchronize()
-    return out.tolist()
-
-
 def _epi_mode_label(accumulate, have_ws, f32, bf16, bias, act, res) -> int:
     """EPI_* enum value gemm.hip's epi_mode() selects (0 generic, 1 bf16, 2 bf16+bias+tanh, 3 bf16+dtanh, 4 f32+bias+res, 5 f32, 6 split-K workspace,
     7 split-K atomics) — used only to label timings with the symbol name a profiler reports"""
@@ -467,9 +457,9 @@ def attention_set_kernel(fwd: int = 0, dq: int = 0, dkv: int = 0) -> None:
 
 def attention_forward(qkv, B: int, N: int, H: int, scale: float, out, lse, q_prescaled: bool = False):
     """q_prescaled: the q third of qkv holds q * scale * log2(e) (include/enh_hip.h)"""
-    # (labelled with the symbol rocprofv3 reports: family 5 — the default — serves pre-scaled q, family 1 everything else; 4 = the antiphase kernels)
+    # (labelled with the symbol rocprofv3 reports: family 5 — the default — serves pre-scaled q, family 1 everything else)
     fam = _ATT_FAMILY[0] or 5
-    name = "attn_fwd3_kernel" if (fam == 4 and N % 256 == 0) else ("attn_fwd_pre_kernel" if (fam == 5 and q_prescaled) else "attn_fwd_kernel")
+    name = "attn_fwd_pre_kernel" if (fam == 5 and q_prescaled) else "attn_fwd_kernel"
     _timed(name, 4.0 * B * H * N * N * 64,
            lambda: _check(lib().enh_attention_forward(_p(qkv, BF16, "qkv"), B, N, H, scale, int(q_prescaled), _p(out, BF16, "out"), _p(lse, F32, "lse"),
                                                       _stream()), "enh_attention_forward"))

@@ -39,7 +39,7 @@ extern "C" {
 typedef uint16_t enh_bf16; /* raw bfloat16 bits */
 
 const char* enh_last_error(void);
-#define ENH_ABI_VERSION 12  /* bumped whenever a signature below changes; the bindings check it at load */
+#define ENH_ABI_VERSION 13  /* bumped whenever a signature below changes; the bindings check it at load */
 int enh_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -189,12 +189,6 @@ int enh_debug_gemm_order(int grp_rows, int col_fast);
  * workgroups every XCD holds whole slices (profiles/r05_gemm_landing_lab.txt §5). */
 int enh_debug_gemm_splits(int splits);
 int enh_debug_occupy_cus(int n_wg, float ms, void* stream);
-/* Measurement aid: out16[w] = SIMD id the hardware gave wave w of the first (w < 8) and of the last (8 <= w < 16) 512-thread workgroup of a chip-filling
- * grid — the placement rule the eight-wave antiphase attention kernels depend on (profiles/r04_attention_lab.txt). */
-int enh_debug_wave_simd_map(int* out16, void* stream);
-/* Measurement aid: the eight-wave antiphase forward (pre-scaled q) with s_memtime stamps of waves 0 and 4 of workgroup 0 at the four edges of every
- * period -> trace[2][N / 64][4] (vector segment start | arrival at the first barrier | release | arrival at the second barrier) */
-int enh_debug_attention_fwd3_trace(const enh_bf16* qkv, int B, int N, int H, enh_bf16* out, float* lse, unsigned long long* trace, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused attention — Attention.forward layers.py:122-132 without materialising the N x N matrix
@@ -210,15 +204,12 @@ int enh_debug_attention_fwd3_trace(const enh_bf16* qkv, int B, int N, int H, enh
 int enh_attention_forward(const enh_bf16* qkv, int B, int N, int H, float scale, int q_prescaled, enh_bf16* out, float* lse,
                           void* stream);
 /* kernel family per pass for A/B measurements (explicit library state, like enh_gemm_set_kernel), 0 = the library's choice:
- *   fwd: 1 four-wave kernel (round 2), 4 eight waves per workgroup in two groups in antiphase — one wave of a SIMD in its matrix segment while its
- *        partner runs the softmax (csrc/attention_v3.hip; N % 256 == 0, otherwise family 1 serves the call), 5 the four-wave skeleton with the running
- *        reference as the MFMA C operand and the row sum taken from the packed bf16 numerators (round 5; pre-scaled q, otherwise family 1) [default]
- *   dq : 1 four-wave kernel (round 2), 3 the same skeleton with -delta (-lse too when q is pre-scaled) as MFMA C operands [default since round 5: with the
- *        K / V tiles by LDS-DMA it fits three waves per SIMD]
- *   dkv: 1 four-wave kernel (round 2), 2 the same skeleton with -delta (-lse too when q is pre-scaled) as MFMA C operands [default],
- *        3 eight waves in antiphase (pre-scaled q and N % 256 == 0, otherwise family 2)
- * (fwd 2 / 3 and dq 2 were the software-pipelined round-3 kernels: measured slower, removed in round 4.)
- * Same results up to rounding: every family passes the same parity tests. */
+ *   fwd: 1 four-wave kernel (round 2; serves both q conventions), 5 the same skeleton with the running reference as the MFMA C operand, a packed exact row
+ *        sum and the K / V tiles by LDS-DMA (round 5; pre-scaled q, otherwise family 1) [default]
+ *   dq : 1 round-2 arithmetic, 3 -delta (-lse too when q is pre-scaled) as MFMA C operands [default since round 5]
+ *   dkv: 1 round-2 arithmetic, 2 -delta (-lse too when q is pre-scaled) as MFMA C operands [default]
+ * (the software-pipelined round-3 kernels and the eight-wave antiphase kernels of round 4 were measured slower and are deleted.)
+ * Same results up to rounding: every family passes the same parity and bit-reproducibility tests. */
 int enh_attention_set_kernel(int fwd, int dq, int dkv);
 /* dqkv [B,N,3*H*64] bf16 ; delta_ws [B,H,N] f32 scratch */
 int enh_attention_backward(const enh_bf16* qkv, const enh_bf16* out, const enh_bf16* dout, const float* lse,

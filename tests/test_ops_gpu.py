@@ -436,7 +436,7 @@ def _attn_ref(qkv, B, N, H, scale):
 
 # kernel families per pass (include/enh_hip.h enh_attention_set_kernel): the library's default choice, the round-2 kernels, the software-pipelined
 # round-3 kernels, and the round-2 skeletons with the statistics fed through the MFMA C operand
-ATT_FAMILIES = [(0, 0, 0), (1, 1, 1), (1, 3, 2), (4, 1, 3), (5, 1, 2)]      # forward 4: eight waves in antiphase (round 4; N % 256 == 0, else the four-wave kernel)
+ATT_FAMILIES = [(0, 0, 0), (1, 1, 1), (1, 3, 2), (5, 1, 2), (5, 3, 1)]
 LOG2E = 1.4426950408889634
 
 
