@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC passes (counters only, no tracing) over the attention kernels at the bench shape, one kernel family per run:
-#   bash tools/pmc_attn.sh "1,1,1" "3,2,1"   -> gpurun_out/pmc_attn_<family>.txt
+#   bash tools/pmc_attn.sh "1,1,1" "5,3,2"   -> gpurun_out/pmc_attn_<family>.txt
 R=$PWD; export TMPDIR=/tmp; mkdir -p $R/gpurun_out; cd /tmp
 for FAM in "$@"; do
   TAG=$(echo $FAM | tr -d ,)
