@@ -896,7 +896,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   // vmcnt(8 + the epilogue's stores), lgkmcnt(0): 32 stores for bf16 outputs -> vmcnt(40); 64 for f32 -> more than the counter holds (63): B(1) is
   // then complete by the time the 8 loads behind the stores have issued at all
-  constexpr int EPI_STORES_WAIT = (EPI == EPI_F32 || EPI == EPI_F32_BIAS_RES) ? 0xC07F : 0x8078;
+  // (the x3 split epilogues store 2-4 planes: 64-128 stores, the counter-saturation argument of the f32 modes)
+  constexpr int EPI_STORES_WAIT = (EPI == EPI_F32 || EPI == EPI_F32_BIAS_RES || EPI == EPI_BF16_SPLIT || EPI == EPI_BF16_TANH_SPLIT) ? 0xC07F : 0x8078;
 
 #define W2R_APTR(U, KOFF) ((((U) & 1) ? gA_o : gA_e) + ((U) >> 1) * pairA + (KOFF))
 #define W2R_BPTR(U, KOFF) ((((U) & 1) ? gB_o : gB_e) + ((U) >> 1) * pairB + (KOFF))
@@ -1413,15 +1414,22 @@ extern "C" int enh_gemm_bf16_split(const enh_bf16* A, int64_t lda, const enh_bf1
   g.k_per_split = K; g.splits = 1;
   const int64_t tiles = (int64_t)g.nbm * g.nbn;
   typedef void (*w256_fn)(const GemmArgs);
-  static const w256_fn stable[2][2] = {{gemm_bf16_w256p_kernel<false, false, EPI_BF16_SPLIT, false>, gemm_bf16_w256p_kernel<false, false, EPI_BF16_TANH_SPLIT, false>},
-                                       {gemm_bf16_w256p_kernel<false, false, EPI_BF16_SPLIT, true>, gemm_bf16_w256p_kernel<false, false, EPI_BF16_TANH_SPLIT, true>}};
+  // [A-in-registers form (even number of K stages >= 6: every x3 call of the engine) | plain persistent form][schedule][mode]
+  static const w256_fn stable[2][2][2] = {
+      {{gemm_bf16_w256p_kernel<false, false, EPI_BF16_SPLIT, false>, gemm_bf16_w256p_kernel<false, false, EPI_BF16_TANH_SPLIT, false>},
+       {gemm_bf16_w256p_kernel<false, false, EPI_BF16_SPLIT, true>, gemm_bf16_w256p_kernel<false, false, EPI_BF16_TANH_SPLIT, true>}},
+      {{gemm_bf16_w256r_kernel<false, EPI_BF16_SPLIT, false>, gemm_bf16_w256r_kernel<false, EPI_BF16_TANH_SPLIT, false>},
+       {gemm_bf16_w256r_kernel<false, EPI_BF16_SPLIT, true>, gemm_bf16_w256r_kernel<false, EPI_BF16_TANH_SPLIT, true>}}};
   static const bool s_attr = [] {
-    for (int d = 0; d < 2; ++d)
-      for (int e = 0; e < 2; ++e)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stable[d][e]), hipFuncAttributeMaxDynamicSharedMemorySize, W2P_LDS_BYTES);
+    for (int r = 0; r < 2; ++r)
+      for (int d = 0; d < 2; ++d)
+        for (int e = 0; e < 2; ++e)
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stable[r][d][e]), hipFuncAttributeMaxDynamicSharedMemorySize, W2P_LDS_BYTES);
     return true;
   }();
   (void)s_attr;
+  const int64_t nst_ = K / G_BK;
+  const int regst = (g_kernel_override != 8 && nst_ % 2 == 0 && nst_ >= 6) ? 1 : 0;
   const int n_cu = cu_budget();
   const int64_t wgs = tiles < n_cu ? tiles : n_cu;
   const int dyn = g_dyn_schedule && wgs >= 8 ? 1 : 0;
@@ -1429,6 +1437,6 @@ extern "C" int enh_gemm_bf16_split(const enh_bf16* A, int64_t lda, const enh_bf1
     g.tile_ctr = next_tile_counters();
     ENH_REQUIRE(g.tile_ctr, ENH_E_BADARG, "enh_gemm_bf16_split: tile counters unavailable");
   }
-  hipLaunchKernelGGL(stable[dyn][act == ENH_ACT_TANH ? 1 : 0], dim3((unsigned)wgs), dim3(256), (size_t)W2P_LDS_BYTES, (hipStream_t)stream, g);
+  hipLaunchKernelGGL(stable[regst][dyn][act == ENH_ACT_TANH ? 1 : 0], dim3((unsigned)wgs), dim3(256), (size_t)W2P_LDS_BYTES, (hipStream_t)stream, g);
   return enh_check_launch("enh_gemm_bf16_split");
 }

@@ -784,13 +784,20 @@ def gemm_split_fused(M: int, N: int, K: int) -> bool:
     return bool(lib().enh_gemm_bf16_split_fused(M, N, K))
 
 
+def _split_label(K: int, mode: int) -> str:
+    """the symbol rocprofv3 reports for an enh_gemm_bf16_split call (the A-in-registers form serves an even number >= 6 of K stages)"""
+    dyn = "true" if _DYN_SCHEDULE[0] else "false"
+    nst = K // 64
+    return f"gemm_bf16_w256r_kernel<false, {mode}, {dyn}>" if (nst % 2 == 0 and nst >= 6) else f"gemm_bf16_w256p_kernel<false, false, {mode}, {dyn}>"
+
+
 def _poff(t: torch.Tensor, elems: int):
     return ctypes.c_void_p(t.data_ptr() + elems * t.element_size())
 
 
 def gemm_split2(a, b, M: int, N: int, K: int, hi, lo):
     """hi = bf16(a b^T), lo = bf16(a b^T - hi): mm(...) -> f32 followed by split2, without the f32 round trip (bit-identical)"""
-    _timed("gemm_bf16_w256p_kernel<false, false, 8, %s>" % ("true" if _DYN_SCHEDULE[0] else "false"), 2.0 * M * N * K,
+    _timed(_split_label(K, 8), 2.0 * M * N * K,
            lambda: _check(lib().enh_gemm_bf16_split(_p(a, BF16, "A"), a.stride(0), _p(b, BF16, "B"), b.stride(0), M, N, K, None, ACT_NONE,
                                                     _p(hi, BF16, "hi"), hi.stride(0), _p(lo, BF16, "lo"), lo.stride(0), None, 0, None, 0, _stream()), "enh_gemm_bf16_split"))
 
@@ -800,7 +807,7 @@ def gemm_split3_tanh(a, b, M: int, N: int, K: int, bias, y3, y_hi=None):
     if not (y3.is_cuda and y3.is_contiguous() and y3.dtype == BF16 and y3.shape[-1] == 3 * N):
         raise RuntimeError("y3 must be a contiguous bf16 [M, 3N] device tensor")
     ld3 = y3.stride(0)
-    _timed("gemm_bf16_w256p_kernel<false, false, 9, %s>" % ("true" if _DYN_SCHEDULE[0] else "false"), 2.0 * M * N * K,
+    _timed(_split_label(K, 9), 2.0 * M * N * K,
            lambda: _check(lib().enh_gemm_bf16_split(_p(a, BF16, "A"), a.stride(0), _p(b, BF16, "B"), b.stride(0), M, N, K, _p(bias, F32, "bias"), ACT_TANH,
                                                     _poff(y3, 0), ld3, _poff(y3, N), ld3, _poff(y3, 2 * N), ld3,
                                                     _p(y_hi, BF16, "y_hi"), y_hi.stride(0) if y_hi is not None else 0, _stream()), "enh_gemm_bf16_split"))
