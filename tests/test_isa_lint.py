@@ -50,3 +50,28 @@ def test_every_gemm_kernel_is_an_mfma_kernel(stats):
     for n in stats:
         if n.startswith("void gemm_bf16_w256"):
             assert stats[n].get("mfma", 0) >= 64, (n, stats[n].get("mfma"))
+
+
+def test_no_inline_asm_vector_instructions_in_the_attention_sources():
+    """Round 5: an inline-asm v_max3_f32 behind the S products read the MFMA's destination registers before they were written — inline asm is invisible
+    to the compiler's hazard recognizer (no s_nop inserted), the softmax stayed valid and the bits became launch-dependent (profiles/r05_attention_lab.txt).
+    Vector arithmetic on MFMA results must be compiler-visible: no `asm("v_...")` in the attention sources (the empty register pin `asm volatile("" : "+v")` is fine)."""
+    src = os.path.join(ROOT, "enhancing-transformers_amd", "csrc")
+    bad = []
+    for name in ("attention.hip", "attention_common.h", "x3.hip"):
+        text = open(os.path.join(src, name)).read()
+        for m in re.finditer(r'asm\s*(?:volatile)?\s*\(\s*"\s*(v_\w+)', text):
+            bad.append((name, m.group(1)))
+    assert not bad, bad
+
+
+def test_attention_row_maximum_is_fused_and_hazard_padded(stats):
+    """the nested fmaxf must still become v_max3_f32 (the attention objects are built with -fno-honor-nans), and the kernels keep their occupancy classes"""
+    fwd = "attn_fwd_pre_kernel(unsigned short const*, int, int, int, unsigned short*, float*)"
+    assert stats[fwd].get("max3", 0) >= 15, stats[fwd]                                                                      # the 32-way row maximum: v_max3 chains, no canonicalising v_max x, x
+    assert stats[fwd]["vgpr"] <= 128                                                                                        # four waves per SIMD
+    dkv = [n for n in stats if n.startswith("void attn_bwd_dkv_kernel<true, true>")]
+    dq = [n for n in stats if n.startswith("void attn_bwd_dq_kernel<2>")]
+    assert dkv and dq and stats[dkv[0]]["vgpr"] <= 168 and stats[dq[0]]["vgpr"] <= 168                                          # three waves per SIMD
+    for n in dkv + dq + ["attn_fwd_pre_kernel(unsigned short const*, int, int, int, unsigned short*, float*)"]:
+        assert stats[n].get("scratch_bytes", 0) == 0 and stats[n].get("spills", 0) == 0, (n, stats[n])

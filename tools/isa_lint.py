@@ -59,6 +59,8 @@ def kernel_stats(so_path=DEFAULT_SO):
                     stats[cur]["scratch_ops"] += 1
                 if "v_mfma" in line:
                     stats[cur]["mfma"] += 1
+                if "v_max3_f32" in line:
+                    stats[cur]["max3"] += 1
             notes = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", o], capture_output=True, text=True, check=True).stdout
             for b in re.split(r"\n\s*- \.agpr_count:", notes)[1:]:
                 b = ".agpr_count:" + b
