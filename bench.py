@@ -1,7 +1,8 @@
 """bench.py — images/sec of the ViT-VQGAN-base 256x256 stage-1 AE training step on N MI355X (one process per GPU).
 
 Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches it under
-torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env, RCCL over xGMI).  A "step" = one full AE
+torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env, RCCL over xGMI); started bare (no launcher environment) with
+--gpus N > 1 it re-executes itself under torch.distributed.run, one rank per GPU.  A "step" = one full AE
 training step of configs/imagenet_vitvq_base.yaml on one synthetic ImageNet-shaped batch per GPU: forward + backward +
 gradient all-reduce + fused AdamW, loss = 1.0*L2 + 1.0*codebook (LPIPS / GAN weights 0 — stated in config.workload).
 Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
@@ -15,12 +16,15 @@ Extra objects (rank 0, N = 1 unless noted):
   "vq_match"   second half of BASELINE's metric: the argmin match-rate at the op boundary on ONE extra forward pass (h, indices and codebook snapshotted
                together), every mismatch audited in fp64 (side holding the exact argmin, gap in ulps) and ENFORCED against the derived near-tie bound —
                the process exits with code 3 on a violation; "vq_match_spread": the same kernel and inputs against a trained-like codebook
-               (~1000 distinct codes in play instead of the handful synthetic training collapses to).
+               (~1000 distinct codes in play instead of the handful synthetic training collapses to).  "vq_match_rate" = the spread leg (since round 4);
+               both legs also under explicit names: "vq_match_rate_training_codebook" / "vq_match_rate_spread_codebook".
   "parity_mode"  north_star's parity clause priced: images/s of encode_codes and of the AE train step with the encoder forward on
                split-bf16 ("x3", three MFMA passes, ~1e-5) operands, beside the single-pass bf16 path (the headline) and the exact-fp32 engine mode; plus
-               h error / end-to-end code match of both encoders against the fp32 CPU oracle on a 2-image sample.
+               h error / end-to-end code match of both encoders and the reconstruction error of the bf16 / x3-whole-forward modes against the fp32 CPU
+               oracle on a 2-image sample; 10 timed iterations per mode; "x3_whole_forward_kernels": that step's own per-kernel roofline table.
   "cpu_baseline"  the CPU oracle — a port of the reference's PyTorch path, oracle/vitvq_oracle.py — timed on the host cores on a bounded sample.
-  "comm"       (N > 1) per rank: exposed communication of the timed steps (compute-stream wait and host wait), buckets, bytes reduced, un-announced elements.
+  "comm"       (N > 1) per rank: exposed communication of the timed steps (compute-stream wait and host wait), buckets, bytes reduced, un-announced elements;
+               with the adversarial configs the discriminator's own bucketed all-reduce is reported separately ("discriminator").
 """
 import argparse
 import json

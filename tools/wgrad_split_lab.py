@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "enhancing-transformers_amd"))
 from enhancing import _C
 L = _C.lib()
-K = 131072
+K = int(os.environ.get("LAB_TOKENS", "131072"))
 
 def timed(fn, n=10):
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -14,7 +14,9 @@ def timed(fn, n=10):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / n
 
+CANDS = [int(x) for x in os.environ["LAB_SPLITS"].split(",")] if os.environ.get("LAB_SPLITS") else None
 for name, M, N, cands in (("qkv", 2304, 768, (0, 8, 9, 16)), ("out", 768, 768, (0, 24, 28, 16, 32)), ("fc1", 3072, 768, (0, 7, 8, 6)), ("fc2", 768, 3072, (0, 7, 8, 6))):
+    cands = tuple(CANDS) if CANDS else cands
     a = torch.randn(K, M, device="cuda").to(torch.bfloat16); b = torch.randn(K, N, device="cuda").to(torch.bfloat16)
     c = torch.zeros(M, N, device="cuda")
     fn = lambda: _C.mm(a, b, M, N, K, c, trans_a=True, trans_b=True, accumulate=True)
