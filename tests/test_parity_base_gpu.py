@@ -31,13 +31,25 @@ BASE = dict(image_size=256, patch_size=8, encoder=dict(dim=768, depth=12, heads=
 LARGE = dict(image_size=256, patch_size=8, encoder=dict(dim=512, depth=8, heads=8, mlp_dim=2048),
              decoder=dict(dim=1280, depth=32, heads=16, mlp_dim=5120), quantizer=dict(embed_dim=32, n_embed=8192))
 
-# regression bounds (measured on MI355X, round 2 — see DESIGN.md §4 for the table they come from)
-# measured (profiles/r02_parity_base_configs.txt): stream <= 5.4e-3 (saturating with depth), h 5.7e-3, xrec 6.1e-3, gradients <= 9.6e-3,
-# end-to-end match-rate 0.967 .. 0.981, op-boundary match-rate 1.0
-STREAM_TOL = 8e-3       # residual stream after any layer, oracle downstream of the same codes
-H_TOL, XREC_TOL = 9e-3, 1e-2
-GRAD_TOL = 1.5e-2       # worst parameter gradient
-MATCH_MIN = 0.95        # end-to-end code match-rate (bf16-operand h vs fp32 h feeding an 8192-way argmin)
+# Regression bounds of the HEADLINE (single-pass bf16) path: 1.15 x the values measured on MI355X with the round-5 kernels (profiles/r05_parity_base_configs.txt;
+# the round-2 bounds were ~1.5 x measured and would not have caught a regression of the measured path).  The kernels are bit-reproducible, so the
+# measured values repeat exactly from run to run and box to box; the 15 % are room for deliberate kernel changes that move roundings, not for noise.
+# per case: (max residual-stream error over the layers, h, xrec downstream of the same codes, worst parameter gradient, minimum end-to-end code match-rate)
+MEASURED = {
+    "base":        (5.07e-3, 5.57e-3, 5.68e-3, 8.99e-3, 0.9810),
+    "rq4":         (5.30e-3, 4.04e-3, 5.75e-3, 8.42e-3, 0.9685),
+    "base_spread": (4.81e-3, 7.46e-3, 5.10e-3, 1.00e-2, 0.9507),      # (gradients: the codebook's own bound is separate, see _run_case)
+    "rq4_spread":  (5.03e-3, 4.43e-3, 5.70e-3, 9.00e-3, 0.8895),
+    "large":       (5.42e-3, 5.63e-3, 6.12e-3, 9.63e-3, 0.9775),
+}
+
+
+def _tols(case, match_margin=0.01):
+    st, h, xr, g, mt = MEASURED[case]
+    return (1.15 * st, 1.15 * h, 1.15 * xr, 1.15 * g, mt - match_margin)
+
+
+STREAM_TOL, H_TOL, XREC_TOL, GRAD_TOL, MATCH_MIN = _tols("base")      # (names kept for importers: the base case's bounds)
 
 
 def _build(cfg, P):
@@ -126,38 +138,38 @@ def _run_case(label, cfg, B, seed, tols=None, spread=False, min_distinct=0):
         # with near-duplicate codes z_q ~ z (codebook loss 3e-4): the codebook gradient is a difference of nearly equal unit vectors, so the 7e-3 error of
         # h is a ~8e-2 error of (z_q - z) — cancellation, not arithmetic (measured 8.4e-2); every other parameter keeps the common bound
         cb = errs.pop("quantizer.embedding.weight")
-        assert cb <= 0.2, cb
+        assert cb <= 0.125, cb                     # measured 8.4e-2 (base) / 1.06e-1 (RQ-4)
         worst = max(errs, key=errs.get)
     assert errs[worst] <= grad_tol, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
 
 
 def test_base_config2_bf16_vs_oracle():
     """BASELINE config 2: imagenet_vitvq_base.yaml towers — the configuration bench.py times."""
-    _run_case("imagenet_vitvq_base (config 2)", BASE, 2, 0)
+    _run_case("imagenet_vitvq_base (config 2)", BASE, 2, 0, tols=_tols("base"))
 
 
 def test_base_rq4_config4_bf16_vs_oracle():
     """BASELINE config 4: RQ-VAE base, ResidualQuantizer depth 4, one shared codebook."""
     cfg = copy.deepcopy(BASE)
     cfg["quantizer"].update(use_residual=True, num_quantizers=4)
-    _run_case("imagenet_rqvae_base (config 4)", cfg, 2, 3)
+    _run_case("imagenet_rqvae_base (config 4)", cfg, 2, 3, tols=_tols("rq4"))
 
 
 def test_base_config2_with_a_trained_like_code_spread():
-    """config 2 with >= 1000 distinct codes in play (2048 tokens): the op-boundary match must STILL be exactly 1.0; the end-to-end rate is reported
-    (small top-2 gaps make it the worst case for the bf16-operand h, not a regression bound)."""
-    _run_case("imagenet_vitvq_base (config 2), spread codebook", BASE, 2, 10, tols=(STREAM_TOL, H_TOL, XREC_TOL, GRAD_TOL, 0.0), spread=True, min_distinct=1000)
+    """config 2 with >= 1000 distinct codes in play (2048 tokens): the op-boundary match must STILL be exactly 1.0; the end-to-end rate (small top-2 gaps make
+    it the worst case for the bf16-operand h) is held to the measured value - 0.01 like the others."""
+    _run_case("imagenet_vitvq_base (config 2), spread codebook", BASE, 2, 10, tols=_tols("base_spread"), spread=True, min_distinct=1000)
 
 
 def test_base_rq4_config4_with_a_trained_like_code_spread():
     cfg = copy.deepcopy(BASE)
     cfg["quantizer"].update(use_residual=True, num_quantizers=4)
-    _run_case("imagenet_rqvae_base (config 4), spread codebook", cfg, 2, 13, tols=(STREAM_TOL, H_TOL, XREC_TOL, GRAD_TOL, 0.0), spread=True, min_distinct=1000)
+    _run_case("imagenet_rqvae_base (config 4), spread codebook", cfg, 2, 13, tols=_tols("rq4_spread"), spread=True, min_distinct=1000)
 
 
 def test_large_config5_towers_bf16_vs_oracle():
     """BASELINE config 5 towers: imagenet_vitvq_large.yaml (encoder 512/8/8/2048, decoder 1280/32/16/5120), AE step only."""
-    _run_case("imagenet_vitvq_large towers (config 5)", LARGE, 1, 5)
+    _run_case("imagenet_vitvq_large towers (config 5)", LARGE, 1, 5, tols=_tols("large"))
 
 
 def test_training_step_gradients_are_bit_reproducible():
