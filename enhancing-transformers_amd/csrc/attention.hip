@@ -20,12 +20,13 @@
 // =================================================================================================
 // forward
 // =================================================================================================
+template <typename OT>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, int B, int N, int H, float scale_log2,
                                                           uint16_t* __restrict__ out, float* __restrict__ lse) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][ATT_TILE_BYTES];  // [stage][K | V]
   int blk, head;
   if (!att_block_coords((N + 127) / 128, B * H, blk, head)) return;
-  attn_fwd_exact(qkv, B, N, H, scale_log2, out, lse, smem, blk, head);
+  attn_fwd_exact<OT>(qkv, B, N, H, scale_log2, out, lse, smem, blk, head);
 }
 
 // Round 5 — the forward for PRE-SCALED q (the training path's convention: the products are log2-domain scores), with the vector stream cut where the
@@ -39,6 +40,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
 __device__ __forceinline__ float dot2_ones(uint32_t pk, float acc) {
   return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, pk), __builtin_bit_cast(bf16x2_t, 0x3f803f80u), acc, false);
 }
+template <typename OT>
 __global__ __launch_bounds__(256, 2) void attn_fwd_pre_kernel(const uint16_t* __restrict__ qkv, int B, int N, int H, uint16_t* __restrict__ out, float* __restrict__ lse) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][ATT_TILE_BYTES];  // [stage][K | V]
   int blk, head;
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pre_kernel(const uint16_t* __
         float p8[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) p8[j] = __builtin_amdgcn_exp2f(s[kb][c2 * 8 + j]);
-        const u32x4 pk = {pack_bf16x2(p8[0], p8[1]), pack_bf16x2(p8[2], p8[3]), pack_bf16x2(p8[4], p8[5]), pack_bf16x2(p8[6], p8[7])};
+        const u32x4 pk = {pack2<OT>(p8[0], p8[1]), pack2<OT>(p8[2], p8[3]), pack2<OT>(p8[4], p8[5]), pack2<OT>(p8[6], p8[7])};
 #pragma unroll
         for (int j = 0; j < 4; ++j) l2[j & 1] += (f32x2){p8[2 * j], p8[2 * j + 1]};      // exact f32 row sum, two lanes of one v_pk_add_f32 (lse stays exact to f32), two chains
         const s16x8 pb = __builtin_bit_cast(s16x8, pk);
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pre_kernel(const uint16_t* __
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
       const int d0 = db * 32 + 8 * g4 + 4 * hi;
-      u32x2 w = {pack_bf16x2(o[db][g4 * 4 + 0] * inv, o[db][g4 * 4 + 1] * inv), pack_bf16x2(o[db][g4 * 4 + 2] * inv, o[db][g4 * 4 + 3] * inv)};
+      u32x2 w = {pack2<OT>(o[db][g4 * 4 + 0] * inv, o[db][g4 * 4 + 1] * inv), pack2<OT>(o[db][g4 * 4 + 2] * inv, o[db][g4 * 4 + 3] * inv)};
       *reinterpret_cast<u32x2*>(op + d0) = w;
     }
   if (hi == 0) lse[((int64_t)b * H + h) * N + q0 + l31] = (m_ref + __builtin_amdgcn_logf(l)) * 0.6931471805599453f;
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pre_kernel(const uint16_t* __
 // per-lane constant kept in a 16-register block; D = A B + C with D != C): 32 subtractions per tile gone.  MODE 2 (q pre-scaled by scale*log2e, i.e.
 // the products are already log2-domain scores): -lse enters the S product the same way and the exponential reads the accumulator directly — no
 // vector arithmetic left but exp, the P o dP' multiply and the bf16 packing.  The kernels are vector-ISSUE bound (profiles/r03_attention_lab.txt).
-template <int MODE>
+template <int MODE, typename OT>
 __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ o, const uint16_t* __restrict__ d_o,
                                                              const float* __restrict__ lse, float* __restrict__ delta, int B, int N,
                                                              int H, float scale, float scale_log2, uint16_t* __restrict__ dqkv) {
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __r
   for (int ds = 0; ds < 4; ++ds) {
     const s16x8 of = *reinterpret_cast<const s16x8*>(o + ((int64_t)b * N + qrow) * (H * ATT_D) + h * ATT_D + ds * 16 + hi * 8);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) dpart += bf16_bits_to_f32((uint16_t)of[k]) * bf16_bits_to_f32((uint16_t)dof[ds][k]);
+    for (int k = 0; k < 8; ++k) dpart += unpack1<OT>((uint16_t)of[k]) * unpack1<OT>((uint16_t)dof[ds][k]);
   }
   const float del_q = dpart + __shfl_xor(dpart, 32, 64);
   if (active && hi == 0) delta[((int64_t)b * H + h) * N + qrow] = del_q;
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __r
       }
 #pragma unroll
       for (int c2 = 0; c2 < 2; ++c2) {
-        const s16x8 dsb = pack8_bf16(&dsv[c2 * 8]);
+        const s16x8 dsb = pack8<OT>(&dsv[c2 * 8]);
 #pragma unroll
         for (int db = 0; db < 2; ++db) dq[db] = MFMA32(att_frag_tr(kt_, kb * 32 + 16 * c2, db, lane), dsb, dq[db]);  // dQ^T[d][q] += K^T dS^T
       }
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __r
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
       const int d0 = db * 32 + 8 * g4 + 4 * hi;
-      u32x2 w = {pack_bf16x2(dq[db][g4 * 4 + 0] * scale, dq[db][g4 * 4 + 1] * scale), pack_bf16x2(dq[db][g4 * 4 + 2] * scale, dq[db][g4 * 4 + 3] * scale)};
+      u32x2 w = {pack2<OT>(dq[db][g4 * 4 + 0] * scale, dq[db][g4 * 4 + 1] * scale), pack2<OT>(dq[db][g4 * 4 + 2] * scale, dq[db][g4 * 4 + 3] * scale)};
       *reinterpret_cast<u32x2*>(op + d0) = w;
     }
 }
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const uint16_t* __r
 // CINIT: -delta (and, with PRE — q pre-scaled by scale*log2e — also -lse) enter as the C operands of the first dP / S products: the statistics are
 // loaded from LDS straight into the accumulator registers (the same four 16-byte reads per block as before, no extra registers), which removes the
 // per-element subtraction (and the scale-and-subtract before the exponential).  kscale: the factor of the finished dK (scale, or ln 2 with PRE).
-template <bool CINIT, bool PRE>
+template <bool CINIT, bool PRE, typename OT>
 #ifndef ATT_DKV_DMA
 #define ATT_DKV_DMA 1
 #endif
@@ -384,8 +386,8 @@ __global__ __launch_bounds__(256, ATT_DKV_OCC) void attn_bwd_dkv_kernel(const ui
       }
 #pragma unroll
       for (int c2 = 0; c2 < 2; ++c2) {
-        const s16x8 pa = pack8_bf16(&pv[c2 * 8]);
-        const s16x8 dsa = pack8_bf16(&dsv[c2 * 8]);
+        const s16x8 pa = pack8<OT>(&pv[c2 * 8]);
+        const s16x8 dsa = pack8<OT>(&dsv[c2 * 8]);
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
           dv[db] = MFMA32(att_frag_tr(dot_, qb * 32 + 16 * c2, db, lane), pa, dv[db]);  // dV^T[d][key] += dO^T P
@@ -414,8 +416,8 @@ __global__ __launch_bounds__(256, ATT_DKV_OCC) void attn_bwd_dkv_kernel(const ui
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
       const int d0 = db * 32 + 8 * g4 + 4 * hi;
-      const u32x2 wk = {pack_bf16x2(dk[db][g4 * 4 + 0] * scale, dk[db][g4 * 4 + 1] * scale), pack_bf16x2(dk[db][g4 * 4 + 2] * scale, dk[db][g4 * 4 + 3] * scale)};
-      const u32x2 wv = {pack_bf16x2(dv[db][g4 * 4 + 0], dv[db][g4 * 4 + 1]), pack_bf16x2(dv[db][g4 * 4 + 2], dv[db][g4 * 4 + 3])};
+      const u32x2 wk = {pack2<OT>(dk[db][g4 * 4 + 0] * scale, dk[db][g4 * 4 + 1] * scale), pack2<OT>(dk[db][g4 * 4 + 2] * scale, dk[db][g4 * 4 + 3] * scale)};
+      const u32x2 wv = {pack2<OT>(dv[db][g4 * 4 + 0], dv[db][g4 * 4 + 1]), pack2<OT>(dv[db][g4 * 4 + 2], dv[db][g4 * 4 + 3])};
       *reinterpret_cast<u32x2*>(dkp + d0) = wk;
       *reinterpret_cast<u32x2*>(dvp + d0) = wv;
     }
@@ -445,7 +447,8 @@ extern "C" int enh_attention_set_kernel(int fwd, int dq, int dkv) {
 #define ATT_LOG2E 1.4426950408889634f
 #define ATT_LN2 0.6931471805599453f
 
-extern "C" int enh_attention_forward(const enh_bf16* qkv, int B, int N, int H, float scale, int q_prescaled, enh_bf16* out, float* lse, void* stream) {
+extern "C" int enh_attention_forward(const enh_h16* qkv, int B, int N, int H, float scale, int q_prescaled, enh_h16* out, float* lse, int dtype, void* stream) {
+  ENH_REQUIRE_DT(dtype, "enh_attention_forward");
   ENH_REQUIRE(qkv && out && lse, ENH_E_BADARG, "enh_attention_forward: null pointer");
   ENH_REQUIRE(B > 0 && H > 0 && N > 0 && N % 64 == 0, ENH_E_SHAPE, "enh_attention_forward: need N %% 64 == 0 (B=%d N=%d H=%d)", B, N, H);
   ENH_REQUIRE(scale > 0.f, ENH_E_BADARG, "enh_attention_forward: scale must be positive");
@@ -454,13 +457,14 @@ extern "C" int enh_attention_forward(const enh_bf16* qkv, int B, int N, int H, f
   int fam = g_att_fwd ? g_att_fwd : ATT_DEFAULT_FWD;
   if (fam == 5 && !q_prescaled) fam = 1;                         // -m_ref as a C operand needs log2-domain products
   const float sl2 = q_prescaled ? 1.0f : scale * ATT_LOG2E;       // pre-scaled q: the products are log2-domain scores already
-  if (fam == 5) attn_fwd_pre_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(qkv, B, N, H, out, lse);
-  else attn_fwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(qkv, B, N, H, sl2, out, lse);
+  if (fam == 5) ENH_DT_DISPATCH(dtype, (attn_fwd_pre_kernel<OT><<<grid, 256, 0, (hipStream_t)stream>>>(qkv, B, N, H, out, lse)));
+  else ENH_DT_DISPATCH(dtype, (attn_fwd_kernel<OT><<<grid, 256, 0, (hipStream_t)stream>>>(qkv, B, N, H, sl2, out, lse)));
   return enh_check_launch("enh_attention_forward");
 }
 
-extern "C" int enh_attention_backward(const enh_bf16* qkv, const enh_bf16* out, const enh_bf16* dout, const float* lse, int B, int N,
-                                      int H, float scale, int q_prescaled, enh_bf16* dqkv, float* delta_ws, void* stream) {
+extern "C" int enh_attention_backward(const enh_h16* qkv, const enh_h16* out, const enh_h16* dout, const float* lse, int B, int N,
+                                      int H, float scale, int q_prescaled, enh_h16* dqkv, float* delta_ws, int dtype, void* stream) {
+  ENH_REQUIRE_DT(dtype, "enh_attention_backward");
   ENH_REQUIRE(qkv && out && dout && lse && dqkv && delta_ws, ENH_E_BADARG, "enh_attention_backward: null pointer");
   ENH_REQUIRE(B > 0 && H > 0 && N > 0 && N % 64 == 0, ENH_E_SHAPE, "enh_attention_backward: need N %% 64 == 0 (B=%d N=%d H=%d)", B, N, H);
   ENH_REQUIRE(scale > 0.f, ENH_E_BADARG, "enh_attention_backward: scale must be positive");
@@ -475,11 +479,11 @@ extern "C" int enh_attention_backward(const enh_bf16* qkv, const enh_bf16* out, 
   // (either dQ kernel also writes delta_ws = rowsum(dO * O) for the dK/dV kernel that follows)
   const int fq = g_att_dq ? g_att_dq : ATT_DEFAULT_DQ;
   const int fk = g_att_dkv ? g_att_dkv : ATT_DEFAULT_DKV;
-  if (fq == 1) attn_bwd_dq_kernel<0><<<grid, 256, 0, s>>>(qkv, out, dout, lse, delta_ws, B, N, H, scale, sl2, dqkv);
-  else if (pre) attn_bwd_dq_kernel<2><<<grid, 256, 0, s>>>(qkv, out, dout, lse, delta_ws, B, N, H, scale, sl2, dqkv);
-  else attn_bwd_dq_kernel<1><<<grid, 256, 0, s>>>(qkv, out, dout, lse, delta_ws, B, N, H, scale, sl2, dqkv);
-  if (fk == 1) attn_bwd_dkv_kernel<false, false><<<grid, 256, 0, s>>>(qkv, dout, lse, delta_ws, B, N, H, kscale, sl2, dqkv);
-  else if (pre) attn_bwd_dkv_kernel<true, true><<<grid, 256, 0, s>>>(qkv, dout, lse, delta_ws, B, N, H, kscale, sl2, dqkv);
-  else attn_bwd_dkv_kernel<true, false><<<grid, 256, 0, s>>>(qkv, dout, lse, delta_ws, B, N, H, kscale, sl2, dqkv);
+  if (fq == 1) ENH_DT_DISPATCH(dtype, (attn_bwd_dq_kernel<0, OT><<<grid, 256, 0, s>>>(qkv, out, dout, lse, delta_ws, B, N, H, scale, sl2, dqkv)));
+  else if (pre) ENH_DT_DISPATCH(dtype, (attn_bwd_dq_kernel<2, OT><<<grid, 256, 0, s>>>(qkv, out, dout, lse, delta_ws, B, N, H, scale, sl2, dqkv)));
+  else ENH_DT_DISPATCH(dtype, (attn_bwd_dq_kernel<1, OT><<<grid, 256, 0, s>>>(qkv, out, dout, lse, delta_ws, B, N, H, scale, sl2, dqkv)));
+  if (fk == 1) ENH_DT_DISPATCH(dtype, (attn_bwd_dkv_kernel<false, false, OT><<<grid, 256, 0, s>>>(qkv, dout, lse, delta_ws, B, N, H, kscale, sl2, dqkv)));
+  else if (pre) ENH_DT_DISPATCH(dtype, (attn_bwd_dkv_kernel<true, true, OT><<<grid, 256, 0, s>>>(qkv, dout, lse, delta_ws, B, N, H, kscale, sl2, dqkv)));
+  else ENH_DT_DISPATCH(dtype, (attn_bwd_dkv_kernel<true, false, OT><<<grid, 256, 0, s>>>(qkv, dout, lse, delta_ws, B, N, H, kscale, sl2, dqkv)));
   return enh_check_launch("enh_attention_backward");
 }

@@ -60,8 +60,9 @@ __device__ __forceinline__ s16x8 att_frag_tr(const unsigned char* tile, int rbas
   o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
   return o;
 }
-__device__ __forceinline__ s16x8 pack8_bf16(const float* p) {
-  u32x4 u = {pack_bf16x2(p[0], p[1]), pack_bf16x2(p[2], p[3]), pack_bf16x2(p[4], p[5]), pack_bf16x2(p[6], p[7])};
+template <typename OT>
+__device__ __forceinline__ s16x8 pack8(const float* p) {
+  u32x4 u = {pack2<OT>(p[0], p[1]), pack2<OT>(p[2], p[3]), pack2<OT>(p[4], p[5]), pack2<OT>(p[6], p[7])};
   return __builtin_bit_cast(s16x8, u);
 }
 // Every global load of a kernel's prologue (Q / dO / K / V fragments, statistics) is waited for HERE, before the tile loop: the compiler's wait-count
@@ -97,7 +98,8 @@ __device__ __forceinline__ float xhalf_sum(float v) {
 }
 
 #define ATT_FENCE() __builtin_amdgcn_sched_barrier(0)
-#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
+// (the kernels are templates over the operand type tag OT = BF16 | F16, common.h: `OT` must name it where this macro is used)
+#define MFMA32(a, b, c) mfma32<OT>((a), (b), (c))
 
 // Workgroup -> (block-within-head, head) mapping.  Hardware places workgroup L on XCD L % 8 (each XCD has a private L2), and the nblk
 // workgroups of one (batch, head) all stream the SAME K/V (or Q/dO) — so they are given ids that are congruent mod 8 and adjacent in
@@ -113,6 +115,7 @@ __device__ __forceinline__ bool att_block_coords(int nblk, int n_heads_total, in
 
 // The round-1/2 forward pass of one 128-query block (exact running maximum, O rescaled every tile): the body of attn_fwd_kernel, and the FALLBACK of the
 // pipelined kernel of attention_v2.hip for a workgroup whose scores outgrow its fixed reference.  smem: [2][2][ATT_TILE_BYTES] ([stage][K | V]).
+template <typename OT>
 __device__ __forceinline__ void attn_fwd_exact(const uint16_t* __restrict__ qkv, int B, int N, int H, float scale_log2, uint16_t* __restrict__ out,
                                                float* __restrict__ lse, unsigned char (*smem)[2][ATT_TILE_BYTES], int blk, int head) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -203,7 +206,7 @@ __device__ __forceinline__ void attn_fwd_exact(const uint16_t* __restrict__ qkv,
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int c2 = 0; c2 < 2; ++c2) {
-        const s16x8 pb = pack8_bf16(&p[kb][c2 * 8]);
+        const s16x8 pb = pack8<OT>(&p[kb][c2 * 8]);
 #pragma unroll
         for (int db = 0; db < 2; ++db) o[db] = MFMA32(att_frag_tr(vt_, kb * 32 + 16 * c2, db, lane), pb, o[db]);
       }
@@ -222,7 +225,7 @@ __device__ __forceinline__ void attn_fwd_exact(const uint16_t* __restrict__ qkv,
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
       const int d0 = db * 32 + 8 * g4 + 4 * hi;
-      u32x2 w = {pack_bf16x2(o[db][g4 * 4 + 0] * inv, o[db][g4 * 4 + 1] * inv), pack_bf16x2(o[db][g4 * 4 + 2] * inv, o[db][g4 * 4 + 3] * inv)};
+      u32x2 w = {pack2<OT>(o[db][g4 * 4 + 0] * inv, o[db][g4 * 4 + 1] * inv), pack2<OT>(o[db][g4 * 4 + 2] * inv, o[db][g4 * 4 + 3] * inv)};
       *reinterpret_cast<u32x2*>(op + d0) = w;
     }
   if (hi == 0) lse[((int64_t)b * H + h) * N + q0 + l31] = (m_run + __builtin_amdgcn_logf(l)) * 0.6931471805599453f;

@@ -59,6 +59,65 @@ __device__ inline uint32_t pack_bf16x2(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
+// ---- 16-bit operand types -------------------------------------------------------------------------------------------------------------------
+// The MFMA operands of the product path are 16-bit floats in one of two formats, chosen per CALL by the `dtype` argument of the C ABI (ENH_DT_BF16 /
+// ENH_DT_F16, include/enh_hip.h) and per KERNEL by a type tag: every kernel that reads or writes 16-bit operands is a template over OT = BF16 | F16.  The
+// formats differ in exactly three places — the MFMA opcode, the f32 -> 16-bit packing (round-to-nearest-even in both: v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32;
+// never the round-toward-zero v_cvt_pkrtz) and the 16-bit -> f32 widening — so LDS images, swizzles, LDS-DMA and the transpose reads are shared code.
+// fp16 (the reference's --use_amp dtype, main.py:25,52: Lightning precision=16) has 11 significand bits against bf16's 8: ~8x smaller operand rounding at
+// the same MFMA rate, for a range (max 65504, normals down to 6.1e-5) that the O(1) operands behind a LayerNorm / tanh / softmax never leave; gradients
+// need a loss scale (engine/stage1.py).
+struct BF16 { static constexpr int id = 0; };
+struct F16 { static constexpr int id = 1; };
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+// two f32 -> packed 16-bit pair (element 0 in the low half), round-to-nearest-even
+template <typename OT>
+__device__ inline uint32_t pack2(float lo, float hi) {
+  const f32x2 v = {lo, hi};
+  if constexpr (OT::id == 0) return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+  else return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
+}
+// the low / high element of a packed pair, and a single element, widened to f32 (exact)
+template <typename OT>
+__device__ inline float unpack_lo(uint32_t u) {
+  if constexpr (OT::id == 0) return __builtin_bit_cast(float, u << 16);
+  else return (float)__builtin_bit_cast(f16x2_t, u)[0];
+}
+template <typename OT>
+__device__ inline float unpack_hi(uint32_t u) {
+  if constexpr (OT::id == 0) return __builtin_bit_cast(float, u & 0xffff0000u);
+  else return (float)__builtin_bit_cast(f16x2_t, u)[1];
+}
+template <typename OT>
+__device__ inline float unpack1(uint16_t h) {
+  if constexpr (OT::id == 0) return __builtin_bit_cast(float, (uint32_t)h << 16);
+  else return (float)__builtin_bit_cast(_Float16, h);
+}
+template <typename OT>
+__device__ inline uint16_t pack1(float f) {
+  if constexpr (OT::id == 0) return f32_to_bf16_bits(f);
+  else return __builtin_bit_cast(uint16_t, (_Float16)f);
+}
+// D = A B + C on the matrix cores, f32 accumulation; operands as raw 16-bit lanes (s16x8 = 8 contraction elements per lane)
+template <typename OT>
+__device__ __forceinline__ f32x16 mfma32(const s16x8& a, const s16x8& b, const f32x16& c) {
+  if constexpr (OT::id == 0) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+template <typename OT>
+__device__ __forceinline__ f32x4 mfma16(const s16x8& a, const s16x8& b, const f32x4& c) {
+  if constexpr (OT::id == 0) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// run CALL with `OT` bound to the operand type tag of a C-ABI dtype value (validated by the caller with ENH_REQUIRE_DT)
+#define ENH_DT_DISPATCH(dtype, CALL)                    \
+  do {                                                   \
+    if ((dtype) == ENH_DT_F16) { typedef F16 OT; CALL; } \
+    else { typedef BF16 OT; CALL; }                      \
+  } while (0)
+#define ENH_REQUIRE_DT(dtype, what) ENH_REQUIRE((dtype) == ENH_DT_BF16 || (dtype) == ENH_DT_F16, ENH_E_BADARG, what ": dtype must be ENH_DT_BF16 (0) or ENH_DT_F16 (1), got %d", (int)(dtype))
+
 // LDS transpose read (ds_read_b64_tr_b16).  Verified on MI355X (profiles/hw_probe_r01.txt):
 // within each 16-lane group, result(lane i, elem j) = the 16-bit element (i % 4) of the 8 bytes that lane
 // (j*4 + i/4) of the same group addressed.

@@ -3,10 +3,12 @@
 //   ConvTranspose2d(k=s=p) (reference enhancing/modules/stage1/layers.py:168-171,178,202-205,212) with the
 //   pixel losses of enhancing/losses/vqperceptual.py:113-114 fused into the scatter pass;
 //   colsum: bias gradients; adamw: torch.optim.AdamW as configured at vitvqgan.py:160.
-// All kernels move 8-16 bytes per lane with the contiguous side chosen for the larger tensor.
+// All kernels move 8-16 bytes per lane with the contiguous side chosen for the larger tensor.  Kernels that read or write 16-bit operands are templates
+// over the operand type tag OT = BF16 | F16 (common.h), chosen by the `dtype` argument of their C entry.
 #include "common.h"
 
-// img [B,C,H,W] f32 -> patches [M=B*gy*gx, C*p*p] bf16, element order (c, ph, pw)
+// img [B,C,H,W] f32 -> patches [M=B*gy*gx, C*p*p] (16-bit operand), element order (c, ph, pw)
+template <typename OT>
 __global__ void patchify_kernel(const float* __restrict__ img, int B, int C, int H, int W, int p,
                                 uint16_t* __restrict__ out, int64_t total4) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -20,11 +22,12 @@ __global__ void patchify_kernel(const float* __restrict__ img, int B, int C, int
   const int gy = (int)((r / gx_n) % gy_n);
   const int b = (int)(r / ((int64_t)gx_n * gy_n));
   const float4 v = *reinterpret_cast<const float4*>(img + (((size_t)b * C + c) * H + (size_t)gy * p + ph) * W + (size_t)gx * p + q * 4);
-  *reinterpret_cast<uint2*>(out + (size_t)i * 4) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+  *reinterpret_cast<uint2*>(out + (size_t)i * 4) = make_uint2(pack2<OT>(v.x, v.y), pack2<OT>(v.z, v.w));
 }
 
 // pix [M, C*p*p] f32 -> xrec [B,C,H,W] f32 ; optional pixel-loss sums (double atomics: order-independent
-// to 1e-16, hence deterministic after rounding to f32) and the patch-layout bf16 loss gradient.
+// to 1e-16, hence deterministic after rounding to f32) and the patch-layout 16-bit loss gradient.
+template <typename OT>
 __global__ __launch_bounds__(256) void unpatchify_loss_kernel(
     const float* __restrict__ pix, const float* __restrict__ target, int B, int C, int H, int W, int p, float w_l1,
     float w_l2, float inv_numel, float* __restrict__ xrec, double* __restrict__ sums, uint16_t* __restrict__ dpix,
@@ -55,7 +58,7 @@ __global__ __launch_bounds__(256) void unpatchify_loss_kernel(
         const float sg = d[k] > 0.f ? 1.f : (d[k] < 0.f ? -1.f : 0.f);
         g[k] = (w_l1 * sg + w_l2 * 2.f * d[k]) * inv_numel;
       }
-      if (dpix) *reinterpret_cast<uint2*>(dpix + (size_t)i * 4) = make_uint2(pack_bf16x2(g[0], g[1]), pack_bf16x2(g[2], g[3]));
+      if (dpix) *reinterpret_cast<uint2*>(dpix + (size_t)i * 4) = make_uint2(pack2<OT>(g[0], g[1]), pack2<OT>(g[2], g[3]));
     }
   }
   if (sums) {
@@ -70,10 +73,11 @@ __global__ __launch_bounds__(256) void unpatchify_loss_kernel(
   }
 }
 
-// out[n] += sum_m x[m,n] ; x bf16.  Wave = 128 columns (4 B per lane), 4 waves split the rows of a chunk.
+// out[n] += sum_m x[m,n] ; x 16-bit (OT).  Wave = 128 columns (4 B per lane), 4 waves split the rows of a chunk.
 // part_stride == 0: every row chunk adds into out[n] with f32 atomics; part_stride == N: chunk y stores its partial at out[y*N + n] (deterministic
 // form: colsum_reduce_kernel then adds the chunks in a fixed order)
-__global__ __launch_bounds__(256) void colsum_bf16_kernel(const uint16_t* __restrict__ x, int64_t M, int64_t N,
+template <typename OT>
+__global__ __launch_bounds__(256) void colsum_h16_kernel(const uint16_t* __restrict__ x, int64_t M, int64_t N,
                                                           int64_t ldx, int64_t rows_per_block, float* __restrict__ out, int64_t part_stride) {
   __shared__ float s_part[3][128];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -85,8 +89,8 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const uint16_t* __rest
   if (n0 < N) {  // N is even (N % 8 == 0 enforced by the launcher)
     for (int64_t m = m_begin + wave; m < m_end; m += 4) {
       const uint32_t u = *reinterpret_cast<const uint32_t*>(x + (size_t)m * ldx + n0);
-      a0 += bf16_bits_to_f32((uint16_t)(u & 0xffffu));
-      a1 += bf16_bits_to_f32((uint16_t)(u >> 16));
+      a0 += unpack_lo<OT>(u);
+      a1 += unpack_hi<OT>(u);
     }
   }
   if (wave > 0) { s_part[wave - 1][lane * 2] = a0; s_part[wave - 1][lane * 2 + 1] = a1; }
@@ -100,7 +104,8 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const uint16_t* __rest
 
 // Wide variant (N % 8 == 0, 16-byte aligned rows): a lane owns 8 columns (one 16-byte load per row), a wave covers 512 contiguous
 // columns = 1 KiB of a row, and four rows are in flight per wave.
-__global__ __launch_bounds__(256) void colsum_bf16_wide_kernel(const uint16_t* __restrict__ x, int64_t M, int64_t N, int64_t ldx,
+template <typename OT>
+__global__ __launch_bounds__(256) void colsum_h16_wide_kernel(const uint16_t* __restrict__ x, int64_t M, int64_t N, int64_t ldx,
                                                                int64_t rows_per_block, float* __restrict__ out, int64_t part_stride) {
   __shared__ float s_part[3][512];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -120,16 +125,16 @@ __global__ __launch_bounds__(256) void colsum_bf16_wide_kernel(const uint16_t* _
       for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          acc[2 * k] += __uint_as_float(v[r][k] << 16);
-          acc[2 * k + 1] += __uint_as_float(v[r][k] & 0xffff0000u);
+          acc[2 * k] += unpack_lo<OT>(v[r][k]);
+          acc[2 * k + 1] += unpack_hi<OT>(v[r][k]);
         }
     }
     for (; m < m_end; m += 4) {
       const u32x4 v = *reinterpret_cast<const u32x4*>(col + (size_t)m * ldx);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        acc[2 * k] += __uint_as_float(v[k] << 16);
-        acc[2 * k + 1] += __uint_as_float(v[k] & 0xffff0000u);
+        acc[2 * k] += unpack_lo<OT>(v[k]);
+        acc[2 * k + 1] += unpack_hi<OT>(v[k]);
       }
     }
   }
@@ -148,22 +153,27 @@ __global__ __launch_bounds__(256) void colsum_bf16_wide_kernel(const uint16_t* _
   }
 }
 
-__global__ void cast_f32_bf16_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, int64_t n) {
+template <typename OT>
+__global__ void cast_f32_h16_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, int64_t n) {
   const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i + 3 < n) {
     const float4 v = *reinterpret_cast<const float4*>(x + i);
-    *reinterpret_cast<uint2*>(y + i) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+    *reinterpret_cast<uint2*>(y + i) = make_uint2(pack2<OT>(v.x, v.y), pack2<OT>(v.z, v.w));
   } else {
-    for (int64_t k = i; k < n; ++k) y[k] = f32_to_bf16_bits(x[k]);
+    for (int64_t k = i; k < n; ++k) y[k] = pack1<OT>(x[k]);
   }
 }
 
-// AdamW, decoupled weight decay, bias correction (torch.optim.AdamW semantics; vitvqgan.py:160)
+// AdamW, decoupled weight decay, bias correction (torch.optim.AdamW semantics; vitvqgan.py:160).  skip: optional device flag — non-zero = this step's
+// gradients held an inf / nan (enh_nonfinite_flag): nothing is written, the step is dropped the way torch.cuda.amp.GradScaler.step drops it under the
+// reference's --use_amp (main.py:25,52).
+template <typename OT>
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                              float* __restrict__ v, uint16_t* __restrict__ p16, int64_t n, float lr, float beta1,
-                             float beta2, float eps, float wd, float gscale, float inv_bc1, float inv_sqrt_bc2) {
+                             float beta2, float eps, float wd, float gscale, float inv_bc1, float inv_sqrt_bc2, const float* __restrict__ skip) {
   const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= n) return;
+  if (skip && *skip != 0.f) return;
   float pv[4], gv[4], mv[4], vv[4];
   const bool full = i + 3 < n;
   if (full) {
@@ -190,30 +200,32 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     *reinterpret_cast<float4*>(p + i) = make_float4(pv[0], pv[1], pv[2], pv[3]);
     *reinterpret_cast<float4*>(m + i) = make_float4(mv[0], mv[1], mv[2], mv[3]);
     *reinterpret_cast<float4*>(v + i) = make_float4(vv[0], vv[1], vv[2], vv[3]);
-    if (p16) *reinterpret_cast<uint2*>(p16 + i) = make_uint2(pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3]));
+    if (p16) *reinterpret_cast<uint2*>(p16 + i) = make_uint2(pack2<OT>(pv[0], pv[1]), pack2<OT>(pv[2], pv[3]));
   } else {
     for (int k = 0; k < 4 && i + k < n; ++k) {
       p[i + k] = pv[k]; m[i + k] = mv[k]; v[i + k] = vv[k];
-      if (p16) p16[i + k] = f32_to_bf16_bits(pv[k]);
+      if (p16) p16[i + k] = pack1<OT>(pv[k]);
     }
   }
 }
 
-extern "C" int enh_patchify(const float* img, int B, int C, int H, int W, int p, enh_bf16* patches, void* stream) {
+extern "C" int enh_patchify(const float* img, int B, int C, int H, int W, int p, enh_h16* patches, int dtype, void* stream) {
+  ENH_REQUIRE_DT(dtype, "enh_patchify");
   ENH_REQUIRE(img && patches, ENH_E_BADARG, "enh_patchify: null pointer");
   ENH_REQUIRE(B > 0 && C > 0 && p > 0 && p % 4 == 0 && H % p == 0 && W % p == 0, ENH_E_SHAPE, "enh_patchify: need p %% 4 == 0 and H,W divisible by p (B=%d C=%d H=%d W=%d p=%d)", B, C, H, W, p);
   const int64_t total4 = (int64_t)B * C * H * W / 4;
-  patchify_kernel<<<(int)((total4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(img, B, C, H, W, p, patches, total4);
+  ENH_DT_DISPATCH(dtype, (patchify_kernel<OT><<<(int)((total4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(img, B, C, H, W, p, patches, total4)));
   return enh_check_launch("enh_patchify");
 }
 
 extern "C" int enh_unpatchify_loss(const float* pix, const float* target, int B, int C, int H, int W, int p, float w_l1,
-                                   float w_l2, float* xrec, double* sums, enh_bf16* dpix_bf16, void* stream) {
+                                   float w_l2, float* xrec, double* sums, enh_h16* dpix_bf16, int dtype, void* stream) {
+  ENH_REQUIRE_DT(dtype, "enh_unpatchify_loss");
   ENH_REQUIRE(pix && (xrec || target), ENH_E_BADARG, "enh_unpatchify_loss: null pointer");
   ENH_REQUIRE(B > 0 && C > 0 && p > 0 && p % 4 == 0 && H % p == 0 && W % p == 0, ENH_E_SHAPE, "enh_unpatchify_loss: need p %% 4 == 0 and H,W divisible by p");
   const int64_t numel = (int64_t)B * C * H * W, total4 = numel / 4;
-  unpatchify_loss_kernel<<<(int)((total4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(
-      pix, target, B, C, H, W, p, w_l1, w_l2, 1.0f / (float)numel, xrec, target ? sums : nullptr, dpix_bf16, total4);
+  ENH_DT_DISPATCH(dtype, (unpatchify_loss_kernel<OT><<<(int)((total4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+      pix, target, B, C, H, W, p, w_l1, w_l2, 1.0f / (float)numel, xrec, target ? sums : nullptr, dpix_bf16, total4)));
   return enh_check_launch("enh_unpatchify_loss");
 }
 
@@ -235,11 +247,12 @@ static int64_t colsum_chunks(int64_t M) {
   return chunks > 256 ? 256 : chunks;
 }
 
-extern "C" size_t enh_colsum_bf16_workspace_bytes(int64_t M, int64_t N) { return M > 0 && N > 0 ? (size_t)colsum_chunks(M) * N * sizeof(float) : 0; }
+extern "C" size_t enh_colsum_h16_workspace_bytes(int64_t M, int64_t N) { return M > 0 && N > 0 ? (size_t)colsum_chunks(M) * N * sizeof(float) : 0; }
 
-static int colsum_bf16_impl(const enh_bf16* x, int64_t M, int64_t N, int64_t ldx, float* out, int accumulate, float* part, void* stream) {
-  ENH_REQUIRE(x && out, ENH_E_BADARG, "enh_colsum_bf16: null pointer");
-  ENH_REQUIRE(M > 0 && N > 0 && N % 2 == 0 && ldx % 2 == 0, ENH_E_SHAPE, "enh_colsum_bf16: N and ldx must be even");
+static int colsum_h16_impl(const enh_h16* x, int64_t M, int64_t N, int64_t ldx, float* out, int accumulate, float* part, int dtype, void* stream) {
+  ENH_REQUIRE_DT(dtype, "enh_colsum_h16");
+  ENH_REQUIRE(x && out, ENH_E_BADARG, "enh_colsum_h16: null pointer");
+  ENH_REQUIRE(M > 0 && N > 0 && N % 2 == 0 && ldx % 2 == 0, ENH_E_SHAPE, "enh_colsum_h16: N and ldx must be even");
   hipStream_t s = (hipStream_t)stream;
   if (!accumulate && !part) {
     const int rc = enh_zero_f32_launch(out, N, s);
@@ -251,29 +264,30 @@ static int colsum_bf16_impl(const enh_bf16* x, int64_t M, int64_t N, int64_t ldx
   const int64_t stride = part ? N : 0;
   if (N % 8 == 0 && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0) {
     dim3 grid((unsigned)((N + 511) / 512), (unsigned)chunks);
-    colsum_bf16_wide_kernel<<<grid, 256, 0, s>>>(x, M, N, ldx, rows_per_block, dst, stride);
+    ENH_DT_DISPATCH(dtype, (colsum_h16_wide_kernel<OT><<<grid, 256, 0, s>>>(x, M, N, ldx, rows_per_block, dst, stride)));
   } else {
     dim3 grid((unsigned)((N + 127) / 128), (unsigned)chunks);
-    colsum_bf16_kernel<<<grid, 256, 0, s>>>(x, M, N, ldx, rows_per_block, dst, stride);
+    ENH_DT_DISPATCH(dtype, (colsum_h16_kernel<OT><<<grid, 256, 0, s>>>(x, M, N, ldx, rows_per_block, dst, stride)));
   }
   if (part) colsum_reduce_kernel<<<dim3((unsigned)((N + 15) / 16)), 256, 0, s>>>(part, (int)chunks, N, out, accumulate);
-  return enh_check_launch("enh_colsum_bf16");
+  return enh_check_launch("enh_colsum_h16");
 }
 
-extern "C" int enh_colsum_bf16(const enh_bf16* x, int64_t M, int64_t N, int64_t ldx, float* out, int accumulate, void* stream) {
-  return colsum_bf16_impl(x, M, N, ldx, out, accumulate, nullptr, stream);
+extern "C" int enh_colsum_h16(const enh_h16* x, int64_t M, int64_t N, int64_t ldx, float* out, int accumulate, int dtype, void* stream) {
+  return colsum_h16_impl(x, M, N, ldx, out, accumulate, nullptr, dtype, stream);
 }
 
-// deterministic form: per-chunk partial rows in `ws` (enh_colsum_bf16_workspace_bytes), added in a fixed order
-extern "C" int enh_colsum_bf16_ws(const enh_bf16* x, int64_t M, int64_t N, int64_t ldx, float* out, int accumulate, void* ws, size_t ws_bytes, void* stream) {
-  ENH_REQUIRE(ws && ws_bytes >= enh_colsum_bf16_workspace_bytes(M, N), ENH_E_WORKSPACE, "enh_colsum_bf16_ws: workspace too small (%zu bytes)", ws_bytes);
-  return colsum_bf16_impl(x, M, N, ldx, out, accumulate, (float*)ws, stream);
+// deterministic form: per-chunk partial rows in `ws` (enh_colsum_h16_workspace_bytes), added in a fixed order
+extern "C" int enh_colsum_h16_ws(const enh_h16* x, int64_t M, int64_t N, int64_t ldx, float* out, int accumulate, void* ws, size_t ws_bytes, int dtype, void* stream) {
+  ENH_REQUIRE(ws && ws_bytes >= enh_colsum_h16_workspace_bytes(M, N), ENH_E_WORKSPACE, "enh_colsum_h16_ws: workspace too small (%zu bytes)", ws_bytes);
+  return colsum_h16_impl(x, M, N, ldx, out, accumulate, (float*)ws, dtype, stream);
 }
 
 // y[i] = bf16(x[i] * (i < n_scaled ? alpha : 1)): the forward operand of a packed q | k | v projection whose q rows carry the softmax scale (one rounding,
 // from the fp32 master) — include/enh_hip.h enh_attention_forward, q_prescaled
 // blockIdx.y = one of `count` equally spaced blocks (the same projection of successive transformer layers in the flat parameter store): one launch for a tower
-__global__ void cast_f32_bf16_head_scaled_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, int64_t n, int64_t n_scaled, float alpha,
+template <typename OT>
+__global__ void cast_f32_h16_head_scaled_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, int64_t n, int64_t n_scaled, float alpha,
                                                  int64_t x_stride, int64_t y_stride) {
   x += (int64_t)blockIdx.y * x_stride; y += (int64_t)blockIdx.y * y_stride;
   const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -281,45 +295,74 @@ __global__ void cast_f32_bf16_head_scaled_kernel(const float* __restrict__ x, ui
   if (i + 3 < n) {
     float4 v = *reinterpret_cast<const float4*>(x + i);
     if (i < n_scaled) { v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha; }     // n_scaled % 4 == 0 (checked by the launcher)
-    *reinterpret_cast<uint2*>(y + i) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+    *reinterpret_cast<uint2*>(y + i) = make_uint2(pack2<OT>(v.x, v.y), pack2<OT>(v.z, v.w));
   } else {
-    for (int64_t k = i; k < n; ++k) y[k] = f32_to_bf16_bits(x[k] * (k < n_scaled ? alpha : 1.0f));
+    for (int64_t k = i; k < n; ++k) y[k] = pack1<OT>(x[k] * (k < n_scaled ? alpha : 1.0f));
   }
 }
 
-extern "C" int enh_cast_f32_bf16_head_scaled(const float* x, enh_bf16* y, int64_t n, int64_t n_scaled, float alpha, void* stream) {
-  ENH_REQUIRE(x && y && n > 0 && n_scaled >= 0 && n_scaled <= n && n_scaled % 4 == 0, ENH_E_BADARG, "enh_cast_f32_bf16_head_scaled: bad argument");
+extern "C" int enh_cast_f32_h16_head_scaled(const float* x, enh_h16* y, int64_t n, int64_t n_scaled, float alpha, int dtype, void* stream) {
+  ENH_REQUIRE_DT(dtype, "enh_cast_f32_h16_head_scaled");
+  ENH_REQUIRE(x && y && n > 0 && n_scaled >= 0 && n_scaled <= n && n_scaled % 4 == 0, ENH_E_BADARG, "enh_cast_f32_h16_head_scaled: bad argument");
   const int64_t n4 = (n + 3) / 4;
-  cast_f32_bf16_head_scaled_kernel<<<(int)((n4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, y, n, n_scaled, alpha, 0, 0);
-  return enh_check_launch("enh_cast_f32_bf16_head_scaled");
+  ENH_DT_DISPATCH(dtype, (cast_f32_h16_head_scaled_kernel<OT><<<(int)((n4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, y, n, n_scaled, alpha, 0, 0)));
+  return enh_check_launch("enh_cast_f32_h16_head_scaled");
 }
 
-extern "C" int enh_cast_f32_bf16_head_scaled_strided(const float* x, int64_t x_stride, enh_bf16* y, int64_t y_stride, int64_t n, int64_t n_scaled, float alpha,
-                                                     int count, void* stream) {
+extern "C" int enh_cast_f32_h16_head_scaled_strided(const float* x, int64_t x_stride, enh_h16* y, int64_t y_stride, int64_t n, int64_t n_scaled, float alpha,
+                                                     int count, int dtype, void* stream) {
+  ENH_REQUIRE_DT(dtype, "enh_cast_f32_h16_head_scaled_strided");
   ENH_REQUIRE(x && y && n > 0 && n_scaled >= 0 && n_scaled <= n && n_scaled % 4 == 0 && count > 0 && count <= 65535, ENH_E_BADARG,
-              "enh_cast_f32_bf16_head_scaled_strided: bad argument");
-  ENH_REQUIRE(x_stride % 4 == 0 && y_stride % 4 == 0 && y_stride >= n, ENH_E_SHAPE, "enh_cast_f32_bf16_head_scaled_strided: strides must be multiples of 4 elements and the outputs disjoint");
+              "enh_cast_f32_h16_head_scaled_strided: bad argument");
+  ENH_REQUIRE(x_stride % 4 == 0 && y_stride % 4 == 0 && y_stride >= n, ENH_E_SHAPE, "enh_cast_f32_h16_head_scaled_strided: strides must be multiples of 4 elements and the outputs disjoint");
   const int64_t n4 = (n + 3) / 4;
-  cast_f32_bf16_head_scaled_kernel<<<dim3((unsigned)((n4 + 255) / 256), (unsigned)count), 256, 0, (hipStream_t)stream>>>(x, y, n, n_scaled, alpha, x_stride, y_stride);
-  return enh_check_launch("enh_cast_f32_bf16_head_scaled_strided");
+  ENH_DT_DISPATCH(dtype, (cast_f32_h16_head_scaled_kernel<OT><<<dim3((unsigned)((n4 + 255) / 256), (unsigned)count), 256, 0, (hipStream_t)stream>>>(x, y, n, n_scaled, alpha, x_stride, y_stride)));
+  return enh_check_launch("enh_cast_f32_h16_head_scaled_strided");
 }
 
-extern "C" int enh_cast_f32_bf16(const float* x, enh_bf16* y, int64_t n, void* stream) {
-  ENH_REQUIRE(x && y && n > 0, ENH_E_BADARG, "enh_cast_f32_bf16: bad argument");
+extern "C" int enh_cast_f32_h16(const float* x, enh_h16* y, int64_t n, int dtype, void* stream) {
+  ENH_REQUIRE_DT(dtype, "enh_cast_f32_h16");
+  ENH_REQUIRE(x && y && n > 0, ENH_E_BADARG, "enh_cast_f32_h16: bad argument");
   const int64_t n4 = (n + 3) / 4;
-  cast_f32_bf16_kernel<<<(int)((n4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, y, n);
-  return enh_check_launch("enh_cast_f32_bf16");
+  ENH_DT_DISPATCH(dtype, (cast_f32_h16_kernel<OT><<<(int)((n4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, y, n)));
+  return enh_check_launch("enh_cast_f32_h16");
 }
 
-extern "C" int enh_adamw_step(float* p, const float* g, float* m, float* v, enh_bf16* p_bf16, int64_t n, int step,
+extern "C" int enh_adamw_step(float* p, const float* g, float* m, float* v, enh_h16* p_bf16, int64_t n, int step,
                               float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
-                              void* stream) {
+                              const float* skip_flag, int dtype, void* stream) {
+  ENH_REQUIRE_DT(dtype, "enh_adamw_step");
   ENH_REQUIRE(p && g && m && v && n > 0 && step >= 1, ENH_E_BADARG, "enh_adamw_step: bad argument");
   const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
   const int64_t n4 = (n + 3) / 4;
-  adamw_kernel<<<(int)((n4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(p, g, m, v, p_bf16, n, lr, beta1, beta2, eps, weight_decay,
-                                                                      grad_scale, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)));
+  ENH_DT_DISPATCH(dtype, (adamw_kernel<OT><<<(int)((n4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(p, g, m, v, p_bf16, n, lr, beta1, beta2, eps, weight_decay,
+                                                                                            grad_scale, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), skip_flag)));
   return enh_check_launch("enh_adamw_step");
+}
+
+// flag[0] = 1 if any of x[0..n) is inf / nan, else unchanged (the caller zeroes it): the found-inf check of torch.cuda.amp.GradScaler.unscale_ over one flat
+// gradient buffer (the reference's --use_amp, main.py:25,52).  One read of x at HBM rate; the flag is written with a plain store (every writer stores 1).
+__global__ __launch_bounds__(256) void nonfinite_flag_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ flag) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+  const uint32_t* __restrict__ u = reinterpret_cast<const uint32_t*>(x);
+  const int64_t n4 = n & ~(int64_t)3;
+  uint32_t any = 0u;      // bit 0 set once an element with an all-ones exponent (inf or nan) has been seen
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n4; i += stride) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(u + i);
+    const u32x4 e = (v >> 23) & 0xffu;                               // biased exponents
+    any |= (uint32_t)(e[0] == 0xffu) | (uint32_t)(e[1] == 0xffu) | (uint32_t)(e[2] == 0xffu) | (uint32_t)(e[3] == 0xffu);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (unsigned)(n - n4)) any |= (uint32_t)(((u[n4 + threadIdx.x] >> 23) & 0xffu) == 0xffu);      // the (at most three) tail elements
+  if (__builtin_amdgcn_ballot_w64(any != 0u) != 0 && (threadIdx.x & 63) == 0) *flag = 1.0f;
+}
+
+extern "C" int enh_nonfinite_flag(const float* x, int64_t n, float* flag, void* stream) {
+  ENH_REQUIRE(x && flag && n > 0 && ((uintptr_t)x & 15) == 0, ENH_E_BADARG, "enh_nonfinite_flag: bad argument (x 16-byte aligned)");
+  const int64_t n4 = (n + 3) / 4;
+  const int64_t want = (n4 + 255) / 256;
+  const int grid = (int)(want < 2048 ? want : 2048);
+  nonfinite_flag_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, n, flag);
+  return enh_check_launch("enh_nonfinite_flag");
 }
 
 // Device-side tail of the input pipeline (reference enhancing/dataloader/imagenet.py:26-54: Resize -> RandomCrop / CenterCrop -> RandomHorizontalFlip ->

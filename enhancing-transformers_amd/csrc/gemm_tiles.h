@@ -177,7 +177,7 @@ __device__ __forceinline__ float4 epi_bias(const GemmArgs& args, int64_t n) {
 }
 
 // the arithmetic of an epilogue on one group of 4 columns (bias, activation, residual, accumulate) — everything but the stores
-template <int MODE>
+template <int MODE, typename OT = BF16>
 __device__ __forceinline__ void epi_value(const GemmArgs& args, float (&v)[4], const EpiIn& in, const float4& b4, int64_t n) {
   constexpr bool G = MODE == EPI_GENERIC;
   if (MODE == EPI_BF16_BIAS_TANH || MODE == EPI_F32_BIAS_RES || MODE == EPI_BF16_TANH_SPLIT) { v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w; }
@@ -209,15 +209,15 @@ __device__ __forceinline__ void epi_value(const GemmArgs& args, float (&v)[4], c
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
   } else if (MODE == EPI_BF16_DTANH || (G && args.act == ENH_ACT_DTANH)) {
-    const float h0 = bf16_bits_to_f32((uint16_t)(in.aux.x & 0xffffu)), h1 = bf16_bits_to_f32((uint16_t)(in.aux.x >> 16));
-    const float h2 = bf16_bits_to_f32((uint16_t)(in.aux.y & 0xffffu)), h3 = bf16_bits_to_f32((uint16_t)(in.aux.y >> 16));
+    const float h0 = unpack_lo<OT>(in.aux.x), h1 = unpack_hi<OT>(in.aux.x);
+    const float h2 = unpack_lo<OT>(in.aux.y), h3 = unpack_hi<OT>(in.aux.y);
     v[0] *= 1.f - h0 * h0; v[1] *= 1.f - h1 * h1; v[2] *= 1.f - h2 * h2; v[3] *= 1.f - h3 * h3;
   }
   if (MODE == EPI_F32_BIAS_RES || (G && args.res)) { v[0] += in.res.x; v[1] += in.res.y; v[2] += in.res.z; v[3] += in.res.w; }
   if (G && args.accumulate == 1 && args.c_f32) { v[0] += in.old.x; v[1] += in.old.y; v[2] += in.old.z; v[3] += in.old.w; }
 }
 
-template <int MODE>
+template <int MODE, typename OT = BF16>
 __device__ __forceinline__ void epi4(const GemmArgs& args, float (&v)[4], const EpiIn& in, const float4& b4, int64_t m, int64_t n, int split) {
   constexpr bool G = MODE == EPI_GENERIC;
   if (MODE == EPI_WS || (G && args.accumulate == 3)) {   // split-K partial -> workspace slab [split][M][N] (reduced by splitk_reduce_kernel in a fixed order)
@@ -231,10 +231,10 @@ __device__ __forceinline__ void epi4(const GemmArgs& args, float (&v)[4], const 
     for (int r = 0; r < 4; ++r) atomicAdd(cp + r, v[r]);
     return;
   }
-  epi_value<MODE>(args, v, in, b4, n);
+  epi_value<MODE, OT>(args, v, in, b4, n);
   if (cp) { const f32x4 o_ = {v[0], v[1], v[2], v[3]}; if (ENH_NT_EPILOGUE) __builtin_nontemporal_store(o_, reinterpret_cast<f32x4*>(cp)); else *reinterpret_cast<f32x4*>(cp) = o_; }
   if (MODE == EPI_BF16 || MODE == EPI_BF16_BIAS_TANH || MODE == EPI_BF16_DTANH || (G && args.c_bf16)) {
-    const u32x2 o_ = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    const u32x2 o_ = {pack2<OT>(v[0], v[1]), pack2<OT>(v[2], v[3])};
     if (ENH_NT_EPILOGUE) __builtin_nontemporal_store(o_, reinterpret_cast<u32x2*>(args.c_bf16 + m * args.ldc + n)); else *reinterpret_cast<u32x2*>(args.c_bf16 + m * args.ldc + n) = o_;
   }
 }
@@ -255,7 +255,7 @@ __device__ __forceinline__ void epi4(const GemmArgs& args, float (&v)[4], const 
   } while (0)
 
 // 16x16 accumulator layout (pipe2 / fallback): lane (lg, l16) holds C[m = .. + l16][n = .. + lg*4 + 0..3] (MFMA issued with swapped operands)
-template <int MODE>
+template <int MODE, typename OT = BF16>
 __device__ __forceinline__ void gemm_epilogue_loops(const GemmArgs& args, f32x4 (&acc)[4][4], int64_t m0, int64_t n0, int wm, int wn, int lg, int l16, int split) {
   float4 b4[4];
 #pragma unroll
@@ -278,12 +278,13 @@ __device__ __forceinline__ void gemm_epilogue_loops(const GemmArgs& args, f32x4 
       const int64_t n = n0 + wn * 64 + j * 16 + lg * 4;
       if (n >= args.N) continue;
       float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      epi4<MODE>(args, v, in[j], b4[j], m, n, split);
+      epi4<MODE, OT>(args, v, in[j], b4[j], m, n, split);
     }
   }
 }
+template <typename OT = BF16>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& args, f32x4 (&acc)[4][4], int64_t m0, int64_t n0, int wm, int wn, int lg, int l16, int split) {
-  EPI_DISPATCH((gemm_epilogue_loops<EM>(args, acc, m0, n0, wm, wn, lg, l16, split)));
+  EPI_DISPATCH((gemm_epilogue_loops<EM, OT>(args, acc, m0, n0, wm, wn, lg, l16, split)));
 }
 
 // tile scheduling shared by both kernels
@@ -331,7 +332,7 @@ __device__ __forceinline__ void gemm_tile_coords(const GemmArgs& args, int& spli
 #endif
 
 // epilogue for the swapped 32x32 accumulator layout: acc[i][j][r] = C[mw + i*32 + (lane&31)][nw + j*32 + 8*(r>>2) + 4*(lane>>5) + (r&3)]
-template <int MODE, int NJ, bool BOUNDS>
+template <int MODE, int NJ, bool BOUNDS, typename OT = BF16>
 __device__ __forceinline__ void gemm_epilogue32_loops(const GemmArgs& args, f32x16 (&acc)[4][NJ], int64_t mw, int64_t nw, int lane, int split, float* wave_bias,
                                                       unsigned char* stage, unsigned char* stage32) {
   const int l31 = lane & 31, hi = lane >> 5;
@@ -360,7 +361,7 @@ __device__ __forceinline__ void gemm_epilogue32_loops(const GemmArgs& args, f32x
           const int64_t n = nw + j * 32 + 8 * g4 + 4 * hi;
           if (BOUNDS && n >= args.N) continue;
           float v[4] = {acc[i][j][g4 * 4 + 0], acc[i][j][g4 * 4 + 1], acc[i][j][g4 * 4 + 2], acc[i][j][g4 * 4 + 3]};
-          epi4<MODE>(args, v, in[j][g4], epi_bias<MODE>(args, n), m, n, split);
+          epi4<MODE, OT>(args, v, in[j][g4], epi_bias<MODE>(args, n), m, n, split);
         }
       }
     }
@@ -402,8 +403,8 @@ __device__ __forceinline__ void gemm_epilogue32_loops(const GemmArgs& args, f32x
         for (int g4 = 0; g4 < 4; ++g4) {
           float v[4] = {acc[i][j][g4 * 4 + 0], acc[i][j][g4 * 4 + 1], acc[i][j][g4 * 4 + 2], acc[i][j][g4 * 4 + 3]};
           const float4 b4 = HAS_BIAS ? *reinterpret_cast<const float4*>(wave_bias + j * 32 + 8 * g4 + 4 * hi) : make_float4(0.f, 0.f, 0.f, 0.f);
-          epi_value<MODE>(args, v, in[MODE == EPI_BF16_DTANH ? i : 0][j][g4], b4, nw + j * 32 + 8 * g4 + 4 * hi);
-          const u32x2 o_ = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+          epi_value<MODE, OT>(args, v, in[MODE == EPI_BF16_DTANH ? i : 0][j][g4], b4, nw + j * 32 + 8 * g4 + 4 * hi);
+          const u32x2 o_ = {pack2<OT>(v[0], v[1]), pack2<OT>(v[2], v[3])};
           *reinterpret_cast<u32x2*>(stage + l31 * 256 + (((j * 4 + g4) ^ (l31 & 15)) << 4) + hi * 8) = o_;
         }
 #pragma unroll
@@ -450,7 +451,7 @@ __device__ __forceinline__ void gemm_epilogue32_loops(const GemmArgs& args, f32x
           for (int g4 = 0; g4 < 4; ++g4) {
             float v[4] = {acc[i][j][g4 * 4 + 0], acc[i][j][g4 * 4 + 1], acc[i][j][g4 * 4 + 2], acc[i][j][g4 * 4 + 3]};
             const float4 b4 = HAS_BIAS ? *reinterpret_cast<const float4*>(wave_bias + j * 32 + 8 * g4 + 4 * hi) : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (MODE != EPI_WS) epi_value<MODE>(args, v, in[ii][j][g4], b4, nw + j * 32 + 8 * g4 + 4 * hi);
+            if (MODE != EPI_WS) epi_value<MODE, OT>(args, v, in[ii][j][g4], b4, nw + j * 32 + 8 * g4 + 4 * hi);
             const f32x4 o_ = {v[0], v[1], v[2], v[3]};
             *reinterpret_cast<f32x4*>(st32 + l31 * 512 + (((j * 8 + g4 * 2 + hi) ^ l31) << 4)) = o_;
           }
@@ -494,7 +495,7 @@ __device__ __forceinline__ void gemm_epilogue32_loops(const GemmArgs& args, f32x
           if (BOUNDS && n >= args.N) continue;
           float v[4] = {acc[i][j][g4 * 4 + 0], acc[i][j][g4 * 4 + 1], acc[i][j][g4 * 4 + 2], acc[i][j][g4 * 4 + 3]};
           const float4 b4 = HAS_BIAS ? *reinterpret_cast<const float4*>(wave_bias + j * 32 + 8 * g4 + 4 * hi) : make_float4(0.f, 0.f, 0.f, 0.f);
-          epi4<MODE>(args, v, in[ii][j][g4], b4, m, n, split);
+          epi4<MODE, OT>(args, v, in[ii][j][g4], b4, m, n, split);
         }
       }
     }

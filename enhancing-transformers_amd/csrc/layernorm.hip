@@ -2,13 +2,13 @@
 // coalesced accesses, statistics and all accumulation in f32).
 // Replaces nn.LayerNorm(dim) inside PreNorm and Transformer.norm (reference
 // enhancing/modules/stage1/layers.py:85-92,143): eps 1e-5, biased variance, affine.
-// Forward writes the bf16 operand the following MFMA GEMM consumes (and optionally an f32 copy);
-// backward fuses the residual-stream gradient add and emits the bf16 copy the wgrad/dgrad GEMMs consume.
+// Forward writes the 16-bit operand (bf16 or fp16: the kernels are templates over the operand type tag OT, common.h) the following MFMA GEMM consumes
+// (and optionally an f32 copy); backward fuses the residual-stream gradient add and emits the 16-bit copy the wgrad/dgrad GEMMs consume.
 #include "common.h"
 
 // X3: additionally writes the split-bf16 operand row y3 [M][3*D] = [hi | lo | hi] with hi = bf16(y), lo = bf16(y - hi) (x3.hip: the A operand of a
 // K-concatenated three-pass product); statistics and y are the same bits as in the plain form.
-template <int NCH, bool X3>
+template <int NCH, bool X3, typename OT>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ b, int64_t M, int D, float eps,
                                                      uint16_t* __restrict__ y16, float* __restrict__ y32,
@@ -54,9 +54,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
       o.z = (v[i].z - mean) * rstd * g.z + be.z;
       o.w = (v[i].w - mean) * rstd * g.w + be.w;
       if (y32) reinterpret_cast<float4*>(y32 + (size_t)row * D)[c] = o;
-      const uint2 hi2 = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
+      const uint2 hi2 = make_uint2(pack2<OT>(o.x, o.y), pack2<OT>(o.z, o.w));
       if (y16) reinterpret_cast<uint2*>(y16 + (size_t)row * D)[c] = hi2;
-      if (X3) {
+      if (X3) {   // (bf16 only)
         const uint2 lo2 = make_uint2(pack_bf16x2(o.x - __builtin_bit_cast(float, hi2.x << 16), o.y - __builtin_bit_cast(float, hi2.x & 0xffff0000u)),
                                      pack_bf16x2(o.z - __builtin_bit_cast(float, hi2.y << 16), o.w - __builtin_bit_cast(float, hi2.y & 0xffff0000u)));
         uint2* r3 = reinterpret_cast<uint2*>(y3 + (size_t)row * 3 * D);
@@ -66,10 +66,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   }
 }
 
-// DY16: dy is bf16 (the dgrad GEMM's bf16 output) instead of f32.  The dres loads are issued together with dy / x, not after the row
+// DY16: dy is a 16-bit tensor (the dgrad GEMM's 16-bit output) instead of f32.  The dres loads are issued together with dy / x, not after the row
 // reduction (D = 768: 128 VGPRs, still 4 waves / SIMD).  Measured at M = 131072, D = 768 with distinct buffers
 // (tools/ln_bench.py): 328 us = 4.9 TB/s of algorithmic traffic (16 B / element).
-template <int NCH, bool DY16>
+template <int NCH, bool DY16, typename OT>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy_any, const float* __restrict__ x,
                                                      const float* __restrict__ w, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ dres,
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         in.xv[i] = xr[c];
         if (DY16) {
           const uint2 r = reinterpret_cast<const uint2*>(static_cast<const uint16_t*>(dy_any) + (size_t)row * D)[c];
-          in.dv[i] = make_float4(__uint_as_float(r.x), __uint_as_float(r.y), 0.f, 0.f);   // raw bf16 pairs, unpacked where they are used
+          in.dv[i] = make_float4(__uint_as_float(r.x), __uint_as_float(r.y), 0.f, 0.f);   // raw 16-bit pairs, unpacked where they are used
         } else {
           in.dv[i] = reinterpret_cast<const float4*>(static_cast<const float*>(dy_any) + (size_t)row * D)[c];
         }
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         float4 dv;
         if (DY16) {
           const uint32_t r0 = __float_as_uint(cur.dv[i].x), r1 = __float_as_uint(cur.dv[i].y);
-          dv = make_float4(__uint_as_float(r0 << 16), __uint_as_float(r0 & 0xffff0000u), __uint_as_float(r1 << 16), __uint_as_float(r1 & 0xffff0000u));
+          dv = make_float4(unpack_lo<OT>(r0), unpack_hi<OT>(r0), unpack_lo<OT>(r1), unpack_hi<OT>(r1));
         } else {
           dv = cur.dv[i];
         }
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
           o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
         }
         reinterpret_cast<float4*>(dx32 + (size_t)row * D)[c] = o;
-        if (dx16) reinterpret_cast<uint2*>(dx16 + (size_t)row * D)[c] = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
+        if (dx16) reinterpret_cast<uint2*>(dx16 + (size_t)row * D)[c] = make_uint2(pack2<OT>(o.x, o.y), pack2<OT>(o.z, o.w));
         adx[i].x += o.x; adx[i].y += o.y; adx[i].z += o.z; adx[i].w += o.w;
       }
     }
@@ -228,45 +228,46 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
   }
 }
 
-template <bool X3>
-static void ln_fwd_launch(int grid, hipStream_t s, const float* x, const float* w, const float* b, int64_t M, int D, float eps, enh_bf16* y_bf16, float* y_f32,
-                          float* mean, float* rstd, enh_bf16* y3) {
+template <bool X3, typename OT>
+static void ln_fwd_launch(int grid, hipStream_t s, const float* x, const float* w, const float* b, int64_t M, int D, float eps, enh_h16* y_bf16, float* y_f32,
+                          float* mean, float* rstd, enh_h16* y3) {
   switch ((D + 255) / 256) {  // float4 chunks per lane: registers (hence occupancy) scale with it
-    case 1: ln_fwd_kernel<1, X3><<<grid, 256, 0, s>>>(x, w, b, M, D, eps, y_bf16, y_f32, mean, rstd, y3); break;
-    case 2: ln_fwd_kernel<2, X3><<<grid, 256, 0, s>>>(x, w, b, M, D, eps, y_bf16, y_f32, mean, rstd, y3); break;
-    case 3: ln_fwd_kernel<3, X3><<<grid, 256, 0, s>>>(x, w, b, M, D, eps, y_bf16, y_f32, mean, rstd, y3); break;
-    case 4: ln_fwd_kernel<4, X3><<<grid, 256, 0, s>>>(x, w, b, M, D, eps, y_bf16, y_f32, mean, rstd, y3); break;
-    case 5: ln_fwd_kernel<5, X3><<<grid, 256, 0, s>>>(x, w, b, M, D, eps, y_bf16, y_f32, mean, rstd, y3); break;
-    default: ln_fwd_kernel<8, X3><<<grid, 256, 0, s>>>(x, w, b, M, D, eps, y_bf16, y_f32, mean, rstd, y3); break;
+    case 1: ln_fwd_kernel<1, X3, OT><<<grid, 256, 0, s>>>(x, w, b, M, D, eps, y_bf16, y_f32, mean, rstd, y3); break;
+    case 2: ln_fwd_kernel<2, X3, OT><<<grid, 256, 0, s>>>(x, w, b, M, D, eps, y_bf16, y_f32, mean, rstd, y3); break;
+    case 3: ln_fwd_kernel<3, X3, OT><<<grid, 256, 0, s>>>(x, w, b, M, D, eps, y_bf16, y_f32, mean, rstd, y3); break;
+    case 4: ln_fwd_kernel<4, X3, OT><<<grid, 256, 0, s>>>(x, w, b, M, D, eps, y_bf16, y_f32, mean, rstd, y3); break;
+    case 5: ln_fwd_kernel<5, X3, OT><<<grid, 256, 0, s>>>(x, w, b, M, D, eps, y_bf16, y_f32, mean, rstd, y3); break;
+    default: ln_fwd_kernel<8, X3, OT><<<grid, 256, 0, s>>>(x, w, b, M, D, eps, y_bf16, y_f32, mean, rstd, y3); break;
   }
 }
 
 extern "C" int enh_layernorm_forward(const float* x, const float* w, const float* b, int64_t M, int D, float eps,
-                                     enh_bf16* y_bf16, float* y_f32, float* mean, float* rstd, void* stream) {
+                                     enh_h16* y_bf16, float* y_f32, float* mean, float* rstd, int dtype, void* stream) {
+  ENH_REQUIRE_DT(dtype, "enh_layernorm_forward");
   ENH_REQUIRE(x && w && b && (y_bf16 || y_f32), ENH_E_BADARG, "enh_layernorm_forward: null pointer");
   ENH_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 2048, ENH_E_SHAPE, "enh_layernorm_forward: need D %% 4 == 0 and D <= 2048, got M=%lld D=%d", (long long)M, D);
-  ln_fwd_launch<false>((int)((M + 3) / 4), (hipStream_t)stream, x, w, b, M, D, eps, y_bf16, y_f32, mean, rstd, nullptr);
+  ENH_DT_DISPATCH(dtype, (ln_fwd_launch<false, OT>((int)((M + 3) / 4), (hipStream_t)stream, x, w, b, M, D, eps, y_bf16, y_f32, mean, rstd, nullptr)));
   return enh_check_launch("enh_layernorm_forward");
 }
 
-extern "C" int enh_layernorm_forward_x3(const float* x, const float* w, const float* b, int64_t M, int D, float eps, enh_bf16* y3,
-                                        enh_bf16* y_bf16, float* y_f32, float* mean, float* rstd, void* stream) {
+extern "C" int enh_layernorm_forward_x3(const float* x, const float* w, const float* b, int64_t M, int D, float eps, enh_h16* y3,
+                                        enh_h16* y_bf16, float* y_f32, float* mean, float* rstd, void* stream) {
   ENH_REQUIRE(x && w && b && y3, ENH_E_BADARG, "enh_layernorm_forward_x3: null pointer");
   ENH_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 2048, ENH_E_SHAPE, "enh_layernorm_forward_x3: need D %% 4 == 0 and D <= 2048, got M=%lld D=%d", (long long)M, D);
-  ln_fwd_launch<true>((int)((M + 3) / 4), (hipStream_t)stream, x, w, b, M, D, eps, y_bf16, y_f32, mean, rstd, y3);
+  ln_fwd_launch<true, BF16>((int)((M + 3) / 4), (hipStream_t)stream, x, w, b, M, D, eps, y_bf16, y_f32, mean, rstd, y3);
   return enh_check_launch("enh_layernorm_forward_x3");
 }
 
-template <bool DY16>
+template <bool DY16, typename OT>
 static void ln_bwd_launch(int grid, hipStream_t s, const void* dy, const float* x, const float* w, const float* mean, const float* rstd,
-                          const float* dres, int64_t M, int D, float* dx_f32, enh_bf16* dx_bf16, float* dw, float* db, float* dx_colsum, float* part) {
+                          const float* dres, int64_t M, int D, float* dx_f32, enh_h16* dx_bf16, float* dw, float* db, float* dx_colsum, float* part) {
   switch ((D + 255) / 256) {
-    case 1: ln_bwd_kernel<1, DY16><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum, part); break;
-    case 2: ln_bwd_kernel<2, DY16><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum, part); break;
-    case 3: ln_bwd_kernel<3, DY16><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum, part); break;
-    case 4: ln_bwd_kernel<4, DY16><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum, part); break;
-    case 5: ln_bwd_kernel<5, DY16><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum, part); break;
-    default: ln_bwd_kernel<8, DY16><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum, part); break;
+    case 1: ln_bwd_kernel<1, DY16, OT><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum, part); break;
+    case 2: ln_bwd_kernel<2, DY16, OT><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum, part); break;
+    case 3: ln_bwd_kernel<3, DY16, OT><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum, part); break;
+    case 4: ln_bwd_kernel<4, DY16, OT><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum, part); break;
+    case 5: ln_bwd_kernel<5, DY16, OT><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum, part); break;
+    default: ln_bwd_kernel<8, DY16, OT><<<grid, 256, 0, s>>>(dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum, part); break;
   }
 }
 
@@ -297,28 +298,29 @@ extern "C" size_t enh_layernorm_backward_workspace_bytes(int64_t M, int D) {
   return M > 0 && D > 0 ? (size_t)ln_bwd_grid(M, true) * 3 * D * sizeof(float) : 0;
 }
 
-static int ln_bwd_impl(const float* dy, const enh_bf16* dy_bf16, const float* x, const float* w, const float* mean, const float* rstd, const float* dres,
-                       int64_t M, int D, float* dx_f32, enh_bf16* dx_bf16, float* dw, float* db, float* dx_colsum, float* part, void* stream) {
+static int ln_bwd_impl(const float* dy, const enh_h16* dy_bf16, const float* x, const float* w, const float* mean, const float* rstd, const float* dres,
+                       int64_t M, int D, float* dx_f32, enh_h16* dx_bf16, float* dw, float* db, float* dx_colsum, float* part, int dtype, void* stream) {
+  ENH_REQUIRE_DT(dtype, "enh_layernorm_backward");
   ENH_REQUIRE((dy != nullptr) != (dy_bf16 != nullptr), ENH_E_BADARG, "enh_layernorm_backward: pass exactly one of dy (f32) / dy_bf16");
   ENH_REQUIRE(x && w && mean && rstd && dx_f32 && dw && db, ENH_E_BADARG, "enh_layernorm_backward: null pointer");
   ENH_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 2048, ENH_E_SHAPE, "enh_layernorm_backward: need D %% 4 == 0 and D <= 2048, got M=%lld D=%d", (long long)M, D);
   hipStream_t s = (hipStream_t)stream;
   const int grid = ln_bwd_grid(M);
-  if (dy_bf16) ln_bwd_launch<true>(grid, s, dy_bf16, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum, part);
-  else ln_bwd_launch<false>(grid, s, dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum, part);
+  if (dy_bf16) ENH_DT_DISPATCH(dtype, (ln_bwd_launch<true, OT>(grid, s, dy_bf16, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum, part)));
+  else ENH_DT_DISPATCH(dtype, (ln_bwd_launch<false, OT>(grid, s, dy, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum, part)));
   if (part) ln_bwd_reduce_kernel<<<dim3((unsigned)((D + 15) / 16), 3), 256, 0, s>>>(part, grid, D, dw, db, dx_colsum);
   return enh_check_launch("enh_layernorm_backward");
 }
 
-extern "C" int enh_layernorm_backward(const float* dy, const enh_bf16* dy_bf16, const float* x, const float* w, const float* mean,
+extern "C" int enh_layernorm_backward(const float* dy, const enh_h16* dy_bf16, const float* x, const float* w, const float* mean,
                                       const float* rstd, const float* dres, int64_t M, int D, float* dx_f32,
-                                      enh_bf16* dx_bf16, float* dw, float* db, float* dx_colsum, void* stream) {
-  return ln_bwd_impl(dy, dy_bf16, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum, nullptr, stream);
+                                      enh_h16* dx_bf16, float* dw, float* db, float* dx_colsum, int dtype, void* stream) {
+  return ln_bwd_impl(dy, dy_bf16, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum, nullptr, dtype, stream);
 }
 
-extern "C" int enh_layernorm_backward_ws(const float* dy, const enh_bf16* dy_bf16, const float* x, const float* w, const float* mean,
+extern "C" int enh_layernorm_backward_ws(const float* dy, const enh_h16* dy_bf16, const float* x, const float* w, const float* mean,
                                          const float* rstd, const float* dres, int64_t M, int D, float* dx_f32,
-                                         enh_bf16* dx_bf16, float* dw, float* db, float* dx_colsum, void* ws, size_t ws_bytes, void* stream) {
+                                         enh_h16* dx_bf16, float* dw, float* db, float* dx_colsum, void* ws, size_t ws_bytes, int dtype, void* stream) {
   ENH_REQUIRE(ws && ws_bytes >= enh_layernorm_backward_workspace_bytes(M, D), ENH_E_WORKSPACE, "enh_layernorm_backward_ws: workspace too small (%zu bytes)", ws_bytes);
-  return ln_bwd_impl(dy, dy_bf16, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum, (float*)ws, stream);
+  return ln_bwd_impl(dy, dy_bf16, x, w, mean, rstd, dres, M, D, dx_f32, dx_bf16, dw, db, dx_colsum, (float*)ws, dtype, stream);
 }

@@ -85,7 +85,7 @@ __device__ __forceinline__ void vq_tile_sstore(const f32x4 (&pre)[4], float pre_
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void vq_nn_kernel(
     const float* __restrict__ z, const float* __restrict__ en, const float* __restrict__ ee, int64_t M, int Kpad,
-    int depth, int use_norm, float* __restrict__ zq_out, uint16_t* __restrict__ zq_bf16,
+    int depth, int use_norm, float* __restrict__ zq_out, uint16_t* __restrict__ zq_bf16, int f16,
     int64_t* __restrict__ idx_out, float* __restrict__ loss_partials) {
   __shared__ __attribute__((aligned(16))) float s_tile[2][VQ_TILE * VQ_PITCH];
   __shared__ __attribute__((aligned(16))) float s_ee[2][VQ_TILE];
@@ -211,8 +211,10 @@ __global__ __launch_bounds__(256) void vq_nn_kernel(
     for (int c = 0; c < 4; ++c) dst[c] = make_float4(o[c * 4], o[c * 4 + 1], o[c * 4 + 2], o[c * 4 + 3]);
     if (zq_bf16) {
       uint4* d16 = reinterpret_cast<uint4*>(zq_bf16 + (size_t)tok * VQ_D + hi * 16);
-      d16[0] = make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
-      d16[1] = make_uint4(pack_bf16x2(o[8], o[9]), pack_bf16x2(o[10], o[11]), pack_bf16x2(o[12], o[13]), pack_bf16x2(o[14], o[15]));
+      d16[0] = f16 ? make_uint4(pack2<F16>(o[0], o[1]), pack2<F16>(o[2], o[3]), pack2<F16>(o[4], o[5]), pack2<F16>(o[6], o[7]))
+                   : make_uint4(pack2<BF16>(o[0], o[1]), pack2<BF16>(o[2], o[3]), pack2<BF16>(o[4], o[5]), pack2<BF16>(o[6], o[7]));
+      d16[1] = f16 ? make_uint4(pack2<F16>(o[8], o[9]), pack2<F16>(o[10], o[11]), pack2<F16>(o[12], o[13]), pack2<F16>(o[14], o[15]))
+                   : make_uint4(pack2<BF16>(o[8], o[9]), pack2<BF16>(o[10], o[11]), pack2<BF16>(o[12], o[13]), pack2<BF16>(o[14], o[15]));
     }
   }
 }
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(256) void vq_bwd_kernel(
     const float* __restrict__ z, const float* __restrict__ E, const float* __restrict__ en,
     const float* __restrict__ enrm, const int64_t* __restrict__ idx, const float* __restrict__ g_out, float g_loss,
     const float* __restrict__ g_loss_dev, int64_t M, int depth, int use_norm, int use_residual, float beta,
-    float* __restrict__ dz, uint16_t* __restrict__ dz_bf16, float* __restrict__ contrib, int* __restrict__ codes) {
+    float* __restrict__ dz, uint16_t* __restrict__ dz_bf16, int f16, float* __restrict__ contrib, int* __restrict__ codes) {
   const int lane = threadIdx.x & 63;
   const int col = lane & 31, hi = lane >> 5;
   const int64_t tok = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 32 + col;
@@ -413,15 +415,17 @@ __global__ __launch_bounds__(256) void vq_bwd_kernel(
     for (int q = 0; q < 4; ++q) dst[q] = make_float4(o[q * 4], o[q * 4 + 1], o[q * 4 + 2], o[q * 4 + 3]);
     if (dz_bf16) {
       uint4* d16 = reinterpret_cast<uint4*>(dz_bf16 + (size_t)tok * VQ_D + hi * 16);
-      d16[0] = make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
-      d16[1] = make_uint4(pack_bf16x2(o[8], o[9]), pack_bf16x2(o[10], o[11]), pack_bf16x2(o[12], o[13]), pack_bf16x2(o[14], o[15]));
+      d16[0] = f16 ? make_uint4(pack2<F16>(o[0], o[1]), pack2<F16>(o[2], o[3]), pack2<F16>(o[4], o[5]), pack2<F16>(o[6], o[7]))
+                   : make_uint4(pack2<BF16>(o[0], o[1]), pack2<BF16>(o[2], o[3]), pack2<BF16>(o[4], o[5]), pack2<BF16>(o[6], o[7]));
+      d16[1] = f16 ? make_uint4(pack2<F16>(o[8], o[9]), pack2<F16>(o[10], o[11]), pack2<F16>(o[12], o[13]), pack2<F16>(o[14], o[15]))
+                   : make_uint4(pack2<BF16>(o[8], o[9]), pack2<BF16>(o[10], o[11]), pack2<BF16>(o[12], o[13]), pack2<BF16>(o[14], o[15]));
     }
   }
 }
 
 // decode_codes front half: out = sum_i n(E[idx_i])   (vitvqgan.py:82-87)
 __global__ void vq_lookup_kernel(const float* __restrict__ E, const int64_t* __restrict__ idx, int64_t M, int depth,
-                                 int use_norm, float* __restrict__ out, uint16_t* __restrict__ out_bf16) {
+                                 int use_norm, float* __restrict__ out, uint16_t* __restrict__ out_bf16, int f16) {
   const int64_t tok = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (tok >= M) return;
   float acc[VQ_D];
@@ -439,7 +443,7 @@ __global__ void vq_lookup_kernel(const float* __restrict__ E, const int64_t* __r
   }
   for (int j = 0; j < VQ_D; ++j) {
     if (out) out[(size_t)tok * VQ_D + j] = acc[j];
-    if (out_bf16) out_bf16[(size_t)tok * VQ_D + j] = f32_to_bf16_bits(acc[j]);
+    if (out_bf16) out_bf16[(size_t)tok * VQ_D + j] = f16 ? pack1<F16>(acc[j]) : pack1<BF16>(acc[j]);
   }
 }
 
@@ -472,9 +476,10 @@ extern "C" size_t enh_vq_workspace_bytes(int64_t M, int n_embed, int depth) {
 }
 
 extern "C" int enh_vq_forward(const float* z, const float* codebook, int64_t M, int n_embed, int embed_dim,
-                              float beta, int depth, int use_norm, float* zq_out, enh_bf16* zq_bf16,
+                              float beta, int depth, int use_norm, float* zq_out, enh_h16* zq_bf16,
                               int64_t* idx_out, float* loss_out, void* workspace, size_t workspace_bytes,
-                              void* stream) {
+                              int dtype, void* stream) {
+  ENH_REQUIRE_DT(dtype, "enh_vq_forward");
   ENH_REQUIRE(z && codebook && zq_out && idx_out && loss_out && workspace, ENH_E_BADARG, "enh_vq_forward: null pointer");
   ENH_REQUIRE(M > 0 && n_embed > 0 && depth >= 1, ENH_E_BADARG, "enh_vq_forward: M=%lld n_embed=%d depth=%d", (long long)M, n_embed, depth);
   ENH_REQUIRE(embed_dim == VQ_D, ENH_E_SHAPE, "enh_vq_forward: embed_dim must be 32, got %d", embed_dim);
@@ -484,7 +489,7 @@ extern "C" int enh_vq_forward(const float* z, const float* codebook, int64_t M, 
   VqWs w = vq_carve(workspace, n_embed, M, depth);
   vq_prep_kernel<<<(kp + 255) / 256, 256, 0, s>>>(codebook, w.en, w.ee, w.enrm, n_embed, kp, use_norm);
   const int nb = (int)vq_nblocks(M);
-  vq_nn_kernel<<<nb, 256, 0, s>>>(z, w.en, w.ee, M, kp, depth, use_norm, zq_out, zq_bf16, idx_out, w.partials);
+  vq_nn_kernel<<<nb, 256, 0, s>>>(z, w.en, w.ee, M, kp, depth, use_norm, zq_out, zq_bf16, dtype == ENH_DT_F16, idx_out, w.partials);
   vq_loss_finalize_kernel<<<1, 256, 0, s>>>(w.partials, nb, depth, M, beta, loss_out);
   return enh_check_launch("enh_vq_forward");
 }
@@ -492,8 +497,9 @@ extern "C" int enh_vq_forward(const float* z, const float* codebook, int64_t M, 
 extern "C" int enh_vq_backward(const float* z, const float* codebook, const int64_t* idx, const float* g_out,
                                float g_loss, const float* g_loss_dev, int64_t M, int n_embed, int embed_dim,
                                float beta, int depth, int use_residual, int use_norm, float* dz,
-                               enh_bf16* dz_bf16, float* d_codebook, void* workspace, size_t workspace_bytes,
-                               void* stream) {
+                               enh_h16* dz_bf16, float* d_codebook, void* workspace, size_t workspace_bytes,
+                               int dtype, void* stream) {
+  ENH_REQUIRE_DT(dtype, "enh_vq_backward");
   ENH_REQUIRE(z && codebook && idx && g_out && dz && d_codebook && workspace, ENH_E_BADARG, "enh_vq_backward: null pointer");
   const int D = depth;
   ENH_REQUIRE(M > 0 && n_embed > 0 && D >= 1 && D <= 8, ENH_E_BADARG, "enh_vq_backward: M=%lld n_embed=%d depth=%d (|depth| <= 8)", (long long)M, n_embed, depth);
@@ -505,20 +511,21 @@ extern "C" int enh_vq_backward(const float* z, const float* codebook, const int6
   vq_prep_kernel<<<(kp + 255) / 256, 256, 0, s>>>(codebook, w.en, w.ee, w.enrm, n_embed, kp, use_norm);
   const int nb = (int)vq_nblocks(M);
   if (D == 1)
-    vq_bwd_kernel<1><<<nb, 256, 0, s>>>(z, codebook, w.en, w.enrm, idx, g_out, g_loss, g_loss_dev, M, D, use_norm, use_residual, beta, dz, dz_bf16, w.contrib, w.codes);
+    vq_bwd_kernel<1><<<nb, 256, 0, s>>>(z, codebook, w.en, w.enrm, idx, g_out, g_loss, g_loss_dev, M, D, use_norm, use_residual, beta, dz, dz_bf16, dtype == ENH_DT_F16, w.contrib, w.codes);
   else if (D <= 4)
-    vq_bwd_kernel<4><<<nb, 256, 0, s>>>(z, codebook, w.en, w.enrm, idx, g_out, g_loss, g_loss_dev, M, D, use_norm, use_residual, beta, dz, dz_bf16, w.contrib, w.codes);
+    vq_bwd_kernel<4><<<nb, 256, 0, s>>>(z, codebook, w.en, w.enrm, idx, g_out, g_loss, g_loss_dev, M, D, use_norm, use_residual, beta, dz, dz_bf16, dtype == ENH_DT_F16, w.contrib, w.codes);
   else
-    vq_bwd_kernel<8><<<nb, 256, 0, s>>>(z, codebook, w.en, w.enrm, idx, g_out, g_loss, g_loss_dev, M, D, use_norm, use_residual, beta, dz, dz_bf16, w.contrib, w.codes);
+    vq_bwd_kernel<8><<<nb, 256, 0, s>>>(z, codebook, w.en, w.enrm, idx, g_out, g_loss, g_loss_dev, M, D, use_norm, use_residual, beta, dz, dz_bf16, dtype == ENH_DT_F16, w.contrib, w.codes);
   vq_de_partial_kernel<<<dim3((unsigned)((n_embed + VQ_CPW - 1) / VQ_CPW), VQ_RS), 256, 0, s>>>(w.codes, w.contrib, M * (int64_t)D, n_embed, w.depart);
   vq_de_finalize_kernel<<<(unsigned)(((int64_t)n_embed * VQ_D + 255) / 256), 256, 0, s>>>(w.depart, n_embed, d_codebook);
   return enh_check_launch("enh_vq_backward");
 }
 
 extern "C" int enh_vq_lookup(const float* codebook, const int64_t* idx, int64_t M, int n_embed, int embed_dim,
-                             int depth, int use_norm, float* out, enh_bf16* out_bf16, void* stream) {
+                             int depth, int use_norm, float* out, enh_h16* out_bf16, int dtype, void* stream) {
+  ENH_REQUIRE_DT(dtype, "enh_vq_lookup");
   ENH_REQUIRE(codebook && idx && (out || out_bf16), ENH_E_BADARG, "enh_vq_lookup: null pointer");
   ENH_REQUIRE(embed_dim == VQ_D && depth >= 1 && M > 0, ENH_E_SHAPE, "enh_vq_lookup: embed_dim must be 32, depth >= 1");
-  vq_lookup_kernel<<<(int)((M + 127) / 128), 128, 0, (hipStream_t)stream>>>(codebook, idx, M, depth, use_norm, out, out_bf16);
+  vq_lookup_kernel<<<(int)((M + 127) / 128), 128, 0, (hipStream_t)stream>>>(codebook, idx, M, depth, use_norm, out, out_bf16, dtype == ENH_DT_F16);
   return enh_check_launch("enh_vq_lookup");
 }

@@ -13,6 +13,7 @@
 // (S = Q K^T and O = P V each as three MFMA passes, softmax statistics in fp32 as in attention.hip).  LayerNorm writes its x3 row itself
 // (layernorm.hip, enh_layernorm_forward_x3).
 #include "attention_common.h"
+typedef BF16 OT;   // the x3 path is bf16 by construction (hi / lo bf16 planes): the shared helpers of attention_common.h are used at that operand type
 
 // hi / lo of eight consecutive values -> two 16-byte packets
 __device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo) {
@@ -194,10 +195,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_x3_kernel(const uint16_t* __r
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int c2 = 0; c2 < 2; ++c2) {
-        const s16x8 pbh = pack8_bf16(&p[kb][c2 * 8]);
+        const s16x8 pbh = pack8<BF16>(&p[kb][c2 * 8]);
 #pragma unroll
         for (int e = 0; e < 8; ++e) pl[kb][c2 * 8 + e] = p[kb][c2 * 8 + e] - bf16_bits_to_f32((uint16_t)pbh[e]);
-        const s16x8 pbl = pack8_bf16(&pl[kb][c2 * 8]);
+        const s16x8 pbl = pack8<BF16>(&pl[kb][c2 * 8]);
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
           const s16x8 fvh = att_frag_tr(vh_, kb * 32 + 16 * c2, db, lane), fvl = att_frag_tr(vl_, kb * 32 + 16 * c2, db, lane);

@@ -33,38 +33,38 @@ SIGNATURES = {
     "enh_last_error": (_c.c_char_p, []),
     "enh_abi_version": (_i32, []),
     "enh_vq_workspace_bytes": (_sz, [_i64, _i32, _i32]),
-    "enh_vq_forward": (_i32, [_vp, _vp, _i64, _i32, _i32, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "enh_vq_backward": (_i32, [_vp, _vp, _vp, _vp, _f32, _vp, _i64, _i32, _i32, _f32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "enh_vq_lookup": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
-    "enh_layernorm_forward": (_i32, [_vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp, _vp]),
-    "enh_layernorm_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "enh_layernorm_backward_ws": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "enh_vq_forward": (_i32, [_vp, _vp, _i64, _i32, _i32, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _i32, _vp]),
+    "enh_vq_backward": (_i32, [_vp, _vp, _vp, _vp, _f32, _vp, _i64, _i32, _i32, _f32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _i32, _vp]),
+    "enh_vq_lookup": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
+    "enh_layernorm_forward": (_i32, [_vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "enh_layernorm_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "enh_layernorm_backward_ws": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i32, _vp]),
     "enh_layernorm_backward_workspace_bytes": (_sz, [_i64, _i32]),
-    "enh_gemm_bf16": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _i64, _i64, _i64, _vp, _i32, _vp, _i64, _vp, _i64, _i64,
-                             _i32, _vp, _vp, _i64, _vp]),
-    "enh_gemm_bf16_ws": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _i64, _i64, _i64, _vp, _i32, _vp, _i64, _vp, _i64, _i64,
-                                _i32, _vp, _vp, _i64, _vp, _sz, _vp]),
-    "enh_gemm_bf16_workspace_bytes": (_sz, [_i32, _i32, _i64, _i64, _i64]),
+    "enh_gemm_h16": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _i64, _i64, _i64, _vp, _i32, _vp, _i64, _vp, _i64, _i64,
+                            _i32, _vp, _vp, _i64, _i32, _vp]),
+    "enh_gemm_h16_ws": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _i64, _i64, _i64, _vp, _i32, _vp, _i64, _vp, _i64, _i64,
+                               _i32, _vp, _vp, _i64, _vp, _sz, _i32, _vp]),
+    "enh_gemm_h16_workspace_bytes": (_sz, [_i32, _i32, _i64, _i64, _i64]),
     "enh_gemm_set_kernel": (_i32, [_i32]),
     "enh_gemm_set_scheduler": (_i32, [_i32]),
     "enh_set_cu_budget": (_i32, [_i32]),
     "enh_get_cu_budget": (_i32, []),
     "enh_debug_occupy_cus": (_i32, [_i32, _f32, _vp]),
-    "enh_gemm_bf16_variant": (_c.c_char_p, [_i32, _i32, _i64, _i64, _i64]),
-    "enh_gemm_bf16_variant_mode": (_c.c_char_p, [_i32, _i32, _i64, _i64, _i64, _i32]),
-    "enh_gemm_bf16_dtanh_colsum_workspace_bytes": (_c.c_size_t, [_i32, _i64, _i64, _i64]),
-    "enh_gemm_bf16_dtanh_colsum": (_i32, [_vp, _i64, _vp, _i64, _i32, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _c.c_size_t, _vp]),
+    "enh_gemm_h16_variant": (_c.c_char_p, [_i32, _i32, _i64, _i64, _i64]),
+    "enh_gemm_h16_variant_mode": (_c.c_char_p, [_i32, _i32, _i64, _i64, _i64, _i32]),
+    "enh_gemm_h16_dtanh_colsum_workspace_bytes": (_c.c_size_t, [_i32, _i64, _i64, _i64]),
+    "enh_gemm_h16_dtanh_colsum": (_i32, [_vp, _i64, _vp, _i64, _i32, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _c.c_size_t, _i32, _vp]),
     "enh_attention_set_kernel": (_i32, [_i32, _i32, _i32]),
-    "enh_attention_forward": (_i32, [_vp, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp]),
-    "enh_attention_backward": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp]),
-    "enh_patchify": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
-    "enh_unpatchify_loss": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp]),
-    "enh_colsum_bf16": (_i32, [_vp, _i64, _i64, _i64, _vp, _i32, _vp]),
-    "enh_colsum_bf16_ws": (_i32, [_vp, _i64, _i64, _i64, _vp, _i32, _vp, _sz, _vp]),
-    "enh_colsum_bf16_workspace_bytes": (_sz, [_i64, _i64]),
-    "enh_cast_f32_bf16": (_i32, [_vp, _vp, _i64, _vp]),
-    "enh_cast_f32_bf16_head_scaled": (_i32, [_vp, _vp, _i64, _i64, _f32, _vp]),
-    "enh_cast_f32_bf16_head_scaled_strided": (_i32, [_vp, _i64, _vp, _i64, _i64, _i64, _f32, _i32, _vp]),
+    "enh_attention_forward": (_i32, [_vp, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _i32, _vp]),
+    "enh_attention_backward": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _i32, _vp]),
+    "enh_patchify": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
+    "enh_unpatchify_loss": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _i32, _vp]),
+    "enh_colsum_h16": (_i32, [_vp, _i64, _i64, _i64, _vp, _i32, _i32, _vp]),
+    "enh_colsum_h16_ws": (_i32, [_vp, _i64, _i64, _i64, _vp, _i32, _vp, _sz, _i32, _vp]),
+    "enh_colsum_h16_workspace_bytes": (_sz, [_i64, _i64]),
+    "enh_cast_f32_h16": (_i32, [_vp, _vp, _i64, _i32, _vp]),
+    "enh_cast_f32_h16_head_scaled": (_i32, [_vp, _vp, _i64, _i64, _f32, _i32, _vp]),
+    "enh_cast_f32_h16_head_scaled_strided": (_i32, [_vp, _i64, _vp, _i64, _i64, _i64, _f32, _i32, _i32, _vp]),
     "enh_crop_flip_u8": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),
     "enh_resize_u8_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "enh_resize_u8": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _sz, _vp]),
@@ -110,11 +110,12 @@ SIGNATURES = {
     "enh_gemm_bf16_split": (_i32, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     "enh_layernorm_forward_x3": (_i32, [_vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "enh_attention_forward_x3": (_i32, [_vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp]),
-    "enh_adamw_step": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
+    "enh_adamw_step": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _i32, _vp]),
+    "enh_nonfinite_flag": (_i32, [_vp, _i64, _vp, _vp]),
 }
 
 _LIB = None
-ABI_VERSION = 13  # ENH_ABI_VERSION of the include/enh_hip.h these signatures were written against
+ABI_VERSION = 14  # ENH_ABI_VERSION of the include/enh_hip.h these signatures were written against
 
 
 def lib():
@@ -171,7 +172,7 @@ def _p(t: Optional[torch.Tensor], dtype: Optional[torch.dtype] = None, name: str
         raise RuntimeError(f"{name} must be on a ROCm device (got {t.device}); the HIP path has no CPU fallback")
     if not t.is_contiguous():
         raise RuntimeError(f"{name} must be contiguous")
-    if dtype is not None and t.dtype != dtype:
+    if dtype is not None and (t.dtype not in dtype if isinstance(dtype, tuple) else t.dtype != dtype):
         raise RuntimeError(f"{name} must be {dtype}, got {t.dtype}")
     return ctypes.c_void_p(t.data_ptr())
 
@@ -180,7 +181,18 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-F32, BF16, I64, F64 = torch.float32, torch.bfloat16, torch.int64, torch.float64
+F32, BF16, F16, I64, F64 = torch.float32, torch.bfloat16, torch.float16, torch.int64, torch.float64
+H16 = (BF16, F16)      # the two 16-bit operand formats of the product path (include/enh_hip.h ENH_DT_BF16 / ENH_DT_F16)
+DT_BF16, DT_F16 = 0, 1
+
+
+def _dt(*tensors) -> int:
+    """the C ABI's dtype argument of a call, inferred from its 16-bit containers (torch.bfloat16 -> ENH_DT_BF16, torch.float16 -> ENH_DT_F16): all of one call's
+    16-bit tensors must have the same format.  Calls without a 16-bit tensor pass the default (bf16)."""
+    dts = {t.dtype for t in tensors if t is not None and t.dtype in H16}
+    if len(dts) > 1:
+        raise RuntimeError("the 16-bit operands of one call must all be bf16 or all be fp16")
+    return DT_F16 if dts == {F16} else DT_BF16
 
 
 class KernelTimer:
@@ -232,13 +244,13 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
     return ws
 
 
-def vq_forward(z: torch.Tensor, codebook: torch.Tensor, beta: float, depth: int, use_norm: bool, want_bf16: bool = True):
-    """z [M,32] f32, codebook [K,32] f32 -> (zq f32 [M,32], zq_bf16|None, idx i64 [M,depth], loss f32 [1])."""
+def vq_forward(z: torch.Tensor, codebook: torch.Tensor, beta: float, depth: int, use_norm: bool, want_bf16: bool = True, h16: torch.dtype = BF16):
+    """z [M,32] f32, codebook [K,32] f32 -> (zq f32 [M,32], zq 16-bit copy (format h16) | None, idx i64 [M,depth], loss f32 [1])."""
     _p(z, F32, "z"); _p(codebook, F32, "codebook")  # device / dtype / contiguity first: fail before allocating
     M, d = z.shape
     K = codebook.shape[0]
     zq = torch.empty_like(z)
-    zq16 = torch.empty(M, d, dtype=BF16, device=z.device) if want_bf16 else None
+    zq16 = torch.empty(M, d, dtype=h16, device=z.device) if want_bf16 else None
     idx = torch.empty(M, depth, dtype=I64, device=z.device)
     loss = torch.empty(1, dtype=F32, device=z.device)
     L = lib()
@@ -247,37 +259,37 @@ def vq_forward(z: torch.Tensor, codebook: torch.Tensor, beta: float, depth: int,
     # work model: 2*K*d FLOP per token per depth on the exact-f32 MFMA (157.3 TF peak); the call = vq_prep + vq_nn + vq_loss_finalize
     _timed("vq_forward (vq_prep + vq_nn_kernel + vq_loss_finalize)", 2.0 * M * K * d * depth,
            lambda: _check(L.enh_vq_forward(_p(z, F32, "z"), _p(codebook, F32, "codebook"), M, K, d, beta, depth, int(use_norm), _p(zq), _p(zq16),
-                                           _p(idx), _p(loss), _p(ws), ws.numel(), _stream()), "enh_vq_forward"), unit="flop_f32")
+                                           _p(idx), _p(loss), _p(ws), ws.numel(), _dt(zq16), _stream()), "enh_vq_forward"), unit="flop_f32")
     return zq, zq16, idx, loss
 
 
 def vq_backward(z, codebook, idx, g_out, g_loss: float, g_loss_dev: Optional[torch.Tensor], beta: float, depth: int,
-                use_residual: bool, use_norm: bool, d_codebook: torch.Tensor, want_bf16: bool = True):
+                use_residual: bool, use_norm: bool, d_codebook: torch.Tensor, want_bf16: bool = True, h16: torch.dtype = BF16):
     """Returns (dz f32, dz_bf16|None); ACCUMULATES into d_codebook [K,32] f32."""
     _p(z, F32, "z"); _p(codebook, F32, "codebook")
     M, d = z.shape
     K = codebook.shape[0]
     dz = torch.empty_like(z)
-    dz16 = torch.empty(M, d, dtype=BF16, device=z.device) if want_bf16 else None
+    dz16 = torch.empty(M, d, dtype=h16, device=z.device) if want_bf16 else None
     L = lib()
     nb = L.enh_vq_workspace_bytes(M, K, depth)
     ws = _workspace(nb, z.device)
     _check(L.enh_vq_backward(_p(z, F32, "z"), _p(codebook, F32, "codebook"), _p(idx, I64, "idx"), _p(g_out, F32, "g_out"),
                              float(g_loss), _p(g_loss_dev, F32, "g_loss_dev"), M, K, d, beta, depth, int(use_residual),
-                             int(use_norm), _p(dz), _p(dz16), _p(d_codebook, F32, "d_codebook"), _p(ws), ws.numel(), _stream()),
+                             int(use_norm), _p(dz), _p(dz16), _p(d_codebook, F32, "d_codebook"), _p(ws), ws.numel(), _dt(dz16), _stream()),
            "enh_vq_backward")
     return dz, dz16
 
 
-def vq_lookup(codebook, idx, use_norm: bool, want_bf16: bool = True):
+def vq_lookup(codebook, idx, use_norm: bool, want_bf16: bool = True, h16: torch.dtype = BF16):
     """idx [M,depth] i64 -> (sum_i n(E[idx_i]) f32 [M,32], bf16 copy)."""
     _p(idx, I64, "idx"); _p(codebook, F32, "codebook")
     M, depth = idx.shape
     K, d = codebook.shape
     out = torch.empty(M, d, dtype=F32, device=idx.device)
-    out16 = torch.empty(M, d, dtype=BF16, device=idx.device) if want_bf16 else None
+    out16 = torch.empty(M, d, dtype=h16, device=idx.device) if want_bf16 else None
     _check(lib().enh_vq_lookup(_p(codebook, F32, "codebook"), _p(idx, I64, "idx"), M, K, d, depth, int(use_norm), _p(out), _p(out16),
-                               _stream()), "enh_vq_lookup")
+                               _dt(out16), _stream()), "enh_vq_lookup")
     return out, out16
 
 
@@ -286,29 +298,30 @@ def vq_lookup(codebook, idx, use_norm: bool, want_bf16: bool = True):
 # ------------------------------------------------------------------------------------------------
 def layernorm_forward(x, w, b, eps: float = 1e-5, y_bf16=None, y_f32=None, mean=None, rstd=None):
     M, D = x.shape
-    _check(lib().enh_layernorm_forward(_p(x, F32, "x"), _p(w, F32, "w"), _p(b, F32, "b"), M, D, eps, _p(y_bf16, BF16, "y_bf16"),
-                                       _p(y_f32, F32, "y_f32"), _p(mean, F32, "mean"), _p(rstd, F32, "rstd"), _stream()),
+    _check(lib().enh_layernorm_forward(_p(x, F32, "x"), _p(w, F32, "w"), _p(b, F32, "b"), M, D, eps, _p(y_bf16, H16, "y_bf16"),
+                                       _p(y_f32, F32, "y_f32"), _p(mean, F32, "mean"), _p(rstd, F32, "rstd"), _dt(y_bf16), _stream()),
            "enh_layernorm_forward")
 
 
 def layernorm_backward(dy, x, w, mean, rstd, dres, dx_f32, dx_bf16, dw, db, dx_colsum=None):
     M, D = x.shape
-    dy32, dy16 = (None, dy) if dy.dtype == BF16 else (dy, None)   # upstream gradient: f32, or the dgrad GEMM's bf16 output
+    dy32, dy16 = (None, dy) if dy.dtype in H16 else (dy, None)   # upstream gradient: f32, or the dgrad GEMM's 16-bit output
+    dt = _dt(dy16, dx_bf16)
     if not DETERMINISTIC:
-        _check(lib().enh_layernorm_backward(_p(dy32, F32, "dy"), _p(dy16, BF16, "dy_bf16"), _p(x, F32, "x"), _p(w, F32, "w"), _p(mean, F32, "mean"),
+        _check(lib().enh_layernorm_backward(_p(dy32, F32, "dy"), _p(dy16, H16, "dy_bf16"), _p(x, F32, "x"), _p(w, F32, "w"), _p(mean, F32, "mean"),
                                             _p(rstd, F32, "rstd"), _p(dres, F32, "dres"), M, D, _p(dx_f32, F32, "dx_f32"),
-                                            _p(dx_bf16, BF16, "dx_bf16"), _p(dw, F32, "dw"), _p(db, F32, "db"), _p(dx_colsum, F32, "dx_colsum"),
-                                            _stream()), "enh_layernorm_backward")
+                                            _p(dx_bf16, H16, "dx_bf16"), _p(dw, F32, "dw"), _p(db, F32, "db"), _p(dx_colsum, F32, "dx_colsum"),
+                                            dt, _stream()), "enh_layernorm_backward")
         return
     # deterministic form: per-workgroup column partials in a caller-owned workspace + a fixed-order second pass (no f32 atomics)
     nb = lib().enh_layernorm_backward_workspace_bytes(M, D)
     ws = _workspace(nb, x.device)
     # algorithmic HBM bytes per element: dy (2 or 4) + x 4 + dres 4 in, dx f32 4 + dx bf16 2 out  (16 B/elem with bf16 dy)
     bpe = (2 if dy16 is not None else 4) + 4 + (4 if dres is not None else 0) + (4 if dx_f32 is not None else 0) + (2 if dx_bf16 is not None else 0)
-    _timed("ln_bwd_kernel", float(bpe) * M * D, lambda: _check(lib().enh_layernorm_backward_ws(_p(dy32, F32, "dy"), _p(dy16, BF16, "dy_bf16"), _p(x, F32, "x"), _p(w, F32, "w"), _p(mean, F32, "mean"),
+    _timed("ln_bwd_kernel", float(bpe) * M * D, lambda: _check(lib().enh_layernorm_backward_ws(_p(dy32, F32, "dy"), _p(dy16, H16, "dy_bf16"), _p(x, F32, "x"), _p(w, F32, "w"), _p(mean, F32, "mean"),
                                            _p(rstd, F32, "rstd"), _p(dres, F32, "dres"), M, D, _p(dx_f32, F32, "dx_f32"),
-                                           _p(dx_bf16, BF16, "dx_bf16"), _p(dw, F32, "dw"), _p(db, F32, "db"), _p(dx_colsum, F32, "dx_colsum"),
-                                           _p(ws), ws.numel(), _stream()), "enh_layernorm_backward_ws"), unit="byte")
+                                           _p(dx_bf16, H16, "dx_bf16"), _p(dw, F32, "dw"), _p(db, F32, "db"), _p(dx_colsum, F32, "dx_colsum"),
+                                           _p(ws), ws.numel(), dt, _stream()), "enh_layernorm_backward_ws"), unit="byte")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -317,7 +330,8 @@ def layernorm_backward(dy, x, w, mean, rstd, dres, dx_f32, dx_bf16, dw, db, dx_c
 def gemm(a, b, M: int, N: int, K: int, trans_a: bool = False, trans_b: bool = False, bias=None, act: int = ACT_NONE, aux=None,
          res=None, res_rows: int = 0, accumulate: bool = False, out_f32=None, out_bf16=None, lda: Optional[int] = None,
          ldb: Optional[int] = None, ldc: Optional[int] = None):
-    """C[M,N] = epilogue(A(m,k) * B(n,k)); see include/enh_hip.h.  a / b are 2-D bf16 tensors (row-major storage)."""
+    """C[M,N] = epilogue(A(m,k) * B(n,k)); see include/enh_hip.h.  a / b are 2-D 16-bit tensors (row-major storage), both torch.bfloat16 or both
+    torch.float16: the container dtype selects the MFMA operand format (ENH_DT_BF16 / ENH_DT_F16)."""
     lda = a.stride(0) if lda is None else lda
     ldb = b.stride(0) if ldb is None else ldb
     out = out_f32 if out_f32 is not None else out_bf16
@@ -328,44 +342,47 @@ def gemm(a, b, M: int, N: int, K: int, trans_a: bool = False, trans_b: bool = Fa
     # to call — found by the graph-replay bit-identity test.)
     ws, ws_bytes = None, 0
     if accumulate and out_f32 is not None and out_bf16 is None and bias is None and res is None and act == ACT_NONE and ldc == N:
-        ws_bytes = lib().enh_gemm_bf16_workspace_bytes(int(trans_a), int(trans_b), M, N, K)
+        ws_bytes = lib().enh_gemm_h16_workspace_bytes(int(trans_a), int(trans_b), M, N, K)
         if ws_bytes:
             ws = _gemm_workspace(a.device, ws_bytes)
-    args = (_p(a, BF16, "A"), lda, int(trans_a), _p(b, BF16, "B"), ldb, int(trans_b), M, N, K, _p(bias, F32, "bias"),
-            act, _p(aux, BF16, "aux"), aux.stride(0) if aux is not None else 0, _p(res, F32, "res"),
+    dt = _dt(a, b, aux, out_bf16)
+    args = (_p(a, H16, "A"), lda, int(trans_a), _p(b, H16, "B"), ldb, int(trans_b), M, N, K, _p(bias, F32, "bias"),
+            act, _p(aux, H16, "aux"), aux.stride(0) if aux is not None else 0, _p(res, F32, "res"),
             res.stride(0) if res is not None else 0, res_rows if res is not None else 0, int(accumulate),
-            _p(out_f32, F32, "out_f32"), _p(out_bf16, BF16, "out_bf16"), ldc, _p(ws), ws_bytes if ws is not None else 0, _stream())
+            _p(out_f32, F32, "out_f32"), _p(out_bf16, H16, "out_bf16"), ldc, _p(ws), ws_bytes if ws is not None else 0, dt, _stream())
     if TIMER is None:
-        _check(lib().enh_gemm_bf16_ws(*args), "enh_gemm_bf16")
-    else:  # label with the symbol rocprofv3 will report, e.g. "gemm_bf16_pipe2_kernel<false, true>" / "gemm_bf16_w256_kernel<false, false, 1>"
+        _check(lib().enh_gemm_h16_ws(*args), "enh_gemm_h16")
+    else:  # label with the symbol rocprofv3 will report, e.g. "gemm_pipe2_kernel<BF16, false, true>" / "gemm_w256_kernel<F16, false, false, 1>"
         mode = _epi_mode_label(accumulate, ws is not None, out_f32 is not None, out_bf16 is not None, bias is not None, act, res is not None)
         # (a position-table residual, res_rows != M, is not the persistent kernel's case: ask with the generic mode)
-        fam = lib().enh_gemm_bf16_variant_mode(int(trans_a), int(trans_b), M, N, K, 0 if (res is not None and res_rows != M) else mode).decode()
-        targs = f"{'true' if trans_a else 'false'}, {'true' if trans_b else 'false'}"
-        dyn = "true" if _DYN_SCHEDULE[0] else "false"      # the persistent kernels' last template argument: the tile schedule (gemm.hip DYN)
-        if fam == "gemm_bf16_w256r_kernel":   # template <TB, EPI, DYN>: A is never transposed there
-            targs = f"{'true' if trans_b else 'false'}, {mode}, {dyn}"
-        elif fam == "gemm_bf16_w256p_kernel":
+        fam = lib().enh_gemm_h16_variant_mode(int(trans_a), int(trans_b), M, N, K, 0 if (res is not None and res_rows != M) else mode).decode()
+        ot = _OT_NAME[dt]                                   # the kernels' first template argument: the operand type tag (csrc/common.h)
+        targs = f"{ot}, {'true' if trans_a else 'false'}, {'true' if trans_b else 'false'}"
+        dyn = "true" if _DYN_SCHEDULE[0] else "false"      # the persistent kernels' last template argument: the tile schedule (gemm_kernels.h DYN)
+        if fam == "gemm_w256r_kernel":   # template <OT, TB, EPI, DYN>: A is never transposed there
+            targs = f"{ot}, {'true' if trans_b else 'false'}, {mode}, {dyn}"
+        elif fam == "gemm_w256p_kernel":
             targs += f", {mode}, {dyn}"
-        elif fam == "gemm_bf16_w256_kernel":   # the epilogue mode is a template parameter (gemm.hip epi_mode(), mirrored here for the label only)
+        elif fam == "gemm_w256_kernel":   # the epilogue mode is a template parameter (gemm_tiles.h epi_mode(), mirrored here for the label only)
             targs += f", {mode}"
-        TIMER.run(f"{fam}<{targs}>", 2.0 * M * N * K, lambda: _check(lib().enh_gemm_bf16_ws(*args), "enh_gemm_bf16"))
+        TIMER.run(f"{fam}<{targs}>", 2.0 * M * N * K, lambda: _check(lib().enh_gemm_h16_ws(*args), "enh_gemm_h16"))
 
 
 def gemm_dtanh_colsum(a, b, M: int, N: int, K: int, aux, out_bf16, colsum_out, trans_b: bool = True, accumulate_colsum: bool = True):
     """out = (a b) * (1 - aux^2) -> bf16 and colsum_out (+)= column sums of out: enh_gemm_bf16_dtanh_colsum (the tanh' input gradient with the bias
     gradient of the Linear in front of the tanh taken in the GEMM's epilogue instead of by a second pass over `out`)"""
-    nb = lib().enh_gemm_bf16_dtanh_colsum_workspace_bytes(int(trans_b), M, N, K)
+    nb = lib().enh_gemm_h16_dtanh_colsum_workspace_bytes(int(trans_b), M, N, K)
     ws = _workspace(nb, a.device)
-    args = (_p(a, BF16, "A"), a.stride(0), _p(b, BF16, "B"), b.stride(0), int(trans_b), M, N, K, _p(aux, BF16, "aux"), aux.stride(0),
-            _p(out_bf16, BF16, "out_bf16"), out_bf16.stride(0), _p(colsum_out, F32, "colsum"), int(accumulate_colsum), _p(ws), ws.numel(), _stream())
-    call = lambda: _check(lib().enh_gemm_bf16_dtanh_colsum(*args), "enh_gemm_bf16_dtanh_colsum")
+    dt = _dt(a, b, aux, out_bf16)
+    args = (_p(a, H16, "A"), a.stride(0), _p(b, H16, "B"), b.stride(0), int(trans_b), M, N, K, _p(aux, H16, "aux"), aux.stride(0),
+            _p(out_bf16, H16, "out_bf16"), out_bf16.stride(0), _p(colsum_out, F32, "colsum"), int(accumulate_colsum), _p(ws), ws.numel(), dt, _stream())
+    call = lambda: _check(lib().enh_gemm_h16_dtanh_colsum(*args), "enh_gemm_h16_dtanh_colsum")
     if TIMER is None:
         call()
     else:   # labelled with the GEMM kernel's symbol (the partial-row second pass and, off the tile grid, the column-sum kernel ride along)
-        fam = lib().enh_gemm_bf16_variant_mode(0, int(trans_b), M, N, K, 3).decode()
+        fam = lib().enh_gemm_h16_variant_mode(0, int(trans_b), M, N, K, 3).decode()
         dyn = ", true>" if _DYN_SCHEDULE[0] else ", false>"
-        TIMER.run(f"{fam}<false, {'true' if trans_b else 'false'}" + ((", 3" + (dyn if fam == "gemm_bf16_w256p_kernel" else ">")) if "w256" in fam else ">"),
+        TIMER.run(f"{fam}<{_OT_NAME[dt]}, false, {'true' if trans_b else 'false'}" + ((", 3" + (dyn if fam == "gemm_w256p_kernel" else ">")) if "w256" in fam else ">"),
                   2.0 * M * N * K, call)
 
 
@@ -392,6 +409,7 @@ def device_cus() -> int:
 _DEVICE_CUS = [None]
 
 
+_OT_NAME = {DT_BF16: "BF16", DT_F16: "F16"}      # operand type tags as they appear in the kernels' symbol names
 _DYN_SCHEDULE = [True]      # mirrors the library's default (enh_gemm_set_scheduler), for timing labels only
 
 
@@ -460,15 +478,17 @@ def attention_forward(qkv, B: int, N: int, H: int, scale: float, out, lse, q_pre
     # (labelled with the symbol rocprofv3 reports: family 5 — the default — serves pre-scaled q, family 1 everything else)
     fam = _ATT_FAMILY[0] or 5
     name = "attn_fwd_pre_kernel" if (fam == 5 and q_prescaled) else "attn_fwd_kernel"
-    _timed(name, 4.0 * B * H * N * N * 64,
-           lambda: _check(lib().enh_attention_forward(_p(qkv, BF16, "qkv"), B, N, H, scale, int(q_prescaled), _p(out, BF16, "out"), _p(lse, F32, "lse"),
-                                                      _stream()), "enh_attention_forward"))
+    dt = _dt(qkv, out)
+    _timed(f"{name}<{_OT_NAME[dt]}>", 4.0 * B * H * N * N * 64,
+           lambda: _check(lib().enh_attention_forward(_p(qkv, H16, "qkv"), B, N, H, scale, int(q_prescaled), _p(out, H16, "out"), _p(lse, F32, "lse"),
+                                                      dt, _stream()), "enh_attention_forward"))
 
 
 def attention_backward(qkv, out, dout, lse, B: int, N: int, H: int, scale: float, dqkv, delta_ws, q_prescaled: bool = False):
+    dt = _dt(qkv, out, dout, dqkv)
     _timed("attn_bwd (dq+dkv kernels)", 10.0 * B * H * N * N * 64,
-           lambda: _check(lib().enh_attention_backward(_p(qkv, BF16, "qkv"), _p(out, BF16, "out"), _p(dout, BF16, "dout"), _p(lse, F32, "lse"), B, N, H,
-                                                       scale, int(q_prescaled), _p(dqkv, BF16, "dqkv"), _p(delta_ws, F32, "delta_ws"), _stream()),
+           lambda: _check(lib().enh_attention_backward(_p(qkv, H16, "qkv"), _p(out, H16, "out"), _p(dout, H16, "dout"), _p(lse, F32, "lse"), B, N, H,
+                                                       scale, int(q_prescaled), _p(dqkv, H16, "dqkv"), _p(delta_ws, F32, "delta_ws"), dt, _stream()),
                           "enh_attention_backward"))
 
 
@@ -477,38 +497,39 @@ def attention_backward(qkv, out, dout, lse, B: int, N: int, H: int, scale: float
 # ------------------------------------------------------------------------------------------------
 def patchify(img, p: int, out):
     B, C, H, W = img.shape
-    _check(lib().enh_patchify(_p(img, F32, "img"), B, C, H, W, p, _p(out, BF16, "patches"), _stream()), "enh_patchify")
+    _check(lib().enh_patchify(_p(img, F32, "img"), B, C, H, W, p, _p(out, H16, "patches"), _dt(out), _stream()), "enh_patchify")
 
 
 def unpatchify_loss(pix, target, B: int, C: int, H: int, W: int, p: int, w_l1: float, w_l2: float, xrec, sums, dpix):
     _check(lib().enh_unpatchify_loss(_p(pix, F32, "pix"), _p(target, F32, "target"), B, C, H, W, p, w_l1, w_l2, _p(xrec, F32, "xrec"),
-                                     _p(sums, F64, "sums"), _p(dpix, BF16, "dpix"), _stream()), "enh_unpatchify_loss")
+                                     _p(sums, F64, "sums"), _p(dpix, H16, "dpix"), _dt(dpix), _stream()), "enh_unpatchify_loss")
 
 
 def colsum(x, M: int, N: int, out, accumulate: bool = False):
     """out[n] (+)= sum_m x[m, n]; deterministic two-pass form (per-chunk partials in a workspace, fixed-order second pass)"""
     if not DETERMINISTIC:
-        _check(lib().enh_colsum_bf16(_p(x, BF16, "x"), M, N, x.stride(0), _p(out, F32, "out"), int(accumulate), _stream()), "enh_colsum_bf16")
+        _check(lib().enh_colsum_h16(_p(x, H16, "x"), M, N, x.stride(0), _p(out, F32, "out"), int(accumulate), _dt(x), _stream()), "enh_colsum_h16")
         return
-    nb = lib().enh_colsum_bf16_workspace_bytes(M, N)
+    nb = lib().enh_colsum_h16_workspace_bytes(M, N)
     ws = _workspace(nb, x.device)
-    _check(lib().enh_colsum_bf16_ws(_p(x, BF16, "x"), M, N, x.stride(0), _p(out, F32, "out"), int(accumulate), _p(ws), ws.numel(), _stream()), "enh_colsum_bf16_ws")
+    _check(lib().enh_colsum_h16_ws(_p(x, H16, "x"), M, N, x.stride(0), _p(out, F32, "out"), int(accumulate), _p(ws), ws.numel(), _dt(x), _stream()), "enh_colsum_h16_ws")
 
 
 def cast_bf16_head_scaled(x, y, n_scaled: int, alpha: float):
     """y = bf16(x * alpha) for the first n_scaled elements, bf16(x) for the rest"""
-    _check(lib().enh_cast_f32_bf16_head_scaled(_p(x, F32, "x"), _p(y, BF16, "y"), x.numel(), n_scaled, alpha, _stream()), "enh_cast_f32_bf16_head_scaled")
+    _check(lib().enh_cast_f32_h16_head_scaled(_p(x, F32, "x"), _p(y, H16, "y"), x.numel(), n_scaled, alpha, _dt(y), _stream()), "enh_cast_f32_h16_head_scaled")
 
 
 def cast_bf16_head_scaled_strided(x0, x_stride: int, y, n: int, n_scaled: int, alpha: float):
     """y [count, n] bf16 (contiguous) <- the blocks x0 + b * x_stride (x0: the first block, a view into the flat f32 store), q rows scaled by alpha"""
     count = y.shape[0]
-    _check(lib().enh_cast_f32_bf16_head_scaled_strided(_p(x0, F32, "x"), x_stride, _p(y, BF16, "y"), y.stride(0), n, n_scaled, alpha, count, _stream()),
-           "enh_cast_f32_bf16_head_scaled_strided")
+    _check(lib().enh_cast_f32_h16_head_scaled_strided(_p(x0, F32, "x"), x_stride, _p(y, H16, "y"), y.stride(0), n, n_scaled, alpha, count, _dt(y), _stream()),
+           "enh_cast_f32_h16_head_scaled_strided")
 
 
 def cast_bf16(x, y):
-    _check(lib().enh_cast_f32_bf16(_p(x, F32, "x"), _p(y, BF16, "y"), x.numel(), _stream()), "enh_cast_f32_bf16")
+    """y = round-to-nearest-even 16-bit image of x; y's container dtype (torch.bfloat16 / torch.float16) selects the format"""
+    _check(lib().enh_cast_f32_h16(_p(x, F32, "x"), _p(y, H16, "y"), x.numel(), _dt(y), _stream()), "enh_cast_f32_h16")
 
 
 def crop_flip_u8(src, meta, R: int):
@@ -530,12 +551,19 @@ def resize_u8(src, meta, bounds, weights, dst):
     return dst
 
 
+def nonfinite_flag(x, flag):
+    """flag[0] = 1.0 if x (f32, flat) holds an inf / nan; untouched otherwise (zero it once per step)"""
+    _timed("nonfinite_flag_kernel", 4.0 * x.numel(),
+           lambda: _check(lib().enh_nonfinite_flag(_p(x, F32, "x"), x.numel(), _p(flag, F32, "flag"), _stream()), "enh_nonfinite_flag"), unit="byte")
+
+
 def adamw_step(p, g, m, v, p_bf16, step: int, lr: float, beta1: float = 0.9, beta2: float = 0.99, eps: float = 1e-8,
-               weight_decay: float = 1e-4, grad_scale: float = 1.0):
+               weight_decay: float = 1e-4, grad_scale: float = 1.0, skip_flag=None):
     # 30 B per parameter: p, g, m, v read (16) + p, m, v written (12) + the bf16 operand shadow written (2)
     _timed("adamw_kernel", (28.0 + (2.0 if p_bf16 is not None else 0.0)) * p.numel(),
-           lambda: _check(lib().enh_adamw_step(_p(p, F32, "p"), _p(g, F32, "g"), _p(m, F32, "m"), _p(v, F32, "v"), _p(p_bf16, BF16, "p_bf16"),
-                                               p.numel(), step, lr, beta1, beta2, eps, weight_decay, grad_scale, _stream()), "enh_adamw_step"), unit="byte")
+           lambda: _check(lib().enh_adamw_step(_p(p, F32, "p"), _p(g, F32, "g"), _p(m, F32, "m"), _p(v, F32, "v"), _p(p_bf16, H16, "p_bf16"),
+                                               p.numel(), step, lr, beta1, beta2, eps, weight_decay, grad_scale, _p(skip_flag, F32, "skip_flag"),
+                                               _dt(p_bf16), _stream()), "enh_adamw_step"), unit="byte")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -724,8 +752,8 @@ def colsum_nhwc(x):
 def mm(a, b, M: int, N: int, K: int, out, trans_a: bool = False, trans_b: bool = False, bias=None, act: int = ACT_NONE, aux=None, res=None,
        res_rows: int = 0, accumulate: bool = False):
     """C = epilogue(A B^T) into `out`; bf16 operands -> MFMA kernel (out may be bf16 or f32), f32 operands -> exact f32 kernel."""
-    if a.dtype == BF16:
-        if out.dtype == BF16:
+    if a.dtype in H16:
+        if out.dtype in H16:
             gemm(a, b, M, N, K, trans_a, trans_b, bias, act, aux, res, res_rows, accumulate, out_bf16=out)
         else:
             gemm(a, b, M, N, K, trans_a, trans_b, bias, act, aux, res, res_rows, accumulate, out_f32=out)
@@ -736,7 +764,7 @@ def mm(a, b, M: int, N: int, K: int, out, trans_a: bool = False, trans_b: bool =
 
 
 def ln_fwd(x, w, b, y, mean, rstd, y_extra_f32=None):
-    if y.dtype == BF16:
+    if y.dtype in H16:
         layernorm_forward(x, w, b, 1e-5, y, y_extra_f32, mean, rstd)
     else:
         layernorm_forward(x, w, b, 1e-5, None, y, mean, rstd)
@@ -744,18 +772,18 @@ def ln_fwd(x, w, b, y, mean, rstd, y_extra_f32=None):
 
 def ln_bwd(dy, x, w, mean, rstd, dres, dx, dx_operand, dw, db, dx_colsum=None):
     """dx_operand: the tensor the following GEMMs read (a bf16 copy in the product path, dx itself in exact mode)."""
-    layernorm_backward(dy, x, w, mean, rstd, dres, dx, dx_operand if dx_operand.dtype == BF16 else None, dw, db, dx_colsum)
+    layernorm_backward(dy, x, w, mean, rstd, dres, dx, dx_operand if dx_operand.dtype in H16 else None, dw, db, dx_colsum)
 
 
 def attn_fwd(qkv, B, N, H, scale, out, lse, q_prescaled: bool = False):
-    if qkv.dtype == BF16:
+    if qkv.dtype in H16:
         attention_forward(qkv, B, N, H, scale, out, lse, q_prescaled)
     else:
         _check(lib().enh_attention_forward_f32(_p(qkv, F32, "qkv"), B, N, H, scale, _p(out, F32, "out"), _p(lse, F32, "lse"), _stream()), "enh_attention_forward_f32")
 
 
 def attn_bwd(qkv, out, dout, lse, B, N, H, scale, dqkv, delta_ws, q_prescaled: bool = False):
-    if qkv.dtype == BF16:
+    if qkv.dtype in H16:
         attention_backward(qkv, out, dout, lse, B, N, H, scale, dqkv, delta_ws, q_prescaled)
     else:
         _check(lib().enh_attention_backward_f32(_p(qkv, F32, "qkv"), _p(out, F32, "out"), _p(dout, F32, "dout"), _p(lse, F32, "lse"), B, N, H, scale,
@@ -788,7 +816,7 @@ def _split_label(K: int, mode: int) -> str:
     """the symbol rocprofv3 reports for an enh_gemm_bf16_split call (the A-in-registers form serves an even number >= 6 of K stages)"""
     dyn = "true" if _DYN_SCHEDULE[0] else "false"
     nst = K // 64
-    return f"gemm_bf16_w256r_kernel<false, {mode}, {dyn}>" if (nst % 2 == 0 and nst >= 6) else f"gemm_bf16_w256p_kernel<false, false, {mode}, {dyn}>"
+    return f"gemm_w256r_kernel<BF16, false, {mode}, {dyn}>" if (nst % 2 == 0 and nst >= 6) else f"gemm_w256p_kernel<BF16, false, false, {mode}, {dyn}>"
 
 
 def _poff(t: torch.Tensor, elems: int):
@@ -827,14 +855,14 @@ def attention_forward_x3(qkv_hi, qkv_lo, B: int, N: int, H: int, scale: float, o
 
 
 def colsum_any(x, M, N, out, accumulate=False):
-    if x.dtype == BF16:
+    if x.dtype in H16:
         colsum(x, M, N, out, accumulate)
     else:
         _check(lib().enh_colsum_f32(_p(x, F32, "x"), M, N, x.stride(0), _p(out, F32, "out"), int(accumulate), _stream()), "enh_colsum_f32")
 
 
 def patchify_any(img, p, out):
-    if out.dtype == BF16:
+    if out.dtype in H16:
         patchify(img, p, out)
     else:
         B, C, H, W = img.shape
@@ -842,7 +870,7 @@ def patchify_any(img, p, out):
 
 
 def unpatchify_loss_any(pix, target, B, C, H, W, p, w_l1, w_l2, xrec, sums, dpix):
-    if dpix is None or dpix.dtype == BF16 or target is None:
+    if dpix is None or dpix.dtype in H16 or target is None:
         unpatchify_loss(pix, target, B, C, H, W, p, w_l1, w_l2, xrec, sums, dpix)
     else:
         _check(lib().enh_unpatchify_loss_f32(_p(pix, F32, "pix"), _p(target, F32, "target"), B, C, H, W, p, w_l1, w_l2, _p(xrec, F32, "xrec"),

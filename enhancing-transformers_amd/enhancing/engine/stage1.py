@@ -23,7 +23,10 @@ import torch.nn as nn
 
 from .. import _C
 
-F32, BF16 = torch.float32, torch.bfloat16
+F32, BF16, F16 = torch.float32, torch.bfloat16, torch.float16
+# precision modes of the engine: the two product paths ("bf16" / "fp16": 16-bit MFMA operands of that format, fp32 accumulation / residual stream /
+# statistics / master weights) and the exact mode ("fp32": every operand fp32, vector-ALU kernels — the parity instrument)
+OPERAND_DTYPE = {"bf16": BF16, "fp16": F16, "fp32": F32}
 _ALIGN = 64  # elements; keeps every parameter view 16-byte aligned in both the fp32 and the bf16 buffer
 
 
@@ -34,6 +37,8 @@ class ParamStore:
         """prefixes: restrict the store to parameters whose name starts with one of them (one store per optimizer)"""
         self.device = device
         self.precision = precision
+        self.half = precision in ("bf16", "fp16")          # a product path: 16-bit operand shadow of the weights, rewritten by the AdamW kernel
+        self.op_dtype = OPERAND_DTYPE[precision]
         mine = (lambda n: True) if prefixes is None else (lambda n: n.startswith(prefixes))
         params = [(n, p) for n, p in module.named_parameters() if p.requires_grad and mine(n)]
         self.names, self.offsets, total = self.layout(params)
@@ -42,7 +47,7 @@ class ParamStore:
         self.g = torch.zeros(total, dtype=F32, device=device)
         self.m = torch.zeros(total, dtype=F32, device=device)
         self.v = torch.zeros(total, dtype=F32, device=device)
-        self.p16 = torch.zeros(total, dtype=BF16, device=device)
+        self.p16 = torch.zeros(total, dtype=self.op_dtype if self.half else BF16, device=device)
         self.w: Dict[str, torch.Tensor] = {}
         self.w16: Dict[str, torch.Tensor] = {}
         self.grad: Dict[str, torch.Tensor] = {}
@@ -58,8 +63,8 @@ class ParamStore:
             if not p.requires_grad and mine(n):
                 p.data = p.data.to(device=device, dtype=F32).contiguous()
                 self.w[n] = p.data
-        # GEMM operand view of every weight: the bf16 shadow (product path) or the fp32 master itself (exact mode)
-        self.wa = self.w16 if precision == "bf16" else self.w
+        # GEMM operand view of every weight: the 16-bit shadow (product paths) or the fp32 master itself (exact mode)
+        self.wa = self.w16 if self.half else self.w
         self.step_count = 0
         self.version = 0                   # bumped whenever the fp32 masters may have changed: lazily rebuilt operand images (the x3 weights) compare it
         self.operand_hooks: List = []      # callables that rebuild derived GEMM operands (e.g. the towers' pre-scaled q | k | v weights) from the masters
@@ -87,7 +92,7 @@ class ParamStore:
 
     def refresh_shadows(self) -> None:
         """to be called after ANY write to the fp32 masters that did not go through Stage1Engine.optimizer_step (initial broadcast, weight loading)"""
-        if self.precision == "bf16":
+        if self.half:
             _C.cast_bf16(self.p, self.p16)
         self.refresh_operands()
 
@@ -143,10 +148,10 @@ class _Tower:
         # Known asymmetry: forward operand / alpha and the backward operand bf16(W_q) are two separate roundings of the same master, so they differ by
         # up to one bf16 ulp (2^-7 relative worst case, 2^-9 rms) — the size of the rounding either already carries against the master; bounded in
         # tests/test_ops_gpu.py::test_head_scaled_cast_and_the_forward_backward_operand_gap.  x3 and fp32 modes use the unscaled operand both ways.
-        self.q_prescaled = store.precision == "bf16" and os.environ.get("ENH_ATTN_PRESCALE", "1") != "0"
+        self.q_prescaled = store.half and os.environ.get("ENH_ATTN_PRESCALE", "1") != "0"
         self.wqkv_fwd: List[torch.Tensor] = []
         if self.q_prescaled:
-            self._wqkv_fwd_all = torch.empty(depth, 3 * self.inner, dim, dtype=torch.bfloat16, device=store.device)
+            self._wqkv_fwd_all = torch.empty(depth, 3 * self.inner, dim, dtype=store.op_dtype, device=store.device)
             self.wqkv_fwd = [self._wqkv_fwd_all[i] for i in range(depth)]
             store.operand_hooks.append(self.refresh_qkv_operands)
             self.refresh_qkv_operands()
@@ -169,7 +174,7 @@ class _Tower:
         if key in self._bufs:
             return self._bufs[key]
         dev, M, H, N = self.s.device, B * self.n_tok, self.heads, self.n_tok
-        BF16 = torch.bfloat16 if self.s.precision == "bf16" else torch.float32  # activation-operand dtype of this precision mode
+        BF16 = self.s.op_dtype  # activation-operand dtype of this precision mode (bf16 | fp16 | fp32)
         e = lambda *shape, dt=F32: torch.empty(*shape, dtype=dt, device=dev)
         n_layer_sets = self.depth if save else 1
         layers = []
@@ -180,7 +185,7 @@ class _Tower:
         b = dict(layers=layers, x=[e(M, self.dim) for _ in range(self.depth + 1 if save else 2)],
                  xf16=e(M, self.dim, dt=BF16), xf32=e(M, self.dim), meanf=e(M), rstdf=e(M))
         if save:  # backward scratch, shared by all layers (in exact mode the "16" operand copies ARE the f32 tensors)
-            exact = self.s.precision != "bf16"
+            exact = not self.s.half
             gA, gB = e(M, self.dim), e(M, self.dim)
             b.update(gA=gA, gA16=gA if exact else e(M, self.dim, dt=BF16), gB=gB, gB16=gB if exact else e(M, self.dim, dt=BF16),
                      dA=e(M, self.dim, dt=F32 if exact else BF16), dhid16=e(M, self.mlp, dt=BF16), do16=e(M, self.inner, dt=BF16),
@@ -223,6 +228,8 @@ class _Tower:
         cores).  With save=True the arena receives exactly what the bf16 forward would have saved (the hi planes), so backward() is unchanged —
         except that q is NOT pre-scaled here (recorded in the buffer dict)."""
         s, b, X, W3 = self.s, self.bufs(B, save), self.x3_bufs(B), self.x3_weights()
+        if s.precision != "bf16" and save:
+            raise RuntimeError("the x3 forward saves bf16 hi planes for a bf16 backward: training with an x3 tower needs precision='bf16'")
         M, dim, inner, mlp = B * self.n_tok, self.dim, self.inner, self.mlp
         fuse = os.environ.get("ENH_X3_FUSED_SPLIT", "1") != "0"      # A/B switch: the round-4 form (GEMM -> f32, split kernel) with 0
         fused_qkv = fuse and _C.gemm_split_fused(M, 3 * inner, 3 * dim)
@@ -230,6 +237,8 @@ class _Tower:
         x = b["x"][0]
         for i, P in enumerate(self.L):
             A, W = b["layers"][i if save else 0], W3[i]
+            if not save and A["qkv"].dtype != torch.bfloat16:      # (no-save arena of an fp16 engine: the buffer is scratch here, its bits are bf16 hi planes)
+                A = dict(A, qkv=A["qkv"].view(torch.bfloat16))
             _C.ln_fwd_x3(x, s.w[P["ln1_w"]], s.w[P["ln1_b"]], X["a3"], A["mean1"], A["rstd1"], y_bf16=A["a1"] if save else None)
             if fused_qkv:      # hi / lo planes straight from the GEMM's epilogue (no f32 [M, 3 inner] round trip)
                 _C.gemm_split2(X["a3"], W["wqkv"], M, 3 * inner, 3 * dim, A["qkv"], X["qkv_lo"])
@@ -296,7 +305,7 @@ class _Tower:
             P, A = self.L[i], b["layers"][i]
             # ---- MLP: x_out = fc2(tanh(fc1(a2))) + x_mid ----
             _C.mm(gA16, A["hid"], dim, mlp, M, g[P["w2"]], trans_a=True, trans_b=True, accumulate=True)
-            if gA16.dtype == torch.bfloat16:   # input gradient through the tanh + fc1's bias gradient (column sums of it) in one launch
+            if gA16.dtype in _C.H16:   # input gradient through the tanh + fc1's bias gradient (column sums of it) in one launch
                 _C.gemm_dtanh_colsum(gA16, s.wa[P["w2"]], M, mlp, dim, A["hid"], b["dhid16"], g[P["b1"]], trans_b=True, accumulate_colsum=True)
             else:                               # exact-f32 mode
                 _C.mm(gA16, s.wa[P["w2"]], M, mlp, dim, b["dhid16"], trans_b=True, act=_C.ACT_DTANH, aux=A["hid"])
@@ -333,12 +342,14 @@ class _AEFunction(torch.autograd.Function):
     def backward(ctx, g_xrec, g_qloss):
         engine, st = ctx.engine, ctx.st
         B, io = st["B"], engine._io_bufs(st["B"])
+        S = engine.loss_scale      # fp16: the incoming gradients are scaled here; optimizer_step divides the parameter gradients by S again
         if g_xrec is None:
             io["dpix16"].zero_()
         else:
-            _C.patchify_any(g_xrec.to(dtype=F32).contiguous(), engine.patch, io["dpix16"])
+            g32 = g_xrec.to(dtype=F32).contiguous()
+            _C.patchify_any(g32 * S if S != 1.0 else g32, engine.patch, io["dpix16"])
         g_dev = None if g_qloss is None else g_qloss.reshape(1).to(dtype=F32).contiguous()
-        engine.backward_from(st, io["dpix16"], 1.0 if g_qloss is not None else 0.0, g_dev)
+        engine.backward_from(st, io["dpix16"], S if g_qloss is not None else 0.0, g_dev)
         return None, None, None
 
 
@@ -356,8 +367,8 @@ class _EncodeFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_h):
         engine, st = ctx.engine, ctx.st
-        dh = g_h.reshape(st["B"] * engine.n_tok, engine.ed).to(dtype=F32).contiguous()
-        engine.backward_encoder(st, dh if engine.precision != "bf16" else dh.to(BF16), announce_quantizer=False)
+        dh = g_h.reshape(st["B"] * engine.n_tok, engine.ed).to(dtype=F32).contiguous()      # (arrives scaled by the loss scale: _DecodeFn.backward scaled its output)
+        engine.backward_encoder(st, dh.to(engine.adt), announce_quantizer=False)
         return None, None, None
 
 
@@ -376,8 +387,12 @@ class _DecodeFn(torch.autograd.Function):
     def backward(ctx, g_xrec):
         engine, st = ctx.engine, ctx.st
         io = engine._io_bufs(st["B"])
-        _C.patchify_any(g_xrec.to(dtype=F32).contiguous(), engine.patch, io["dpix16"])
+        S = engine.loss_scale
+        g32 = g_xrec.to(dtype=F32).contiguous()
+        _C.patchify_any(g32 * S if S != 1.0 else g32, engine.patch, io["dpix16"])
         dzq = engine.backward_decoder(st, io["dpix16"])
+        # the quantizer between the two halves is plain torch autograd (linear in its upstream gradient): the scaled gradient flows through it into
+        # _EncodeFn.backward unchanged; the quantizer's OWN parameters (differentiated by torch into the flat store) receive scaled gradients as well
         return None, dzq.view(ctx.qshape).clone(), None
 
 
@@ -386,8 +401,12 @@ class Stage1Engine:
 
     def __init__(self, model: nn.Module, device: Optional[torch.device] = None, precision: Optional[str] = None,
                  encoder_precision: Optional[str] = None, codes_precision: Optional[str] = None, decoder_precision: Optional[str] = None) -> None:
-        """precision: "bf16" (product path: bf16 MFMA operands, fp32 accumulation / residual stream / master weights) or "fp32" (exact
-        mode for parity runs: every operand fp32, vector-ALU kernels); default from ENH_PRECISION, else "bf16".
+        """precision: "fp16" | "bf16" (product paths: 16-bit MFMA operands of that format, fp32 accumulation / residual stream / master weights) or
+        "fp32" (exact mode for parity runs: every operand fp32, vector-ALU kernels); default from ENH_PRECISION, else "bf16".
+        "fp16" is the reference's --use_amp dtype (main.py:25,52: Lightning precision=16): 11-bit significands bring the single-pass forward within 1e-3
+        of the fp32 reference (bf16: ~5e-3) at the same MFMA rate; the backward runs on fp16 operands too, with the loss gradient multiplied by a
+        static power-of-two `loss_scale` (ENH_LOSS_SCALE, default 2^16 — GradScaler's initial scale) that the AdamW launch divides out again, and an
+        inf / nan check of the flat gradient that makes that launch a no-op (GradScaler.step's skip).
         Within the bf16 product path the ENCODER forward (patch embedding .. pre_quant, the part that decides the codes) can run on split-bf16
         ("x3") operands — three MFMA passes, ~1e-5 relative, codes equal to the fp32 reference's up to its own near-ties (csrc/x3.hip):
           encoder_precision  "bf16" | "x3": training / reconstruct / forward (ENH_ENCODER_PRECISION, default "bf16": the measured headline path)
@@ -396,16 +415,25 @@ class Stage1Engine:
                              on x3 the whole forward — codes, reconstruction, losses — is within ~1e-5 of the fp32 reference (the backward stays bf16)"""
         import os
         precision = precision or os.environ.get("ENH_PRECISION", "bf16")
-        if precision not in ("bf16", "fp32"):
-            raise ValueError(f"precision must be 'bf16' or 'fp32', got {precision!r}")
+        if precision not in OPERAND_DTYPE:
+            raise ValueError(f"precision must be 'bf16', 'fp16' or 'fp32', got {precision!r}")
         self.precision = precision
-        self.encoder_precision = encoder_precision or os.environ.get("ENH_ENCODER_PRECISION", "bf16")
-        self.codes_precision = codes_precision or os.environ.get("ENH_CODES_PRECISION", "x3")
-        self.decoder_precision = decoder_precision or os.environ.get("ENH_DECODER_PRECISION", "bf16")
+        self.half = precision in ("bf16", "fp16")
+        # per-part precision of the forward: "x3" or the engine's own single-pass operand format (spelled as `precision`; "bf16" is accepted as that
+        # spelling under fp16 too, for the environment variables of earlier rounds).  Under fp16 the codes default to the single fp16 pass: it meets the
+        # 1e-3 clause on its own; x3 stays available as the instrument (encode_codes(precision="x3")).
+        self.encoder_precision = encoder_precision or os.environ.get("ENH_ENCODER_PRECISION", precision)
+        self.codes_precision = codes_precision or os.environ.get("ENH_CODES_PRECISION", "x3" if precision == "bf16" else precision)
+        self.decoder_precision = decoder_precision or os.environ.get("ENH_DECODER_PRECISION", precision)
         for name, v in (("encoder_precision", self.encoder_precision), ("codes_precision", self.codes_precision), ("decoder_precision", self.decoder_precision)):
-            if v not in ("bf16", "x3"):
-                raise ValueError(f"{name} must be 'bf16' or 'x3', got {v!r}")
-        self.adt = BF16 if precision == "bf16" else F32
+            if v not in ("bf16", "fp16", "fp32", "x3"):
+                raise ValueError(f"{name} must be 'x3' or the engine's precision, got {v!r}")
+        if precision != "bf16" and "x3" in (self.encoder_precision, self.decoder_precision):
+            raise ValueError("x3 towers in the TRAINING forward save bf16 hi planes for a bf16 backward: they need precision='bf16' (fp16 meets the tolerance in one pass)")
+        self.adt = OPERAND_DTYPE[precision]
+        # loss scale of the fp16 backward (1 elsewhere): a power of two, so scaling and unscaling are exact
+        self.loss_scale = float(os.environ.get("ENH_LOSS_SCALE", 65536.0)) if precision == "fp16" else 1.0
+        self.check_nonfinite = precision == "fp16" and os.environ.get("ENH_NONFINITE_CHECK", "1") != "0"
         if not torch.cuda.is_available():
             raise RuntimeError("Stage1Engine needs a ROCm device (MI355X); the HIP path has no CPU fallback")
         _C.lib()
@@ -436,6 +464,10 @@ class Stage1Engine:
         self.use_graphs = os.environ.get("ENH_GRAPHS", "0") == "1"
         self._graphs: Dict[tuple, tuple] = {}
         self.store.operand_hooks.append(self._refresh_x3_operands)
+        self.found_inf = torch.zeros(1, dtype=F32, device=self.device) if self.check_nonfinite else None      # written by nonfinite_flag, read by the AdamW launch
+        self.skipped_steps = None      # device counter of dropped steps (fp16): accumulated without a host sync
+        if self.check_nonfinite:
+            self.skipped_steps = torch.zeros(1, dtype=F32, device=self.device)
 
     # ---- helpers -----------------------------------------------------------------------------
     def _invalidate_saved(self) -> None:
@@ -486,7 +518,7 @@ class Stage1Engine:
         """patch-embed GEMM (+bias +pos table) -> encoder tower.  reference layers.py:177-182.  x3: on split-bf16 operands (product path only)."""
         B, s, io = img.shape[0], self.store, self._io_bufs(img.shape[0])
         M = B * self.n_tok
-        if x3 and self.precision == "bf16":
+        if x3 and self.half:
             X = self._x3_io(B)
             _C.patchify_any(img, self.patch, X["patches32"])
             _C.split3(X["patches32"], X["patches3"], y_hi=io["patches"] if save else None)
@@ -514,7 +546,7 @@ class Stage1Engine:
         s, io, M = self.store, self._io_bufs(B), B * self.n_tok
         pp = self.patch * self.patch
         io["bias_pix"].view(self.C, pp).copy_(s.w["decoder.to_pixel.1.bias"].view(self.C, 1).expand(self.C, pp))
-        if zq32 is not None and self.precision == "bf16":
+        if zq32 is not None and self.half:
             X = self._x3_io(B)
             _C.split3(zq32, X["zq3"])
             _C.mm(X["zq3"], X["wpost"], M, self.dec.dim, 3 * self.ed, self.dec.input_buffer(B, save), bias=s.w["post_quant.bias"],
@@ -549,9 +581,9 @@ class Stage1Engine:
         B, io = img.shape[0], self._io_bufs(img.shape[0])
         b = self._encode_tokens(img, save=False, x3=self.encoder_precision == "x3")
         h = self._pre_quant(b, B)
-        exact = self.precision != "bf16"
+        exact = not self.half
         zq, zq16, idx, qloss = _C.vq_forward(h, self.store.w["quantizer.embedding.weight"], float(self.q.beta), self.q.depth, self.q.use_norm,
-                                             want_bf16=not exact)
+                                             want_bf16=not exact, h16=self.adt if self.half else BF16)
         pix = self._decode_tokens(zq if exact else zq16, B, save=False, zq32=zq if self.decoder_precision == "x3" else None)
         _C.unpatchify_loss(pix, None, B, self.C, self.size, self.size, self.patch, 0.0, 0.0, io["xrec"], None, None)
         idx = idx.view(B, self.n_tok, self.q.depth) if self.q.use_residual else idx.view(B, self.n_tok)
@@ -611,8 +643,8 @@ class Stage1Engine:
         outstanding per batch size: a later forward_train overwrites the arena (checked through `_fwd_serial`)."""
         st = self.encode_train(img)
         E = self.store.w["quantizer.embedding.weight"]
-        exact = self.precision != "bf16"
-        zq, zq16, idx, qloss = _C.vq_forward(st["h"], E, float(self.q.beta), self.q.depth, self.q.use_norm, want_bf16=not exact)
+        exact = not self.half
+        zq, zq16, idx, qloss = _C.vq_forward(st["h"], E, float(self.q.beta), self.q.depth, self.q.use_norm, want_bf16=not exact, h16=self.adt if self.half else BF16)
         st.update(idx=idx, qloss=qloss)
         return self.decode_train(st, zq if exact else zq16, zq32=zq)
 
@@ -668,9 +700,10 @@ class Stage1Engine:
         """Backward of forward_train given dpix16 = d loss / d pix in the patch layout [M, C*p*p] (bf16) and the gradient
         flowing into the codebook loss (host scalar g_loss times optional device scalar).  ACCUMULATES into the flat grads."""
         dzq = self.backward_decoder(st, dpix16)
-        exact = self.precision != "bf16"
+        exact = not self.half
         dh, dh16 = _C.vq_backward(st["h"], self.store.w["quantizer.embedding.weight"], st["idx"], dzq, g_loss, g_loss_dev, float(self.q.beta), self.q.depth,
-                                  bool(self.q.use_residual), self.q.use_norm, self.store.grad["quantizer.embedding.weight"], want_bf16=not exact)
+                                  bool(self.q.use_residual), self.q.use_norm, self.store.grad["quantizer.embedding.weight"], want_bf16=not exact,
+                                  h16=self.adt if self.half else BF16)
         self.backward_encoder(st, dh if exact else dh16)
 
     def forward_backward(self, img: torch.Tensor, w_l1: float = 0.0, w_l2: float = 1.0, codebook_weight: float = 1.0,
@@ -684,8 +717,11 @@ class Stage1Engine:
         st = self.forward_train(img)
         img, B, io = st["img"], st["B"], self._io_bufs(st["B"])
         io["sums"].zero_()
-        _C.unpatchify_loss_any(st["pix"], img, B, self.C, self.size, self.size, self.patch, w_l1, w_l2, io["xrec"], io["sums"], io["dpix16"])
-        self.backward_from(st, io["dpix16"], codebook_weight)
+        # (fp16: the loss gradient enters the backward multiplied by the loss scale S — folded into the weights of the pixel-loss gradient and into the
+        # codebook-loss gradient; the loss VALUES below are formed from the unscaled sums; optimizer_step divides the gradients by S again)
+        S = self.loss_scale
+        _C.unpatchify_loss_any(st["pix"], img, B, self.C, self.size, self.size, self.patch, w_l1 * S, w_l2 * S, io["xrec"], io["sums"], io["dpix16"])
+        self.backward_from(st, io["dpix16"], codebook_weight * S)
         numel = float(img.numel())
         l1 = (io["sums"][0] / numel).float()
         l2 = (io["sums"][1] / numel).float()
@@ -738,10 +774,12 @@ class Stage1Engine:
         torch.autograd.grad(loss, last_layer) in the reference (vqperceptual.py:95-103); nothing is accumulated into the gradient buffers."""
         B = g_xrec.shape[0]
         io, db, M = self._io_bufs(B), self.dec.bufs(B, True), B * self.n_tok
-        _C.patchify_any(g_xrec.to(dtype=F32).contiguous(), self.patch, io["dpix16"])
+        S = self.loss_scale
+        g32 = g_xrec.to(dtype=F32).contiguous()
+        _C.patchify_any(g32 * S if S != 1.0 else g32, self.patch, io["dpix16"])
         tmp = torch.zeros(self.dec.dim, self.pd, dtype=F32, device=self.device)
         _C.mm(db["xf16"], io["dpix16"], self.dec.dim, self.pd, M, tmp, trans_a=True, trans_b=True, accumulate=True)
-        return tmp.norm()
+        return tmp.norm() / S if S != 1.0 else tmp.norm()
 
     def differentiable_forward(self, img: torch.Tensor):
         """(xrec, qloss) connected to autograd: `.backward()` on any function of them runs backward_from and leaves the
@@ -769,15 +807,27 @@ class Stage1Engine:
             self.comm.finish()
             grad_scale = grad_scale / self.comm.world
         s.step_count += 1
-        _C.adamw_step(s.p, s.g, s.m, s.v, s.p16 if self.precision == "bf16" else None, s.step_count, lr, betas[0], betas[1], eps, weight_decay,
-                      grad_scale)
+        skip = None
+        if self.loss_scale != 1.0:
+            grad_scale = grad_scale / self.loss_scale
+        if self.check_nonfinite:
+            # GradScaler.step's found-inf skip (reference main.py:25,52 --use_amp), without a host round trip: one pass over the flat gradient sets the
+            # flag, the AdamW launch reads it and writes nothing when it is set.  (The scale itself is static; skipped_steps counts the drops on the
+            # device — read it with .item() outside the step if wanted.  The host step count advances either way: a dropped step then only shifts the
+            # bias correction by one step.)
+            skip = self.found_inf
+            skip.zero_()
+            _C.nonfinite_flag(s.g, skip)
+            self.skipped_steps.add_(skip)
+        _C.adamw_step(s.p, s.g, s.m, s.v, s.p16 if self.half else None, s.step_count, lr, betas[0], betas[1], eps, weight_decay,
+                      grad_scale, skip_flag=skip)
         s.refresh_operands()      # operands derived from the masters (the towers' pre-scaled q | k | v weights, the x3 images: _refresh_x3_operands)
 
     def _refresh_x3_operands(self) -> None:
         """operand hook of the store (runs after EVERY write to the masters: optimizer_step, and refresh_shadows after a checkpoint load / broadcast — ADVICE
         r4): with an x3 TRAINING precision the split weight images are rebuilt eagerly.  They are otherwise rebuilt lazily by the next x3 forward — which a
         HIP-graph replay never runs on the host, so a replay after refresh_shadows() would read the images of the old weights."""
-        if "x3" in (self.encoder_precision, self.decoder_precision) and self.precision == "bf16":
+        if "x3" in (self.encoder_precision, self.decoder_precision) and self.precision == "bf16":      # (x3 training towers exist under bf16 only)
             if self.encoder_precision == "x3":
                 self.enc.x3_weights()
             if self.decoder_precision == "x3":

@@ -3,8 +3,8 @@
 vqperceptual.py:157-158), lowered onto this library's kernels instead of cuDNN:
 
     cols = im2col(x)                       enh_im2col_bf16   (bf16 rows (b,ho,wo) x columns (c,kh,kw))
-    y    = W[Cout, Kp] . cols^T            enh_gemm_bf16     (bf16 MFMA, f32 accumulate, f32 out)
-    dW   = dy . cols ;  dcols = dy^T . W   enh_gemm_bf16     (same kernel family, other storage flags)
+    y    = W[Cout, Kp] . cols^T            enh_gemm_h16     (bf16 MFMA, f32 accumulate, f32 out)
+    dW   = dy . cols ;  dcols = dy^T . W   enh_gemm_h16     (same kernel family, other storage flags)
     dx   = col2im(dcols)                   enh_col2im_f32
 
 Every backward is expressed with the same two differentiable primitives (`_Gemm`, `_Im2col` / `_Col2im`), so gradients of gradients
@@ -46,7 +46,7 @@ def _bf16(t: torch.Tensor) -> torch.Tensor:
 
 
 class _Gemm(Function):
-    """C[M,N] = sum_k A(m,k) B(n,k) on enh_gemm_bf16.  `a` is stored [M,K] (ta False) or [K,M]; `b` is stored [N,K] (tb False) or
+    """C[M,N] = sum_k A(m,k) B(n,k) on enh_gemm_h16.  `a` is stored [M,K] (ta False) or [K,M]; `b` is stored [N,K] (tb False) or
     [K,N]; f32 operands are cast to bf16, bf16 operands are used as they are; the result is f32 unless out_bf16.  wa / wb mark an
     operand as a weight (its gradient is skipped under no_weight_gradients()).  M, N, K must be multiples of 8 so that every
     derivative (which permutes the three roles) satisfies the kernel's alignment rules."""

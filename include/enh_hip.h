@@ -36,10 +36,22 @@ extern "C" {
 #define ENH_E_WORKSPACE (-3)   /* workspace too small */
 #define ENH_E_HIP_BASE (-1000) /* rc = ENH_E_HIP_BASE - hipError_t */
 
-typedef uint16_t enh_bf16; /* raw bfloat16 bits */
+/* 16-bit operand types.  Every MFMA operand of the product path is a 16-bit float in ONE of two formats, selected per call by the `dtype`
+ * argument (always the parameter in front of `stream`):
+ *   ENH_DT_BF16  bfloat16 (8 significand bits, f32's exponent range)         — v_mfma_f32_*_bf16, v_cvt_pk_bf16_f32
+ *   ENH_DT_F16   IEEE binary16 (11 significand bits, max 65504, min normal 6.1e-5) — v_mfma_f32_*_f16, v_cvt_pk_f16_f32
+ * Both roundings are round-to-nearest-even, accumulation is f32 in both, and the two run at the same MFMA rate.  fp16 is the reference's own
+ * mixed-precision dtype (main.py:25,52: --use_amp -> Lightning precision=16 = fp16 autocast + GradScaler): its operand rounding is 8x smaller than
+ * bf16's, which is what brings the activations within 1e-3 of the fp32 reference in ONE MFMA pass; gradients need a loss scale (enh_nonfinite_flag,
+ * enh_adamw_step skip_flag).  Every 16-bit tensor of one call has the call's dtype; entries whose names still say "bf16" and take no dtype (the x3
+ * split-operand family, the convolution family) are bf16-only. */
+#define ENH_DT_BF16 0
+#define ENH_DT_F16 1
+typedef uint16_t enh_h16;  /* raw 16-bit float bits: bfloat16 or binary16, per the call's dtype */
+typedef enh_h16 enh_bf16;  /* raw bfloat16 bits (bf16-only entries) */
 
 const char* enh_last_error(void);
-#define ENH_ABI_VERSION 13  /* bumped whenever a signature below changes; the bindings check it at load */
+#define ENH_ABI_VERSION 14  /* bumped whenever a signature below changes; the bindings check it at load */
 int enh_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -61,103 +73,104 @@ size_t enh_vq_workspace_bytes(int64_t M, int n_embed, int depth);
  *   codebook [K,32] f32   quantizer.embedding.weight
  *   depth    1 = plain VQ ; >1 = residual quantizer with one shared codebook (use_residual, num_quantizers)
  *   zq_out   [M,32] f32   straight-through VALUE  z + (sum_i en_i - z)          (quantizers.py:61)
- *   zq_bf16  [M,32] bf16  optional (may be NULL): same, rounded to bf16 (operand of post_quant GEMM)
+ *   zq_h16   [M,32] 16-bit optional (may be NULL): same, rounded to `dtype` (operand of post_quant GEMM)
  *   idx_out  [M,depth] i64 code indices (stacked on the last axis as quantizers.py:55)
  *   loss_out [1] f32      mean_i( beta*mean((en_i-zn_i)^2) + mean((en_i-zn_i)^2) ) (quantizers.py:56,89-90)
  */
 int enh_vq_forward(const float* z, const float* codebook, int64_t M, int n_embed, int embed_dim,
-                   float beta, int depth, int use_norm, float* zq_out, enh_bf16* zq_bf16,
+                   float beta, int depth, int use_norm, float* zq_out, enh_h16* zq_h16,
                    int64_t* idx_out, float* loss_out, void* workspace, size_t workspace_bytes,
-                   void* stream);
+                   int dtype, void* stream);
 
 /* Backward (derived from the reference autograd graph):
  *   g_out   [M,32] f32  grad wrt returned z_q;  g_loss_dev: optional device scalar multiplying g_loss
  *   use_residual: 1 when the forward ran the residual loop (z is detached at quantizers.py:43, so the
  *           encoder then receives g_out only, and the codebook grad gets the cross-depth term)
  *   dz      [M,32] f32  (VQ: g_out + beta-term through the normalise Jacobian; RQ: g_out only)
- *   dz_bf16 optional bf16 copy ; d_codebook [K,32] f32 is ACCUMULATED into (caller zeroes it).
+ *   dz_h16 optional 16-bit copy (`dtype`) ; d_codebook [K,32] f32 is ACCUMULATED into (caller zeroes it).
  */
 int enh_vq_backward(const float* z, const float* codebook, const int64_t* idx, const float* g_out,
                     float g_loss, const float* g_loss_dev, int64_t M, int n_embed, int embed_dim,
-                    float beta, int depth, int use_residual, int use_norm, float* dz, enh_bf16* dz_bf16,
-                    float* d_codebook, void* workspace, size_t workspace_bytes, void* stream);
+                    float beta, int depth, int use_residual, int use_norm, float* dz, enh_h16* dz_h16,
+                    float* d_codebook, void* workspace, size_t workspace_bytes, int dtype, void* stream);
 
-/* decode_codes front half (vitvqgan.py:81-87): out[m] = sum_i n(codebook[idx[m,i]]) as f32 and bf16 */
+/* decode_codes front half (vitvqgan.py:81-87): out[m] = sum_i n(codebook[idx[m,i]]) as f32 and as a 16-bit operand (`dtype`) */
 int enh_vq_lookup(const float* codebook, const int64_t* idx, int64_t M, int n_embed, int embed_dim,
-                  int depth, int use_norm, float* out, enh_bf16* out_bf16, void* stream);
+                  int depth, int use_norm, float* out, enh_h16* out_h16, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * LayerNorm — nn.LayerNorm(dim), eps 1e-5, biased variance (enhancing/modules/stage1/layers.py:85-92,143)
  * ------------------------------------------------------------------------------------------------ */
-/* y = (x-mean)*rstd*w + b.  x [M,D] f32; y_bf16 [M,D] (GEMM operand) and/or y_f32 (either may be NULL);
+/* y = (x-mean)*rstd*w + b.  x [M,D] f32; y_h16 [M,D] (GEMM operand, `dtype`) and/or y_f32 (either may be NULL);
  * mean,rstd [M] f32 saved for backward (may be NULL for inference).  D % 4 == 0, D <= 2048. */
 int enh_layernorm_forward(const float* x, const float* w, const float* b, int64_t M, int D, float eps,
-                          enh_bf16* y_bf16, float* y_f32, float* mean, float* rstd, void* stream);
-/* dx = LN-backward(dy) [+ dres];  the upstream gradient [M,D] is passed EITHER as dy (f32) OR as dy_bf16 (the bf16 output of the dgrad
+                          enh_h16* y_h16, float* y_f32, float* mean, float* rstd, int dtype, void* stream);
+/* dx = LN-backward(dy) [+ dres];  the upstream gradient [M,D] is passed EITHER as dy (f32) OR as dy_h16 (the 16-bit output of the dgrad
  * GEMM that produced it) — exactly one non-NULL;  dres optional f32 residual-stream gradient that is added;
- * dx_f32 [M,D] f32 and optional dx_bf16 copy; dw,db [D] f32 are ACCUMULATED (atomics; caller zeroes);
+ * dx_f32 [M,D] f32 and optional dx_h16 copy; dw,db [D] f32 are ACCUMULATED (atomics; caller zeroes);
  * dx_colsum [D] f32, optional: += column sums of dx — the bias gradient of the Linear whose output feeds this
  * residual stream (to_out / fc2), fused here so no separate reduction pass over dx is needed. */
-int enh_layernorm_backward(const float* dy, const enh_bf16* dy_bf16, const float* x, const float* w, const float* mean,
+int enh_layernorm_backward(const float* dy, const enh_h16* dy_h16, const float* x, const float* w, const float* mean,
                            const float* rstd, const float* dres, int64_t M, int D, float* dx_f32,
-                           enh_bf16* dx_bf16, float* dw, float* db, float* dx_colsum, void* stream);
+                           enh_h16* dx_h16, float* dw, float* db, float* dx_colsum, int dtype, void* stream);
 /* Deterministic form: the per-workgroup column partials of dw / db / dx_colsum go to `ws` (enh_layernorm_backward_workspace_bytes) and a second pass
  * adds them in a fixed order — bit-reproducible from run to run; enh_layernorm_backward uses f32 atomics instead. */
 size_t enh_layernorm_backward_workspace_bytes(int64_t M, int D);
-int enh_layernorm_backward_ws(const float* dy, const enh_bf16* dy_bf16, const float* x, const float* w, const float* mean,
-                              const float* rstd, const float* dres, int64_t M, int D, float* dx_f32, enh_bf16* dx_bf16, float* dw,
-                              float* db, float* dx_colsum, void* ws, size_t ws_bytes, void* stream);
+int enh_layernorm_backward_ws(const float* dy, const enh_h16* dy_h16, const float* x, const float* w, const float* mean,
+                              const float* rstd, const float* dres, int64_t M, int D, float* dx_f32, enh_h16* dx_h16, float* dw,
+                              float* db, float* dx_colsum, void* ws, size_t ws_bytes, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * bf16 MFMA GEMM with fused epilogue — every nn.Linear / patch conv on the path
+ * 16-bit-operand MFMA GEMM with fused epilogue — every nn.Linear / patch conv on the path
  * (layers.py:99-101,118,120,169,204; vitvqgan.py:38-39) and their dgrad / wgrad.
  * ------------------------------------------------------------------------------------------------
- * C[M,N] = epilogue( sum_k A(m,k) * B(n,k) ),  f32 accumulation on v_mfma_f32_16x16x32_bf16.
+ * C[M,N] = epilogue( sum_k A(m,k) * B(n,k) ),  A, B (and aux, c_h16) in `dtype`, f32 accumulation on v_mfma_f32_32x32x16_{bf16,f16} /
+ * v_mfma_f32_16x16x32_{bf16,f16}.  Shapes, plans, tile order and split-K decisions do not depend on dtype.
  *   trans_a = 0: A stored [M][K] (lda elements between rows) ; 1: A stored [K][M]
  *   trans_b = 0: B stored [N][K] (nn.Linear.weight layout)   ; 1: B stored [K][N]
  *   epilogue, in this order:  v = acc ; v += bias[n] (f32, optional) ; v = tanh(v) if act == 1 ;
- *     v *= (1 - aux[m,n]^2) if act == 2 (aux bf16 = saved tanh output: tanh backward) ;
+ *     v *= (1 - aux[m,n]^2) if act == 2 (aux = saved tanh output: tanh backward) ;
  *     v += res[(m % res_rows), n] (f32, optional; res_rows = M for a residual, n_tokens for a pos-embed) ;
- *     v += C_old if accumulate ;  store to c_f32 and/or c_bf16 (ldc).
+ *     v += C_old if accumulate ;  store to c_f32 and/or c_h16 (ldc).
  *   Requirements: K % 8 == 0, lda/ldb % 8 == 0, 16-byte aligned bases; for trans_a M % 8 == 0; trans_b N % 8 == 0.
  */
 #define ENH_ACT_NONE 0
 #define ENH_ACT_TANH 1
 #define ENH_ACT_DTANH 2
-int enh_gemm_bf16(const enh_bf16* A, int64_t lda, int trans_a, const enh_bf16* B, int64_t ldb, int trans_b,
-                  int64_t M, int64_t N, int64_t K, const float* bias, int act, const enh_bf16* aux,
-                  int64_t ldaux, const float* res, int64_t ldres, int64_t res_rows, int accumulate,
-                  float* c_f32, enh_bf16* c_bf16, int64_t ldc, void* stream);
+int enh_gemm_h16(const enh_h16* A, int64_t lda, int trans_a, const enh_h16* B, int64_t ldb, int trans_b,
+                 int64_t M, int64_t N, int64_t K, const float* bias, int act, const enh_h16* aux,
+                 int64_t ldaux, const float* res, int64_t ldres, int64_t res_rows, int accumulate,
+                 float* c_f32, enh_h16* c_h16, int64_t ldc, int dtype, void* stream);
 
 /* The same with a caller-owned split-K workspace.  Weight-gradient-shaped calls (accumulate = 1, f32 output only, no bias / act / res) whose
- * output tiles cannot fill the chip are split along K; with a workspace of enh_gemm_bf16_workspace_bytes() the K slices write partial slabs
+ * output tiles cannot fill the chip are split along K; with a workspace of enh_gemm_h16_workspace_bytes() the K slices write partial slabs
  * [splits][M][N] and a second pass adds them to C in a fixed order: bit-reproducible, no f32 atomics (needs ldc == N).  workspace = NULL
- * (what enh_gemm_bf16 passes) falls back to f32 atomicAdd into C.  Replaces the autograd wgrad of every nn.Linear (layers.py:99-101,118,120). */
-int enh_gemm_bf16_ws(const enh_bf16* A, int64_t lda, int trans_a, const enh_bf16* B, int64_t ldb, int trans_b,
-                     int64_t M, int64_t N, int64_t K, const float* bias, int act, const enh_bf16* aux,
-                     int64_t ldaux, const float* res, int64_t ldres, int64_t res_rows, int accumulate,
-                     float* c_f32, enh_bf16* c_bf16, int64_t ldc, void* workspace, size_t workspace_bytes, void* stream);
-/* C[M,N] = (A B) * (1 - aux^2) -> bf16 AND colsum[n] (+)= sum_m C[m][n] over the stored (rounded) values: the input gradient through a tanh plus the
+ * (what enh_gemm_h16 passes) falls back to f32 atomicAdd into C.  Replaces the autograd wgrad of every nn.Linear (layers.py:99-101,118,120). */
+int enh_gemm_h16_ws(const enh_h16* A, int64_t lda, int trans_a, const enh_h16* B, int64_t ldb, int trans_b,
+                    int64_t M, int64_t N, int64_t K, const float* bias, int act, const enh_h16* aux,
+                    int64_t ldaux, const float* res, int64_t ldres, int64_t res_rows, int accumulate,
+                    float* c_f32, enh_h16* c_h16, int64_t ldc, void* workspace, size_t workspace_bytes, int dtype, void* stream);
+/* C[M,N] = (A B) * (1 - aux^2) -> 16-bit AND colsum[n] (+)= sum_m C[m][n] over the stored (rounded) values: the input gradient through a tanh plus the
  * bias gradient of the Linear in front of it — the autograd of `nn.Linear -> nn.Tanh` in FeedForward (layers.py:99-101).  On whole 256 x 256 tiles
  * the tanh' kernel's epilogue leaves one partial row per 128 rows in `ws` and a fixed-order second pass adds them (bit-reproducible; the separate
- * column-sum kernel re-reads all of C: 805 MB per layer at the base config); any other shape runs enh_gemm_bf16 then enh_colsum_bf16_ws.
- * A is [M][K] (never transposed here); trans_b as in enh_gemm_bf16. */
-size_t enh_gemm_bf16_dtanh_colsum_workspace_bytes(int trans_b, int64_t M, int64_t N, int64_t K);
-int enh_gemm_bf16_dtanh_colsum(const enh_bf16* A, int64_t lda, const enh_bf16* B, int64_t ldb, int trans_b, int64_t M, int64_t N, int64_t K,
-                               const enh_bf16* aux, int64_t ldaux, enh_bf16* c_bf16, int64_t ldc, float* colsum, int accumulate_colsum,
-                               void* ws, size_t ws_bytes, void* stream);
+ * column-sum kernel re-reads all of C: 805 MB per layer at the base config); any other shape runs enh_gemm_h16 then enh_colsum_h16_ws.
+ * A is [M][K] (never transposed here); trans_b as in enh_gemm_h16. */
+size_t enh_gemm_h16_dtanh_colsum_workspace_bytes(int trans_b, int64_t M, int64_t N, int64_t K);
+int enh_gemm_h16_dtanh_colsum(const enh_h16* A, int64_t lda, const enh_h16* B, int64_t ldb, int trans_b, int64_t M, int64_t N, int64_t K,
+                              const enh_h16* aux, int64_t ldaux, enh_h16* c_h16, int64_t ldc, float* colsum, int accumulate_colsum,
+                              void* ws, size_t ws_bytes, int dtype, void* stream);
 /* bytes of workspace the split-K plan of this shape needs (0 = the shape is not split) */
-size_t enh_gemm_bf16_workspace_bytes(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K);
+size_t enh_gemm_h16_workspace_bytes(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K);
 
-/* name of the kernel family enh_gemm_bf16 launches for this shape (measurement aid: lets callers label timings with
+/* name of the kernel family enh_gemm_h16 launches for this shape (measurement aid: lets callers label timings with
  * the symbol a profiler will report); the choice is per shape */
-const char* enh_gemm_bf16_variant(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K);
-/* the same for a call with a given fused epilogue (epi_mode: 0 generic, 1 bf16, 2 bf16 + bias + tanh, 3 bf16 * tanh', 4 f32 + bias + residual stream,
+const char* enh_gemm_h16_variant(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K);
+/* the same for a call with a given fused epilogue (epi_mode: 0 generic, 1 16-bit, 2 16-bit + bias + tanh, 3 16-bit * tanh', 4 f32 + bias + residual stream,
  * 5 f32, 6 / 7 split-K partials): forward / input-gradient calls of modes 1-5 on whole 256 x 256 tiles run a PERSISTENT form of the 256 x 256
- * kernel — "gemm_bf16_w256p_kernel": one workgroup per CU walks the tiles, the next tile's operands are requested before the stores of this one;
- * "gemm_bf16_w256r_kernel" (modes 1, 2, 5; an even number >= 6 of 64-deep K stages): the same with the A operand staged through registers two
+ * kernel — "gemm_w256p_kernel": one workgroup per CU walks the tiles, the next tile's operands are requested before the stores of this one;
+ * "gemm_w256r_kernel" (modes 1, 2, 5; an even number >= 6 of 64-deep K stages): the same with the A operand staged through registers two
  * stages ahead, which lets its requests stay in flight 1.75 stages instead of 0.75 */
-const char* enh_gemm_bf16_variant_mode(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, int epi_mode);
+const char* enh_gemm_h16_variant_mode(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, int epi_mode);
 /* A/B measurement aid: force a kernel family for every later call that it can serve (-1 = per-shape choice [default], 0 = register-staged
  * fallback, 3 = pipe2 128x128, 7 = w256 256x256 / 4 waves with one tile per workgroup everywhere, 8 = w256 with the persistent form w256p where it
  * serves, 9 = as 8 plus w256r where that serves [what the default picks]).  Process-global, set explicitly by the caller (the Python
@@ -193,16 +206,16 @@ int enh_debug_occupy_cus(int n_wg, float ms, void* stream);
 /* ------------------------------------------------------------------------------------------------
  * Fused attention — Attention.forward layers.py:122-132 without materialising the N x N matrix
  * ------------------------------------------------------------------------------------------------
- * qkv [B,N,3*H*64] bf16 packed exactly as to_qkv emits it (q | k | v thirds, head-major, layers.py:123-124);
- * out [B,N,H*64] bf16 in the 'b n (h d)' layout to_out consumes (layers.py:130); lse [B,H,N] f32 =
+ * qkv [B,N,3*H*64] 16-bit (`dtype`) packed exactly as to_qkv emits it (q | k | v thirds, head-major, layers.py:123-124);
+ * out [B,N,H*64] 16-bit in the 'b n (h d)' layout to_out consumes (layers.py:130); lse [B,H,N] f32 =
  * row log-sum-exp of the scaled scores (saved for backward).  dim_head = 64, N % 64 == 0.
  * q_prescaled = 1: the q third already holds q * scale * log2(e) (the caller folded the softmax scale into the projection's q rows, once, in
- * fp32 before the bf16 rounding).  The score products are then log2-domain logits and the kernels feed -max / -lse / -delta through the MFMA C
+ * fp32 before the 16-bit rounding).  The score products are then log2-domain logits and the kernels feed -max / -lse / -delta through the MFMA C
  * operand instead of spending vector instructions on them (the kernels are vector-issue bound, profiles/r03_attention_lab.txt).  Semantics are
  * unchanged: out / lse are those of softmax(q k^T scale) v for the UNSCALED q, dqkv's q third is the gradient with respect to the unscaled q.
  */
-int enh_attention_forward(const enh_bf16* qkv, int B, int N, int H, float scale, int q_prescaled, enh_bf16* out, float* lse,
-                          void* stream);
+int enh_attention_forward(const enh_h16* qkv, int B, int N, int H, float scale, int q_prescaled, enh_h16* out, float* lse,
+                          int dtype, void* stream);
 /* kernel family per pass for A/B measurements (explicit library state, like enh_gemm_set_kernel), 0 = the library's choice:
  *   fwd: 1 four-wave kernel (round 2; serves both q conventions), 5 the same skeleton with the running reference as the MFMA C operand, a packed exact row
  *        sum and the K / V tiles by LDS-DMA (round 5; pre-scaled q, otherwise family 1) [default]
@@ -211,16 +224,17 @@ int enh_attention_forward(const enh_bf16* qkv, int B, int N, int H, float scale,
  * (the software-pipelined round-3 kernels and the eight-wave antiphase kernels of round 4 were measured slower and are deleted.)
  * Same results up to rounding: every family passes the same parity and bit-reproducibility tests. */
 int enh_attention_set_kernel(int fwd, int dq, int dkv);
-/* dqkv [B,N,3*H*64] bf16 ; delta_ws [B,H,N] f32 scratch */
-int enh_attention_backward(const enh_bf16* qkv, const enh_bf16* out, const enh_bf16* dout, const float* lse,
-                           int B, int N, int H, float scale, int q_prescaled, enh_bf16* dqkv, float* delta_ws, void* stream);
+/* dqkv [B,N,3*H*64] 16-bit ; delta_ws [B,H,N] f32 scratch.  With ENH_DT_F16 the caller keeps dout inside fp16's range (loss scale): p o (dP - delta) is
+ * packed to fp16 before the dQ / dK products. */
+int enh_attention_backward(const enh_h16* qkv, const enh_h16* out, const enh_h16* dout, const float* lse,
+                           int B, int N, int H, float scale, int q_prescaled, enh_h16* dqkv, float* delta_ws, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * "x3" split-bf16 operands — the parity-grade ENCODER forward (round 4).  The reference's forward is fp32 end to end
  * (layers.py:118-132,145-150; vitvqgan.py:61-66; quantizers.py:74-92 consumes its output); bf16 operands flip ~2 % of the argmin decisions
  * downstream.  A value v is carried as hi = bf16(v), lo = bf16(v - hi) and a product as a_hi b_hi + a_lo b_hi + a_hi b_lo in the fp32 MFMA
  * accumulator: ~1e-5 relative end to end at a third of the bf16 MFMA rate (the exact-f32 MFMA has a sixteenth).
- * A GEMM is ONE enh_gemm_bf16 call with K' = 3K on K-concatenated rows  A' = [a_hi | a_lo | a_hi],  B' = [b_hi | b_hi | b_lo].
+ * A GEMM is ONE enh_gemm_h16 (ENH_DT_BF16) call with K' = 3K on K-concatenated rows  A' = [a_hi | a_lo | a_hi],  B' = [b_hi | b_hi | b_lo].
  * ------------------------------------------------------------------------------------------------ */
 /* y3[m] = the x3 row of f(x[m] (+ bias)), f = identity (act 0) or tanh (act 1: FeedForward's activation, layers.py:99-100);
  * order 0: [hi | lo | hi] (A operand), order 1: [hi | hi | lo] (B operand = weights).  x f32 [M,K] (ldx), y3 bf16 [M,3K] (ldy3),
@@ -231,7 +245,7 @@ int enh_split3_bf16(const float* x, int64_t ldx, int64_t M, int64_t K, const flo
 int enh_split2_bf16(const float* x, int64_t n, enh_bf16* hi, enh_bf16* lo, void* stream);
 /* The x3 producers fused into the GEMM that computes their input (round 5): v = A B^T (A [M][K'], B [N][K'] row-major, K' = 3K x3 rows) or
  * v = tanh(A B^T + bias) — reference layers.py:118 (to_qkv) and :99-100 (Linear + Tanh) — leaves hi = bf16(v) in `hi` (and in `hi2`, `hi3` where non-null)
- * and lo = bf16(v - hi) in `lo` (each [M][N] with its own leading dimension), i.e. enh_gemm_bf16 (f32 out) + enh_split2_bf16 / enh_split3_bf16 without the f32
+ * and lo = bf16(v - hi) in `lo` (each [M][N] with its own leading dimension), i.e. enh_gemm_h16 (f32 out) + enh_split2_bf16 / enh_split3_bf16 without the f32
  * round trip; plain mode bit-identical to that pair.  act: ENH_ACT_NONE (bias must be null) | ENH_ACT_TANH (bias required).  Served where the persistent
  * 256 x 256 kernel serves: enh_gemm_bf16_split_fused(M, N, K') == 1 (M, N multiples of 256, enough tiles to fill the chip); ENH_E_SHAPE otherwise. */
 int enh_gemm_bf16_split_fused(int64_t M, int64_t N, int64_t K);
@@ -251,31 +265,37 @@ int enh_attention_forward_x3(const enh_bf16* qkv_hi, const enh_bf16* qkv_lo, int
  * ------------------------------------------------------------------------------------------------ */
 /* 'b c h w -> (b gy gx) (c ph pw)' gather of Conv2d(k=s=p) as a GEMM operand (layers.py:168-171,178);
  * also maps an image-layout gradient to the patch layout (same permutation). */
-int enh_patchify(const float* img, int B, int C, int H, int W, int p, enh_bf16* patches, void* stream);
+int enh_patchify(const float* img, int B, int C, int H, int W, int p, enh_h16* patches, int dtype, void* stream);
 /* Inverse scatter of ConvTranspose2d(k=s=p) (layers.py:202-205,212) fused with the pixel losses
  * (vqperceptual.py:113-114): pix [M, C*p*p] f32 (to_pixel GEMM output incl. bias) -> xrec [B,C,H,W] f32;
  * if target != NULL: sums[0] += sum|xrec-x|, sums[1] += sum (xrec-x)^2 (f64 atomics; caller zeroes) and
- * dpix_bf16 [M, C*p*p] = (w_l1*sign(diff) + w_l2*2*diff) / numel  (grad of w_l1*L1 + w_l2*L2), optional. */
+ * dpix_h16 [M, C*p*p] (`dtype`) = (w_l1*sign(diff) + w_l2*2*diff) / numel  (grad of w_l1*L1 + w_l2*L2), optional — a loss scale for ENH_DT_F16 is
+ * folded into w_l1 / w_l2 by the caller (the sums are unaffected). */
 int enh_unpatchify_loss(const float* pix, const float* target, int B, int C, int H, int W, int p, float w_l1,
-                        float w_l2, float* xrec, double* sums, enh_bf16* dpix_bf16, void* stream);
-/* out[n] (+)= sum_m x[m,n] (bias gradients); x bf16 [M,N] */
-int enh_colsum_bf16(const enh_bf16* x, int64_t M, int64_t N, int64_t ldx, float* out, int accumulate, void* stream);
-/* deterministic form: per-row-chunk partials in `ws` (enh_colsum_bf16_workspace_bytes), added in a fixed order; enh_colsum_bf16 uses f32 atomics */
-size_t enh_colsum_bf16_workspace_bytes(int64_t M, int64_t N);
-int enh_colsum_bf16_ws(const enh_bf16* x, int64_t M, int64_t N, int64_t ldx, float* out, int accumulate, void* ws, size_t ws_bytes, void* stream);
-/* f32 -> bf16 cast (weight shadows) */
-int enh_cast_f32_bf16(const float* x, enh_bf16* y, int64_t n, void* stream);
-/* y[i] = bf16(x[i] * (i < n_scaled ? alpha : 1)), n_scaled % 4 == 0: forward operand of a packed q | k | v projection weight whose leading q rows carry
+                        float w_l2, float* xrec, double* sums, enh_h16* dpix_h16, int dtype, void* stream);
+/* out[n] (+)= sum_m x[m,n] (bias gradients); x 16-bit [M,N] (`dtype`) */
+int enh_colsum_h16(const enh_h16* x, int64_t M, int64_t N, int64_t ldx, float* out, int accumulate, int dtype, void* stream);
+/* deterministic form: per-row-chunk partials in `ws` (enh_colsum_h16_workspace_bytes), added in a fixed order; enh_colsum_h16 uses f32 atomics */
+size_t enh_colsum_h16_workspace_bytes(int64_t M, int64_t N);
+int enh_colsum_h16_ws(const enh_h16* x, int64_t M, int64_t N, int64_t ldx, float* out, int accumulate, void* ws, size_t ws_bytes, int dtype, void* stream);
+/* f32 -> 16-bit cast, round-to-nearest-even (weight shadows) */
+int enh_cast_f32_h16(const float* x, enh_h16* y, int64_t n, int dtype, void* stream);
+/* y[i] = h16(x[i] * (i < n_scaled ? alpha : 1)), n_scaled % 4 == 0: forward operand of a packed q | k | v projection weight whose leading q rows carry
  * the softmax scale * log2(e) (one rounding from the fp32 master; see enh_attention_forward, q_prescaled) */
-int enh_cast_f32_bf16_head_scaled(const float* x, enh_bf16* y, int64_t n, int64_t n_scaled, float alpha, void* stream);
+int enh_cast_f32_h16_head_scaled(const float* x, enh_h16* y, int64_t n, int64_t n_scaled, float alpha, int dtype, void* stream);
 /* the same for `count` equally spaced blocks (block b reads x + b*x_stride, writes y + b*y_stride; strides in elements, multiples of 4): the to_qkv weights of
  * every layer of a tower in one launch */
-int enh_cast_f32_bf16_head_scaled_strided(const float* x, int64_t x_stride, enh_bf16* y, int64_t y_stride, int64_t n, int64_t n_scaled, float alpha,
-                                          int count, void* stream);
+int enh_cast_f32_h16_head_scaled_strided(const float* x, int64_t x_stride, enh_h16* y, int64_t y_stride, int64_t n, int64_t n_scaled, float alpha,
+                                         int count, int dtype, void* stream);
 /* torch.optim.AdamW(lr, betas=(0.9,0.99), weight_decay=1e-4) step over one flat buffer (vitvqgan.py:160),
- * also refreshes the bf16 shadow used by the GEMMs.  grad_scale multiplies g first (DDP mean / accumulation). */
-int enh_adamw_step(float* p, const float* g, float* m, float* v, enh_bf16* p_bf16, int64_t n, int step, float lr,
-                   float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream);
+ * also refreshes the 16-bit operand shadow p_h16 (`dtype`) used by the GEMMs.  grad_scale multiplies g first (DDP mean / accumulation / 1 / loss scale).
+ * skip_flag (optional device float): non-zero = drop this step — nothing is written (p, m, v, p_h16 unchanged): the inf / nan skip of
+ * torch.cuda.amp.GradScaler.step under the reference's --use_amp (main.py:25,52); the flag comes from enh_nonfinite_flag. */
+int enh_adamw_step(float* p, const float* g, float* m, float* v, enh_h16* p_h16, int64_t n, int step, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, float grad_scale, const float* skip_flag, int dtype, void* stream);
+/* flag[0] = 1.0f if any of x[0..n) is inf or nan, otherwise untouched (the caller zeroes it once per step): GradScaler's found-inf check over one flat
+ * gradient buffer, one pass at HBM rate.  x 16-byte aligned. */
+int enh_nonfinite_flag(const float* x, int64_t n, float* flag, void* stream);
 
 /* Device-side tail of the input pipeline (enhancing/dataloader/imagenet.py:26-54: ... RandomCrop / CenterCrop -> RandomHorizontalFlip -> ToTensor):
  * src uint8 [B,Hs,Ws,3] (decoded + resized images, each in the top-left corner of its slot), meta int32 [B,3] = (y0, x0, flip) -> out f32 [B,3,R,R] in [0,1].
@@ -307,7 +327,7 @@ int enh_upfirdn2d(const float* in, const float* kernel, float* out, int64_t majo
                   int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
 
 /* Equalised-lr convolution lowering (EqualConv2d, enhancing/losses/layers.py:163-185: conv2d(x, weight*scale, stride, padding),
- * k in {1,3}, stride in {1,2}) onto enh_gemm_bf16:  cols[(b,ho,wo), c*k*k + kh*k + kw] = x[b,c,ho*stride-pad+kh,wo*stride-pad+kw]
+ * k in {1,3}, stride in {1,2}) onto enh_gemm_h16:  cols[(b,ho,wo), c*k*k + kh*k + kw] = x[b,c,ho*stride-pad+kh,wo*stride-pad+kw]
  * (zero outside the image), bf16, row stride ld = C*k*k rounded up to a multiple of 8 with the pad columns zeroed.  The image is
  * addressed as x[b*stride_b + c*stride_c + h*W + w], so [B,C,H,W] and channel-major [C,B,H,W] activations are both accepted.
  * enh_col2im_f32 is the adjoint (the convolution's input gradient given dcols = dy^T . W): dx is overwritten, no atomics. */

@@ -35,20 +35,20 @@ def test_tile_claim_atomic_is_one_in_flight_instruction(stats):
 
 def test_one_wave_per_simd_kernels_have_no_scratch(stats):
     """a scratch reload is a vector-memory load, i.e. a vmcnt wait on the operand requests in flight"""
-    hot = [n for n in stats if re.search(r"gemm_bf16_w256[pr]_kernel|gemm_bf16_w256_kernel<(true|false), (true|false), [01456]>|"
+    hot = [n for n in stats if re.search(r"gemm_w256[pr]_kernel|gemm_w256_kernel<(BF16|F16), (true|false), (true|false), [01456]>|"
                                          r"conv_igemm_w(256|512)_kernel|conv_wgrad_w256_kernel|attn_(fwd|bwd)", n)]
-    assert len(hot) >= 50, len(hot)
+    assert len(hot) >= 100, len(hot)      # both operand types (BF16, F16) of every persistent / one-tile GEMM and attention kernel
     for n in hot:
         s = stats[n]
         assert s.get("scratch_bytes", 0) == 0 and s.get("spills", 0) == 0 and s.get("scratch_ops", 0) == 0, (n, s)
     for n in stats:
-        if "gemm_bf16_w256" in n and "lab" not in n:
+        if "gemm_w256" in n and "lab" not in n:
             assert stats[n].get("agpr", 0) == 256 and stats[n].get("vgpr", 0) <= 512, (n, stats[n])
 
 
 def test_every_gemm_kernel_is_an_mfma_kernel(stats):
     for n in stats:
-        if n.startswith("void gemm_bf16_w256"):
+        if n.startswith("void gemm_w256"):
             assert stats[n].get("mfma", 0) >= 64, (n, stats[n].get("mfma"))
 
 
@@ -67,11 +67,12 @@ def test_no_inline_asm_vector_instructions_in_the_attention_sources():
 
 def test_attention_row_maximum_is_fused_and_hazard_padded(stats):
     """the nested fmaxf must still become v_max3_f32 (the attention objects are built with -fno-honor-nans), and the kernels keep their occupancy classes"""
-    fwd = "attn_fwd_pre_kernel(unsigned short const*, int, int, int, unsigned short*, float*)"
-    assert stats[fwd].get("max3", 0) >= 15, stats[fwd]                                                                      # the 32-way row maximum: v_max3 chains, no canonicalising v_max x, x
-    assert stats[fwd]["vgpr"] <= 128                                                                                        # four waves per SIMD
-    dkv = [n for n in stats if n.startswith("void attn_bwd_dkv_kernel<true, true>")]
-    dq = [n for n in stats if n.startswith("void attn_bwd_dq_kernel<2>")]
-    assert dkv and dq and stats[dkv[0]]["vgpr"] <= 168 and stats[dq[0]]["vgpr"] <= 168                                          # three waves per SIMD
-    for n in dkv + dq + ["attn_fwd_pre_kernel(unsigned short const*, int, int, int, unsigned short*, float*)"]:
-        assert stats[n].get("scratch_bytes", 0) == 0 and stats[n].get("spills", 0) == 0, (n, stats[n])
+    for ot in ("BF16", "F16"):      # both operand types: same instruction stream up to the MFMA / pack opcodes
+        fwd = f"void attn_fwd_pre_kernel<{ot}>(unsigned short const*, int, int, int, unsigned short*, float*)"
+        assert stats[fwd].get("max3", 0) >= 15, stats[fwd]                                                                      # the 32-way row maximum: v_max3 chains, no canonicalising v_max x, x
+        assert stats[fwd]["vgpr"] <= 128                                                                                        # four waves per SIMD
+        dkv = [n for n in stats if n.startswith(f"void attn_bwd_dkv_kernel<true, true, {ot}>")]
+        dq = [n for n in stats if n.startswith(f"void attn_bwd_dq_kernel<2, {ot}>")]
+        assert dkv and dq and stats[dkv[0]]["vgpr"] <= 168 and stats[dq[0]]["vgpr"] <= 168                                          # three waves per SIMD
+        for n in dkv + dq + [fwd]:
+            assert stats[n].get("scratch_bytes", 0) == 0 and stats[n].get("spills", 0) == 0, (n, stats[n])

@@ -215,9 +215,9 @@ def test_gemm_epilogues(C, kernel_shape):
 
 @pytest.mark.parametrize("kind", ["fwd", "dgrad", "fwd_tanh", "dgrad_dtanh", "fwd_res", "fwd_f32"])
 def test_persistent_gemm_is_bitwise_the_one_tile_kernel(C, kind):
-    """gemm_bf16_w256p_kernel (one workgroup per CU walks the tiles; the next tile's operands are requested before this tile's stores) and
-    gemm_bf16_w256r_kernel (the same with the A operand staged through registers) issue the same MFMA sequence per output element as
-    gemm_bf16_w256_kernel and the same epilogue arithmetic: every output must be BIT-identical — on fewer tiles than CUs, on a ragged last round
+    """gemm_w256p_kernel (one workgroup per CU walks the tiles; the next tile's operands are requested before this tile's stores) and
+    gemm_w256r_kernel (the same with the A operand staged through registers) issue the same MFMA sequence per output element as
+    gemm_w256_kernel and the same epilogue arithmetic: every output must be BIT-identical — on fewer tiles than CUs, on a ragged last round
     (300 tiles), on odd and minimal stage counts (w256r needs an even count >= 6: 448 / 64 = 7 falls back to w256p), in both B layouts and every
     fused mode; one case is also checked against fp64."""
     L = C.lib()
@@ -226,8 +226,8 @@ def test_persistent_gemm_is_bitwise_the_one_tile_kernel(C, kind):
     try:
         for (m, n, k) in ((1024, 768, 192), (256 * 100, 768, 320), (256 * 37, 2304, 448), (256 * 50, 768, 384), (8192, 3072, 768)):
             if not os.environ.get("ENH_GEMM_KERNEL"):   # (a family override re-runs this file with that family pinned)
-                want = "gemm_bf16_w256r_kernel" if (k // 64) % 2 == 0 and k // 64 >= 6 else "gemm_bf16_w256p_kernel"
-                assert L.enh_gemm_bf16_variant_mode(0, int(tb), 131072, n, k, 1).decode() == want    # the per-shape default at training sizes
+                want = "gemm_w256r_kernel" if (k // 64) % 2 == 0 and k // 64 >= 6 else "gemm_w256p_kernel"
+                assert L.enh_gemm_h16_variant_mode(0, int(tb), 131072, n, k, 1).decode() == want    # the per-shape default at training sizes
             A, B = _mk((m, k), g, 0.5), _mk((n, k), g, 0.1)
             a = A.to(torch.bfloat16).cuda()
             b = (B.t().contiguous() if tb else B).to(torch.bfloat16).cuda()
@@ -334,8 +334,8 @@ def test_persistent_gemm_with_row_strides(C, kind):
 
 @pytest.mark.parametrize("M,N,K", [(2048, 768, 192), (256 * 37, 3072, 768), (1000, 192, 256)])
 def test_gemm_dtanh_with_fused_bias_gradient(C, M, N, K):
-    """enh_gemm_bf16_dtanh_colsum: C = (A B) * (1 - aux^2) exactly as enh_gemm_bf16 with act = tanh' produces it (bit for bit), and the column sums of
-    the STORED values as enh_colsum_bf16_ws adds them (same inputs, another fixed summation order: f32 rounding only) — on the tile grid (epilogue
+    """enh_gemm_h16_dtanh_colsum: C = (A B) * (1 - aux^2) exactly as enh_gemm_h16 with act = tanh' produces it (bit for bit), and the column sums of
+    the STORED values as enh_colsum_h16_ws adds them (same inputs, another fixed summation order: f32 rounding only) — on the tile grid (epilogue
     partials + second pass) and off it (the two-call fallback); accumulate adds to the previous bias gradient; two runs are bit-identical."""
     g = torch.Generator().manual_seed(M + N + K)
     a = _mk((M, K), g, 0.5).to(torch.bfloat16).cuda()
@@ -378,9 +378,9 @@ def test_gemm_wgrad_splitk_two_pass_is_deterministic(C):
     g = torch.Generator().manual_seed(10)
     tokens, n_out, k_in = 16384, 768, 768
     if not os.environ.get("ENH_GEMM_KERNEL"):   # (a family override re-runs this file with another kernel: then only the numerics are checked)
-        assert C.lib().enh_gemm_bf16_variant(1, 1, n_out, k_in, tokens).decode() == "gemm_bf16_w256_kernel"
-    assert C.lib().enh_gemm_bf16_workspace_bytes(1, 1, n_out, k_in, tokens) % (n_out * k_in * 4) == 0
-    assert C.lib().enh_gemm_bf16_workspace_bytes(1, 1, n_out, k_in, tokens) >= 2 * n_out * k_in * 4
+        assert C.lib().enh_gemm_h16_variant(1, 1, n_out, k_in, tokens).decode() == "gemm_w256_kernel"
+    assert C.lib().enh_gemm_h16_workspace_bytes(1, 1, n_out, k_in, tokens) % (n_out * k_in * 4) == 0
+    assert C.lib().enh_gemm_h16_workspace_bytes(1, 1, n_out, k_in, tokens) >= 2 * n_out * k_in * 4
     dY, X = _mk((tokens, n_out), g, 0.1).to(torch.bfloat16).cuda(), _mk((tokens, k_in), g).to(torch.bfloat16).cuda()
     ref = dY.double().t() @ X.double()
     base = torch.randn(n_out, k_in, generator=g).cuda()
@@ -403,7 +403,7 @@ def test_split_k_accumulate_is_bit_reproducible_in_every_layout(C, ta, tb):
     M, N, K = 8, 512, 8192
     A, B = _mk((K, M) if ta else (M, K), g, 0.5), _mk((K, N) if tb else (N, K), g, 0.1)
     a, b = A.to(torch.bfloat16).cuda(), B.to(torch.bfloat16).cuda()
-    assert C.lib().enh_gemm_bf16_workspace_bytes(int(ta), int(tb), M, N, K) > 0      # the shape IS split
+    assert C.lib().enh_gemm_h16_workspace_bytes(int(ta), int(tb), M, N, K) > 0      # the shape IS split
     outs = []
     for _ in range(12):
         o = torch.zeros(M, N, device="cuda")
@@ -610,7 +610,7 @@ def test_colsum_cast_adamw(C):
 # ---------------------------------------------------------------------------------------------
 # every GEMM kernel family on every shape it can serve (the per-shape default only exercises one of them)
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("sel,symbol", [("w256", "gemm_bf16_w256_kernel"), ("w256p", "gemm_bf16_w256_kernel"), ("w256r", "gemm_bf16_w256_kernel"), ("pipe2", "gemm_bf16_pipe2_kernel")])
+@pytest.mark.parametrize("sel,symbol", [("w256", "gemm_w256_kernel"), ("w256p", "gemm_w256_kernel"), ("w256r", "gemm_w256_kernel"), ("pipe2", "gemm_pipe2_kernel")])
 def test_gemm_suite_under_each_kernel_family(sel, symbol):
     """the family override is process-global (enh_gemm_set_kernel, mapped from ENH_GEMM_KERNEL by the binding), so the GEMM tests are re-run
     in a child process per family; shapes a family cannot serve fall back to the per-shape choice"""
@@ -618,7 +618,7 @@ def test_gemm_suite_under_each_kernel_family(sel, symbol):
     import sys
     env = dict(os.environ, ENH_GEMM_KERNEL=sel)
     probe = ("import sys; sys.path.insert(0, 'enhancing-transformers_amd'); from enhancing import _C; "
-             "print(_C.lib().enh_gemm_bf16_variant(0, 0, 4096, 4096, 4096).decode())")
+             "print(_C.lib().enh_gemm_h16_variant(0, 0, 4096, 4096, 4096).decode())")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     assert subprocess.run([sys.executable, "-c", probe], env=env, cwd=root, capture_output=True, text=True).stdout.strip() == symbol
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_ops_gpu.py", "-q", "-x", "-m", "gpu", "-k", "gemm and not under_each", "-p", "no:cacheprovider"],

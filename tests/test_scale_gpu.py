@@ -56,7 +56,7 @@ def test_gemm_bench_scale_rows(C, name, N, K, tb, out):
     got = (o32 if o32 is not None else o16)[rows]
     assert torch.isfinite((o32 if o32 is not None else o16).float()).all(), f"{name}: unwritten (NaN) outputs"
     e = rel(got.float(), ref)
-    print(f"{name:10s} M={M} N={N} K={K} [{C.lib().enh_gemm_bf16_variant(0, int(tb), M, N, K).decode()}]: rel {e:.2e} over {len(rows)} rows")
+    print(f"{name:10s} M={M} N={N} K={K} [{C.lib().enh_gemm_h16_variant(0, int(tb), M, N, K).decode()}]: rel {e:.2e} over {len(rows)} rows")
     if out == "f32":
         assert e <= 1e-5
     else:
@@ -78,7 +78,7 @@ def test_gemm_bench_scale_wgrad_splitk(C, name, NO, KI):
     rows = _sample_rows(NO, 192, 7)
     ref = dy[:, rows].double().t() @ x.double() + base[rows].double()
     e = rel(dW[rows], ref)
-    print(f"{name:10s} NO={NO} KI={KI} tokens={M} [{C.lib().enh_gemm_bf16_variant(1, 1, NO, KI, M).decode()}]: rel {e:.2e}")
+    print(f"{name:10s} NO={NO} KI={KI} tokens={M} [{C.lib().enh_gemm_h16_variant(1, 1, NO, KI, M).decode()}]: rel {e:.2e}")
     assert torch.isfinite(dW).all()
     assert e <= 2e-5   # fp32 accumulation over 131072-long sums, split-K partial order
 

@@ -81,7 +81,7 @@ def test_split2_and_layernorm_x3(C):
 
 @pytest.mark.parametrize("M,N,K", [(2048, 2304, 768), (2048, 768, 3072), (2048, 768, 192), (2048, 32, 768), (384, 256, 128)])
 def test_three_pass_product_on_concatenated_operands_vs_fp64(C, M, N, K):
-    """ONE enh_gemm_bf16 call with K' = 3K on [a_hi | a_lo | a_hi] x [b_hi | b_hi | b_lo] == the fp64 product to ~1e-5 (a single bf16 pass: ~3e-3)"""
+    """ONE enh_gemm_h16 call with K' = 3K on [a_hi | a_lo | a_hi] x [b_hi | b_hi | b_lo] == the fp64 product to ~1e-5 (a single bf16 pass: ~3e-3)"""
     torch.manual_seed(2)
     a = torch.randn(M, K, device="cuda")
     b = torch.randn(N, K, device="cuda") * K ** -0.5
@@ -299,7 +299,7 @@ def test_x3_graph_replay_after_refresh_shadows_reads_the_new_weights():
 
 
 def test_gemm_split2_is_bitwise_the_gemm_then_split2(C):
-    """round 5: the qkv projection's hi / lo planes straight from the persistent GEMM's epilogue (enh_gemm_bf16_split) == enh_gemm_bf16 (f32 out) followed
+    """round 5: the qkv projection's hi / lo planes straight from the persistent GEMM's epilogue (enh_gemm_bf16_split) == enh_gemm_h16 (f32 out) followed
     by enh_split2_bf16, bit for bit (same accumulator, same definition hi = bf16(v), lo = bf16(v - hi)); leading dimensions respected"""
     torch.manual_seed(5)
     M, N, K = 8192, 2304, 3 * 768

@@ -40,7 +40,7 @@ def case(name, m, n, k, ta=False, tb=False, out="bf16", acc=False):
     ob = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
     t2 = timeit(lambda: torch.matmul(A, Bm, out=ob))
     fl = 2 * m * n * k
-    var = _C.lib().enh_gemm_bf16_variant(int(ta), int(tb), m, n, k).decode().replace("gemm_bf16_", "").replace("_kernel", "")
+    var = _C.lib().enh_gemm_h16_variant(int(ta), int(tb), m, n, k).decode().replace("gemm_", "").replace("_kernel", "")
     print(f"{name:12s} M={m:7d} N={n:5d} K={k:7d} ours[{var:5s}] {t*1e3:7.3f} ms {fl/t/1e12:7.1f} TF | hipblaslt(bf16 out) {t2*1e3:7.3f} ms {fl/t2/1e12:7.1f} TF", flush=True)
 
 

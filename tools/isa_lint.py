@@ -83,7 +83,7 @@ def persistent_gemm_pairs(stats):
     """(dynamic-schedule symbol, its static-schedule twin) for every persistent GEMM instantiation"""
     pairs = []
     for n in stats:
-        m = re.match(r"void (gemm_bf16_w256[pr]_kernel)<(.*), true>\(GemmArgs\)$", n)
+        m = re.match(r"void (gemm_w256[pr]_kernel)<(.*), true>\(GemmArgs\)$", n)
         if m:
             twin = f"void {m.group(1)}<{m.group(2)}, false>(GemmArgs)"
             assert twin in stats, twin
@@ -98,7 +98,7 @@ def main():
     print(f"{'kernel':84s} vgpr agpr scratch spills vmcnt0 mbcnt bcnt1 atomics")
     for n in sorted(st):
         s = st[n]
-        if s.get("agpr", 0) or s.get("scratch_bytes", 0) or "gemm_bf16_w256" in n:
+        if s.get("agpr", 0) or s.get("scratch_bytes", 0) or "gemm_w256" in n:
             print(f"{n[:84]:84s} {s.get('vgpr', 0):4d} {s.get('agpr', 0):4d} {s.get('scratch_bytes', 0):7d} {s.get('spills', 0):6d} "
                   f"{s.get('vmcnt0', 0):6d} {s.get('mbcnt', 0):5d} {s.get('bcnt1', 0):5d} {s.get('atomics', 0):7d}")
     bad = 0

@@ -15,7 +15,7 @@ for d in ("/tmp/pg1", "/tmp/pg2"):
         except Exception as e:
             print("  (no counters in", db, e, ")"); continue
         for name, cn, val in rows:
-            if 'gemm_bf16_w256' in name: acc[name.split('(')[0]][cn].append(val)
+            if 'gemm_w256' in name: acc[name.split('(')[0]][cn].append(val)
 for k, d in sorted(acc.items()):
     print(k)
     wc = sum(d.get('SQ_WAVE_CYCLES', [1])) / max(len(d.get('SQ_WAVE_CYCLES', [1])), 1)

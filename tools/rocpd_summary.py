@@ -30,7 +30,7 @@ def stats(db, out):
 
 
 def kernel_key(name: str):
-    """'void gemm_bf16_w256_kernel<true, true, 6>(Args...)' -> 'gemm_bf16_w256_kernel<true, true, 6>';  'attn_fwd_kernel(...)' -> 'attn_fwd_kernel'"""
+    """'void gemm_w256_kernel<true, true, 6>(Args...)' -> 'gemm_w256_kernel<true, true, 6>';  'attn_fwd_kernel(...)' -> 'attn_fwd_kernel'"""
     name = re.sub(r"^void ", "", name)
     depth = 0
     for i, ch in enumerate(name):
