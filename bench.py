@@ -18,10 +18,10 @@ Extra objects (rank 0, N = 1 unless noted):
                the process exits with code 3 on a violation; "vq_match_spread": the same kernel and inputs against a trained-like codebook
                (~1000 distinct codes in play instead of the handful synthetic training collapses to).  "vq_match_rate" = the spread leg (since round 4);
                both legs also under explicit names: "vq_match_rate_training_codebook" / "vq_match_rate_spread_codebook".
-  "parity_mode"  north_star's parity clause priced: images/s of encode_codes and of the AE train step with the encoder forward on
-               split-bf16 ("x3", three MFMA passes, ~1e-5) operands, beside the single-pass bf16 path (the headline) and the exact-fp32 engine mode; plus
-               h error / end-to-end code match of both encoders and the reconstruction error of the bf16 / x3-whole-forward modes against the fp32 CPU
-               oracle on a 2-image sample; 10 timed iterations per mode; "x3_whole_forward_kernels": that step's own per-kernel roofline table.
+  "parity_mode"  north_star's parity clause priced per precision mode: images/s of encode_codes and of the AE train step for the headline engine (fp16 MFMA
+               operands since round 6), the other single-pass 16-bit format (bf16), the split-bf16 "x3" instrument (three MFMA passes, ~1e-5) and the
+               exact-fp32 engine mode; plus h error / end-to-end code match / free-running reconstruction error of each against the fp32 CPU oracle on a
+               2-image sample; 10 timed iterations per mode.
   "cpu_baseline"  the CPU oracle — a port of the reference's PyTorch path, oracle/vitvq_oracle.py — timed on the host cores on a bounded sample.
   "comm"       (N > 1) per rank: exposed communication of the timed steps (compute-stream wait and host wait), buckets, bytes reduced, un-announced elements;
                with the adversarial configs the discriminator's own bucketed all-reduce is reported separately ("discriminator").
@@ -99,7 +99,10 @@ def cpu_baseline(max_seconds: float = 40.0):
         times.append(one_step())
     med = statistics.median(times)
     return {"value": B / med, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"median of {len(times)} post-warm-up AE train steps (fwd+bwd+AdamW, fp32) of ViT-VQGAN-base at batch {B}; "
+            "kind_note": "port = oracle/vitvq_oracle.py, the CPU restatement of the reference's PyTorch path, pinned to the reference's own modules by "
+                         "oracle/make_golden.py -> tests/golden; /root/reference does not exist on the GPU box, so the reference itself cannot be timed here",
+            "sample": f"median of {len(times)} post-warm-up AE train steps (fwd+bwd+AdamW, fp32) of ViT-VQGAN-base at batch {B} (BASELINE.md plans batch 8: "
+                      f"bounded to {B} so that the default run stays within minutes; images/s is per image either way); "
                       f"thread sweep (s/step): {', '.join(f'{c}: {t:.2f}' for c, t in sweep.items())}",
             "step_seconds": [round(t, 3) for t in times]}
 
@@ -145,10 +148,15 @@ def vq_match_rate(h_dev, idx_dev, codebook_dev, depth: int, use_residual: bool):
                         "HIP indices vs the reference formula (fp32, torch CPU) on the host"}
 
 
-def parity_mode_block(model, eng, cfg, batches, B, lr, dev):
-    """what meeting north_star's "indices bit-exact / activations 1e-3 vs the reference fp32 path" costs, measured (outside the timed region):
-    encode-only and training throughput per precision mode, and the parity each mode reaches against the fp32 CPU oracle (2-image sample)."""
+def parity_mode_block(model, eng, cfg, batches, B, lr, dev, headline_precision):
+    """north_star's "indices bit-exact / activations within 1e-3 of the reference fp32 path" priced per precision mode, outside the timed region:
+    encode-only and training throughput, and the parity each mode reaches against the fp32 CPU oracle on a 2-image sample (h = the quantizer input,
+    xrec downstream of the oracle's own run, end-to-end code match).  Modes: "fp16" (one MFMA pass, fp16 operands: the headline since round 6 and the
+    reference's --use_amp dtype), "bf16" (one pass, bf16 operands: the round-1..5 headline), "x3" (three passes on split-bf16 operands, ~1e-5: the
+    instrument; needs the bf16 engine) and the exact-fp32 engine mode.  The headline engine is measured in place; the other 16-bit engine is a second
+    model with the same weights."""
     import torch
+    from enhancing import _C
     from enhancing.utils.general import initialize_from_config
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import vitvq_oracle as O
@@ -161,69 +169,74 @@ def parity_mode_block(model, eng, cfg, batches, B, lr, dev):
         torch.cuda.synchronize()
         return round(iters * n_img / (time.perf_counter() - t0), 1)
 
-    from enhancing import _C
-    N_IT = 10          # timed iterations per mode after one warm-up call (these are the parity-meeting product numbers)
-    out = {"encode_only_images_per_s": {}, "train_images_per_s": {}, "timed_iterations": N_IT}
+    N_IT = 10          # timed iterations per mode after one warm-up call
+    out = {"encode_only_images_per_s": {}, "train_images_per_s": {}, "timed_iterations": N_IT, "headline": headline_precision}
     x = batches[0]
-    for prec in ("bf16", "x3"):
-        out["encode_only_images_per_s"][prec] = rate(lambda: eng.encode_codes(x, precision=prec), B, N_IT)
-    eng.encoder_precision = "x3"
-    try:
-        def tstep():
-            eng.forward_backward(x, w_l1=0.0, w_l2=1.0, codebook_weight=1.0)
-            eng.optimizer_step(lr)
-        out["train_images_per_s"]["x3_encoder_forward"] = rate(tstep, B, N_IT)
-        eng.decoder_precision = "x3"
-        out["train_images_per_s"]["x3_whole_forward"] = rate(tstep, B, N_IT)
-        # the x3 whole-forward step's own kernel table (two extra steps under the per-launch HIP-event timer): every kernel against ITS roofline; the
-        # x3 GEMMs execute 3x the algorithmic FLOP of their product (K' = 3K), `achieved` counts the executed FLOP
-        tm = _C.KernelTimer()
-        _C.TIMER = tm
-        try:
-            torch.cuda.synchronize(); t0 = time.perf_counter()
-            for _ in range(2):
-                tstep()
-            torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / 2 * 1e3
-        finally:
-            _C.TIMER = None
-        rows = kernel_rooflines(tm.summary(), 2, ms, None)
-        top = sorted(rows.values(), key=lambda r: -r["share_of_step"])[:14]
-        out["x3_whole_forward_kernels"] = {"ms_per_step_under_timer": round(ms, 2),
-                                           "top": [{k: r[k] for k in ("kernel", "bound", "achieved", "unit", "frac", "avg_launch_ms", "share_of_step")} for r in top]}
-        # reconstruction parity of the whole-forward mode on the 2-image sample is reported below (xrec_rel_err)
-        xs2 = x[:2].contiguous()
-        xrec_x3 = eng.reconstruct(xs2)[0].detach().float().cpu()
-    finally:
-        eng.encoder_precision = eng.decoder_precision = "bf16"
-    xrec_bf16 = eng.reconstruct(x[:2].contiguous())[0].detach().float().cpu()
-    # parity of the two encoders against the fp32 oracle (the reference's arithmetic on the host), same weights, 2 images
+    xs = x[:2].contiguous()
+    weights = {k: v for k, v in model.state_dict().items() if not k.startswith("loss.")}
+    # the oracle on the host (the reference's arithmetic, fp32), same weights, 2 images
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
-    P = {k: v.detach().float().cpu() for k, v in model.state_dict().items() if not k.startswith("loss.")}
+    P = {k: v.detach().float().cpu() for k, v in weights.items()}
     ocfg = dict(image_size=cfg.model.params.image_size, patch_size=cfg.model.params.patch_size, encoder=dict(cfg.model.params.encoder),
                 decoder=dict(cfg.model.params.decoder), quantizer=dict(cfg.model.params.quantizer))
-    xs = x[:2].contiguous()
     with torch.no_grad():
         _, _, o_idx, o_h = O.encode(xs.cpu(), P, ocfg)
         o_xrec = O.forward(xs.cpu(), P, ocfg)[0]
-    par = {}
     relerr = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
-    out["xrec_rel_err_vs_fp32_cpu_oracle_2_images"] = {"bf16": relerr(xrec_bf16, o_xrec), "x3_whole_forward": relerr(xrec_x3, o_xrec),
-                                                        "note": "free-running: a flipped near-tie code moves a whole token of the reconstruction"}
-    for prec in ("bf16", "x3"):
-        h = model.pre_quant_tokens(xs, precision=prec).cpu()
-        codes = eng.encode_codes(xs, precision=prec).cpu()
-        par[prec] = {"h_rel_err": float((h.double() - o_h.double()).norm() / o_h.double().norm()),
-                     "code_match_end_to_end": float((codes.view(o_idx.shape) == o_idx).float().mean())}
+    par = {}
+
+    def parity_of(name, m_, e_, prec=None):
+        h = m_.pre_quant_tokens(xs, precision=prec).cpu()
+        codes = e_.encode_codes(xs, precision=prec).cpu().view(o_idx.shape)
+        par[name] = {"h_rel_err": relerr(h, o_h), "code_match_end_to_end": float((codes == o_idx).float().mean())}
+
+    def tstep_of(e_):
+        def f():
+            e_.forward_backward(x, w_l1=0.0, w_l2=1.0, codebook_weight=1.0)
+            e_.optimizer_step(lr)
+        return f
+
+    # ---- parity first (the timed training steps below move the weights) ----
+    other = "bf16" if headline_precision == "fp16" else "fp16"
+    parity_of(headline_precision, model, eng)
+    par[headline_precision]["xrec_rel_err_free_running"] = relerr(eng.reconstruct(xs)[0].detach().float().cpu(), o_xrec)
+    m2 = initialize_from_config(cfg.model)
+    m2.precision = other
+    m2.load_state_dict(weights, strict=False)
+    e2 = m2.engine
+    parity_of(other, m2, e2)
+    par[other]["xrec_rel_err_free_running"] = relerr(e2.reconstruct(xs)[0].detach().float().cpu(), o_xrec)
+    mb, eb = (model, eng) if headline_precision == "bf16" else (m2, e2)      # the bf16 engine hosts the x3 instrument
+    parity_of("x3", mb, eb, prec="x3")
+    eb.encoder_precision = eb.decoder_precision = "x3"
+    try:
+        par["x3"]["xrec_rel_err_free_running"] = relerr(eb.reconstruct(xs)[0].detach().float().cpu(), o_xrec)
+    finally:
+        eb.encoder_precision = eb.decoder_precision = "bf16"
     out["vs_fp32_cpu_oracle_2_images"] = par
+    out["vs_fp32_cpu_oracle_note"] = ("h: relative Frobenius error of the quantizer input; xrec free-running: a flipped near-tie code moves a whole token of the "
+                                      "reconstruction (the same-codes figure is tests/test_fp16_gpu.py / test_parity_base_gpu.py)")
+    # ---- throughput ----
+    out["encode_only_images_per_s"][headline_precision] = rate(lambda: eng.encode_codes(x, precision=headline_precision), B, N_IT)
+    out["encode_only_images_per_s"][other] = rate(lambda: e2.encode_codes(x, precision=other), B, N_IT)
+    out["encode_only_images_per_s"]["x3"] = rate(lambda: eb.encode_codes(x, precision="x3"), B, N_IT)
+    out["train_images_per_s"][other] = rate(tstep_of(e2), B, N_IT)
+    eb.encoder_precision = "x3"
+    try:
+        out["train_images_per_s"]["x3_encoder_forward"] = rate(tstep_of(eb), B, N_IT)
+        eb.decoder_precision = "x3"
+        out["train_images_per_s"]["x3_whole_forward"] = rate(tstep_of(eb), B, N_IT)
+    finally:
+        eb.encoder_precision = eb.decoder_precision = "bf16"
+    del m2, e2
+    torch.cuda.empty_cache()
     # the exact-fp32 engine mode (vector-ALU kernels, csrc/exact_f32.hip): the parity instrument, timed at a small batch
     try:
         m32 = initialize_from_config(cfg.model)
         m32.precision = "fp32"
-        m32.load_state_dict({k: v for k, v in model.state_dict().items() if not k.startswith("loss.")}, strict=False)
+        m32.load_state_dict({k: v for k, v in weights.items()}, strict=False)
         e32, b32 = m32.engine, 8
         x8 = x[:b32].contiguous()
-        c32 = e32.encode_codes(xs).cpu()         # parity first: the timed training steps below move this copy's weights
-        out["vs_fp32_cpu_oracle_2_images"]["fp32_exact_mode"] = {"code_match_end_to_end": float((c32.view(o_idx.shape) == o_idx).float().mean())}
         out["encode_only_images_per_s"]["fp32_exact_mode"] = rate(lambda: e32.encode_codes(x8), b32, 2)
 
         def tstep32():
@@ -235,9 +248,9 @@ def parity_mode_block(model, eng, cfg, batches, B, lr, dev):
         torch.cuda.empty_cache()
     except Exception as ex:      # the block is a report, not the product: never lose the headline line to it
         out["fp32_exact_mode_error"] = repr(ex)[:200]
-    out["note"] = ("x3 = every MFMA operand of the ENCODER forward (patch embedding .. pre_quant) as hi + lo bf16 planes, products a_hi b_hi + a_lo b_hi + a_hi b_lo "
-                   "in the fp32 accumulator (csrc/x3.hip); the default of encode_codes / tools/tokenize_dataset.py.  Training keeps the single-pass encoder "
-                   "unless ENH_ENCODER_PRECISION=x3.")
+    out["note"] = ("fp16 / bf16 = every MFMA operand in that 16-bit format, one pass (csrc/common.h operand type tags); x3 = every operand of the forward as hi + lo "
+                   "bf16 planes, products a_hi b_hi + a_lo b_hi + a_hi b_lo in the fp32 accumulator (csrc/x3.hip; bf16 engine only).  encode_codes defaults to the "
+                   "engine's own single pass under fp16 and to x3 under bf16.")
     return out
 
 
@@ -293,9 +306,15 @@ def main():
     # `python bench.py --gpus N` with no launcher environment re-executes itself under torch.distributed.run, one rank per GPU (as main.py does;
     # reference main.py:54-57 hands the same job to Lightning's DDP plugin).  Under a launcher (RANK set) WORLD_SIZE must equal --gpus.
     if args.gpus > 1 and "RANK" not in os.environ:
+        import socket
         import subprocess
+        port = os.environ.get("MASTER_PORT")
+        if not port:      # a free port (two concurrent bare runs on one box must not meet at rendezvous); MASTER_PORT overrides
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = str(sk.getsockname()[1])
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-               "--master-port", os.environ.get("MASTER_PORT", "29517"), os.path.abspath(__file__)] + sys.argv[1:]
+               "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")))
 
     import torch
@@ -487,8 +506,8 @@ def main():
                 res["vq_match_rate_training_codebook"] = mr["value"]
                 res["vq_match_rate_spread_codebook"] = ms["value"]
             if is_base and not args.no_parity_mode:
-                res["parity_mode"] = parity_mode_block(model, eng, cfg, batches, B, lr, dev)
-                res["parity_mode"]["train_images_per_s"]["bf16_encoder_forward (headline)"] = round(img_per_s, 1)
+                res["parity_mode"] = parity_mode_block(model, eng, cfg, batches, B, lr, dev, args.precision)
+                res["parity_mode"]["train_images_per_s"][f"{args.precision} (headline)"] = round(img_per_s, 1)
         res["cpu_baseline"] = cpu_baseline()
     print(json.dumps(res), flush=True)
     if world > 1:

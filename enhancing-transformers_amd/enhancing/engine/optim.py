@@ -42,8 +42,24 @@ class FlatAdamW:
     def attach_sync(self, module, **kw):
         """bucketed asynchronous gradient all-reduce for this store, driven by autograd hooks on `module`'s parameters (engine/ddp.py)"""
         from .ddp import AutogradGradSync
+        # one sync per store: a previous attach (Trainer.fit calls configure_optimizers + attach_sync on every invocation) left post-accumulate-grad hooks on
+        # the same parameters — still live, they would all-reduce every bucket a second time and the step would divide by the world size only once
+        # (ADVICE r5); the old object's hooks are removed and its in-flight handles drained before it is replaced
+        old = getattr(self.store, "_grad_sync", None) or self.comm
+        if old is not None:
+            old.finish()
+            old.remove_hooks()
         self.comm = AutogradGradSync(self.store, list(module.named_parameters()), **kw)
+        self.store._grad_sync = self.comm
         return self.comm
+
+    def detach_sync(self) -> None:
+        """remove the autograd hooks of attach_sync (end of Trainer.fit: the module may be fitted again, or used without a process group)"""
+        if self.comm is not None:
+            self.comm.finish()
+            self.comm.remove_hooks()
+            self.comm = None
+            self.store._grad_sync = None
 
     def zero_grad(self, set_to_none: bool = False) -> None:
         self.store.zero_grad()

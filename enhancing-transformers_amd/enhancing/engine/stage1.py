@@ -66,6 +66,8 @@ class ParamStore:
         # GEMM operand view of every weight: the 16-bit shadow (product paths) or the fp32 master itself (exact mode)
         self.wa = self.w16 if self.half else self.w
         self.step_count = 0
+        self.comm_done = False             # data-parallel: this step's gradient all-reduce has already been waited for (unscale_grads before the step)
+        self.grads_unscaled = False        # fp16 engine: the flat gradient holds loss_scale x gradient from backward until unscale_grads() / the optimizer step
         self.version = 0                   # bumped whenever the fp32 masters may have changed: lazily rebuilt operand images (the x3 weights) compare it
         self.operand_hooks: List = []      # callables that rebuild derived GEMM operands (e.g. the towers' pre-scaled q | k | v weights) from the masters
         self.refresh_shadows()
@@ -103,6 +105,8 @@ class ParamStore:
 
     def zero_grad(self) -> None:
         self.g.zero_()
+        self.grads_unscaled = False      # (fp16 engine: see Stage1Engine.unscale_grads)
+        self.comm_done = False
 
     def slice_of(self, prefix: str) -> Tuple[int, int]:
         """[begin, end) range of the flat buffers covered by parameters whose name starts with prefix."""
@@ -342,14 +346,15 @@ class _AEFunction(torch.autograd.Function):
     def backward(ctx, g_xrec, g_qloss):
         engine, st = ctx.engine, ctx.st
         B, io = st["B"], engine._io_bufs(st["B"])
-        S = engine.loss_scale      # fp16: the incoming gradients are scaled here; optimizer_step divides the parameter gradients by S again
+        # fp16 engine: the caller backpropagates engine.scale_loss(loss) (torch.cuda.amp's scaler.scale(loss).backward() idiom: the incoming gradients
+        # then carry the loss scale, which keeps them inside fp16's range when they are packed into the 16-bit operands below); optimizer_step /
+        # unscale_grads divide it out of the parameter gradients again
         if g_xrec is None:
             io["dpix16"].zero_()
         else:
-            g32 = g_xrec.to(dtype=F32).contiguous()
-            _C.patchify_any(g32 * S if S != 1.0 else g32, engine.patch, io["dpix16"])
+            _C.patchify_any(g_xrec.to(dtype=F32).contiguous(), engine.patch, io["dpix16"])
         g_dev = None if g_qloss is None else g_qloss.reshape(1).to(dtype=F32).contiguous()
-        engine.backward_from(st, io["dpix16"], S if g_qloss is not None else 0.0, g_dev)
+        engine.backward_from(st, io["dpix16"], 1.0 if g_qloss is not None else 0.0, g_dev)
         return None, None, None
 
 
@@ -367,7 +372,9 @@ class _EncodeFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_h):
         engine, st = ctx.engine, ctx.st
-        dh = g_h.reshape(st["B"] * engine.n_tok, engine.ed).to(dtype=F32).contiguous()      # (arrives scaled by the loss scale: _DecodeFn.backward scaled its output)
+        dh = g_h.reshape(st["B"] * engine.n_tok, engine.ed).to(dtype=F32).contiguous()      # (carries the loss scale of the caller's engine.scale_loss(loss).backward())
+        engine._check_serial(st)
+        engine._check_scaled_accumulation()
         engine.backward_encoder(st, dh.to(engine.adt), announce_quantizer=False)
         return None, None, None
 
@@ -387,12 +394,10 @@ class _DecodeFn(torch.autograd.Function):
     def backward(ctx, g_xrec):
         engine, st = ctx.engine, ctx.st
         io = engine._io_bufs(st["B"])
-        S = engine.loss_scale
-        g32 = g_xrec.to(dtype=F32).contiguous()
-        _C.patchify_any(g32 * S if S != 1.0 else g32, engine.patch, io["dpix16"])
+        _C.patchify_any(g_xrec.to(dtype=F32).contiguous(), engine.patch, io["dpix16"])      # (scaled by the caller: engine.scale_loss(loss).backward())
+        engine._check_serial(st)
+        engine._check_scaled_accumulation()
         dzq = engine.backward_decoder(st, io["dpix16"])
-        # the quantizer between the two halves is plain torch autograd (linear in its upstream gradient): the scaled gradient flows through it into
-        # _EncodeFn.backward unchanged; the quantizer's OWN parameters (differentiated by torch into the flat store) receive scaled gradients as well
         return None, dzq.view(ctx.qshape).clone(), None
 
 
@@ -402,7 +407,8 @@ class Stage1Engine:
     def __init__(self, model: nn.Module, device: Optional[torch.device] = None, precision: Optional[str] = None,
                  encoder_precision: Optional[str] = None, codes_precision: Optional[str] = None, decoder_precision: Optional[str] = None) -> None:
         """precision: "fp16" | "bf16" (product paths: 16-bit MFMA operands of that format, fp32 accumulation / residual stream / master weights) or
-        "fp32" (exact mode for parity runs: every operand fp32, vector-ALU kernels); default from ENH_PRECISION, else "bf16".
+        "fp32" (exact mode for parity runs: every operand fp32, vector-ALU kernels); default from ENH_PRECISION, else "fp16" (since round 6: the
+        single-pass mode that meets the 1e-3 parity clause; "bf16" is the round-1..5 default, ~3 % faster, ~5e-3).
         "fp16" is the reference's --use_amp dtype (main.py:25,52: Lightning precision=16): 11-bit significands bring the single-pass forward within 1e-3
         of the fp32 reference (bf16: ~5e-3) at the same MFMA rate; the backward runs on fp16 operands too, with the loss gradient multiplied by a
         static power-of-two `loss_scale` (ENH_LOSS_SCALE, default 2^16 — GradScaler's initial scale) that the AdamW launch divides out again, and an
@@ -414,7 +420,7 @@ class Stage1Engine:
           decoder_precision  "bf16" | "x3": post_quant .. to_pixel of training / reconstruct / decode (ENH_DECODER_PRECISION, default "bf16"); with both towers
                              on x3 the whole forward — codes, reconstruction, losses — is within ~1e-5 of the fp32 reference (the backward stays bf16)"""
         import os
-        precision = precision or os.environ.get("ENH_PRECISION", "bf16")
+        precision = precision or os.environ.get("ENH_PRECISION", "fp16")
         if precision not in OPERAND_DTYPE:
             raise ValueError(f"precision must be 'bf16', 'fp16' or 'fp32', got {precision!r}")
         self.precision = precision
@@ -652,6 +658,31 @@ class Stage1Engine:
         if st["serial"] != self._fwd_serial:
             raise RuntimeError("backward called for a forward whose saved activations were overwritten by a later forward_train")
 
+    def _check_scaled_accumulation(self) -> None:
+        if self.loss_scale != 1.0 and self.store.grads_unscaled:
+            raise RuntimeError("the flat gradient was unscaled (unscale_grads) and not zeroed since: a loss-scaled backward cannot accumulate onto it — call "
+                               "zero_grad() first")
+
+    def scale_loss(self, loss: torch.Tensor) -> torch.Tensor:
+        """loss * loss_scale (fp16 engine; the identity otherwise): what to call .backward() on when the loss is built on differentiable_forward /
+        differentiable_encode + differentiable_decode — torch.cuda.amp's `scaler.scale(loss).backward()` under the reference's --use_amp (main.py:25,52).
+        The upstream gradients then reach the 16-bit backward inside fp16's range (a mean-reduced pixel loss has |d loss / d xrec| ~ 1e-8, below fp16's
+        smallest subnormal); |gradient| * loss_scale must stay below 65504 — an overflow sets found_inf and the optimizer step is dropped."""
+        return loss * self.loss_scale if self.loss_scale != 1.0 else loss
+
+    @torch.no_grad()
+    def unscale_grads(self) -> None:
+        """fp16 engine: param.grad (views of the flat gradient) holds loss_scale x gradient after a backward — torch.cuda.amp's convention under the
+        reference's --use_amp (GradScaler: gradients stay scaled until unscale_ / step).  optimizer_step divides the scale out inside the AdamW launch
+        for free; call this (GradScaler.unscale_'s counterpart: one pass over the flat buffer) to READ true gradients before the step — gradient-norm
+        logging, a custom optimizer, tests.  Idempotent until the next zero_grad(); a no-op for bf16 / fp32 engines."""
+        if self.loss_scale != 1.0 and not self.store.grads_unscaled:
+            if self.comm is not None and not self.store.comm_done:      # the reduced gradient is what gets unscaled; optimizer_step will not reduce again
+                self.comm.finish()
+                self.store.comm_done = True
+            self.store.g.mul_(1.0 / self.loss_scale)
+            self.store.grads_unscaled = True
+
     def backward_decoder(self, st: dict, dpix16: torch.Tensor) -> torch.Tensor:
         """to_pixel + decoder tower + post_quant backward given dpix16 = d loss / d pix in the patch layout [M, C*p*p]; ACCUMULATES the parameter
         gradients, returns d loss / d (quantized tokens) as f32 [M, embed_dim] (an engine buffer)."""
@@ -697,8 +728,11 @@ class Stage1Engine:
             notify("encoder.to_patch_embedding.")
 
     def backward_from(self, st: dict, dpix16: torch.Tensor, g_loss: float, g_loss_dev: Optional[torch.Tensor] = None) -> None:
-        """Backward of forward_train given dpix16 = d loss / d pix in the patch layout [M, C*p*p] (bf16) and the gradient
-        flowing into the codebook loss (host scalar g_loss times optional device scalar).  ACCUMULATES into the flat grads."""
+        """Backward of forward_train given dpix16 = d loss / d pix in the patch layout [M, C*p*p] (16-bit operand) and the gradient
+        flowing into the codebook loss (host scalar g_loss times optional device scalar).  ACCUMULATES into the flat grads.  With a loss scale
+        (fp16) both incoming gradients carry it, and so does everything accumulated: see unscale_grads()."""
+        self._check_serial(st)
+        self._check_scaled_accumulation()
         dzq = self.backward_decoder(st, dpix16)
         exact = not self.half
         dh, dh16 = _C.vq_backward(st["h"], self.store.w["quantizer.embedding.weight"], st["idx"], dzq, g_loss, g_loss_dev, float(self.q.beta), self.q.depth,
@@ -804,11 +838,13 @@ class Stage1Engine:
         """torch.optim.AdamW over the single parameter group of vitvqgan.py:153-160 (one fused launch)."""
         s = self.store
         if self.comm is not None:
-            self.comm.finish()
+            if not s.comm_done:
+                self.comm.finish()
+            s.comm_done = False
             grad_scale = grad_scale / self.comm.world
         s.step_count += 1
         skip = None
-        if self.loss_scale != 1.0:
+        if self.loss_scale != 1.0 and not s.grads_unscaled:
             grad_scale = grad_scale / self.loss_scale
         if self.check_nonfinite:
             # GradScaler.step's found-inf skip (reference main.py:25,52 --use_amp), without a host round trip: one pass over the flat gradient sets the

@@ -21,12 +21,12 @@ class Trainer:
                  default_root_dir: str = "experiments", log_every_n_steps: int = 10, limit_val_batches: Optional[int] = None,
                  val_batches: Optional[int] = None) -> None:
         self.max_epochs, self.max_steps = max_epochs, max_steps
-        # Lightning's `precision` (reference main.py:52): 16 = --use_amp = mixed precision.  On MI355X the mixed-precision dtype is bf16 (fp32 master
-        # weights / accumulation; bf16 keeps fp32's exponent range, so Lightning's fp16 GradScaler has nothing to do and its semantics are the
-        # identity); 32 = no AMP = the fp32 "exact" engine mode.  The model's engine precision must AGREE with it: fit() checks and raises.
+        # Lightning's `precision` (reference main.py:52): 16 = --use_amp = fp16 autocast + GradScaler -> the fp16 engine mode (fp16 MFMA operands, fp32
+        # master weights / accumulation, loss-scaled backward with the inf / nan step skip: engine/stage1.py); "bf16" = Lightning's bf16 mixed precision
+        # (bf16 operands, no loss scale); 32 = no AMP = the fp32 "exact" engine mode.  The model's engine precision must AGREE with it: fit() checks and raises.
         if precision not in (16, 32, "bf16", "16", "32"):
-            raise ValueError(f"precision must be 16 (mixed, bf16 on this hardware) or 32, got {precision!r}")
-        self.precision = 32 if str(precision) == "32" else 16
+            raise ValueError(f"precision must be 16 (fp16 mixed precision), 'bf16' or 32, got {precision!r}")
+        self.precision = 32 if str(precision) == "32" else ("bf16" if str(precision) == "bf16" else 16)
         self.accum = max(int(accumulate_grad_batches), 1)
         self.strategy = strategy
         self.root = default_root_dir
@@ -77,7 +77,7 @@ class Trainer:
     def fit(self, model, data) -> None:
         self.rank, self.local_rank, self.world = init_process_group_from_env()
         torch.cuda.set_device(self.local_rank)
-        want = "bf16" if self.precision == 16 else "fp32"
+        want = {16: "fp16", "bf16": "bf16", 32: "fp32"}[self.precision]
         if getattr(model, "_engine", None) is None and hasattr(model, "precision") and model.precision is None:
             model.precision = want          # engine not bound yet: bind it in the requested mode
         eng = model.engine
@@ -145,3 +145,6 @@ class Trainer:
                             "global_step": self.global_step, "optimizer": opt.state_dict(), "optimizer_states": [o.state_dict() for o in opts]}, os.path.join(ck, f"epoch={epoch:02d}.ckpt"))
             if self.max_steps is not None and self.global_step >= self.max_steps:
                 break
+        for o in opts:      # the autograd hooks of attach_sync must not outlive this fit (a second fit would otherwise reduce every bucket twice: ADVICE r5)
+            if hasattr(o, "detach_sync"):
+                o.detach_sync()

@@ -254,7 +254,7 @@ class ViTVQ(nn.Module):
             try:
                 aeloss, log_dict_ae = self.loss(qloss, x.to(xrec.device), xrec, optimizer_idx, self.global_step, batch_idx,
                                                 last_layer=self.decoder.get_last_layer(), split="train")
-                aeloss.backward()
+                self.engine.scale_loss(aeloss).backward()      # (fp16 engine: the loss scale of the 16-bit backward; the identity for bf16 / fp32)
             finally:
                 for p in frozen:
                     p.requires_grad_(True)

@@ -47,7 +47,7 @@ def _worker(rank, world, port, q, algo="allreduce"):
 import pytest
 
 
-@pytest.mark.parametrize("world,algo", [(2, "allreduce"), (2, "rs_ag"), (3, "rs_ag")])
+@pytest.mark.parametrize("world,algo", [(2, "allreduce"), (2, "rs_ag"), (3, "rs_ag"), (4, "rs_ag"), (4, "allreduce")])
 def test_gradsync_gloo_world2(world, algo):
     """bucketed gradient sum, as one all-reduce per bucket or as reduce-scatter + all-gather (world 3: bucket sizes are not multiples of the world size,
     so the remainder path runs too)"""
@@ -185,7 +185,9 @@ def _autograd_sync_worker(rank, world, port, q):
             self.g.zero_()
     st = Store(net)
     opt = FlatAdamW(st, lr=1e-3)
-    sync = opt.attach_sync(net, min_bucket_elems=128)
+    first = opt.attach_sync(net, min_bucket_elems=128)
+    sync = opt.attach_sync(net, min_bucket_elems=128)      # a re-attach (Trainer.fit called twice) must REPLACE the hooks: every bucket travels once (bytes check below)
+    assert first is not sync and not first._hooks and st._grad_sync is sync
     assert len(sync.buckets) >= 3 and sync.buckets[0][1] == st.g.numel() and sync.buckets[-1][0] == 0
     for (b0, e0), (b1, e1) in zip(sync.buckets, sync.buckets[1:]):
         assert b0 == e1                                           # contiguous, descending: the buffer is tiled exactly once

@@ -229,12 +229,15 @@ def test_adaptive_adversarial_weight(C):
     eng = m.engine
     x = O.make_images(5, 2, cfg["image_size"])
     # (1) the norm primitive against the engine's own backward
-    g = torch.randn(2, 3, cfg["image_size"], cfg["image_size"], generator=torch.Generator().manual_seed(1)).cuda()
+    # (upstream gradient at the size a mean-reduced loss produces: under the fp16 engine's static loss scale 2^16, |g| * 2^16 must stay below 65504)
+    g = 1e-4 * torch.randn(2, 3, cfg["image_size"], cfg["image_size"], generator=torch.Generator().manual_seed(1)).cuda()
     eng.store.zero_grad()
     xrec, _ = m(x)
     n_fast = eng.last_layer_grad_norm(g).item()
-    (xrec * g).sum().backward()
+    eng.scale_loss((xrec * g).sum()).backward()
+    eng.unscale_grads()
     n_ref = m.decoder.get_last_layer().grad.norm().item()
+    eng.store.zero_grad()
     assert abs(n_fast - n_ref) <= 2e-3 * n_ref, (n_fast, n_ref)
     # (2) the training step logs d_weight = 0.1 * ||d nll|| / (||d g|| + 1e-4), recomputed here from the two upstream gradients
     l0 = m.training_step({"image": x}, 0, 0)

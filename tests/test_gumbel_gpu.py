@@ -54,6 +54,7 @@ def test_vitvq_gumbel_training_step_vs_oracle(monkeypatch):
     grads = {k: (q.embedding.weight.grad if k == "quantizer.embedding.weight" else v.grad) for k, v in leaves.items()}
     grads = {k: g for k, g in grads.items() if g is not None}
     assert abs(float(out) - float(o_loss)) <= 1e-2 * abs(float(o_loss)), (float(out), float(o_loss))
+    m.engine.unscale_grads()      # fp16 engine: param.grad carries the loss scale until the step (or this call)
     errs = {k: rel(p.grad, grads[k]) for k, p in m.named_parameters() if k in grads}
     worst = max(errs, key=errs.get)
     print(f"ViTVQGumbel train step: loss {float(out):.5f} vs oracle {float(o_loss):.5f}; grads median rel {np.median(list(errs.values())):.2e}, worst {worst} {errs[worst]:.2e}")

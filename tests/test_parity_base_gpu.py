@@ -59,6 +59,7 @@ def _build(cfg, P):
             "params": dict(codebook_weight=1.0, loglaplace_weight=0.0, loggaussian_weight=1.0, perceptual_weight=0.0)}
     m = ViTVQ("image", cfg["image_size"], cfg["patch_size"], AttrDict.wrap(cfg["encoder"]), AttrDict.wrap(cfg["decoder"]),
               AttrDict.wrap(cfg["quantizer"]), AttrDict.wrap(loss))
+    m.precision = "bf16"      # this file holds the regression bounds of the bf16 product path; the fp16 default is tests/test_fp16_gpu.py's
     m.load_state_dict(P, strict=True)
     assert m.engine.precision == "bf16"
     return m

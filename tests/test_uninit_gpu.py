@@ -58,6 +58,7 @@ def _run_steps(loss_cfg, n_steps, cfg_name="tiny", rq=False, x3=False):
         m = ViTVQ("image", cfg["image_size"], cfg["patch_size"], AttrDict.wrap(cfg["encoder"]), AttrDict.wrap(cfg["decoder"]),
                   AttrDict.wrap(cfg["quantizer"]), AttrDict.wrap(loss_cfg))
     if x3:
+        m.precision = "bf16"      # x3 training towers exist under the bf16 engine
         m.encoder_precision = m.decoder_precision = "x3"
     m.load_state_dict(O.make_params(cfg, seed=11), strict=False)
     m.train()

@@ -132,6 +132,7 @@ def _build(cfg, P, **kw):
             "params": dict(codebook_weight=1.0, loglaplace_weight=0.0, loggaussian_weight=1.0, perceptual_weight=0.0)}
     m = ViTVQ("image", cfg["image_size"], cfg["patch_size"], AttrDict.wrap(cfg["encoder"]), AttrDict.wrap(cfg["decoder"]),
               AttrDict.wrap(cfg["quantizer"]), AttrDict.wrap(loss))
+    m.precision = "bf16"      # x3 = split-bf16 operands: the instrument of the bf16 product path (the fp16 default of round 6 meets the tolerance in one pass)
     for k, v in kw.items():
         setattr(m, k, v)
     m.load_state_dict(P, strict=True)
@@ -216,6 +217,7 @@ def test_training_step_with_the_x3_encoder_forward():
     assert m.engine.encoder_precision == "x3"
     loss = m.training_step({"image": x}, 0, 0)
     o_loss, _, o_grads, _ = O.train_step_grads(x, P, cfg)
+    m.engine.unscale_grads()      # fp16 engine: param.grad carries the loss scale until the step (or this call)
     errs = {k: rel(p.grad, o_grads[k]) for k, p in m.named_parameters() if k in o_grads}
     worst = max(errs, key=errs.get)
     print(f"x3-encoder train step: loss {loss.item():.6f} vs oracle {o_loss.item():.6f}; grads median rel {np.median(list(errs.values())):.2e}, worst {worst} {errs[worst]:.2e}")
@@ -247,6 +249,7 @@ def test_full_x3_forward_reconstruction_and_loss_vs_fp32_oracle():
     assert e_x <= 1e-4 and abs(qloss.item() - o_q.item()) <= 1e-4 * abs(o_q.item())
     out = m.engine.forward_backward(x, w_l1=0.0, w_l2=1.0, codebook_weight=1.0)
     o_loss, _, o_grads, _ = O.train_step_grads(x, P, BASE)
+    m.engine.unscale_grads()      # fp16 engine: param.grad carries the loss scale until the step (or this call)
     errs = {k: rel(p.grad, o_grads[k]) for k, p in m.named_parameters() if k in o_grads}
     worst = max(errs, key=errs.get)
     print(f"  train step: loss {out['loss'].item():.7f} vs {o_loss.item():.7f}; grads median rel {np.median(list(errs.values())):.2e}, worst {worst} {errs[worst]:.2e}")
@@ -279,6 +282,7 @@ def test_x3_graph_replay_after_refresh_shadows_reads_the_new_weights():
     def build():
         m = ViTVQ("image", cfg["image_size"], cfg["patch_size"], AttrDict.wrap(cfg["encoder"]), AttrDict.wrap(cfg["decoder"]), AttrDict.wrap(cfg["quantizer"]),
                   AttrDict.wrap(loss))
+        m.precision = "bf16"
         m.load_state_dict(P)
         e = m.engine
         e.encoder_precision = e.decoder_precision = "x3"
