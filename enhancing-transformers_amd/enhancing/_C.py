@@ -71,8 +71,8 @@ SIGNATURES = {
     "enh_fused_bias_act": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _f32, _f32, _vp]),
     "enh_channel_sum_f32": (_i32, [_vp, _i32, _i32, _i64, _vp, _i32, _vp]),
     "enh_upfirdn2d": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
-    "enh_im2col_bf16": (_i32, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp]),
-    "enh_col2im_f32": (_i32, [_vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _i64, _vp]),
+    "enh_im2col": (_i32, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _i32, _vp]),
+    "enh_col2im": (_i32, [_vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _i64, _i32, _vp]),
     "enh_conv_nhwc_bf16": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _f32, _f32, _vp, _vp]),
     "enh_conv_nhwc_bf16_ws": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _sz, _vp]),
     "enh_conv_workspace_bytes": (_sz, [_vp]),
@@ -115,7 +115,7 @@ SIGNATURES = {
 }
 
 _LIB = None
-ABI_VERSION = 14  # ENH_ABI_VERSION of the include/enh_hip.h these signatures were written against
+ABI_VERSION = 15  # ENH_ABI_VERSION of the include/enh_hip.h these signatures were written against
 
 
 def lib():
@@ -183,7 +183,7 @@ def _stream():
 
 F32, BF16, F16, I64, F64 = torch.float32, torch.bfloat16, torch.float16, torch.int64, torch.float64
 H16 = (BF16, F16)      # the two 16-bit operand formats of the product path (include/enh_hip.h ENH_DT_BF16 / ENH_DT_F16)
-DT_BF16, DT_F16 = 0, 1
+DT_BF16, DT_F16, DT_F32 = 0, 1, 2
 
 
 def _dt(*tensors) -> int:
@@ -610,21 +610,25 @@ def conv_out_size(n: int, k: int, stride: int, pad: int) -> int:
     return (n + 2 * pad - k) // stride + 1
 
 
-def im2col(x, sb: int, sc: int, B: int, C: int, H: int, W: int, k: int, stride: int, pad: int):
-    """x f32, element (b,c,h,w) at b*sb + c*sc + h*W + w  ->  bf16 cols [B*Ho*Wo, Kp], Kp = C*k*k rounded up to 8 (pad columns zero)."""
+_DT_OF = {BF16: DT_BF16, F16: DT_F16, F32: DT_F32}
+
+
+def im2col(x, sb: int, sc: int, B: int, C: int, H: int, W: int, k: int, stride: int, pad: int, dtype: torch.dtype = BF16):
+    """x f32, element (b,c,h,w) at b*sb + c*sc + h*W + w  ->  cols [B*Ho*Wo, Kp] in `dtype` (bf16 | fp16: MFMA operands; f32: the exact instrument),
+    Kp = C*k*k rounded up to 8 (pad columns zero)."""
     _p(x, F32, "x")
     Ho, Wo = conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad)
     ld = (C * k * k + 7) // 8 * 8
-    cols = torch.empty(B * Ho * Wo, ld, dtype=BF16, device=x.device)
-    _check(lib().enh_im2col_bf16(_p(x), sb, sc, B, C, H, W, k, stride, pad, Ho, Wo, _p(cols), ld, _stream()), "enh_im2col_bf16")
+    cols = torch.empty(B * Ho * Wo, ld, dtype=dtype, device=x.device)
+    _check(lib().enh_im2col(_p(x), sb, sc, B, C, H, W, k, stride, pad, Ho, Wo, _p(cols), ld, _DT_OF[dtype], _stream()), "enh_im2col")
     return cols
 
 
 def col2im(dcols, B: int, C: int, H: int, W: int, k: int, stride: int, pad: int, out, sb: int, sc: int):
-    """adjoint of im2col: bf16 dcols [B*Ho*Wo, Kp] -> f32 `out`, element (b,c,h,w) at b*sb + c*sc + h*W + w (overwritten)."""
-    _p(dcols, BF16, "dcols"); _p(out, F32, "dx")
+    """adjoint of im2col: dcols [B*Ho*Wo, Kp] (bf16 | fp16 | f32) -> f32 `out`, element (b,c,h,w) at b*sb + c*sc + h*W + w (overwritten)."""
+    _p(dcols, (BF16, F16, F32), "dcols"); _p(out, F32, "dx")
     Ho, Wo = conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad)
-    _check(lib().enh_col2im_f32(_p(dcols), dcols.stride(0), B, C, H, W, k, stride, pad, Ho, Wo, _p(out), sb, sc, _stream()), "enh_col2im_f32")
+    _check(lib().enh_col2im(_p(dcols), dcols.stride(0), B, C, H, W, k, stride, pad, Ho, Wo, _p(out), sb, sc, _DT_OF[dcols.dtype], _stream()), "enh_col2im")
     return out
 
 

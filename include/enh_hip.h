@@ -47,11 +47,12 @@ extern "C" {
  * split-operand family, the convolution family) are bf16-only. */
 #define ENH_DT_BF16 0
 #define ENH_DT_F16 1
+#define ENH_DT_F32 2   /* enh_im2col / enh_col2im only: f32 columns for the exact-f32 GEMM (the discriminator's parity instrument) */
 typedef uint16_t enh_h16;  /* raw 16-bit float bits: bfloat16 or binary16, per the call's dtype */
 typedef enh_h16 enh_bf16;  /* raw bfloat16 bits (bf16-only entries) */
 
 const char* enh_last_error(void);
-#define ENH_ABI_VERSION 14  /* bumped whenever a signature below changes; the bindings check it at load */
+#define ENH_ABI_VERSION 15  /* bumped whenever a signature below changes; the bindings check it at load */
 int enh_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -327,14 +328,15 @@ int enh_upfirdn2d(const float* in, const float* kernel, float* out, int64_t majo
                   int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
 
 /* Equalised-lr convolution lowering (EqualConv2d, enhancing/losses/layers.py:163-185: conv2d(x, weight*scale, stride, padding),
- * k in {1,3}, stride in {1,2}) onto enh_gemm_h16:  cols[(b,ho,wo), c*k*k + kh*k + kw] = x[b,c,ho*stride-pad+kh,wo*stride-pad+kw]
- * (zero outside the image), bf16, row stride ld = C*k*k rounded up to a multiple of 8 with the pad columns zeroed.  The image is
- * addressed as x[b*stride_b + c*stride_c + h*W + w], so [B,C,H,W] and channel-major [C,B,H,W] activations are both accepted.
- * enh_col2im_f32 is the adjoint (the convolution's input gradient given dcols = dy^T . W): dx is overwritten, no atomics. */
-int enh_im2col_bf16(const float* x, int64_t stride_b, int64_t stride_c, int B, int C, int H, int W, int k, int stride, int pad,
-                    int Ho, int Wo, enh_bf16* cols, int64_t ld, void* stream);
-int enh_col2im_f32(const enh_bf16* dcols, int64_t ld, int B, int C, int H, int W, int k, int stride, int pad, int Ho, int Wo,
-                   float* dx, int64_t stride_b, int64_t stride_c, void* stream);
+ * k in {1,3}, stride in {1,2}) onto enh_gemm_h16 / enh_gemm_f32:  cols[(b,ho,wo), c*k*k + kh*k + kw] = x[b,c,ho*stride-pad+kh,wo*stride-pad+kw]
+ * (zero outside the image) in `dtype` (ENH_DT_BF16 / ENH_DT_F16: 16-bit MFMA operands; ENH_DT_F32: the exact-f32 instrument), row stride ld = C*k*k
+ * rounded up to a multiple of 8 with the pad columns zeroed.  The image is addressed as x[b*stride_b + c*stride_c + h*W + w], so [B,C,H,W] and
+ * channel-major [C,B,H,W] activations are both accepted.  enh_col2im is the adjoint (the convolution's input gradient given dcols = dy^T . W, in
+ * `dtype`): dx (f32) is overwritten, no atomics. */
+int enh_im2col(const float* x, int64_t stride_b, int64_t stride_c, int B, int C, int H, int W, int k, int stride, int pad,
+               int Ho, int Wo, void* cols, int64_t ld, int dtype, void* stream);
+int enh_col2im(const void* dcols, int64_t ld, int B, int C, int H, int W, int k, int stride, int pad, int Ho, int Wo,
+               float* dx, int64_t stride_b, int64_t stride_c, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Implicit-GEMM convolutions on channels-last bf16 activations [B,H,W,C] (no im2col tensor): EqualConv2d forward, input gradient and

@@ -32,7 +32,11 @@ def install(monkeypatch, exact: bool = True):
         ar = torch.arange
         return ar(B)[:, None, None, None] * sb + ar(C)[None, :, None, None] * sc + ar(H)[None, None, :, None] * W + ar(W)[None, None, None, :]
 
-    def im2col(x, sb, sc, B, C, H, W, k, s, p):
+    def mm(a, b, M, N, K, out, trans_a=False, trans_b=False, **kw):      # the exact-f32 GEMM the fp32 instrument of conv2d_gradfix runs on
+        assert not kw
+        gemm(a, b, M, N, K, trans_a, trans_b, out_f32=out)
+
+    def im2col(x, sb, sc, B, C, H, W, k, s, p, dtype=None):
         img = x.reshape(-1)[_idx(B, C, H, W, sb, sc)]
         Ho, Wo = _C.conv_out_size(H, k, s, p), _C.conv_out_size(W, k, s, p)
         cols = F.unfold(img, k, padding=p, stride=s).permute(0, 2, 1).reshape(B * Ho * Wo, C * k * k)
@@ -163,7 +167,7 @@ def install(monkeypatch, exact: bool = True):
             dx, = torch.autograd.grad(_stddev_torch(x32, group, g.shape[3]), x32, g.float())
         return dx.to(low)
 
-    for name, fn in dict(gemm=gemm, cast_bf16=cast_bf16, im2col=im2col, col2im=col2im, fused_bias_act=fused_bias_act,
+    for name, fn in dict(gemm=gemm, mm=mm, cast_bf16=cast_bf16, im2col=im2col, col2im=col2im, fused_bias_act=fused_bias_act,
                          channel_sum=channel_sum, upfirdn2d=upfirdn2d, conv_nhwc=conv_nhwc, conv_wgrad_nhwc=conv_wgrad_nhwc,
                          conv_pack_weight=conv_pack_weight, conv_unpack_wgrad=conv_unpack_wgrad, blur_nhwc=blur_nhwc, lrelu_gate=lrelu_gate,
                          img_to_nhwc8=img_to_nhwc8, nhwc8_to_img=nhwc8_to_img, colsum_nhwc=colsum_nhwc,
@@ -176,3 +180,4 @@ def install(monkeypatch, exact: bool = True):
             def __getattr__(self, n):
                 return getattr(torch, n)
         monkeypatch.setattr(cg, "torch", _Torch())
+        monkeypatch.setattr(cg, "_OPERAND", torch.float32)      # = conv2d_gradfix.operand_dtype("fp32"): the fp32 instrument's code path

@@ -31,8 +31,39 @@ import vitvq_oracle as O  # noqa: E402
 CLASSES = ["w", "patch", "ln", "qkv", "p", "o", "hid"]
 
 
+RB_DTYPE = torch.bfloat16      # --dtype: the 16-bit format of the rounding points (round 6: fp16 = the engine's default operand format, 11 significand bits against 8)
+
+
 def rb(t, on):
-    return t.to(torch.bfloat16).to(torch.float32) if on else t
+    return t.to(RB_DTYPE).to(torch.float32) if on else t
+
+
+def decoder_xrec(zq, P, cfg, on: set):
+    """oracle post_quant + decoder + to_pixel (vitvq_oracle.decode) with the engine's rounding points: the quantized tokens (A operand of post_quant) count as "ln"-class
+    activations, the rest as in encoder_h"""
+    W = lambda k: rb(P[k], "w" in on)
+    patch, heads, depth = cfg["patch_size"], cfg["decoder"]["heads"], cfg["decoder"]["depth"]
+    x = rb(zq, "ln" in on) @ W("post_quant.weight").t() + P["post_quant.bias"] + P["decoder.de_pos_embedding"]
+    B, N, _ = x.shape
+    for i in range(depth):
+        p = f"decoder.transformer.layers.{i}."
+        a1 = rb(O.layer_norm(x, P[p + "0.norm.weight"], P[p + "0.norm.bias"]), "ln" in on)
+        qkv = rb(a1 @ W(p + "0.fn.to_qkv.weight").t(), "qkv" in on)
+        q, k, v = qkv.chunk(3, dim=-1)
+        sp = lambda t: t.reshape(B, N, heads, 64).permute(0, 2, 1, 3)
+        q, k, v = sp(q), sp(k), sp(v)
+        s_ = (q @ k.transpose(-1, -2)) * 64 ** -0.5
+        e = torch.exp(s_ - s_.amax(-1, keepdim=True))
+        att = (rb(e, "p" in on) @ v) / e.sum(-1, keepdim=True)
+        o = rb(att.permute(0, 2, 1, 3).reshape(B, N, heads * 64), "o" in on)
+        x = o @ W(p + "0.fn.to_out.weight").t() + P[p + "0.fn.to_out.bias"] + x
+        a2 = rb(O.layer_norm(x, P[p + "1.norm.weight"], P[p + "1.norm.bias"]), "ln" in on)
+        hid = rb(torch.tanh(a2 @ W(p + "1.fn.net.0.weight").t() + P[p + "1.fn.net.0.bias"]), "hid" in on)
+        x = hid @ W(p + "1.fn.net.2.weight").t() + P[p + "1.fn.net.2.bias"] + x
+    a = rb(O.layer_norm(x, P["decoder.transformer.norm.weight"], P["decoder.transformer.norm.bias"]), "ln" in on)
+    w = W("decoder.to_pixel.1.weight")
+    pix = a @ w.reshape(w.shape[0], -1) + P["decoder.to_pixel.1.bias"].repeat_interleave(patch * patch)
+    return pix      # (the patch layout: the permutation to [B,C,H,W] does not change a Frobenius-relative error)
 
 
 def encoder_h(img, P, cfg, on: set, trace=None):
@@ -102,6 +133,17 @@ def run(batch: int, spread: bool, cfg=None, seed: int = 0, out=sys.stdout):
             print(f"  {name:<14} {r['h']:>10.2e} {r['l1']:>10.2e} {r['l12']:>10.2e} {flips:>11.4f}", file=out)
         quad = sum(rows[c]["h"] ** 2 for c in CLASSES) ** 0.5
         print(f"# quadrature sum of the seven single-class errors: {quad:.2e} (all together: {rows['all']['h']:.2e}) -> the contributions are independent", file=out)
+        # residual quantizer (BASELINE config 4: depth 4, one shared codebook): per-depth match of the all-classes-rounded h against the unrounded one
+        q4 = dict(q, use_residual=True, num_quantizers=4)
+        i0 = O.quantizer_forward(h0, E, **q4)[2]
+        i1 = O.quantizer_forward(encoder_h(img, P, cfg, set(CLASSES)), E, **q4)[2]
+        print(f"# RQ-4 on the same h: per-depth match {(i0 == i1).float().mean().item():.4f}, whole-tuple match {(i0 == i1).all(-1).float().mean().item():.4f}", file=out)
+        # decoder side: xrec downstream of the SAME quantized tokens (the unrounded encoder's), every class rounded
+        zq = O.encode(img, P, cfg)[0]
+        x0 = decoder_xrec(zq, P, cfg, set())
+        x1 = decoder_xrec(zq, P, cfg, set(CLASSES))
+        rows["xrec"] = dict(h=rel(x1, x0))
+        print(f"# decoder (post_quant .. to_pixel) with every class rounded, same codes: xrec rel err {rows['xrec']['h']:.2e}", file=out)
     return rows
 
 
@@ -109,6 +151,9 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=2)
     ap.add_argument("--spread", action="store_true")
+    ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16", help="16-bit format of the rounding points")
     a = ap.parse_args()
+    RB_DTYPE = torch.float16 if a.dtype == "fp16" else torch.bfloat16
+    print(f"# rounding points in {a.dtype}")
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
     run(a.batch, a.spread)

@@ -69,12 +69,35 @@ def test_conv2d_values_and_gradients(C, B, Cin, Cout, H, k, s, p):
     assert rel(xd.grad, xr.grad) <= 4e-3      # dcols leaves the dgrad GEMM in bf16: up to k*k rounded terms per input pixel
 
 
-def test_discriminator_against_reference_golden(C, golden_dir):
+# (lowering, operand format) -> bounds (logits, dx of the R1 pass, r1, d_loss, gradient norms, generator-side dx, parameter gradients) against the REFERENCE's own
+# golden (oracle/make_golden_disc.py runs /root/reference/enhancing/losses/layers.py): the product path (implicit GEMM, bf16 operands: leaky-ReLU gates of a random-init
+# network flip under the operand rounding, see the emulation test below), the same arithmetic on fp16 operands through the im2col lowering (11 significand bits: ~8x fewer
+# flips), and the fp32 INSTRUMENT (f32 columns, exact-f32 GEMM: no 16-bit rounding anywhere) — the mode in which f1 meets north_star's tolerance, as the fp32 engine mode
+# does for the towers.  Bounds: 1.3 x the values measured on MI355X (profiles/r06_disc_parity.txt) for the two new modes.
+DISC_MODES = {
+    "igemm_bf16":  ("igemm", "bf16", (2e-2, 0.15, 2e-2, 1e-2, 6e-2, 0.15, 0.2)),
+    "im2col_fp16": ("im2col", "fp16", (3e-3, 3e-2, 4e-3, 2e-3, 1.2e-2, 3e-2, 6e-2)),      # measured 2.1e-3, 2.0e-2, 2.4e-3, 9.8e-4, 7.4e-3, 2.0e-2, 4.5e-2 (final_conv bias; the others 1.0e-2)
+    "im2col_fp32": ("im2col", "fp32", (1e-4, 1e-3, 1e-4, 1e-4, 1e-3, 1e-3, 1e-3)),        # measured 8.8e-6, 7.7e-4 (one leaky-ReLU gate of the random-init network sits within an fp32 ulp of zero), 2.0e-5, 8.0e-6, 5.8e-5, 2.8e-4, 1.1e-4: every quantity within north_star's 1e-3
+}
+
+
+@pytest.mark.parametrize("mode", list(DISC_MODES))
+def test_discriminator_against_reference_golden(C, golden_dir, mode):
+    from enhancing.engine.stage1 import ParamStore
+    from enhancing.losses.layers import vanilla_d_loss
+    from enhancing.losses.op import conv2d_gradfix
+    lowering, operand, (b_logits, b_dx, b_r1, b_loss, b_norm, b_gf, b_grad) = DISC_MODES[mode]
+    with conv2d_gradfix.operand_dtype(operand):
+        _disc_golden_case(C, golden_dir, lowering, mode, b_logits, b_dx, b_r1, b_loss, b_norm, b_gf, b_grad)
+
+
+def _disc_golden_case(C, golden_dir, lowering, mode, b_logits, b_dx, b_r1, b_loss, b_norm, b_gf, b_grad):
     from enhancing.engine.stage1 import ParamStore
     from enhancing.losses.layers import vanilla_d_loss
     from enhancing.losses.op import conv2d_gradfix
     G = np.load(os.path.join(golden_dir, "disc_tiny.npz"))
     D, real, fake = disc_case(G)
+    D.lowering = lowering
     dev = torch.device("cuda")
     D.to(dev)
     store = ParamStore(D, dev, precision="fp32")
@@ -100,11 +123,16 @@ def test_discriminator_against_reference_golden(C, golden_dir):
     g_loss = vanilla_d_loss(D(xf))
     gf, = torch.autograd.grad(g_loss, xf)
     e_gf = rel(gf, torch.from_numpy(G["g_fake"]))
-    print(f"discriminator vs reference golden: logits {e_logits:.2e}, dx {e_dx:.2e}, r1 {e_r1:.2e}, d_loss {e_loss:.2e}, grad norms {e_norm:.2e}, "
-          f"grads {e_t}, generator-side dx {e_gf:.2e}")
-    assert e_logits <= 2e-2 and e_dx <= 0.15 and e_r1 <= 2e-2 and e_loss <= 1e-2 and e_norm <= 6e-2 and e_gf <= 0.15
-    assert max(e_t.values()) <= 0.2, e_t
-    assert abs(g_loss.item() - float(G["g_loss"])) <= 1e-2
+    line = (f"discriminator [{mode}] vs reference golden: logits {e_logits:.2e}, dx {e_dx:.2e}, r1 {e_r1:.2e}, d_loss {e_loss:.2e}, grad norms {e_norm:.2e}, "
+            f"grads {({k: float(f'{v:.2e}') for k, v in e_t.items()})}, generator-side dx {e_gf:.2e}")
+    print(line)
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "disc_parity.txt"), "a") as f:
+            f.write(line + "\n")
+    assert e_logits <= b_logits and e_dx <= b_dx and e_r1 <= b_r1 and e_loss <= b_loss and e_norm <= b_norm and e_gf <= b_gf, line
+    assert max(e_t.values()) <= b_grad, e_t
+    assert abs(g_loss.item() - float(G["g_loss"])) <= max(1e-2 if mode == "igemm_bf16" else 2e-3 * abs(float(G["g_loss"])), 1e-5)
 
 
 def test_hip_discriminator_vs_the_same_rounding_points_in_torch(C, golden_dir, monkeypatch):
