@@ -292,6 +292,8 @@ def main():
     ap.add_argument("--precision", choices=["fp16", "bf16"], default=os.environ.get("ENH_PRECISION", "fp16"),
                     help="16-bit MFMA operand format of the product path: fp16 (the reference's --use_amp dtype; meets the 1e-3 parity clause in one pass; "
                          "loss-scaled backward) or bf16")
+    ap.add_argument("--timer-every", type=int, default=4, help="per-launch HIP-event timing (the roofline / kernels blocks) on every n-th step of the timed region "
+                                                              "(1 = every step: ~3600 events per step cost ~3 %% of it; the sampled steps are inside the timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the parity_mode block (x3 / fp32 throughput and parity beside the headline)")
     ap.add_argument("--graphs", action="store_true", help="replay the fused AE step from a captured HIP graph (for launch-bound small batches); the per-kernel "
@@ -382,13 +384,16 @@ def main():
     for i in range(args.warmup):
         out = step(i)
     timer = _C.KernelTimer()
-    if not use_graphs:
-        _C.TIMER = timer
+    every = max(1, min(args.timer_every, args.steps))
+    timed_steps = [i for i in range(args.steps) if (not use_graphs) and i % every == every - 1]      # live per-launch timing on these steps of the timed region
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    t_last_step_ms = 0.0
     for i in range(args.steps):
+        _C.TIMER = timer if i in timed_steps else None
+        t_last_step_ms = time.perf_counter() * 1e3      # (host clock of engine/ddp.py's per-bucket issue log)
         out = step(i)
     torch.cuda.synchronize()
     if world > 1:
@@ -412,10 +417,13 @@ def main():
         # per-rank exposed communication (so that the first real multi-GPU run explains itself) + the bucket accounting the DDP tests insist on
         mine = eng.comm.comm_wait_ms(last=args.steps)
         mine.update(rank=rank, bytes_reduced_per_step=eng.comm.bytes_reduced / max(args.warmup + args.steps, 1), gap_elems=eng.comm.gap_elems)
+        # last timed step: when each bucket was handed to the collective library, as an offset from the step's start on the host clock
+        mine["bucket_issue_timeline_last_step"] = eng.comm.issue_timeline(t_last_step_ms)
         if adversarial and len(opts) > 1 and opts[1].comm is not None:      # the second optimizer's collectives, reported separately
             dsync = opts[1].comm
             mine["discriminator"] = dict(dsync.comm_wait_ms(last=args.steps), bytes_reduced_per_step=dsync.bytes_reduced / max(args.warmup + args.steps, 1),
-                                         gap_elems=dsync.gap_elems, n_params=int(dsync.store.g.numel()), n_buckets=len(dsync.buckets))
+                                         gap_elems=dsync.gap_elems, n_params=int(dsync.store.g.numel()), n_buckets=len(dsync.buckets),
+                                         bucket_issue_timeline_last_step=dsync.issue_timeline(t_last_step_ms))      # same clock as the autoencoder's list above: interleave to see the queue order
         allr = [None] * world
         dist.all_gather_object(allr, mine)
         comm_info = {"backend": dist.get_backend(), "algo": args.grad_algo, "comm_cus": args.comm_cus, "bucket_dtype": "bf16" if args.grad_bf16 else "fp32",
@@ -429,7 +437,7 @@ def main():
     img_per_s = args.steps * B * world / elapsed
     ms_per_step = elapsed / args.steps * 1e3
     ks = timer.summary()
-    steps_timed = 2 if use_graphs else args.steps
+    steps_timed = 2 if use_graphs else len(timed_steps)
     # PMC traffic only from a pass over the SAME config and batch (profiles/pmc_step.json: {"config":, "batch":, "kernels": {symbol: {...}}})
     pmc, pmc_path = None, os.path.join(ROOT, "profiles", "pmc_step.json")
     if os.path.exists(pmc_path):
@@ -458,6 +466,9 @@ def main():
         "final_loss": loss,
         "step_mfma_frac": round(img_per_s / world * STEP_TFLOP_PER_IMG_BASE / MFMA_BF16_PEAK_TFLOPS, 4) if is_base else None,
         "roofline": roofs[dom],
+        "kernel_timing": {"steps_with_per_launch_hip_events": steps_timed, "of_timed_steps": args.steps,
+                          "note": "launch durations (roofline / kernels) are measured live with HIP events on the launch stream, on every "
+                                  f"{every}-th step inside the timed region" if not use_graphs else "two eager steps after the graph-replayed timed region"},
         "kernels": {k: {"launches": v["launches"], "total_ms": round(v["total_ms"], 2), "bound": roofs[k]["bound"], "achieved": roofs[k]["achieved"],
                         "unit": roofs[k]["unit"], "frac": roofs[k]["frac"], "share_of_step": roofs[k]["share_of_step"], "traffic": roofs[k]["traffic"]}
                     for k, v in sorted(ks.items())},

@@ -28,20 +28,32 @@ extern "C" int enh_abi_version(void) { return ENH_ABI_VERSION; }
 // the LayerNorm backward's one-workgroup-per-CU grid.  Data-parallel training runs RCCL's kernels beside the backward pass (enhancing/engine/ddp.py;
 // reference main.py:54-57); a grid sized for ALL CUs then has workgroups that wait for a CU until another retires (2x on that launch, measured in
 // profiles/r04_comm_contention.txt).  0 = every CU of the device.  Explicit state behind an explicit call: the library reads no environment.
-static int g_cu_budget = 0;
-int enh_device_cus() {
-  static const int n = [] {
-    int dev = 0, c = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev);
-    return c > 0 ? c : 256;
-  }();
-  return n;
+// Device-bound state is keyed by the CURRENT device of the calling thread (round 6; until round 5 the CU count, the budget and the persistent GEMMs' tile-claim
+// counters belonged to the first device the library was used on — fine for one process per GPU, a trap for a process that drives several devices through
+// the C ABI): a budget set while device d is current applies to launches issued while d is current.
+int enh_current_device() {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  return dev >= 0 && dev < ENH_MAX_DEVICES ? dev : 0;
 }
-int enh_cu_budget() { return g_cu_budget > 0 && g_cu_budget < enh_device_cus() ? g_cu_budget : enh_device_cus(); }
+static int g_cu_budget[ENH_MAX_DEVICES] = {0};
+static int g_device_cus[ENH_MAX_DEVICES] = {0};      // 0 = not asked yet (benign race: every thread writes the same value)
+int enh_device_cus() {
+  const int dev = enh_current_device();
+  if (g_device_cus[dev] == 0) {
+    int c = 256;
+    (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev);
+    g_device_cus[dev] = c > 0 ? c : 256;
+  }
+  return g_device_cus[dev];
+}
+int enh_cu_budget() {
+  const int b = g_cu_budget[enh_current_device()], n = enh_device_cus();
+  return b > 0 && b < n ? b : n;
+}
 extern "C" int enh_set_cu_budget(int n_cus) {
   ENH_REQUIRE(n_cus >= 0, ENH_E_BADARG, "enh_set_cu_budget: n_cus must be >= 0 (0 = all)");
-  g_cu_budget = n_cus;
+  g_cu_budget[enh_current_device()] = n_cus;
   return ENH_OK;
 }
 extern "C" int enh_get_cu_budget(void) { return enh_cu_budget(); }

@@ -29,6 +29,8 @@ typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4_t;
 void enh_set_error(const char* fmt, ...);
 int enh_check_launch(const char* what);
 int enh_zero_f32_launch(float* p, int64_t n, hipStream_t s);   // p[0..n) = 0 as a kernel launch (graph-safe; see common.cpp)
+#define ENH_MAX_DEVICES 64
+int enh_current_device();   // hipGetDevice of the calling thread, clamped to [0, ENH_MAX_DEVICES)
 int enh_device_cus();   // CUs of the current device (256 on MI355X)
 int enh_cu_budget();    // CUs a launch sized by the CU count may count on (enh_set_cu_budget; = enh_device_cus() unless a budget is set)
 int enh_colsum_reduce_launch(const float* part, int chunks, int64_t N, float* out, int accumulate, hipStream_t s);   // elementwise.hip

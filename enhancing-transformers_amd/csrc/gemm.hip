@@ -62,13 +62,17 @@ extern "C" int enh_gemm_set_scheduler(int dynamic) {
   return ENH_OK;
 }
 static unsigned int* next_tile_counters() {
-  static unsigned int* base = [] {
+  // the counter words are a __device__ symbol: one instance per device.  Address and launch-slot sequence are kept per device (keyed by the current
+  // device: a process that drives several GPUs claims tiles from the counters of the device it launches on)
+  static unsigned int* base[ENH_MAX_DEVICES] = {nullptr};
+  static unsigned seq[ENH_MAX_DEVICES] = {0};
+  const int dev = enh_current_device();
+  if (!base[dev]) {
     void* p = nullptr;
     (void)hipGetSymbolAddress(&p, HIP_SYMBOL(g_tile_ctr));
-    return (unsigned int*)p;
-  }();
-  static unsigned seq = 0;
-  return base ? base + (size_t)((seq++) & 63u) * 8 : nullptr;
+    base[dev] = (unsigned int*)p;
+  }
+  return base[dev] ? base[dev] + (size_t)((seq[dev]++) & 63u) * 8 : nullptr;
 }
 
 struct GemmPlan { int family, splits; int64_t k_per_split; };

@@ -68,6 +68,12 @@ class GradSync:
         self.host_wait_ms: List[float] = []
         self._wait_events: List[Tuple[torch.cuda.Event, torch.cuda.Event]] = []
         self.buckets_last_step = 0
+        # per-bucket issue log of the step in flight / of the last finished step: (host time of the issue in ms on the process-wide time.perf_counter
+        # clock, first element, elements).  Two synchronisers of one process (the autoencoder's GradSync and the discriminator's AutogradGradSync share
+        # RCCL's one stream per process group) log on the SAME clock, so their lists interleave into the order the collectives were queued in —
+        # bench.py's `comm` block prints them side by side (does a discriminator bucket wait behind autoencoder buckets?).
+        self._issue_log: List[Tuple[float, int, int]] = []
+        self.last_issue_log: List[Tuple[float, int, int]] = []
 
     def broadcast_parameters(self, src: int = 0) -> None:
         """DDP's initial parameter broadcast: every rank starts from rank `src`'s weights."""
@@ -103,6 +109,7 @@ class GradSync:
             self._budget_on = on
 
     def _reduce(self, b: int, e: int) -> None:
+        self._issue_log.append((time.perf_counter() * 1e3, b, e - b))
         self._set_budget(True)
         view = self.store.g[b:e]
         if self._g16 is not None:
@@ -159,6 +166,11 @@ class GradSync:
         self._handles = []
         self._shards = []
         self._done = []
+        self.last_issue_log, self._issue_log = self._issue_log, []
+
+    def issue_timeline(self, t0_ms: float = 0.0) -> List[dict]:
+        """the last finished step's collectives in issue order: offset of the issue from t0_ms (host clock, time.perf_counter() * 1e3), first element, elements"""
+        return [dict(t_ms=round(t - t0_ms, 3), begin=b, elems=n) for t, b, n in self.last_issue_log]
 
     def begin_step(self) -> None:
         self.announced = []

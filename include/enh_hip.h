@@ -12,9 +12,9 @@
  *     the reference's native-op precedent, where TORCH_CHECK failures surface as a Python RuntimeError
  *     (enhancing/losses/op/fused_bias_act.cpp:9-15); the Python wrapper raises RuntimeError on rc != 0.
  *   - All functions are stateless and re-entrant (they are called from autograd worker threads too), EXCEPT the explicit library
- *     state behind the enh_*_set_* / enh_set_cu_budget / enh_debug_* setters (process-global, meant for A/B measurements and for the
- *     data-parallel driver) and the persistent GEMMs' tile-claim counters, which together with the cached CU count belong to the
- *     FIRST device the library is used on: one device per process (the deployment model: one process per GPU, torchrun).
+ *     state behind the enh_*_set_* / enh_set_cu_budget / enh_debug_* setters (process-global kernel-family switches, meant for A/B measurements).
+ *     Device-bound state — the CU count, the CU budget and the persistent GEMMs' tile-claim counters — is keyed by the calling thread's CURRENT
+ *     device (hipGetDevice) since round 6: a process may drive several GPUs through this ABI (the library still never sets a device).
  *
  * The reference reaches this path through stock PyTorch ops, not an FFI; each entry
  * below cites the reference lines whose arithmetic it replaces.  Paths are relative to the reference

@@ -39,6 +39,9 @@ def _worker(rank, world, port, q, algo="allreduce"):
         for prefix in ["decoder.b.", "decoder.a.", "quantizer.", "encoder.b.", "encoder.a."]:  # backward order
             sync.layer_done(prefix)
         sync.finish()
+        # the per-bucket issue log (bench.py's comm block): the finished step's collectives in issue order, covering every element exactly once
+        tl = sync.issue_timeline(0.0)
+        assert tl and sum(r["elems"] for r in tl) == store.g.numel() and all(a["t_ms"] <= b["t_ms"] for a, b in zip(tl, tl[1:])), tl
     q.put((rank, store.g.numpy().copy(), local.numpy().copy()))   # numpy, not tensors: a tensor travels as a shared-memory handle that dies with this process
     dist.barrier()
     dist.destroy_process_group()
