@@ -120,6 +120,18 @@ __device__ __forceinline__ f32x4 mfma16(const s16x8& a, const s16x8& b, const f3
   } while (0)
 #define ENH_REQUIRE_DT(dtype, what) ENH_REQUIRE((dtype) == ENH_DT_BF16 || (dtype) == ENH_DT_F16, ENH_E_BADARG, what ": dtype must be ENH_DT_BF16 (0) or ENH_DT_F16 (1), got %d", (int)(dtype))
 
+// tanh for the x3 path, ONE function for the stand-alone split kernel (x3.hip split3) and the fused GEMM epilogue (gemm_tiles.h EPI_BF16_TANH_SPLIT), so the
+// two forms of the x3 forward produce the same bits whatever the batch size selects: the path keeps ~2^-17 relative per element (hi + lo), which
+// 1 - 2 / (exp(2x) + 1) alone loses below |x| ~ 0.1 (absolute error ~1e-7 against a small result) — small arguments take the odd series
+// x (1 - x^2/3 + 2 x^4/15 - 17 x^6/315) (next term 62 x^9/2835: < 3e-9 relative at 0.12).  exp2 / rcp on the transcendental unit.
+__device__ __forceinline__ float tanh_x3(float x) {
+  const float x2 = x * x;
+  const float t = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+  const float big = 1.f - 2.f * __builtin_amdgcn_rcpf(t + 1.f);
+  const float small = x * (1.f + x2 * (-0.33333333333f + x2 * (0.13333333333f + x2 * -0.05396825397f)));
+  return x2 < 0.0144f ? small : big;
+}
+
 // LDS transpose read (ds_read_b64_tr_b16).  Verified on MI355X (profiles/hw_probe_r01.txt):
 // within each 16-lane group, result(lane i, elem j) = the 16-bit element (i % 4) of the 8 bytes that lane
 // (j*4 + i/4) of the same group addressed.

@@ -31,8 +31,9 @@ template <typename OT>
 __global__ __launch_bounds__(256) void unpatchify_loss_kernel(
     const float* __restrict__ pix, const float* __restrict__ target, int B, int C, int H, int W, int p, float w_l1,
     float w_l2, float inv_numel, float* __restrict__ xrec, double* __restrict__ sums, uint16_t* __restrict__ dpix,
-    int64_t total4) {
+    int64_t total4, const float* __restrict__ gscale) {
   __shared__ float s_l1[4], s_l2[4];
+  if (gscale) inv_numel *= *gscale;      // the loss scale of the fp16 backward (a device scalar: GradScaler's scale, updated on the device) multiplies the GRADIENT only
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   float l1 = 0.f, l2 = 0.f;
   if (i < total4) {
@@ -170,10 +171,12 @@ __global__ void cast_f32_h16_kernel(const float* __restrict__ x, uint16_t* __res
 template <typename OT>
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                              float* __restrict__ v, uint16_t* __restrict__ p16, int64_t n, float lr, float beta1,
-                             float beta2, float eps, float wd, float gscale, float inv_bc1, float inv_sqrt_bc2, const float* __restrict__ skip) {
+                             float beta2, float eps, float wd, float gscale, float inv_bc1, float inv_sqrt_bc2, const float* __restrict__ skip,
+                             const float* __restrict__ loss_scale) {
   const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= n) return;
   if (skip && *skip != 0.f) return;
+  if (loss_scale) gscale /= *loss_scale;      // GradScaler's unscale, folded into the step (the scale is a power of two: exact)
   float pv[4], gv[4], mv[4], vv[4];
   const bool full = i + 3 < n;
   if (full) {
@@ -219,13 +222,13 @@ extern "C" int enh_patchify(const float* img, int B, int C, int H, int W, int p,
 }
 
 extern "C" int enh_unpatchify_loss(const float* pix, const float* target, int B, int C, int H, int W, int p, float w_l1,
-                                   float w_l2, float* xrec, double* sums, enh_h16* dpix_bf16, int dtype, void* stream) {
+                                   float w_l2, float* xrec, double* sums, enh_h16* dpix_bf16, const float* grad_scale_dev, int dtype, void* stream) {
   ENH_REQUIRE_DT(dtype, "enh_unpatchify_loss");
   ENH_REQUIRE(pix && (xrec || target), ENH_E_BADARG, "enh_unpatchify_loss: null pointer");
   ENH_REQUIRE(B > 0 && C > 0 && p > 0 && p % 4 == 0 && H % p == 0 && W % p == 0, ENH_E_SHAPE, "enh_unpatchify_loss: need p %% 4 == 0 and H,W divisible by p");
   const int64_t numel = (int64_t)B * C * H * W, total4 = numel / 4;
   ENH_DT_DISPATCH(dtype, (unpatchify_loss_kernel<OT><<<(int)((total4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(
-      pix, target, B, C, H, W, p, w_l1, w_l2, 1.0f / (float)numel, xrec, target ? sums : nullptr, dpix_bf16, total4)));
+      pix, target, B, C, H, W, p, w_l1, w_l2, 1.0f / (float)numel, xrec, target ? sums : nullptr, dpix_bf16, total4, grad_scale_dev)));
   return enh_check_launch("enh_unpatchify_loss");
 }
 
@@ -330,14 +333,35 @@ extern "C" int enh_cast_f32_h16(const float* x, enh_h16* y, int64_t n, int dtype
 
 extern "C" int enh_adamw_step(float* p, const float* g, float* m, float* v, enh_h16* p_bf16, int64_t n, int step,
                               float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
-                              const float* skip_flag, int dtype, void* stream) {
+                              const float* skip_flag, const float* loss_scale_dev, int dtype, void* stream) {
   ENH_REQUIRE_DT(dtype, "enh_adamw_step");
   ENH_REQUIRE(p && g && m && v && n > 0 && step >= 1, ENH_E_BADARG, "enh_adamw_step: bad argument");
   const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
   const int64_t n4 = (n + 3) / 4;
   ENH_DT_DISPATCH(dtype, (adamw_kernel<OT><<<(int)((n4 + 255) / 256), 256, 0, (hipStream_t)stream>>>(p, g, m, v, p_bf16, n, lr, beta1, beta2, eps, weight_decay,
-                                                                                            grad_scale, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), skip_flag)));
+                                                                                            grad_scale, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), skip_flag, loss_scale_dev)));
   return enh_check_launch("enh_adamw_step");
+}
+
+// torch.cuda.amp.GradScaler.update() on the device (the reference's --use_amp, main.py:25,52): found_inf != 0 -> scale *= backoff, tracker = 0; otherwise
+// ++tracker and, after growth_interval clean steps in a row, scale *= growth, tracker = 0.  scale stays inside [1, 2^24] (powers of two with the default factors
+// 2 / 0.5: scaling and unscaling are exact).  One thread; no host round trip, HIP-graph safe.
+__global__ void loss_scale_update_kernel(float* __restrict__ scale, const float* __restrict__ found_inf, int* __restrict__ tracker, float growth, float backoff, int interval) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float s = *scale;
+  int t = *tracker;
+  if (*found_inf != 0.f) { s *= backoff; t = 0; }
+  else if (interval > 0 && ++t >= interval) { s *= growth; t = 0; }
+  *scale = fminf(fmaxf(s, 1.0f), 16777216.0f);
+  *tracker = t;
+}
+
+extern "C" int enh_loss_scale_update(float* scale, const float* found_inf, int* growth_tracker, float growth_factor, float backoff_factor, int growth_interval,
+                                     void* stream) {
+  ENH_REQUIRE(scale && found_inf && growth_tracker && growth_factor >= 1.f && backoff_factor > 0.f && backoff_factor <= 1.f && growth_interval >= 0, ENH_E_BADARG,
+              "enh_loss_scale_update: bad argument (growth >= 1, 0 < backoff <= 1, interval >= 0)");
+  loss_scale_update_kernel<<<1, 64, 0, (hipStream_t)stream>>>(scale, found_inf, growth_tracker, growth_factor, backoff_factor, growth_interval);
+  return enh_check_launch("enh_loss_scale_update");
 }
 
 // flag[0] = 1 if any of x[0..n) is inf / nan, else unchanged (the caller zeroes it): the found-inf check of torch.cuda.amp.GradScaler.unscale_ over one flat

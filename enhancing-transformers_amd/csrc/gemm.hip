@@ -300,6 +300,7 @@ extern "C" int enh_gemm_bf16_split(const enh_h16* A, int64_t lda, const enh_h16*
                                    enh_h16* hi, int64_t ldhi, enh_h16* lo, int64_t ldlo, enh_h16* hi2, int64_t ldhi2, enh_h16* hi3, int64_t ldhi3,
                                    void* stream) {
   ENH_REQUIRE(A && B && hi && lo, ENH_E_BADARG, "enh_gemm_bf16_split: null pointer");
+  ENH_REQUIRE(M > 0 && N > 0 && K > 0, ENH_E_BADARG, "enh_gemm_bf16_split: M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
   ENH_REQUIRE(gemm_split_plan_ok(M, N, K), ENH_E_SHAPE, "enh_gemm_bf16_split: M=%lld N=%lld K=%lld is not served by the persistent 256 x 256 kernel (ask enh_gemm_bf16_split_fused)",
               (long long)M, (long long)N, (long long)K);
   ENH_REQUIRE((act == ENH_ACT_NONE && !bias) || (act == ENH_ACT_TANH && bias), ENH_E_BADARG, "enh_gemm_bf16_split: plain (no bias) or bias + tanh");

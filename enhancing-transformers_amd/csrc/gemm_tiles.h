@@ -182,16 +182,8 @@ __device__ __forceinline__ void epi_value(const GemmArgs& args, float (&v)[4], c
   constexpr bool G = MODE == EPI_GENERIC;
   if (MODE == EPI_BF16_BIAS_TANH || MODE == EPI_F32_BIAS_RES || MODE == EPI_BF16_TANH_SPLIT) { v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w; }
   if (MODE == EPI_BF16_TANH_SPLIT) {
-    // the x3 path keeps ~2^-17 relative per element (hi + lo): 1 - 2 / (exp(2x) + 1) alone loses that below |x| ~ 0.1 (absolute error ~1e-7 against a small
-    // result), so small arguments take the odd series x (1 - x^2/3 + 2 x^4/15 - 17 x^6/315) (next term 62 x^9/2835: < 3e-9 relative at 0.12)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float x = v[r], x2 = x * x;
-      const float t = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
-      const float big = 1.f - 2.f * __builtin_amdgcn_rcpf(t + 1.f);
-      const float small = x * (1.f + x2 * (-0.33333333333f + x2 * (0.13333333333f + x2 * -0.05396825397f)));
-      v[r] = x2 < 0.0144f ? small : big;
-    }
+    for (int r = 0; r < 4; ++r) v[r] = tanh_x3(v[r]);      // common.h: the same function as the stand-alone split3 kernel (same bits in both forms)
   }
   if (G && args.bias) {
     const float4 bg = *reinterpret_cast<const float4*>(args.bias + n);

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x
   }
   if (TANH) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
+    for (int e = 0; e < 8; ++e) v[e] = tanh_x3(v[e]);      // (common.h; the fused GEMM epilogue uses the same function: identical bits)
   }
   u32x4 hi, lo;
   split8(v, hi, lo);

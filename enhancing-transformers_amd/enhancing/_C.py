@@ -58,7 +58,7 @@ SIGNATURES = {
     "enh_attention_forward": (_i32, [_vp, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _i32, _vp]),
     "enh_attention_backward": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _i32, _vp]),
     "enh_patchify": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
-    "enh_unpatchify_loss": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _i32, _vp]),
+    "enh_unpatchify_loss": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _i32, _vp]),
     "enh_colsum_h16": (_i32, [_vp, _i64, _i64, _i64, _vp, _i32, _i32, _vp]),
     "enh_colsum_h16_ws": (_i32, [_vp, _i64, _i64, _i64, _vp, _i32, _vp, _sz, _i32, _vp]),
     "enh_colsum_h16_workspace_bytes": (_sz, [_i64, _i64]),
@@ -110,12 +110,13 @@ SIGNATURES = {
     "enh_gemm_bf16_split": (_i32, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     "enh_layernorm_forward_x3": (_i32, [_vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "enh_attention_forward_x3": (_i32, [_vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp]),
-    "enh_adamw_step": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _i32, _vp]),
+    "enh_adamw_step": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _vp, _i32, _vp]),
+    "enh_loss_scale_update": (_i32, [_vp, _vp, _vp, _f32, _f32, _i32, _vp]),
     "enh_nonfinite_flag": (_i32, [_vp, _i64, _vp, _vp]),
 }
 
 _LIB = None
-ABI_VERSION = 15  # ENH_ABI_VERSION of the include/enh_hip.h these signatures were written against
+ABI_VERSION = 16  # ENH_ABI_VERSION of the include/enh_hip.h these signatures were written against
 
 
 def lib():
@@ -452,12 +453,13 @@ _GEMM_WS = {}
 
 
 def _gemm_workspace(device, nbytes: int):
-    """one grow-only split-K workspace per device (the library never allocates: SURVEY.md §8b ownership rule); all GEMMs of a process run on
-    one stream, so a single buffer is safe"""
-    t = _GEMM_WS.get(device)
+    """one grow-only split-K workspace per (device, stream) (the library never allocates: SURVEY.md §8b ownership rule): the GEMMs of one stream run in
+    order, so they share a buffer; the engine's weight-gradient side stream (small batches, engine/stage1.py) gets its own"""
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    t = _GEMM_WS.get(key)
     if t is None or t.numel() < nbytes:
         t = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        _GEMM_WS[device] = t
+        _GEMM_WS[key] = t
     return t
 
 
@@ -500,9 +502,10 @@ def patchify(img, p: int, out):
     _check(lib().enh_patchify(_p(img, F32, "img"), B, C, H, W, p, _p(out, H16, "patches"), _dt(out), _stream()), "enh_patchify")
 
 
-def unpatchify_loss(pix, target, B: int, C: int, H: int, W: int, p: int, w_l1: float, w_l2: float, xrec, sums, dpix):
+def unpatchify_loss(pix, target, B: int, C: int, H: int, W: int, p: int, w_l1: float, w_l2: float, xrec, sums, dpix, grad_scale=None):
+    """grad_scale: optional device scalar (f32 [1]) multiplying the gradient dpix only (the loss scale of the fp16 backward)"""
     _check(lib().enh_unpatchify_loss(_p(pix, F32, "pix"), _p(target, F32, "target"), B, C, H, W, p, w_l1, w_l2, _p(xrec, F32, "xrec"),
-                                     _p(sums, F64, "sums"), _p(dpix, H16, "dpix"), _dt(dpix), _stream()), "enh_unpatchify_loss")
+                                     _p(sums, F64, "sums"), _p(dpix, H16, "dpix"), _p(grad_scale, F32, "grad_scale"), _dt(dpix), _stream()), "enh_unpatchify_loss")
 
 
 def colsum(x, M: int, N: int, out, accumulate: bool = False):
@@ -558,12 +561,18 @@ def nonfinite_flag(x, flag):
 
 
 def adamw_step(p, g, m, v, p_bf16, step: int, lr: float, beta1: float = 0.9, beta2: float = 0.99, eps: float = 1e-8,
-               weight_decay: float = 1e-4, grad_scale: float = 1.0, skip_flag=None):
+               weight_decay: float = 1e-4, grad_scale: float = 1.0, skip_flag=None, loss_scale=None):
     # 30 B per parameter: p, g, m, v read (16) + p, m, v written (12) + the bf16 operand shadow written (2)
     _timed("adamw_kernel", (28.0 + (2.0 if p_bf16 is not None else 0.0)) * p.numel(),
            lambda: _check(lib().enh_adamw_step(_p(p, F32, "p"), _p(g, F32, "g"), _p(m, F32, "m"), _p(v, F32, "v"), _p(p_bf16, H16, "p_bf16"),
                                                p.numel(), step, lr, beta1, beta2, eps, weight_decay, grad_scale, _p(skip_flag, F32, "skip_flag"),
-                                               _dt(p_bf16), _stream()), "enh_adamw_step"), unit="byte")
+                                               _p(loss_scale, F32, "loss_scale"), _dt(p_bf16), _stream()), "enh_adamw_step"), unit="byte")
+
+
+def loss_scale_update(scale, found_inf, tracker, growth: float = 2.0, backoff: float = 0.5, interval: int = 2000):
+    """torch.cuda.amp.GradScaler.update() on the device (scale f32 [1], found_inf f32 [1], tracker int32 [1])"""
+    _check(lib().enh_loss_scale_update(_p(scale, F32, "scale"), _p(found_inf, F32, "found_inf"), _p(tracker, torch.int32, "tracker"), growth, backoff, int(interval),
+                                       _stream()), "enh_loss_scale_update")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -873,9 +882,9 @@ def patchify_any(img, p, out):
         _check(lib().enh_patch_perm_f32(_p(img, F32, "img"), _p(out, F32, "patches"), B, C, H, W, p, 1, _stream()), "enh_patch_perm_f32")
 
 
-def unpatchify_loss_any(pix, target, B, C, H, W, p, w_l1, w_l2, xrec, sums, dpix):
+def unpatchify_loss_any(pix, target, B, C, H, W, p, w_l1, w_l2, xrec, sums, dpix, grad_scale=None):
     if dpix is None or dpix.dtype in H16 or target is None:
-        unpatchify_loss(pix, target, B, C, H, W, p, w_l1, w_l2, xrec, sums, dpix)
+        unpatchify_loss(pix, target, B, C, H, W, p, w_l1, w_l2, xrec, sums, dpix, grad_scale)
     else:
         _check(lib().enh_unpatchify_loss_f32(_p(pix, F32, "pix"), _p(target, F32, "target"), B, C, H, W, p, w_l1, w_l2, _p(xrec, F32, "xrec"),
                                              _p(sums, F64, "sums"), _p(dpix, F32, "dpix"), _stream()), "enh_unpatchify_loss_f32")

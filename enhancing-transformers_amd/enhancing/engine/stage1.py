@@ -236,15 +236,17 @@ class _Tower:
             raise RuntimeError("the x3 forward saves bf16 hi planes for a bf16 backward: training with an x3 tower needs precision='bf16'")
         M, dim, inner, mlp = B * self.n_tok, self.dim, self.inner, self.mlp
         fuse = os.environ.get("ENH_X3_FUSED_SPLIT", "1") != "0"      # A/B switch: the round-4 form (GEMM -> f32, split kernel) with 0
-        fused_qkv = fuse and _C.gemm_split_fused(M, 3 * inner, 3 * dim)
-        fused_fc1 = fuse and _C.gemm_split_fused(M, mlp, 3 * dim)
+        # (asked per launch, not once per forward: the plan depends on the CU budget and the kernel-family override, which a collective's begin / end or an
+        # A/B switch may change between two layers — the launcher would then refuse the fused form mid-forward: ADVICE r5)
+        fused_qkv = lambda: fuse and _C.gemm_split_fused(M, 3 * inner, 3 * dim)
+        fused_fc1 = lambda: fuse and _C.gemm_split_fused(M, mlp, 3 * dim)
         x = b["x"][0]
         for i, P in enumerate(self.L):
             A, W = b["layers"][i if save else 0], W3[i]
             if not save and A["qkv"].dtype != torch.bfloat16:      # (no-save arena of an fp16 engine: the buffer is scratch here, its bits are bf16 hi planes)
                 A = dict(A, qkv=A["qkv"].view(torch.bfloat16))
             _C.ln_fwd_x3(x, s.w[P["ln1_w"]], s.w[P["ln1_b"]], X["a3"], A["mean1"], A["rstd1"], y_bf16=A["a1"] if save else None)
-            if fused_qkv:      # hi / lo planes straight from the GEMM's epilogue (no f32 [M, 3 inner] round trip)
+            if fused_qkv():      # hi / lo planes straight from the GEMM's epilogue (no f32 [M, 3 inner] round trip)
                 _C.gemm_split2(X["a3"], W["wqkv"], M, 3 * inner, 3 * dim, A["qkv"], X["qkv_lo"])
             else:
                 _C.mm(X["a3"], W["wqkv"], M, 3 * inner, 3 * dim, X["qkv32"])
@@ -252,7 +254,7 @@ class _Tower:
             _C.attention_forward_x3(A["qkv"], X["qkv_lo"], B, self.n_tok, self.heads, self.scale, X["o3"], A["o"] if save else None, A["lse"])
             _C.mm(X["o3"], W["wout"], M, dim, 3 * inner, A["x_mid"], bias=s.w[P["bout"]], res=x, res_rows=M)
             _C.ln_fwd_x3(A["x_mid"], s.w[P["ln2_w"]], s.w[P["ln2_b"]], X["a3"], A["mean2"], A["rstd2"], y_bf16=A["a2"] if save else None)
-            if fused_fc1:
+            if fused_fc1():
                 _C.gemm_split3_tanh(X["a3"], W["w1"], M, mlp, 3 * dim, s.w[P["b1"]], X["hid3"], A["hid"] if save else None)
             else:
                 _C.mm(X["a3"], W["w1"], M, mlp, 3 * dim, X["fc32"])
@@ -411,8 +413,10 @@ class Stage1Engine:
         single-pass mode that meets the 1e-3 parity clause; "bf16" is the round-1..5 default, ~3 % faster, ~5e-3).
         "fp16" is the reference's --use_amp dtype (main.py:25,52: Lightning precision=16): 11-bit significands bring the single-pass forward within 1e-3
         of the fp32 reference (bf16: ~5e-3) at the same MFMA rate; the backward runs on fp16 operands too, with the loss gradient multiplied by a
-        static power-of-two `loss_scale` (ENH_LOSS_SCALE, default 2^16 — GradScaler's initial scale) that the AdamW launch divides out again, and an
-        inf / nan check of the flat gradient that makes that launch a no-op (GradScaler.step's skip).
+        power-of-two loss scale that lives ON THE DEVICE (`scale_t`; initial value ENH_LOSS_SCALE, default 2^16 — GradScaler's initial scale): the
+        AdamW launch divides it out again, an inf / nan check of the flat gradient makes that launch a no-op (GradScaler.step's skip), and
+        enh_loss_scale_update applies GradScaler.update (x 0.5 after an overflow, x 2 after ENH_LOSS_SCALE_INTERVAL = 2000 clean steps) — all without a
+        host round trip, so the step stays HIP-graph capturable.  ENH_LOSS_SCALE_INTERVAL=0 keeps the scale from growing.
         Within the bf16 product path the ENCODER forward (patch embedding .. pre_quant, the part that decides the codes) can run on split-bf16
         ("x3") operands — three MFMA passes, ~1e-5 relative, codes equal to the fp32 reference's up to its own near-ties (csrc/x3.hip):
           encoder_precision  "bf16" | "x3": training / reconstruct / forward (ENH_ENCODER_PRECISION, default "bf16": the measured headline path)
@@ -438,8 +442,10 @@ class Stage1Engine:
             raise ValueError("x3 towers in the TRAINING forward save bf16 hi planes for a bf16 backward: they need precision='bf16' (fp16 meets the tolerance in one pass)")
         self.adt = OPERAND_DTYPE[precision]
         # loss scale of the fp16 backward (1 elsewhere): a power of two, so scaling and unscaling are exact
-        self.loss_scale = float(os.environ.get("ENH_LOSS_SCALE", 65536.0)) if precision == "fp16" else 1.0
-        self.check_nonfinite = precision == "fp16" and os.environ.get("ENH_NONFINITE_CHECK", "1") != "0"
+        self.scaled = precision == "fp16"                       # the backward runs under a loss scale
+        self._init_scale = float(os.environ.get("ENH_LOSS_SCALE", 65536.0)) if self.scaled else 1.0
+        self.scale_growth_interval = int(os.environ.get("ENH_LOSS_SCALE_INTERVAL", 2000))      # torch.cuda.amp.GradScaler's default
+        self.check_nonfinite = self.scaled and os.environ.get("ENH_NONFINITE_CHECK", "1") != "0"
         if not torch.cuda.is_available():
             raise RuntimeError("Stage1Engine needs a ROCm device (MI355X); the HIP path has no CPU fallback")
         _C.lib()
@@ -474,6 +480,14 @@ class Stage1Engine:
         self.skipped_steps = None      # device counter of dropped steps (fp16): accumulated without a host sync
         if self.check_nonfinite:
             self.skipped_steps = torch.zeros(1, dtype=F32, device=self.device)
+        # the loss scale and GradScaler's growth tracker, on the device (None for bf16 / fp32 engines: no scaling anywhere)
+        self.scale_t = torch.full((1,), self._init_scale, dtype=F32, device=self.device) if self.scaled else None
+        self._growth_tracker = torch.zeros(1, dtype=torch.int32, device=self.device) if self.scaled else None
+
+    @property
+    def loss_scale(self) -> float:
+        """current loss scale as a host number (reads the device scalar: synchronises; for tests and logging — the step itself never needs it)"""
+        return float(self.scale_t.item()) if self.scaled else 1.0
 
     # ---- helpers -----------------------------------------------------------------------------
     def _invalidate_saved(self) -> None:
@@ -659,7 +673,7 @@ class Stage1Engine:
             raise RuntimeError("backward called for a forward whose saved activations were overwritten by a later forward_train")
 
     def _check_scaled_accumulation(self) -> None:
-        if self.loss_scale != 1.0 and self.store.grads_unscaled:
+        if self.scaled and self.store.grads_unscaled:
             raise RuntimeError("the flat gradient was unscaled (unscale_grads) and not zeroed since: a loss-scaled backward cannot accumulate onto it — call "
                                "zero_grad() first")
 
@@ -668,7 +682,7 @@ class Stage1Engine:
         differentiable_encode + differentiable_decode — torch.cuda.amp's `scaler.scale(loss).backward()` under the reference's --use_amp (main.py:25,52).
         The upstream gradients then reach the 16-bit backward inside fp16's range (a mean-reduced pixel loss has |d loss / d xrec| ~ 1e-8, below fp16's
         smallest subnormal); |gradient| * loss_scale must stay below 65504 — an overflow sets found_inf and the optimizer step is dropped."""
-        return loss * self.loss_scale if self.loss_scale != 1.0 else loss
+        return loss * self.scale_t.to(loss.device).view(()) if self.scaled else loss
 
     @torch.no_grad()
     def unscale_grads(self) -> None:
@@ -676,11 +690,11 @@ class Stage1Engine:
         reference's --use_amp (GradScaler: gradients stay scaled until unscale_ / step).  optimizer_step divides the scale out inside the AdamW launch
         for free; call this (GradScaler.unscale_'s counterpart: one pass over the flat buffer) to READ true gradients before the step — gradient-norm
         logging, a custom optimizer, tests.  Idempotent until the next zero_grad(); a no-op for bf16 / fp32 engines."""
-        if self.loss_scale != 1.0 and not self.store.grads_unscaled:
+        if self.scaled and not self.store.grads_unscaled:
             if self.comm is not None and not self.store.comm_done:      # the reduced gradient is what gets unscaled; optimizer_step will not reduce again
                 self.comm.finish()
                 self.store.comm_done = True
-            self.store.g.mul_(1.0 / self.loss_scale)
+            self.store.g.div_(self.scale_t)
             self.store.grads_unscaled = True
 
     def backward_decoder(self, st: dict, dpix16: torch.Tensor) -> torch.Tensor:
@@ -751,11 +765,10 @@ class Stage1Engine:
         st = self.forward_train(img)
         img, B, io = st["img"], st["B"], self._io_bufs(st["B"])
         io["sums"].zero_()
-        # (fp16: the loss gradient enters the backward multiplied by the loss scale S — folded into the weights of the pixel-loss gradient and into the
+        # (fp16: the loss gradient enters the backward multiplied by the loss scale S, a DEVICE scalar — applied inside the pixel-loss gradient kernel and to the
         # codebook-loss gradient; the loss VALUES below are formed from the unscaled sums; optimizer_step divides the gradients by S again)
-        S = self.loss_scale
-        _C.unpatchify_loss_any(st["pix"], img, B, self.C, self.size, self.size, self.patch, w_l1 * S, w_l2 * S, io["xrec"], io["sums"], io["dpix16"])
-        self.backward_from(st, io["dpix16"], codebook_weight * S)
+        _C.unpatchify_loss_any(st["pix"], img, B, self.C, self.size, self.size, self.patch, w_l1, w_l2, io["xrec"], io["sums"], io["dpix16"], grad_scale=self.scale_t)
+        self.backward_from(st, io["dpix16"], codebook_weight, self.scale_t)
         numel = float(img.numel())
         l1 = (io["sums"][0] / numel).float()
         l2 = (io["sums"][1] / numel).float()
@@ -808,12 +821,11 @@ class Stage1Engine:
         torch.autograd.grad(loss, last_layer) in the reference (vqperceptual.py:95-103); nothing is accumulated into the gradient buffers."""
         B = g_xrec.shape[0]
         io, db, M = self._io_bufs(B), self.dec.bufs(B, True), B * self.n_tok
-        S = self.loss_scale
         g32 = g_xrec.to(dtype=F32).contiguous()
-        _C.patchify_any(g32 * S if S != 1.0 else g32, self.patch, io["dpix16"])
+        _C.patchify_any(g32 * self.scale_t if self.scaled else g32, self.patch, io["dpix16"])      # (scaled into fp16's range; divided out of the norm below)
         tmp = torch.zeros(self.dec.dim, self.pd, dtype=F32, device=self.device)
         _C.mm(db["xf16"], io["dpix16"], self.dec.dim, self.pd, M, tmp, trans_a=True, trans_b=True, accumulate=True)
-        return tmp.norm() / S if S != 1.0 else tmp.norm()
+        return tmp.norm() / self.scale_t.view(()) if self.scaled else tmp.norm()
 
     def differentiable_forward(self, img: torch.Tensor):
         """(xrec, qloss) connected to autograd: `.backward()` on any function of them runs backward_from and leaves the
@@ -844,19 +856,19 @@ class Stage1Engine:
             grad_scale = grad_scale / self.comm.world
         s.step_count += 1
         skip = None
-        if self.loss_scale != 1.0 and not s.grads_unscaled:
-            grad_scale = grad_scale / self.loss_scale
         if self.check_nonfinite:
-            # GradScaler.step's found-inf skip (reference main.py:25,52 --use_amp), without a host round trip: one pass over the flat gradient sets the
-            # flag, the AdamW launch reads it and writes nothing when it is set.  (The scale itself is static; skipped_steps counts the drops on the
-            # device — read it with .item() outside the step if wanted.  The host step count advances either way: a dropped step then only shifts the
-            # bias correction by one step.)
+            # GradScaler.step's found-inf skip + GradScaler.update (reference main.py:25,52 --use_amp), without a host round trip: one pass over the flat
+            # gradient sets the flag, the AdamW launch reads it and writes nothing when it is set, and the scale is halved / doubled on the device.
+            # skipped_steps counts the drops on the device (read it with .item() outside the step if wanted).  The host step count advances either way:
+            # a dropped step then only shifts the bias correction by one step.
             skip = self.found_inf
             skip.zero_()
             _C.nonfinite_flag(s.g, skip)
             self.skipped_steps.add_(skip)
         _C.adamw_step(s.p, s.g, s.m, s.v, s.p16 if self.half else None, s.step_count, lr, betas[0], betas[1], eps, weight_decay,
-                      grad_scale, skip_flag=skip)
+                      grad_scale, skip_flag=skip, loss_scale=self.scale_t if (self.scaled and not s.grads_unscaled) else None)
+        if self.check_nonfinite:
+            _C.loss_scale_update(self.scale_t, skip, self._growth_tracker, 2.0, 0.5, self.scale_growth_interval)
         s.refresh_operands()      # operands derived from the masters (the towers' pre-scaled q | k | v weights, the x3 images: _refresh_x3_operands)
 
     def _refresh_x3_operands(self) -> None:

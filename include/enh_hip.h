@@ -52,7 +52,7 @@ typedef uint16_t enh_h16;  /* raw 16-bit float bits: bfloat16 or binary16, per t
 typedef enh_h16 enh_bf16;  /* raw bfloat16 bits (bf16-only entries) */
 
 const char* enh_last_error(void);
-#define ENH_ABI_VERSION 15  /* bumped whenever a signature below changes; the bindings check it at load */
+#define ENH_ABI_VERSION 16  /* bumped whenever a signature below changes; the bindings check it at load */
 int enh_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -215,6 +215,8 @@ int enh_debug_occupy_cus(int n_wg, float ms, void* stream);
  * operand instead of spending vector instructions on them (the kernels are vector-issue bound, profiles/r03_attention_lab.txt).  Semantics are
  * unchanged: out / lse are those of softmax(q k^T scale) v for the UNSCALED q, dqkv's q third is the gradient with respect to the unscaled q.
  */
+/* NaN note: the attention objects are built with -fno-honor-nans (the row maxima must fuse into v_max3_f32 without canonicalising moves): scores that
+ * contain NaN (a diverged run) are NOT guaranteed to propagate as NaN through out / lse — check the loss / the gradients (enh_nonfinite_flag) instead. */
 int enh_attention_forward(const enh_h16* qkv, int B, int N, int H, float scale, int q_prescaled, enh_h16* out, float* lse,
                           int dtype, void* stream);
 /* kernel family per pass for A/B measurements (explicit library state, like enh_gemm_set_kernel), 0 = the library's choice:
@@ -270,10 +272,10 @@ int enh_patchify(const float* img, int B, int C, int H, int W, int p, enh_h16* p
 /* Inverse scatter of ConvTranspose2d(k=s=p) (layers.py:202-205,212) fused with the pixel losses
  * (vqperceptual.py:113-114): pix [M, C*p*p] f32 (to_pixel GEMM output incl. bias) -> xrec [B,C,H,W] f32;
  * if target != NULL: sums[0] += sum|xrec-x|, sums[1] += sum (xrec-x)^2 (f64 atomics; caller zeroes) and
- * dpix_h16 [M, C*p*p] (`dtype`) = (w_l1*sign(diff) + w_l2*2*diff) / numel  (grad of w_l1*L1 + w_l2*L2), optional — a loss scale for ENH_DT_F16 is
- * folded into w_l1 / w_l2 by the caller (the sums are unaffected). */
+ * dpix_h16 [M, C*p*p] (`dtype`) = (w_l1*sign(diff) + w_l2*2*diff) / numel  (grad of w_l1*L1 + w_l2*L2), optional; grad_scale_dev (optional device
+ * float) multiplies dpix only — the loss scale of an ENH_DT_F16 backward, kept on the device (enh_loss_scale_update); the sums are unaffected. */
 int enh_unpatchify_loss(const float* pix, const float* target, int B, int C, int H, int W, int p, float w_l1,
-                        float w_l2, float* xrec, double* sums, enh_h16* dpix_h16, int dtype, void* stream);
+                        float w_l2, float* xrec, double* sums, enh_h16* dpix_h16, const float* grad_scale_dev, int dtype, void* stream);
 /* out[n] (+)= sum_m x[m,n] (bias gradients); x 16-bit [M,N] (`dtype`) */
 int enh_colsum_h16(const enh_h16* x, int64_t M, int64_t N, int64_t ldx, float* out, int accumulate, int dtype, void* stream);
 /* deterministic form: per-row-chunk partials in `ws` (enh_colsum_h16_workspace_bytes), added in a fixed order; enh_colsum_h16 uses f32 atomics */
@@ -291,9 +293,16 @@ int enh_cast_f32_h16_head_scaled_strided(const float* x, int64_t x_stride, enh_h
 /* torch.optim.AdamW(lr, betas=(0.9,0.99), weight_decay=1e-4) step over one flat buffer (vitvqgan.py:160),
  * also refreshes the 16-bit operand shadow p_h16 (`dtype`) used by the GEMMs.  grad_scale multiplies g first (DDP mean / accumulation / 1 / loss scale).
  * skip_flag (optional device float): non-zero = drop this step — nothing is written (p, m, v, p_h16 unchanged): the inf / nan skip of
- * torch.cuda.amp.GradScaler.step under the reference's --use_amp (main.py:25,52); the flag comes from enh_nonfinite_flag. */
+ * torch.cuda.amp.GradScaler.step under the reference's --use_amp (main.py:25,52); the flag comes from enh_nonfinite_flag.
+ * loss_scale_dev (optional device float): g is additionally divided by it (GradScaler's unscale folded into the step). */
 int enh_adamw_step(float* p, const float* g, float* m, float* v, enh_h16* p_h16, int64_t n, int step, float lr,
-                   float beta1, float beta2, float eps, float weight_decay, float grad_scale, const float* skip_flag, int dtype, void* stream);
+                   float beta1, float beta2, float eps, float weight_decay, float grad_scale, const float* skip_flag, const float* loss_scale_dev,
+                   int dtype, void* stream);
+/* GradScaler.update() on the device: found_inf != 0 -> *scale *= backoff_factor, *growth_tracker = 0; otherwise ++*growth_tracker and after
+ * growth_interval clean steps in a row *scale *= growth_factor (growth_interval = 0: never grow = a static scale with backoff).  *scale is kept
+ * inside [1, 2^24].  torch defaults: growth 2, backoff 0.5, interval 2000, initial scale 65536. */
+int enh_loss_scale_update(float* scale, const float* found_inf, int* growth_tracker, float growth_factor, float backoff_factor, int growth_interval,
+                          void* stream);
 /* flag[0] = 1.0f if any of x[0..n) is inf or nan, otherwise untouched (the caller zeroes it once per step): GradScaler's found-inf check over one flat
  * gradient buffer, one pass at HBM rate.  x 16-byte aligned. */
 int enh_nonfinite_flag(const float* x, int64_t n, float* flag, void* stream);

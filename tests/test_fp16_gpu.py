@@ -225,10 +225,11 @@ def test_colsum_patchify_unpatchify_vq_copies_fp16(C):
     xrec = torch.empty(2, 3, 64, 64, device="cuda"); sums = torch.zeros(2, dtype=torch.float64, device="cuda")
     d16 = torch.empty(128, 192, dtype=F16, device="cuda")
     S = 65536.0
-    C.unpatchify_loss(pix.cuda(), img.cuda(), 2, 3, 64, 64, 8, 0.0, 1.0 * S, xrec, sums, d16)
+    C.unpatchify_loss(pix.cuda(), img.cuda(), 2, 3, 64, 64, 8, 0.0, 1.0, xrec, sums, d16, grad_scale=torch.full((1,), S, device="cuda"))      # the loss scale as a DEVICE scalar
     rec = pix.view(2, 8, 8, 3, 8, 8).permute(0, 3, 1, 4, 2, 5).reshape(2, 3, 64, 64)
     gref = (2 * (rec - img) / img.numel() * S).view(2, 3, 8, 8, 8, 8).permute(0, 2, 4, 1, 3, 5).reshape(128, 192)
     assert rel(d16.float(), gref) <= 1.15 * f16_floor(gref) + 1e-6
+    assert abs(sums[1].item() / img.numel() - ((rec - img) ** 2).mean().item()) <= 1e-6      # the loss VALUE is not scaled
     z, E, gq = O.make_vq_inputs(5, 512, 1024)
     zq, zq16, idx, loss = C.vq_forward(z.cuda(), E.cuda(), 0.25, 1, True, h16=F16)
     assert zq16.dtype == F16 and torch.equal(zq16.cpu(), zq.cpu().to(F16))
@@ -264,6 +265,38 @@ def test_adamw_fp16_shadow_and_the_nonfinite_skip(C):
         C.adamw_step(pd, gd2, md, vd, p16, 2, 1e-3, grad_scale=1.0 / 65536.0, skip_flag=flag)
         for t, b in zip((pd, md, vd, p16), before):
             assert torch.equal(t, b)
+    # the same step with the unscale folded in through a device scalar (what the engine passes): identical bits to the host-float form
+    p2, m2, v2 = p.clone().cuda(), torch.zeros(n).cuda(), torch.zeros(n).cuda()      # (p is the oracle's post-step-1 state: any starting point will do)
+    p3, m3, v3 = p2.clone(), m2.clone(), v2.clone()
+    C.adamw_step(p2, gd, m2, v2, None, 1, 1e-3, grad_scale=1.0 / 65536.0)
+    C.adamw_step(p3, gd, m3, v3, None, 1, 1e-3, grad_scale=1.0, loss_scale=torch.full((1,), 65536.0, device="cuda"))
+    assert torch.equal(p2, p3) and torch.equal(m2, m3) and torch.equal(v2, v3)
+
+
+def test_loss_scale_update_is_gradscaler_update(C):
+    """enh_loss_scale_update against torch.cuda.amp.GradScaler's rule (growth 2, backoff 0.5, interval 3 here): overflow halves and resets the tracker, `interval`
+    clean steps in a row double; the scale stays inside [1, 2^24]"""
+    scale = torch.full((1,), 65536.0, device="cuda"); trk = torch.zeros(1, dtype=torch.int32, device="cuda")
+    flag = torch.zeros(1, device="cuda")
+    ref_s, ref_t, seq = 65536.0, 0, [0, 0, 1, 0, 0, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0]
+    for bad in seq:
+        flag.fill_(float(bad))
+        C.loss_scale_update(scale, flag, trk, 2.0, 0.5, 3)
+        if bad:
+            ref_s, ref_t = ref_s * 0.5, 0
+        else:
+            ref_t += 1
+            if ref_t >= 3:
+                ref_s, ref_t = ref_s * 2.0, 0
+        assert scale.item() == ref_s and trk.item() == ref_t, (scale.item(), ref_s, trk.item(), ref_t)
+    scale.fill_(2.0 ** 24); flag.zero_(); trk.fill_(2)
+    C.loss_scale_update(scale, flag, trk, 2.0, 0.5, 3)
+    assert scale.item() == 2.0 ** 24
+    scale.fill_(1.0); flag.fill_(1.0)
+    C.loss_scale_update(scale, flag, trk, 2.0, 0.5, 3)
+    assert scale.item() == 1.0
+    C.loss_scale_update(scale, flag.zero_(), trk, 2.0, 0.5, 0)      # interval 0: never grows
+    assert scale.item() == 1.0 and trk.item() == 0
 
 
 # ---------------------------------------------------------------------------------------------
@@ -461,6 +494,13 @@ def test_fp16_training_steps_follow_the_oracle_and_skip_on_overflow():
     assert eng.skipped_steps.item() == 1.0
     for t, b in zip((eng.store.p, eng.store.m, eng.store.v, eng.store.p16), before):
         assert torch.equal(t, b)
+    assert eng.loss_scale == 32768.0, "GradScaler.update: an overflow halves the scale (on the device)"
+    # the next step runs under the new scale and lands on the oracle's next step
+    out = eng.forward_backward(xs[0], w_l1=0.0, w_l2=1.0, codebook_weight=1.0)
+    eng.unscale_grads()
+    o_loss, _, o_grads, _ = O.train_step_grads(xs[0], {k: v.detach().cpu() for k, v in m.state_dict().items() if k in Po}, cfg)
+    worst_g = max(rel(p.grad, o_grads[k]) for k, p in m.named_parameters() if k in o_grads)
+    assert worst_g <= 5e-3, worst_g
 
 
 def test_encode_codes_defaults_to_the_single_fp16_pass_and_x3_stays_available():
