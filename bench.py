@@ -460,7 +460,7 @@ def main():
                                 f"(lazy R1 every 16 batches) + AdamW" + (f"; LPIPS weight {pw}" if pw else "; LPIPS weight 0") if adversarial else
                                 f"{args.config}.yaml AE training step (1 fwd + 1 bwd + grad all-reduce + AdamW), loss = 1.0*L2 + 1.0*codebook "
                                 f"(LPIPS/GAN weights 0)") + f", K=8192 x 32 l2-normalised codes, fp32 master weights, {args.precision} MFMA operands / fp32 accumulate" +
-                               (f", static loss scale {int(eng.loss_scale)} + inf/nan step skip" if args.precision == "fp16" else ""),
+                               (f", dynamic loss scale (now {int(eng.loss_scale)}; device-side inf/nan step skip + GradScaler update rule)" if args.precision == "fp16" else ""),
                    "per_gpu_batch": B, "global_batch": B * world, "image": f"{size}x{size}", "parallelism": f"dp{world}",
                    "hip_graph_replay": bool(use_graphs)},
         "final_loss": loss,

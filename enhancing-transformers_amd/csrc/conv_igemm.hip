@@ -25,9 +25,9 @@
 
 // conv_pointwise.hip: the dense 1 x 1 geometries with an 8-channel side (the discriminator's first layer) as streaming kernels
 int conv_pointwise_forward(const uint16_t* src, const uint16_t* wt, const enh_conv_geom& g, int mode, const float* bias, float p0, float p1, uint16_t* out,
-                           hipStream_t stream);
+                           int dtype, hipStream_t stream);
 int conv_pointwise_wgrad_slabs(const enh_conv_geom& g);
-void conv_pointwise_wgrad(const uint16_t* src, const uint16_t* dy, const enh_conv_geom& g, float* ws, float* dw, hipStream_t stream);
+void conv_pointwise_wgrad(const uint16_t* src, const uint16_t* dy, const enh_conv_geom& g, float* ws, float* dw, int dtype, hipStream_t stream);
 
 struct ConvArgs {
   const uint16_t* X; const uint16_t* Wt;
@@ -57,10 +57,11 @@ __device__ __forceinline__ int64_t conv_out_pixel(const enh_conv_geom& g, int64_
 }
 
 // the five epilogue modes on four consecutive output columns (bias b4, saved activation ax, addend ad as they were loaded)
+template <typename OT>
 __device__ __forceinline__ void conv_epi_value(const ConvArgs& args, float (&v)[4], const float4& b4, const uint2& ax, const uint2& ad) {
   const uint32_t d0 = ad.x, d1 = ad.y;
-  const float e0 = bf16_bits_to_f32((uint16_t)(d0 & 0xffffu)), e1 = bf16_bits_to_f32((uint16_t)(d0 >> 16));
-  const float e2 = bf16_bits_to_f32((uint16_t)(d1 & 0xffffu)), e3 = bf16_bits_to_f32((uint16_t)(d1 >> 16));
+  const float e0 = unpack1<OT>((uint16_t)(d0 & 0xffffu)), e1 = unpack1<OT>((uint16_t)(d0 >> 16));
+  const float e2 = unpack1<OT>((uint16_t)(d1 & 0xffffu)), e3 = unpack1<OT>((uint16_t)(d1 >> 16));
   if (args.mode == 0) {
     v[0] = fmaxf(v[0] + b4.x, 0.f); v[1] = fmaxf(v[1] + b4.y, 0.f); v[2] = fmaxf(v[2] + b4.z, 0.f); v[3] = fmaxf(v[3] + b4.w, 0.f);
   } else if (args.mode == 1) {
@@ -78,6 +79,7 @@ __device__ __forceinline__ void conv_epi_value(const ConvArgs& args, float (&v)[
   }
 }
 
+template <typename OT>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& args, f32x4 (&acc)[4][4], int64_t m0, int64_t n0, int wm, int wn, int lg, int l16,
                                               unsigned char* stage) {
   const enh_conv_geom& g = args.g;
@@ -119,8 +121,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& args, f32x4 (&acc)
       if (n >= g.N) continue;   // N % 8 == 0: the 4 columns are in or out together
       float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
       const uint32_t d0 = ad[i][j].x, d1 = ad[i][j].y;
-      const float e0 = bf16_bits_to_f32((uint16_t)(d0 & 0xffffu)), e1 = bf16_bits_to_f32((uint16_t)(d0 >> 16));
-      const float e2 = bf16_bits_to_f32((uint16_t)(d1 & 0xffffu)), e3 = bf16_bits_to_f32((uint16_t)(d1 >> 16));
+      const float e0 = unpack1<OT>((uint16_t)(d0 & 0xffffu)), e1 = unpack1<OT>((uint16_t)(d0 >> 16));
+      const float e2 = unpack1<OT>((uint16_t)(d1 & 0xffffu)), e3 = unpack1<OT>((uint16_t)(d1 >> 16));
       if (args.mode == 0) {
         v[0] = fmaxf(v[0] + b4[j].x, 0.f); v[1] = fmaxf(v[1] + b4[j].y, 0.f); v[2] = fmaxf(v[2] + b4[j].z, 0.f); v[3] = fmaxf(v[3] + b4[j].w, 0.f);
       } else if (args.mode == 1) {
@@ -136,7 +138,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& args, f32x4 (&acc)
       } else if (args.mode == 4) {
         v[0] += args.p0 * e0; v[1] += args.p0 * e1; v[2] += args.p0 * e2; v[3] += args.p0 * e3;
       }
-      const u32x2 o_ = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+      const u32x2 o_ = {pack2<OT>(v[0], v[1]), pack2<OT>(v[2], v[3])};
       if (staged) {
         const int row = i * 16 + l16;
         *reinterpret_cast<u32x2*>(stage + row * 128 + (((j * 2 + (lg >> 1)) ^ (row & 7)) << 4) + (lg & 1) * 8) = o_;
@@ -165,6 +167,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& args, f32x4 (&acc)
 //   mode 2: out = acc
 //   mode 3: out = lrelu(acc + bias[n], slope p0) * p1                   (EqualConv2d + FusedLeakyReLU; bias optional)
 //   mode 4: out = acc + p0 * add[o,n]                                   (the residual merge of a StyleBlock folded into its skip convolution)
+template <typename OT>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2 stages][A tile | B tile]
   const enh_conv_geom& g = args.g;
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs args)
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[j]), __builtin_bit_cast(bf16x8, fa[i]), acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma16<OT>(fb[j], fa[i], acc[i][j]);
     }
     if (kt + 1 < nk) {
       unsigned char* na = smem + (stage ^ 1) * (2 * G_TILE_BYTES);
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs args)
     }
     __syncthreads();
   }
-  conv_epilogue(args, acc, m0, n0, wm, wn, lg, l16, smem + wave * 8192);   // the stages are free: no LDS read follows the loop's last barrier
+  conv_epilogue<OT>(args, acc, m0, n0, wm, wn, lg, l16, smem + wave * 8192);   // the stages are free: no LDS read follows the loop's last barrier
 }
 
 // =================================================================================================
@@ -263,6 +266,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs args)
 // =================================================================================================
 __device__ __attribute__((aligned(16))) uint32_t g_conv_zero_page[4] = {0u, 0u, 0u, 0u};
 
+template <typename OT>
 __global__ __launch_bounds__(256, 2) void conv_igemm_glds_kernel(const ConvArgs args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2 stages][A tile | B tile]
   const enh_conv_geom& g = args.g;
@@ -356,7 +360,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_glds_kernel(const ConvArgs 
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb0[j]), __builtin_bit_cast(bf16x8, fa0[i]), acc[i][j], 0, 0, 0);
+        acc[i][j] = mfma16<OT>(fb0[j], fa0[i], acc[i][j]);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0): F1 in registers, my share of stage kt+1 landed
     __builtin_amdgcn_s_barrier();
@@ -370,8 +374,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_glds_kernel(const ConvArgs 
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
-        acc[i][jj * 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb1[jj * 2]), __builtin_bit_cast(bf16x8, fa1[i]), acc[i][jj * 2], 0, 0, 0);
-        acc[i][jj * 2 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb1[jj * 2 + 1]), __builtin_bit_cast(bf16x8, fa1[i]), acc[i][jj * 2 + 1], 0, 0, 0);
+        acc[i][jj * 2] = mfma16<OT>(fb1[jj * 2], fa1[i], acc[i][jj * 2]);
+        acc[i][jj * 2 + 1] = mfma16<OT>(fb1[jj * 2 + 1], fa1[i], acc[i][jj * 2 + 1]);
         if (more) {
           if (jj == 0) CG_LOAD(ap[i], buf, 0, i);
           else { CG_LOAD(bsrc[i], buf, 1, i); bsrc[i] += G_BK; }
@@ -397,10 +401,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_glds_kernel(const ConvArgs 
     }
     return;
   }
-  conv_epilogue(args, acc, m0, n0, wm, wn, lg, l16, smem + wave * 8192);   // the stages are free: no LDS read follows the loop's last barrier
+  conv_epilogue<OT>(args, acc, m0, n0, wm, wn, lg, l16, smem + wave * 8192);   // the stages are free: no LDS read follows the loop's last barrier
 }
 
 // second pass of a split convolution: out[o, n..n+3] = epilogue( sum over the slabs in ascending order ) — one thread per four columns
+template <typename OT>
 __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const ConvArgs args) {
   const enh_conv_geom& g = args.g;
   const int n4 = g.N >> 2;
@@ -419,8 +424,8 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const ConvArgs 
   const float4 b4 = ((args.mode == 0 || args.mode == 3) && args.bias) ? *reinterpret_cast<const float4*>(args.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
   const uint2 ax = args.mode == 1 ? *reinterpret_cast<const uint2*>(args.aux + orow + n) : make_uint2(0u, 0u);
   const uint2 ad = ((args.mode == 1 || args.mode == 4) && args.add) ? *reinterpret_cast<const uint2*>(args.add + orow + n) : make_uint2(0u, 0u);
-  conv_epi_value(args, v, b4, ax, ad);
-  const u32x2 o_ = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+  conv_epi_value<OT>(args, v, b4, ax, ad);
+  const u32x2 o_ = {pack2<OT>(v[0], v[1]), pack2<OT>(v[2], v[3])};
   *reinterpret_cast<u32x2*>(args.out + orow + n) = o_;
 }
 
@@ -439,7 +444,7 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const ConvArgs 
 #define CW_LDS_BYTES (2 * CW_SLOT + 2048)
 
 // accumulator layout of the swapped 32x32 MFMA: acc[i][j][r] = C[mw + i*32 + (lane&31)][nw + j*32 + 8*(r>>2) + 4*(lane>>5) + (r&3)]
-template <int NJ>
+template <typename OT, int NJ>
 __device__ __forceinline__ void conv_epilogue32(const ConvArgs& args, f32x16 (&acc)[4][NJ], int64_t mw, int64_t nw, int lane, float* wave_bias, unsigned char* stage) {
   const enh_conv_geom& g = args.g;
   const int l31 = lane & 31, hi = lane >> 5;
@@ -472,8 +477,8 @@ __device__ __forceinline__ void conv_epilogue32(const ConvArgs& args, f32x16 (&a
       for (int g4 = 0; g4 < 4; ++g4) {
         float v[4] = {acc_read(acc[i][j][g4 * 4 + 0]), acc_read(acc[i][j][g4 * 4 + 1]), acc_read(acc[i][j][g4 * 4 + 2]), acc_read(acc[i][j][g4 * 4 + 3])};
         const float4 b4 = *reinterpret_cast<const float4*>(wave_bias + j * 32 + 8 * g4 + 4 * hi);
-        conv_epi_value(args, v, b4, ax[g4], ad[g4]);
-        const u32x2 o_ = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        conv_epi_value<OT>(args, v, b4, ax[g4], ad[g4]);
+        const u32x2 o_ = {pack2<OT>(v[0], v[1]), pack2<OT>(v[2], v[3])};
         if (dense) *reinterpret_cast<u32x2*>(stage + l31 * (CH * 16) + (((j * 4 + g4) ^ (l31 & (CH - 1))) << 4) + hi * 8) = o_;
         else if (orow >= 0) *reinterpret_cast<u32x2*>(args.out + orow + nw + j * 32 + 8 * g4 + 4 * hi) = o_;
       }
@@ -490,7 +495,7 @@ __device__ __forceinline__ void conv_epilogue32(const ConvArgs& args, f32x16 (&a
   }
 }
 
-template <int NJ>
+template <typename OT, int NJ>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_igemm_w256_kernel(const ConvArgs args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2 slots][A0 | A1 | B0 | B1] + bias strips
   const enh_conv_geom& g = args.g;
@@ -561,7 +566,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     else FB[(U) & 3] = frag32<false>(smem + (SLOT) * CW_SLOT + (2 + wn) * G_TILE_BYTES, ((U) & 3) * 32, S, lane);                 \
   } while (0)
 #define CW_MM(Q, FA, FB)                                                                                                          \
-  acc[(Q) / NJ][(Q) % NJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, FB[(Q) % NJ]), __builtin_bit_cast(bf16x8, FA[(Q) / NJ]), acc[(Q) / NJ][(Q) % NJ], 0, 0, 0)
+  acc[(Q) / NJ][(Q) % NJ] = mfma32<OT>(FB[(Q) % NJ], FA[(Q) / NJ], acc[(Q) / NJ][(Q) % NJ])
 #define CW_FENCE() __builtin_amdgcn_sched_barrier(0)
   // one k16 step: 16 MFMAs on (FA, FB); under the first 8 one fragment read each (k-step RS of slot RSLOT into RA / RB); 8 staging requests (pieces
   // G0 .. G0+7 into slot GSLOT) under the odd MFMAs
@@ -630,7 +635,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #undef CW_MM
 #undef CW_KSTEP
 #undef CW_FENCE
-  conv_epilogue32<NJ>(args, acc, m0 + wm * 128, n0 + wn * (32 * NJ), lane, reinterpret_cast<float*>(smem + 2 * CW_SLOT) + wave * 128, smem + wave * 8192);
+  conv_epilogue32<OT, NJ>(args, acc, m0 + wm * 128, n0 + wn * (32 * NJ), lane, reinterpret_cast<float*>(smem + 2 * CW_SLOT) + wave * 128, smem + wave * 8192);
 }
 
 // =================================================================================================
@@ -645,6 +650,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define CX_SLOT (5 * G_TILE_BYTES)
 #define CX_LDS_BYTES (2 * CX_SLOT)
 
+template <typename OT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_igemm_w512_kernel(const ConvArgs args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2 slots][A0 | A1 | A2 | A3 | B0]
   const enh_conv_geom& g = args.g;
@@ -707,7 +713,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     else FB[(U) & 3] = frag32<false>(smem + (SLOT) * CX_SLOT + 4 * G_TILE_BYTES, ((U) & 3) * 32, S, lane);                        \
   } while (0)
 #define CX_MM(Q, FA, FB)                                                                                                          \
-  acc[(Q) >> 2][(Q) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, FB[(Q) & 3]), __builtin_bit_cast(bf16x8, FA[(Q) >> 2]), acc[(Q) >> 2][(Q) & 3], 0, 0, 0)
+  acc[(Q) >> 2][(Q) & 3] = mfma32<OT>(FB[(Q) & 3], FA[(Q) >> 2], acc[(Q) >> 2][(Q) & 3])
 #define CX_FENCE() __builtin_amdgcn_sched_barrier(0)
   // one k16 step: 16 MFMAs; under the first 8 one fragment read each; HALF = 0 / 1: requests of the first / second half of a stage (A pieces 8*HALF..+7 under
   // the odd MFMAs, weight pieces 2*HALF, +1 under MFMAs 4 and 10)
@@ -781,7 +787,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #undef CX_MM
 #undef CX_KSTEP
 #undef CX_FENCE
-  conv_epilogue32<4>(args, acc, m0 + wave * 128, n0, lane, reinterpret_cast<float*>(smem + 32768) + wave * 128, smem + wave * 8192);
+  conv_epilogue32<OT, 4>(args, acc, m0 + wave * 128, n0, lane, reinterpret_cast<float*>(smem + 32768) + wave * 128, smem + wave * 8192);
 }
 
 static int conv_geom_check(const enh_conv_geom* g, const char* who) {
@@ -821,12 +827,13 @@ static int conv_w256_nj(const ConvArgs& a) {
   return tiles >= enh_device_cus() ? nj : 0;   // below one tile per CU the 128-row kernels (four times the workgroups, two per CU) fill the chip better
 }
 
+template <typename OT>
 static void conv_lds_attr_once() {
   static const bool attr_set = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_glds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G_TILE_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G_TILE_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_w256_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_w512_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CX_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_glds_kernel<OT>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G_TILE_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<OT>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G_TILE_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_w256_kernel<OT, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_w512_kernel<OT>), hipFuncAttributeMaxDynamicSharedMemorySize, CX_LDS_BYTES);
     return true;
   }();
   (void)attr_set;
@@ -862,67 +869,68 @@ extern "C" size_t enh_conv_workspace_bytes(const enh_conv_geom* g) {
   return sp.splits > 1 ? (size_t)sp.splits * M * g->N * sizeof(float) : 0;
 }
 
-static int conv_nhwc_impl(const enh_bf16* src, const enh_bf16* wt, const enh_conv_geom* g, int mode, const float* bias, const enh_bf16* aux,
-                          const enh_bf16* add, float p0, float p1, enh_bf16* out, void* ws, size_t ws_bytes, void* stream);
+static int conv_nhwc_impl(const enh_h16* src, const enh_h16* wt, const enh_conv_geom* g, int mode, const float* bias, const enh_h16* aux,
+                          const enh_h16* add, float p0, float p1, enh_h16* out, void* ws, size_t ws_bytes, int dtype, void* stream);
 
-extern "C" int enh_conv_nhwc_bf16(const enh_bf16* src, const enh_bf16* wt, const enh_conv_geom* g, int mode, const float* bias, const enh_bf16* aux,
-                                  const enh_bf16* add, float p0, float p1, enh_bf16* out, void* stream) {
-  return conv_nhwc_impl(src, wt, g, mode, bias, aux, add, p0, p1, out, nullptr, 0, stream);
+extern "C" int enh_conv_nhwc_h16(const enh_h16* src, const enh_h16* wt, const enh_conv_geom* g, int mode, const float* bias, const enh_h16* aux,
+                                  const enh_h16* add, float p0, float p1, enh_h16* out, int dtype, void* stream) {
+  return conv_nhwc_impl(src, wt, g, mode, bias, aux, add, p0, p1, out, nullptr, 0, dtype, stream);
 }
 
 // the same with a caller-provided workspace (enh_conv_workspace_bytes): small grids are then split over the contraction
-extern "C" int enh_conv_nhwc_bf16_ws(const enh_bf16* src, const enh_bf16* wt, const enh_conv_geom* g, int mode, const float* bias, const enh_bf16* aux,
-                                     const enh_bf16* add, float p0, float p1, enh_bf16* out, void* ws, size_t ws_bytes, void* stream) {
-  return conv_nhwc_impl(src, wt, g, mode, bias, aux, add, p0, p1, out, ws, ws_bytes, stream);
+extern "C" int enh_conv_nhwc_h16_ws(const enh_h16* src, const enh_h16* wt, const enh_conv_geom* g, int mode, const float* bias, const enh_h16* aux,
+                                     const enh_h16* add, float p0, float p1, enh_h16* out, void* ws, size_t ws_bytes, int dtype, void* stream) {
+  return conv_nhwc_impl(src, wt, g, mode, bias, aux, add, p0, p1, out, ws, ws_bytes, dtype, stream);
 }
 
-static int conv_nhwc_impl(const enh_bf16* src, const enh_bf16* wt, const enh_conv_geom* g, int mode, const float* bias, const enh_bf16* aux,
-                          const enh_bf16* add, float p0, float p1, enh_bf16* out, void* ws, size_t ws_bytes, void* stream) {
-  ENH_REQUIRE(src && wt && out, ENH_E_BADARG, "enh_conv_nhwc_bf16: bad argument");
-  const int rc = conv_geom_check(g, "enh_conv_nhwc_bf16");
+static int conv_nhwc_impl(const enh_h16* src, const enh_h16* wt, const enh_conv_geom* g, int mode, const float* bias, const enh_h16* aux,
+                          const enh_h16* add, float p0, float p1, enh_h16* out, void* ws, size_t ws_bytes, int dtype, void* stream) {
+  ENH_REQUIRE_DT(dtype, "enh_conv_nhwc_h16");
+  ENH_REQUIRE(src && wt && out, ENH_E_BADARG, "enh_conv_nhwc_h16: bad argument");
+  const int rc = conv_geom_check(g, "enh_conv_nhwc_h16");
   if (rc != ENH_OK) return rc;
-  ENH_REQUIRE(mode >= 0 && mode <= 4, ENH_E_BADARG, "enh_conv_nhwc_bf16: mode must be 0..4");
-  ENH_REQUIRE((mode != 0 || bias) && (mode != 1 || aux) && (mode != 4 || add), ENH_E_BADARG, "enh_conv_nhwc_bf16: mode 0 needs bias, mode 1 aux, mode 4 add");
-  if (g_conv_variant == 0 && conv_pointwise_forward(src, wt, *g, mode, bias, p0, p1, out, (hipStream_t)stream)) return enh_check_launch("enh_conv_nhwc_bf16");
+  ENH_REQUIRE(mode >= 0 && mode <= 4, ENH_E_BADARG, "enh_conv_nhwc_h16: mode must be 0..4");
+  ENH_REQUIRE((mode != 0 || bias) && (mode != 1 || aux) && (mode != 4 || add), ENH_E_BADARG, "enh_conv_nhwc_h16: mode 0 needs bias, mode 1 aux, mode 4 add");
+  if (g_conv_variant == 0 && conv_pointwise_forward(src, wt, *g, mode, bias, p0, p1, out, dtype, (hipStream_t)stream)) return enh_check_launch("enh_conv_nhwc_h16");
   ConvArgs a;
   a.X = src; a.Wt = wt; a.g = *g;
   a.M = (int64_t)g->B * g->Hm * g->Wm; a.K = (int64_t)g->nty * g->ntx * g->C;
   a.bias = bias; a.mode = mode; a.aux = aux; a.add = add; a.p0 = p0; a.p1 = p1; a.out = out;
   a.nbm = (int)((a.M + G_BM - 1) / G_BM); a.nbn = (g->N + G_BN - 1) / G_BN;
   a.ws = nullptr; a.splits = 1; a.st_per_split = (int)(a.K / G_BK);
-  ENH_REQUIRE((int64_t)a.nbm * a.nbn < (1ll << 30) && a.M < (1ll << 31), ENH_E_SHAPE, "enh_conv_nhwc_bf16: grid too large (2^31 GEMM rows or more)");
-  conv_lds_attr_once();
+  ENH_REQUIRE((int64_t)a.nbm * a.nbn < (1ll << 30) && a.M < (1ll << 31), ENH_E_SHAPE, "enh_conv_nhwc_h16: grid too large (2^31 GEMM rows or more)");
+  ENH_DT_DISPATCH(dtype, (conv_lds_attr_once<OT>()));
   const ConvSplit sp = ws ? conv_split_plan(*g, a.M, a.K) : ConvSplit{1, 0};
   if (sp.splits > 1 && ws_bytes >= (size_t)sp.splits * a.M * g->N * sizeof(float)) {
     a.ws = (float*)ws; a.splits = sp.splits; a.st_per_split = sp.st_per_split;
-    conv_igemm_glds_kernel<<<dim3((unsigned)(a.nbm * a.nbn * a.splits)), 256, 4 * G_TILE_BYTES, (hipStream_t)stream>>>(a);
-    conv_splitk_finish_kernel<<<dim3((unsigned)((a.M * (g->N / 4) + 255) / 256)), 256, 0, (hipStream_t)stream>>>(a);
-    return enh_check_launch("enh_conv_nhwc_bf16");
+    ENH_DT_DISPATCH(dtype, (conv_igemm_glds_kernel<OT><<<dim3((unsigned)(a.nbm * a.nbn * a.splits)), 256, 4 * G_TILE_BYTES, (hipStream_t)stream>>>(a)));
+    ENH_DT_DISPATCH(dtype, (conv_splitk_finish_kernel<OT><<<dim3((unsigned)((a.M * (g->N / 4) + 255) / 256)), 256, 0, (hipStream_t)stream>>>(a)));
+    return enh_check_launch("enh_conv_nhwc_h16");
   }
   const int nj = conv_w256_nj(a);
   if (nj) {
     if (nj == 4) {
       a.nbm = (int)((a.M + 255) / 256); a.nbn = g->N / 256;
-      conv_igemm_w256_kernel<4><<<dim3((unsigned)(a.nbm * a.nbn)), 256, CW_LDS_BYTES, (hipStream_t)stream>>>(a);
+      ENH_DT_DISPATCH(dtype, (conv_igemm_w256_kernel<OT, 4><<<dim3((unsigned)(a.nbm * a.nbn)), 256, CW_LDS_BYTES, (hipStream_t)stream>>>(a)));
     } else {
       a.nbm = (int)((a.M + 511) / 512); a.nbn = g->N / 128;
-      conv_igemm_w512_kernel<<<dim3((unsigned)(a.nbm * a.nbn)), 256, CX_LDS_BYTES, (hipStream_t)stream>>>(a);
+      ENH_DT_DISPATCH(dtype, (conv_igemm_w512_kernel<OT><<<dim3((unsigned)(a.nbm * a.nbn)), 256, CX_LDS_BYTES, (hipStream_t)stream>>>(a)));
     }
   } else if (g->C % G_BK == 0 && a.K >= 2 * G_BK && g_conv_variant != 1)
-    conv_igemm_glds_kernel<<<dim3((unsigned)(a.nbm * a.nbn)), 256, 4 * G_TILE_BYTES, (hipStream_t)stream>>>(a);
+    ENH_DT_DISPATCH(dtype, (conv_igemm_glds_kernel<OT><<<dim3((unsigned)(a.nbm * a.nbn)), 256, 4 * G_TILE_BYTES, (hipStream_t)stream>>>(a)));
   else
-    conv_igemm_kernel<<<dim3((unsigned)(a.nbm * a.nbn)), 256, 4 * G_TILE_BYTES, (hipStream_t)stream>>>(a);
-  return enh_check_launch("enh_conv_nhwc_bf16");
+    ENH_DT_DISPATCH(dtype, (conv_igemm_kernel<OT><<<dim3((unsigned)(a.nbm * a.nbn)), 256, 4 * G_TILE_BYTES, (hipStream_t)stream>>>(a)));
+  return enh_check_launch("enh_conv_nhwc_h16");
 }
 
 // the LPIPS entry point: 3x3, stride 1, padding 1 on the general kernel
-extern "C" int enh_conv3x3_nhwc_bf16(const enh_bf16* x, const enh_bf16* wt, int B, int H, int W, int Cin, int Cout, const float* bias, int mode,
-                                     const enh_bf16* aux, const enh_bf16* add, enh_bf16* out, void* stream) {
-  ENH_REQUIRE(mode >= 0 && mode <= 2, ENH_E_BADARG, "enh_conv3x3_nhwc_bf16: mode must be 0, 1 or 2");
+extern "C" int enh_conv3x3_nhwc_h16(const enh_h16* x, const enh_h16* wt, int B, int H, int W, int Cin, int Cout, const float* bias, int mode,
+                                     const enh_h16* aux, const enh_h16* add, enh_h16* out, int dtype, void* stream) {
+  ENH_REQUIRE(mode >= 0 && mode <= 2, ENH_E_BADARG, "enh_conv3x3_nhwc_h16: mode must be 0, 1 or 2");
   enh_conv_geom g;
   g.B = B; g.Hs = H; g.Ws = W; g.C = Cin; g.Hm = H; g.Wm = W; g.gs = 1; g.oy0 = -1; g.ox0 = -1; g.nty = 3; g.ntx = 3; g.sty = 1; g.stx = 1;
   g.N = Cout; g.HO = H; g.WO = W; g.os = 1; g.oph = 0; g.opw = 0;
-  return enh_conv_nhwc_bf16(x, wt, &g, mode, bias, aux, add, 0.f, 1.f, out, stream);
+  return enh_conv_nhwc_h16(x, wt, &g, mode, bias, aux, add, 0.f, 1.f, out, dtype, stream);
 }
 
 // =================================================================================================
@@ -934,6 +942,7 @@ struct ConvWgradArgs {
   GemmArgs e;           // epilogue description: M = g.N, N = taps*C, ws / c_f32 / ldc / accumulate / splits / k_per_split
 };
 
+template <typename OT>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_igemm_kernel(const ConvWgradArgs args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2 stages][A tile (dy, kmaj) | B tile (gathered src, kmaj)]
   const enh_conv_geom& g = args.g;
@@ -1018,7 +1027,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_igemm_kernel(const ConvWgra
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[j]), __builtin_bit_cast(bf16x8, fa[i]), acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma16<OT>(fb[j], fa[i], acc[i][j]);
     }
     if (kt + 1 < nk) {
       unsigned char* na = smem + (stage ^ 1) * (2 * G_TILE_BYTES);
@@ -1027,7 +1036,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_igemm_kernel(const ConvWgra
     }
     __syncthreads();
   }
-  gemm_epilogue(args.e, acc, m0, n0, wm, wn, lg, l16, split);
+  gemm_epilogue<OT>(args.e, acc, m0, n0, wm, wn, lg, l16, split);
 }
 
 // =================================================================================================
@@ -1039,7 +1048,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_igemm_kernel(const ConvWgra
 // a single unsigned compare, lanes outside the image read the zero page.  Waves 0, 1 stage dy (a plain matrix) through the same instruction stream.
 // Split over the pixel axis; partial slabs to the workspace, added in a fixed order by splitk_reduce_kernel (deterministic).
 // =================================================================================================
-template <bool BOUNDS>
+template <typename OT, bool BOUNDS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_wgrad_w256_kernel(const ConvWgradArgs args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2 slots][A0 | A1 | B0 | B1]
   const enh_conv_geom& g = args.g;
@@ -1118,7 +1127,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     else FB[(U) & 3] = frag32<true>(smem + (SLOT) * CW_SLOT + (2 + wn) * G_TILE_BYTES, ((U) & 3) * 32, S, lane);                  \
   } while (0)
 #define WW_MM(Q, FA, FB)                                                                                                          \
-  acc[(Q) >> 2][(Q) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, FB[(Q) & 3]), __builtin_bit_cast(bf16x8, FA[(Q) >> 2]), acc[(Q) >> 2][(Q) & 3], 0, 0, 0)
+  acc[(Q) >> 2][(Q) & 3] = mfma32<OT>(FB[(Q) & 3], FA[(Q) >> 2], acc[(Q) >> 2][(Q) & 3])
 #define WW_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define WW_KSTEP(FA, FB, RA, RB, RSLOT, RS, DO_READ, GSLOT, G0, DO_ISSUE)                                                         \
   do {                                                                                                                            \
@@ -1185,7 +1194,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #undef WW_MM
 #undef WW_KSTEP
 #undef WW_FENCE
-  gemm_epilogue32_loops<EPI_WS, 4, BOUNDS>(args.e, acc, m0 + wm * 128, n0 + wn * 128, lane, split, reinterpret_cast<float*>(smem + 2 * CW_SLOT) + wave * 128,
+  gemm_epilogue32_loops<EPI_WS, 4, BOUNDS, OT>(args.e, acc, m0 + wm * 128, n0 + wn * 128, lane, split, reinterpret_cast<float*>(smem + 2 * CW_SLOT) + wave * 128,
                                            smem + wave * 8192, smem + wave * 16384);
 }
 
@@ -1237,21 +1246,33 @@ extern "C" size_t enh_conv_wgrad_workspace_bytes(const enh_conv_geom* g) {
   return splits > 1 ? (size_t)splits * M * N * sizeof(float) : 0;
 }
 
-extern "C" int enh_conv_wgrad_nhwc_bf16(const enh_bf16* src, const enh_bf16* dy, const enh_conv_geom* g, float* dw, void* ws, size_t ws_bytes, void* stream) {
-  ENH_REQUIRE(src && dy && dw, ENH_E_BADARG, "enh_conv_wgrad_nhwc_bf16: bad argument");
-  ENH_REQUIRE(g, ENH_E_BADARG, "enh_conv_wgrad_nhwc_bf16: geometry is NULL");
+template <typename OT>
+static void conv_wgrad_attr_once() {
+  static const bool attr_set = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_igemm_kernel<OT>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G_TILE_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_w256_kernel<OT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_w256_kernel<OT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS_BYTES);
+    return true;
+  }();
+  (void)attr_set;
+}
+
+extern "C" int enh_conv_wgrad_nhwc_h16(const enh_h16* src, const enh_h16* dy, const enh_conv_geom* g, float* dw, void* ws, size_t ws_bytes, int dtype, void* stream) {
+  ENH_REQUIRE_DT(dtype, "enh_conv_wgrad_nhwc_h16");
+  ENH_REQUIRE(src && dy && dw, ENH_E_BADARG, "enh_conv_wgrad_nhwc_h16: bad argument");
+  ENH_REQUIRE(g, ENH_E_BADARG, "enh_conv_wgrad_nhwc_h16: geometry is NULL");
   enh_conv_geom gg = *g; gg.HO = g->Hm; gg.WO = g->Wm; gg.os = 1; gg.oph = 0; gg.opw = 0;   // the output-addressing fields are not used by this role
-  const int rc = conv_geom_check(&gg, "enh_conv_wgrad_nhwc_bf16");
+  const int rc = conv_geom_check(&gg, "enh_conv_wgrad_nhwc_h16");
   if (rc != ENH_OK) return rc;
-  ENH_REQUIRE(g->nty > 0 && g->ntx > 0, ENH_E_SHAPE, "enh_conv_wgrad_nhwc_bf16: empty tap grid");
-  ENH_REQUIRE((int64_t)g->B * g->Hm * g->Wm < (1ll << 31) && (int64_t)g->B * g->Hs * g->Ws < (1ll << 31), ENH_E_SHAPE, "enh_conv_wgrad_nhwc_bf16: more than 2^31 pixels");
+  ENH_REQUIRE(g->nty > 0 && g->ntx > 0, ENH_E_SHAPE, "enh_conv_wgrad_nhwc_h16: empty tap grid");
+  ENH_REQUIRE((int64_t)g->B * g->Hm * g->Wm < (1ll << 31) && (int64_t)g->B * g->Hs * g->Ws < (1ll << 31), ENH_E_SHAPE, "enh_conv_wgrad_nhwc_h16: more than 2^31 pixels");
   const int pw_slabs = g_conv_variant == 0 ? conv_pointwise_wgrad_slabs(gg) : 0;
   if (pw_slabs > 0) {
     const int64_t MN = (int64_t)g->N * 8;
-    ENH_REQUIRE(pw_slabs == 1 || (ws && ws_bytes >= (size_t)pw_slabs * MN * sizeof(float)), ENH_E_WORKSPACE, "enh_conv_wgrad_nhwc_bf16: workspace too small (%zu < %zu bytes)",
+    ENH_REQUIRE(pw_slabs == 1 || (ws && ws_bytes >= (size_t)pw_slabs * MN * sizeof(float)), ENH_E_WORKSPACE, "enh_conv_wgrad_nhwc_h16: workspace too small (%zu < %zu bytes)",
                 ws_bytes, (size_t)pw_slabs * MN * sizeof(float));
-    conv_pointwise_wgrad(src, dy, gg, (float*)ws, dw, (hipStream_t)stream);
-    return enh_check_launch("enh_conv_wgrad_nhwc_bf16");
+    conv_pointwise_wgrad(src, dy, gg, (float*)ws, dw, dtype, (hipStream_t)stream);
+    return enh_check_launch("enh_conv_wgrad_nhwc_h16");
   }
   ConvWgradArgs a;
   a.X = src; a.DY = dy; a.g = gg;
@@ -1265,29 +1286,23 @@ extern "C" int enh_conv_wgrad_nhwc_bf16(const enh_bf16* src, const enh_bf16* dy,
   e.c_bf16 = nullptr; e.c_f32 = dw; e.ldc = e.N; e.ws = nullptr; e.accumulate = 0;
   const int64_t MN = e.M * e.N;
   if (p.splits > 1) {
-    ENH_REQUIRE(ws && ws_bytes >= (size_t)p.splits * MN * sizeof(float), ENH_E_WORKSPACE, "enh_conv_wgrad_nhwc_bf16: workspace too small (%zu < %zu bytes)",
+    ENH_REQUIRE(ws && ws_bytes >= (size_t)p.splits * MN * sizeof(float), ENH_E_WORKSPACE, "enh_conv_wgrad_nhwc_h16: workspace too small (%zu < %zu bytes)",
                 ws_bytes, (size_t)p.splits * MN * sizeof(float));
     e.ws = (float*)ws; e.accumulate = 3;
   }
-  static const bool attr_set = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_igemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * G_TILE_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_w256_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_w256_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, CW_LDS_BYTES);
-    return true;
-  }();
-  (void)attr_set;
+  ENH_DT_DISPATCH(dtype, (conv_wgrad_attr_once<OT>()));
   hipStream_t s = (hipStream_t)stream;
   if (big.splits) {
     e.nbm = (int)(e.M / 256); e.nbn = (int)((e.N + 255) / 256);
     const dim3 grid((unsigned)(e.nbm * e.nbn * p.splits));
-    if (e.N % 256 == 0) conv_wgrad_w256_kernel<false><<<grid, 256, CW_LDS_BYTES, s>>>(a);
-    else conv_wgrad_w256_kernel<true><<<grid, 256, CW_LDS_BYTES, s>>>(a);
+    if (e.N % 256 == 0) ENH_DT_DISPATCH(dtype, (conv_wgrad_w256_kernel<OT, false><<<grid, 256, CW_LDS_BYTES, s>>>(a)));
+    else ENH_DT_DISPATCH(dtype, (conv_wgrad_w256_kernel<OT, true><<<grid, 256, CW_LDS_BYTES, s>>>(a)));
   } else {
     e.nbm = (int)((e.M + G_BM - 1) / G_BM); e.nbn = (int)((e.N + G_BN - 1) / G_BN);
-    conv_wgrad_igemm_kernel<<<dim3((unsigned)(e.nbm * e.nbn * p.splits)), 256, 4 * G_TILE_BYTES, s>>>(a);
+    ENH_DT_DISPATCH(dtype, (conv_wgrad_igemm_kernel<OT><<<dim3((unsigned)(e.nbm * e.nbn * p.splits)), 256, 4 * G_TILE_BYTES, s>>>(a)));
   }
   if (p.splits > 1) splitk_reduce_kernel<<<dim3((unsigned)((MN / 4 + 255) / 256)), 256, 0, s>>>(e.ws, p.splits, MN, e.N, dw, e.N, 0);
-  return enh_check_launch("enh_conv_wgrad_nhwc_bf16");
+  return enh_check_launch("enh_conv_wgrad_nhwc_h16");
 }
 
 // =================================================================================================
@@ -1296,6 +1311,7 @@ extern "C" int enh_conv_wgrad_nhwc_bf16(const enh_bf16* src, const enh_bf16* dy,
 // transposed = 0: out[co][(jy*ntx + jx)*Cp + ci] = scale * w[co][ci][kh0 + jy*kstep][kw0 + jx*kstep]   rows co < Rp (Rp >= Cout), ci < Cp (Cp >= Cin)
 // transposed = 1: out[ci][(jy*ntx + jx)*Cp + co] = scale * w[co][ci][kh0 + jy*kstep][kw0 + jx*kstep]   rows ci < Rp (Rp >= Cin),  co < Cp (Cp >= Cout)
 // rows / columns beyond the real channel counts are zero
+template <typename OT>
 __global__ void conv_pack_weight_kernel(const float* __restrict__ w, int Cout, int Cin, int k, float scale, int transposed, int kh0, int kw0, int kstep,
                                         int nty, int ntx, int Rp, int Cp, uint16_t* __restrict__ out) {
   const int64_t total = (int64_t)Rp * nty * ntx * Cp;
@@ -1308,19 +1324,20 @@ __global__ void conv_pack_weight_kernel(const float* __restrict__ w, int Cout, i
   const int co = transposed ? col : row, ci = transposed ? row : col;
   float v = 0.f;
   if (co < Cout && ci < Cin) v = scale * w[(((int64_t)co * Cin + ci) * k + kh0 + jy * kstep) * k + kw0 + jx * kstep];
-  out[i] = f32_to_bf16_bits(v);
+  out[i] = pack1<OT>(v);
 }
 
 extern "C" int enh_conv_pack_weight(const float* w, int Cout, int Cin, int k, float scale, int transposed, int kh0, int kw0, int kstep, int nty, int ntx,
-                                    int rows_padded, int cols_padded, enh_bf16* out, void* stream) {
+                                    int rows_padded, int cols_padded, enh_h16* out, int dtype, void* stream) {
+  ENH_REQUIRE_DT(dtype, "enh_conv_pack_weight");
   ENH_REQUIRE(w && out && Cout > 0 && Cin > 0 && k > 0 && kstep > 0, ENH_E_BADARG, "enh_conv_pack_weight: bad argument");
   ENH_REQUIRE(nty >= 0 && ntx >= 0 && kh0 >= 0 && kw0 >= 0 && (nty == 0 || kh0 + (nty - 1) * kstep < k) && (ntx == 0 || kw0 + (ntx - 1) * kstep < k), ENH_E_SHAPE,
               "enh_conv_pack_weight: tap selection outside the %dx%d kernel", k, k);
   ENH_REQUIRE(rows_padded >= (transposed ? Cin : Cout) && cols_padded >= (transposed ? Cout : Cin), ENH_E_SHAPE, "enh_conv_pack_weight: padded sizes too small");
   const int64_t total = (int64_t)rows_padded * nty * ntx * cols_padded;
   if (total == 0) return ENH_OK;
-  conv_pack_weight_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, (hipStream_t)stream>>>(w, Cout, Cin, k, scale, transposed, kh0, kw0, kstep, nty, ntx,
-                                                                                                  rows_padded, cols_padded, out);
+  ENH_DT_DISPATCH(dtype, (conv_pack_weight_kernel<OT><<<dim3((unsigned)((total + 255) / 256)), 256, 0, (hipStream_t)stream>>>(w, Cout, Cin, k, scale, transposed, kh0, kw0, kstep, nty, ntx,
+                                                                                                  rows_padded, cols_padded, out)));
   return enh_check_launch("enh_conv_pack_weight");
 }
 

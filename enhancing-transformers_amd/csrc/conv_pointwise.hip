@@ -8,16 +8,18 @@
 //   input gradient   dx[p][c]  = sum_n dy[p][n] * wt[c][n]                         N/8 lanes per pixel, 64 partial products each, a butterfly over the lanes
 //   weight gradient  dw[n][c]  = sum_p dy[p][n] * x[p][c]                          64 accumulators per thread over a pixel slice, fixed-order reduction:
 //                                                                                  lanes (shuffles) -> waves (LDS) -> workgroups (workspace slabs)
-// All arithmetic in f32 on exact bf16 products, deterministic.  Called by enh_conv_nhwc_bf16 / enh_conv_wgrad_nhwc_bf16 (conv_igemm.hip) when the geometry is
+// All arithmetic in f32 on exact bf16 products, deterministic.  Called by enh_conv_nhwc_h16 / enh_conv_wgrad_nhwc_h16 (conv_igemm.hip) when the geometry is
 // a dense 1 x 1, stride 1 one with C == 8 (forward / weight gradient) or N == 8 (input gradient).
 #include "gemm_tiles.h"
 
+template <typename OT>
 __device__ __forceinline__ void pw_unpack8(const u32x4 v, float (&f)[8]) {
 #pragma unroll
-  for (int k = 0; k < 4; ++k) { f[2 * k] = __uint_as_float(v[k] << 16); f[2 * k + 1] = __uint_as_float(v[k] & 0xffff0000u); }
+  for (int k = 0; k < 4; ++k) { f[2 * k] = unpack_lo<OT>(v[k]); f[2 * k + 1] = unpack_hi<OT>(v[k]); }
 }
 
 // ---- forward: x [M][8], w [N][8] (packed operand of the implicit-GEMM kernels), out [M][N]; mode 2 (plain) or 3 (bias + leaky-ReLU * p1) -------------
+template <typename OT>
 __global__ __launch_bounds__(256) void conv_pw_fwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w, const float* __restrict__ bias,
                                                           uint16_t* __restrict__ out, int64_t M, int N, int mode, float p0, float p1, int pix_per_wg) {
   const int groups = N >> 3, t = threadIdx.x;
@@ -25,7 +27,7 @@ __global__ __launch_bounds__(256) void conv_pw_fwd_kernel(const uint16_t* __rest
   float wr[8][8], b[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    pw_unpack8(*reinterpret_cast<const u32x4*>(w + (int64_t)(ng * 8 + j) * 8), wr[j]);
+    pw_unpack8<OT>(*reinterpret_cast<const u32x4*>(w + (int64_t)(ng * 8 + j) * 8), wr[j]);
     b[j] = (mode == 3 && bias) ? bias[ng * 8 + j] : 0.f;
   }
   const int64_t p0_ = (int64_t)blockIdx.x * pix_per_wg;
@@ -42,7 +44,7 @@ __global__ __launch_bounds__(256) void conv_pw_fwd_kernel(const uint16_t* __rest
       const int64_t p = p0_ + it + u * ppb + pl;
       if (p >= M) continue;
       float f[8], v[8];
-      pw_unpack8(xin[u], f);
+      pw_unpack8<OT>(xin[u], f);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         float a = 0.f;
@@ -51,20 +53,21 @@ __global__ __launch_bounds__(256) void conv_pw_fwd_kernel(const uint16_t* __rest
         if (mode == 3) { a += b[j]; a = (a > 0.f ? a : a * p0) * p1; }
         v[j] = a;
       }
-      const u32x4 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+      const u32x4 o = {pack2<OT>(v[0], v[1]), pack2<OT>(v[2], v[3]), pack2<OT>(v[4], v[5]), pack2<OT>(v[6], v[7])};
       *reinterpret_cast<u32x4*>(out + p * N + ng * 8) = o;
     }
   }
 }
 
 // ---- input gradient: src [M][K] (dy), wt [8][K] (transposed packed operand), out [M][8]; mode 2 ----------------------------------------------------
+template <typename OT>
 __global__ __launch_bounds__(256) void conv_pw_dgrad_kernel(const uint16_t* __restrict__ src, const uint16_t* __restrict__ wt, uint16_t* __restrict__ out,
                                                             int64_t M, int K, int pix_per_wg) {
   const int groups = K >> 3, t = threadIdx.x;          // lanes per pixel: a power of two <= 64, so a pixel lives inside one wave
   const int kg = t % groups, pl = t / groups, ppb = 256 / groups;
   float wr[8][8];                                       // wr[j][k] = wt[j][kg*8 + k]
 #pragma unroll
-  for (int j = 0; j < 8; ++j) pw_unpack8(*reinterpret_cast<const u32x4*>(wt + (int64_t)j * K + kg * 8), wr[j]);
+  for (int j = 0; j < 8; ++j) pw_unpack8<OT>(*reinterpret_cast<const u32x4*>(wt + (int64_t)j * K + kg * 8), wr[j]);
   const int64_t p0_ = (int64_t)blockIdx.x * pix_per_wg;
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
   for (int it = 0; it < pix_per_wg; it += 4 * ppb) {          // four pixels per thread in flight; no early exit: the reductions need every lane of the wave
@@ -78,7 +81,7 @@ __global__ __launch_bounds__(256) void conv_pw_dgrad_kernel(const uint16_t* __re
     for (int u = 0; u < 4; ++u) {
       const int64_t p = p0_ + it + u * ppb + pl;
       float f[8], v[8];
-      pw_unpack8(sin[u], f);
+      pw_unpack8<OT>(sin[u], f);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         float a = 0.f;
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(256) void conv_pw_dgrad_kernel(const uint16_t* __re
         }
       }
       if (p < M && kg == 0) {
-        const u32x4 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+        const u32x4 o = {pack2<OT>(v[0], v[1]), pack2<OT>(v[2], v[3]), pack2<OT>(v[4], v[5]), pack2<OT>(v[6], v[7])};
         *reinterpret_cast<u32x4*>(out + p * 8) = o;
       }
     }
@@ -109,6 +112,7 @@ __global__ __launch_bounds__(256) void conv_pw_dgrad_kernel(const uint16_t* __re
 }
 
 // ---- weight gradient: x [M][8], dy [M][N] -> partial slab [N][8] f32 per workgroup --------------------------------------------------------------------
+template <typename OT>
 __global__ __launch_bounds__(256) void conv_pw_wgrad_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy, float* __restrict__ ws,
                                                             int64_t M, int N, int pix_per_wg) {
   __shared__ float s_part[4][1024];                     // per wave: [N/8 groups <= 16][8 n][8 c]
@@ -132,8 +136,8 @@ __global__ __launch_bounds__(256) void conv_pw_wgrad_kernel(const uint16_t* __re
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       float f[8], d[8];
-      pw_unpack8(xin[u], f);
-      pw_unpack8(din[u], d);
+      pw_unpack8<OT>(xin[u], f);
+      pw_unpack8<OT>(din[u], d);
 #pragma unroll
       for (int j = 0; j < 8; ++j)
 #pragma unroll
@@ -195,17 +199,17 @@ static int pw_pix_per_wg(int64_t M, int ppb, int wgs = 2048) {
 
 // returns 1 if the launch was taken here, 0 if the geometry is not a pointwise one (the caller runs the implicit-GEMM kernels)
 int conv_pointwise_forward(const uint16_t* src, const uint16_t* wt, const enh_conv_geom& g, int mode, const float* bias, float p0, float p1, uint16_t* out,
-                           hipStream_t stream) {
+                           int dtype, hipStream_t stream) {
   if (!pw_geom(g) || (mode != 2 && mode != 3)) return 0;
   const int64_t M = (int64_t)g.B * g.Hm * g.Wm;
   if (g.C == 8 && pw_groups_ok(g.N)) {
     const int ppb = 256 / (g.N / 8), per = pw_pix_per_wg(M, ppb);
-    conv_pw_fwd_kernel<<<dim3((unsigned)((M + per - 1) / per)), 256, 0, stream>>>(src, wt, bias, out, M, g.N, mode, p0, p1, per);
+    ENH_DT_DISPATCH(dtype, (conv_pw_fwd_kernel<OT><<<dim3((unsigned)((M + per - 1) / per)), 256, 0, stream>>>(src, wt, bias, out, M, g.N, mode, p0, p1, per)));
     return 1;
   }
   if (g.N == 8 && mode == 2 && g.C >= 8 && g.C <= 512 && (g.C & (g.C - 1)) == 0) {
     const int ppb = 256 / (g.C / 8), per = pw_pix_per_wg(M, ppb);
-    conv_pw_dgrad_kernel<<<dim3((unsigned)((M + per - 1) / per)), 256, 0, stream>>>(src, wt, out, M, g.C, per);
+    ENH_DT_DISPATCH(dtype, (conv_pw_dgrad_kernel<OT><<<dim3((unsigned)((M + per - 1) / per)), 256, 0, stream>>>(src, wt, out, M, g.C, per)));
     return 1;
   }
   return 0;
@@ -220,10 +224,10 @@ int conv_pointwise_wgrad_slabs(const enh_conv_geom& g) {
 }
 
 // ws: slabs x [N][8] f32 (conv_pointwise_wgrad_slabs) ; dw [N][8]
-void conv_pointwise_wgrad(const uint16_t* src, const uint16_t* dy, const enh_conv_geom& g, float* ws, float* dw, hipStream_t stream) {
+void conv_pointwise_wgrad(const uint16_t* src, const uint16_t* dy, const enh_conv_geom& g, float* ws, float* dw, int dtype, hipStream_t stream) {
   const int64_t M = (int64_t)g.B * g.Hm * g.Wm;
   const int ppb = 256 / (g.N / 8), per = pw_pix_per_wg(M, ppb, 512);
   const int slabs = (int)((M + per - 1) / per), MN = g.N * 8;
-  conv_pw_wgrad_kernel<<<dim3((unsigned)slabs), 256, 0, stream>>>(src, dy, slabs == 1 ? dw : ws, M, g.N, per);
+  ENH_DT_DISPATCH(dtype, (conv_pw_wgrad_kernel<OT><<<dim3((unsigned)slabs), 256, 0, stream>>>(src, dy, slabs == 1 ? dw : ws, M, g.N, per)));
   if (slabs > 1) conv_pw_reduce_kernel<<<dim3((unsigned)((MN + 63) / 64)), 1024, 0, stream>>>(ws, slabs, MN, dw);
 }

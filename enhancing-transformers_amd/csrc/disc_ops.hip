@@ -199,22 +199,26 @@ extern "C" int enh_upfirdn2d(const float* in, const float* kernel, float* out, i
 }
 
 // =================================================================================================
-// Channels-last bf16 element-wise kernels of the implicit-GEMM discriminator path (activations [B,H,W,C] bf16, C % 8 == 0).
+// Channels-last 16-bit element-wise kernels of the implicit-GEMM discriminator path (activations [B,H,W,C] bf16 | fp16: templates over the operand type tag OT,
+// common.h; C % 8 == 0).
 // Each is linear in its data argument and closed under differentiation (the derivative of every one is another launch of
 // the same kernel with other arguments), which is what lets the R1 penalty differentiate through the backward pass.
 // =================================================================================================
+template <typename OT>
 __device__ __forceinline__ void unpack8(const u32x4 v, float (&f)[8]) {
 #pragma unroll
-  for (int k = 0; k < 4; ++k) { f[2 * k] = __uint_as_float(v[k] << 16); f[2 * k + 1] = __uint_as_float(v[k] & 0xffff0000u); }
+  for (int k = 0; k < 4; ++k) { f[2 * k] = unpack_lo<OT>(v[k]); f[2 * k + 1] = unpack_hi<OT>(v[k]); }
 }
+template <typename OT>
 __device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
-  return (u32x4){pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7])};
+  return (u32x4){pack2<OT>(f[0], f[1]), pack2<OT>(f[2], f[3]), pack2<OT>(f[4], f[5]), pack2<OT>(f[6], f[7])};
 }
 
 // FIR filter with unit up / down factors (Blur, reference enhancing/losses/layers.py:140-160 -> upfirdn2d(input, kernel, pad)):
 //   out[b,oy,ox,c] = sum_{i,j} w(i,j) * x[b, oy + i - pad_y0, ox + j - pad_x0, c],  w(i,j) = kernel[kh-1-i][kw-1-j]  (flip = 0: upfirdn2d's convention)
 //                                                                                   or   kernel[i][j]            (flip = 1: its adjoint)
 // one thread = 8 channels x 4 consecutive output columns of one row: (kw + 3) * kh 16-byte loads for 4 outputs
+template <typename OT>
 __global__ __launch_bounds__(256) void blur_nhwc_kernel(const uint16_t* __restrict__ x, const float* __restrict__ kernel, uint16_t* __restrict__ out,
                                                         int B, int H, int W, int C, int Ho, int Wo, int kh, int kw, int pad_y0, int pad_x0, int flip) {
   __shared__ float s_k[64];
@@ -246,7 +250,7 @@ __global__ __launch_bounds__(256) void blur_nhwc_kernel(const uint16_t* __restri
       const int ix = ox0 + jj - pad_x0;
       if (ix < 0 || ix >= W) continue;
       float f[8];
-      unpack8(*reinterpret_cast<const u32x4*>(row + (int64_t)ix * C), f);
+      unpack8<OT>(*reinterpret_cast<const u32x4*>(row + (int64_t)ix * C), f);
 #pragma unroll
       for (int o = 0; o < 4; ++o) {
         const int j = jj - o;
@@ -260,7 +264,7 @@ __global__ __launch_bounds__(256) void blur_nhwc_kernel(const uint16_t* __restri
   }
 #pragma unroll
   for (int o = 0; o < 4; ++o)
-    if (ox0 + o < Wo) *reinterpret_cast<u32x4*>(out + ((b * Ho + oy) * (int64_t)Wo + ox0 + o) * C + c8 * 8) = pack8(acc[o]);
+    if (ox0 + o < Wo) *reinterpret_cast<u32x4*>(out + ((b * Ho + oy) * (int64_t)Wo + ox0 + o) * C + c8 * 8) = pack8<OT>(acc[o]);
 }
 
 // The 4 x 4 case (every Blur of the discriminator) as a column march: one thread = 8 channels x 2 output columns x a strip of RS output rows.  Each input
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(256) void blur_nhwc_kernel(const uint16_t* __restri
 // Lab (B = 16, 256^2 x 128 / 128^2 x 256 / 64^2 x 512, profiles/r04_conv_layers.txt): one-row kernel 245 / 123 / 65 us; this form 117 / 60 / 35 us
 // (4.6 TB/s of input + output); 4 columns per thread 153 / 86 / 49 (282 registers: one wave per SIMD; 285 when forced to two waves, it spills);
 // loads issued unconditionally from clamped addresses and masked instead of predicated: 130 / 64 / 38; 1 column per thread at three waves: 321.
-template <int RS>
+template <typename OT, int RS>
 __global__ __launch_bounds__(256, 2) void blur4x4_nhwc_kernel(const uint16_t* __restrict__ x, const float* __restrict__ kernel, uint16_t* __restrict__ out,
                                                               int B, int H, int W, int C, int Ho, int Wo, int pad_y0, int pad_x0, int flip) {
   static_assert((RS + 3) % 4 == 0, "the march runs in groups of four input rows");
@@ -324,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void blur4x4_nhwc_kernel(const uint16_t* __
 #pragma unroll
       for (int jj = 0; jj < NC + 3; ++jj) {
         float f[8];
-        unpack8(cur[jj], f);
+        unpack8<OT>(cur[jj], f);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -342,7 +346,7 @@ __global__ __launch_bounds__(256, 2) void blur4x4_nhwc_kernel(const uint16_t* __
         uint16_t* dst = ob + (int64_t)(oy0 + orow) * Wo * C + (int64_t)ox0 * C;
 #pragma unroll
         for (int o = 0; o < NC; ++o)
-          if (ox0 + o < Wo) *reinterpret_cast<u32x4*>(dst + (int64_t)o * C) = pack8(acc[(tt - 3) & 3][o]);
+          if (ox0 + o < Wo) *reinterpret_cast<u32x4*>(dst + (int64_t)o * C) = pack8<OT>(acc[(tt - 3) & 3][o]);
       }
 #pragma unroll
       for (int o = 0; o < NC; ++o)
@@ -361,53 +365,57 @@ extern "C" int enh_blur_set_kernel(int variant) {
   return ENH_OK;
 }
 
-extern "C" int enh_blur_nhwc_bf16(const enh_bf16* x, const float* kernel, int B, int H, int W, int C, int kh, int kw, int pad_y0, int pad_y1, int pad_x0,
-                                  int pad_x1, int flip, enh_bf16* out, void* stream) {
-  ENH_REQUIRE(x && kernel && out && B > 0 && H > 0 && W > 0, ENH_E_BADARG, "enh_blur_nhwc_bf16: bad argument");
-  ENH_REQUIRE(C > 0 && C % 8 == 0 && kh > 0 && kw > 0 && kh * kw <= 64, ENH_E_SHAPE, "enh_blur_nhwc_bf16: C must be a multiple of 8 and the kernel at most 64 taps");
+extern "C" int enh_blur_nhwc_h16(const enh_h16* x, const float* kernel, int B, int H, int W, int C, int kh, int kw, int pad_y0, int pad_y1, int pad_x0,
+                                  int pad_x1, int flip, enh_h16* out, int dtype, void* stream) {
+  ENH_REQUIRE_DT(dtype, "enh_blur_nhwc_h16");
+  ENH_REQUIRE(x && kernel && out && B > 0 && H > 0 && W > 0, ENH_E_BADARG, "enh_blur_nhwc_h16: bad argument");
+  ENH_REQUIRE(C > 0 && C % 8 == 0 && kh > 0 && kw > 0 && kh * kw <= 64, ENH_E_SHAPE, "enh_blur_nhwc_h16: C must be a multiple of 8 and the kernel at most 64 taps");
   const int Ho = H + pad_y0 + pad_y1 - kh + 1, Wo = W + pad_x0 + pad_x1 - kw + 1;
-  ENH_REQUIRE(Ho > 0 && Wo > 0, ENH_E_SHAPE, "enh_blur_nhwc_bf16: empty output");
+  ENH_REQUIRE(Ho > 0 && Wo > 0, ENH_E_SHAPE, "enh_blur_nhwc_h16: empty output");
   if (kh == 4 && kw == 4 && g_blur_variant == 0 && (int64_t)W * C < (1ll << 31)) {
     // strips of 13 rows when that still gives every CU several workgroups, else 5
     const int64_t cols = (int64_t)B * ((Wo + 1) / 2) * (C / 8);
     const int64_t t13 = cols * ((Ho + 12) / 13), t5 = cols * ((Ho + 4) / 5);
     if (t13 >= 256ll * 256 * 4)
-      blur4x4_nhwc_kernel<13><<<dim3((unsigned)((t13 + 255) / 256)), 256, 0, (hipStream_t)stream>>>(x, kernel, out, B, H, W, C, Ho, Wo, pad_y0, pad_x0, flip);
+      ENH_DT_DISPATCH(dtype, (blur4x4_nhwc_kernel<OT, 13><<<dim3((unsigned)((t13 + 255) / 256)), 256, 0, (hipStream_t)stream>>>(x, kernel, out, B, H, W, C, Ho, Wo, pad_y0, pad_x0, flip)));
     else
-      blur4x4_nhwc_kernel<5><<<dim3((unsigned)((t5 + 255) / 256)), 256, 0, (hipStream_t)stream>>>(x, kernel, out, B, H, W, C, Ho, Wo, pad_y0, pad_x0, flip);
-    return enh_check_launch("enh_blur_nhwc_bf16");
+      ENH_DT_DISPATCH(dtype, (blur4x4_nhwc_kernel<OT, 5><<<dim3((unsigned)((t5 + 255) / 256)), 256, 0, (hipStream_t)stream>>>(x, kernel, out, B, H, W, C, Ho, Wo, pad_y0, pad_x0, flip)));
+    return enh_check_launch("enh_blur_nhwc_h16");
   }
   const int64_t total = (int64_t)B * Ho * ((Wo + 3) / 4) * (C / 8);
-  blur_nhwc_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, (hipStream_t)stream>>>(x, kernel, out, B, H, W, C, Ho, Wo, kh, kw, pad_y0, pad_x0, flip);
-  return enh_check_launch("enh_blur_nhwc_bf16");
+  ENH_DT_DISPATCH(dtype, (blur_nhwc_kernel<OT><<<dim3((unsigned)((total + 255) / 256)), 256, 0, (hipStream_t)stream>>>(x, kernel, out, B, H, W, C, Ho, Wo, kh, kw, pad_y0, pad_x0, flip)));
+  return enh_check_launch("enh_blur_nhwc_h16");
 }
 
 // y = g * (ref > 0 ? 1 : slope) * scale   (the derivative of FusedLeakyReLU through its saved OUTPUT, fused_act.py:21-45; ref == NULL: y = g * scale)
-__global__ __launch_bounds__(256) void lrelu_gate_bf16_kernel(const uint16_t* __restrict__ g, const uint16_t* __restrict__ ref, uint16_t* __restrict__ y, int64_t n8,
+template <typename OT>
+__global__ __launch_bounds__(256) void lrelu_gate_h16_kernel(const uint16_t* __restrict__ g, const uint16_t* __restrict__ ref, uint16_t* __restrict__ y, int64_t n8,
                                                               float slope, float scale) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n8) return;
   float f[8], r[8];
-  unpack8(*reinterpret_cast<const u32x4*>(g + i * 8), f);
+  unpack8<OT>(*reinterpret_cast<const u32x4*>(g + i * 8), f);
   if (ref) {
-    unpack8(*reinterpret_cast<const u32x4*>(ref + i * 8), r);
+    unpack8<OT>(*reinterpret_cast<const u32x4*>(ref + i * 8), r);
 #pragma unroll
     for (int k = 0; k < 8; ++k) f[k] *= (r[k] > 0.f ? 1.f : slope) * scale;
   } else {
 #pragma unroll
     for (int k = 0; k < 8; ++k) f[k] *= scale;
   }
-  *reinterpret_cast<u32x4*>(y + i * 8) = pack8(f);
+  *reinterpret_cast<u32x4*>(y + i * 8) = pack8<OT>(f);
 }
 
-extern "C" int enh_lrelu_gate_bf16(const enh_bf16* g, const enh_bf16* ref, int64_t n, float slope, float scale, enh_bf16* y, void* stream) {
-  ENH_REQUIRE(g && y && n > 0, ENH_E_BADARG, "enh_lrelu_gate_bf16: bad argument");
-  ENH_REQUIRE(n % 8 == 0, ENH_E_SHAPE, "enh_lrelu_gate_bf16: n must be a multiple of 8");
-  lrelu_gate_bf16_kernel<<<dim3((unsigned)((n / 8 + 255) / 256)), 256, 0, (hipStream_t)stream>>>(g, ref, y, n / 8, slope, scale);
-  return enh_check_launch("enh_lrelu_gate_bf16");
+extern "C" int enh_lrelu_gate_h16(const enh_h16* g, const enh_h16* ref, int64_t n, float slope, float scale, enh_h16* y, int dtype, void* stream) {
+  ENH_REQUIRE_DT(dtype, "enh_lrelu_gate_h16");
+  ENH_REQUIRE(g && y && n > 0, ENH_E_BADARG, "enh_lrelu_gate_h16: bad argument");
+  ENH_REQUIRE(n % 8 == 0, ENH_E_SHAPE, "enh_lrelu_gate_h16: n must be a multiple of 8");
+  ENH_DT_DISPATCH(dtype, (lrelu_gate_h16_kernel<OT><<<dim3((unsigned)((n / 8 + 255) / 256)), 256, 0, (hipStream_t)stream>>>(g, ref, y, n / 8, slope, scale)));
+  return enh_check_launch("enh_lrelu_gate_h16");
 }
 
 // img [B,C,H,W] f32 (C <= 8) -> [B,H,W,8] bf16 with channels C..7 zero, and its adjoint ([B,H,W,8] bf16 -> [B,C,H,W] f32, the padding channels dropped)
+template <typename OT>
 __global__ __launch_bounds__(256) void img_to_nhwc8_kernel(const float* __restrict__ img, uint16_t* __restrict__ out, int C, int64_t HW, int64_t total) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // pixel index over B*H*W
   if (i >= total) return;
@@ -415,29 +423,32 @@ __global__ __launch_bounds__(256) void img_to_nhwc8_kernel(const float* __restri
   float f[8];
 #pragma unroll
   for (int c = 0; c < 8; ++c) f[c] = c < C ? img[(b * C + c) * HW + p] : 0.f;
-  *reinterpret_cast<u32x4*>(out + i * 8) = pack8(f);
+  *reinterpret_cast<u32x4*>(out + i * 8) = pack8<OT>(f);
 }
+template <typename OT>
 __global__ __launch_bounds__(256) void nhwc8_to_img_kernel(const uint16_t* __restrict__ src, float* __restrict__ img, int C, int64_t HW, int64_t total) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int64_t b = i / HW, p = i - b * HW;
   float f[8];
-  unpack8(*reinterpret_cast<const u32x4*>(src + i * 8), f);
+  unpack8<OT>(*reinterpret_cast<const u32x4*>(src + i * 8), f);
 #pragma unroll
   for (int c = 0; c < 8; ++c)
     if (c < C) img[(b * C + c) * HW + p] = f[c];
 }
 
-extern "C" int enh_img_to_nhwc8(const float* img, int B, int C, int H, int W, enh_bf16* out, void* stream) {
+extern "C" int enh_img_to_nhwc8(const float* img, int B, int C, int H, int W, enh_h16* out, int dtype, void* stream) {
+  ENH_REQUIRE_DT(dtype, "enh_img_to_nhwc8");
   ENH_REQUIRE(img && out && B > 0 && H > 0 && W > 0 && C > 0 && C <= 8, ENH_E_BADARG, "enh_img_to_nhwc8: bad argument (1 <= C <= 8)");
   const int64_t total = (int64_t)B * H * W;
-  img_to_nhwc8_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, (hipStream_t)stream>>>(img, out, C, (int64_t)H * W, total);
+  ENH_DT_DISPATCH(dtype, (img_to_nhwc8_kernel<OT><<<dim3((unsigned)((total + 255) / 256)), 256, 0, (hipStream_t)stream>>>(img, out, C, (int64_t)H * W, total)));
   return enh_check_launch("enh_img_to_nhwc8");
 }
-extern "C" int enh_nhwc8_to_img(const enh_bf16* src, int B, int C, int H, int W, float* img, void* stream) {
+extern "C" int enh_nhwc8_to_img(const enh_h16* src, int B, int C, int H, int W, float* img, int dtype, void* stream) {
+  ENH_REQUIRE_DT(dtype, "enh_nhwc8_to_img");
   ENH_REQUIRE(img && src && B > 0 && H > 0 && W > 0 && C > 0 && C <= 8, ENH_E_BADARG, "enh_nhwc8_to_img: bad argument (1 <= C <= 8)");
   const int64_t total = (int64_t)B * H * W;
-  nhwc8_to_img_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, (hipStream_t)stream>>>(src, img, C, (int64_t)H * W, total);
+  ENH_DT_DISPATCH(dtype, (nhwc8_to_img_kernel<OT><<<dim3((unsigned)((total + 255) / 256)), 256, 0, (hipStream_t)stream>>>(src, img, C, (int64_t)H * W, total)));
   return enh_check_launch("enh_nhwc8_to_img");
 }
 
@@ -455,6 +466,7 @@ __device__ __forceinline__ float block_sum_256(float v, float* s_red) {
   return s_red[0] + s_red[1] + s_red[2] + s_red[3];
 }
 
+template <typename OT>
 __global__ __launch_bounds__(256) void stddev_fwd_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ out, int group, int n, int HW, int C, int Cp) {
   __shared__ float s_red[4];
   const int slot = blockIdx.x;
@@ -466,7 +478,7 @@ __global__ __launch_bounds__(256) void stddev_fwd_kernel(const uint16_t* __restr
     for (int k = 0; k < 8; ++k) { m[k] = 0.f; q[k] = 0.f; }
     for (int gi = 0; gi < group; ++gi) {
       float f[8];
-      unpack8(*reinterpret_cast<const u32x4*>(x + ((int64_t)gi * n + slot) * P + p8 * 8), f);
+      unpack8<OT>(*reinterpret_cast<const u32x4*>(x + ((int64_t)gi * n + slot) * P + p8 * 8), f);
 #pragma unroll
       for (int k = 0; k < 8; ++k) m[k] += f[k];
     }
@@ -474,7 +486,7 @@ __global__ __launch_bounds__(256) void stddev_fwd_kernel(const uint16_t* __restr
     for (int k = 0; k < 8; ++k) m[k] /= (float)group;
     for (int gi = 0; gi < group; ++gi) {
       float f[8];
-      unpack8(*reinterpret_cast<const u32x4*>(x + ((int64_t)gi * n + slot) * P + p8 * 8), f);
+      unpack8<OT>(*reinterpret_cast<const u32x4*>(x + ((int64_t)gi * n + slot) * P + p8 * 8), f);
 #pragma unroll
       for (int k = 0; k < 8; ++k) q[k] += (f[k] - m[k]) * (f[k] - m[k]);
     }
@@ -494,8 +506,8 @@ __global__ __launch_bounds__(256) void stddev_fwd_kernel(const uint16_t* __restr
       else {
         float f[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) f[k] = ch + k < C ? bf16_bits_to_f32(x[(b * HW + pix) * C + ch + k]) : (ch + k == C ? sd : 0.f);
-        v = pack8(f);
+        for (int k = 0; k < 8; ++k) f[k] = ch + k < C ? unpack1<OT>(x[(b * HW + pix) * C + ch + k]) : (ch + k == C ? sd : 0.f);
+        v = pack8<OT>(f);
       }
       *reinterpret_cast<u32x4*>(out + (b * HW + pix) * Cp + ch) = v;
     }
@@ -503,6 +515,7 @@ __global__ __launch_bounds__(256) void stddev_fwd_kernel(const uint16_t* __restr
 }
 
 // dx[b,p] = g[b,p] + (sum over the slot's samples and pixels of g[.., C]) / P * (x[b,p] - mean_p) / (group * sd_p)
+template <typename OT>
 __global__ __launch_bounds__(256) void stddev_bwd_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ g, uint16_t* __restrict__ dx, int group, int n,
                                                          int HW, int C, int Cp) {
   __shared__ float s_red[4];
@@ -511,7 +524,7 @@ __global__ __launch_bounds__(256) void stddev_bwd_kernel(const uint16_t* __restr
   float part = 0.f;
   for (int i = threadIdx.x; i < group * HW; i += 256) {
     const int64_t b = (int64_t)(i / HW) * n + slot;
-    part += bf16_bits_to_f32(g[(b * HW + i % HW) * Cp + C]);
+    part += unpack1<OT>(g[(b * HW + i % HW) * Cp + C]);
   }
   const float gsd = block_sum_256(part, s_red) / (float)P;
   const int c8 = C / 8;
@@ -523,7 +536,7 @@ __global__ __launch_bounds__(256) void stddev_bwd_kernel(const uint16_t* __restr
     for (int k = 0; k < 8; ++k) { m[k] = 0.f; q[k] = 0.f; }
     for (int gi = 0; gi < group; ++gi) {
       float f[8];
-      unpack8(*reinterpret_cast<const u32x4*>(x + ((int64_t)gi * n + slot) * P + p8 * 8), f);
+      unpack8<OT>(*reinterpret_cast<const u32x4*>(x + ((int64_t)gi * n + slot) * P + p8 * 8), f);
 #pragma unroll
       for (int k = 0; k < 8; ++k) m[k] += f[k];
     }
@@ -531,7 +544,7 @@ __global__ __launch_bounds__(256) void stddev_bwd_kernel(const uint16_t* __restr
     for (int k = 0; k < 8; ++k) m[k] /= (float)group;
     for (int gi = 0; gi < group; ++gi) {
       float f[8];
-      unpack8(*reinterpret_cast<const u32x4*>(x + ((int64_t)gi * n + slot) * P + p8 * 8), f);
+      unpack8<OT>(*reinterpret_cast<const u32x4*>(x + ((int64_t)gi * n + slot) * P + p8 * 8), f);
 #pragma unroll
       for (int k = 0; k < 8; ++k) q[k] += (f[k] - m[k]) * (f[k] - m[k]);
     }
@@ -541,11 +554,11 @@ __global__ __launch_bounds__(256) void stddev_bwd_kernel(const uint16_t* __restr
     for (int gi = 0; gi < group; ++gi) {
       const int64_t b = (int64_t)gi * n + slot;
       float f[8], gv[8];
-      unpack8(*reinterpret_cast<const u32x4*>(x + b * P + p8 * 8), f);
-      unpack8(*reinterpret_cast<const u32x4*>(g + (b * HW + pix) * Cp + ch), gv);
+      unpack8<OT>(*reinterpret_cast<const u32x4*>(x + b * P + p8 * 8), f);
+      unpack8<OT>(*reinterpret_cast<const u32x4*>(g + (b * HW + pix) * Cp + ch), gv);
 #pragma unroll
       for (int k = 0; k < 8; ++k) f[k] = gv[k] + coef[k] * (f[k] - m[k]);
-      *reinterpret_cast<u32x4*>(dx + b * P + p8 * 8) = pack8(f);
+      *reinterpret_cast<u32x4*>(dx + b * P + p8 * 8) = pack8<OT>(f);
     }
   }
 }
@@ -555,16 +568,18 @@ static int stddev_check(const void* a, const void* b, int B, int HW, int C, int 
   ENH_REQUIRE(B % group == 0 && C % 8 == 0 && Cp % 8 == 0 && Cp > C, ENH_E_SHAPE, "%s: B %% group == 0, C %% 8 == 0 and Cp > C (a multiple of 8) required", who);
   return ENH_OK;
 }
-extern "C" int enh_minibatch_stddev_nhwc(const enh_bf16* x, int B, int HW, int C, int Cp, int group, enh_bf16* out, void* stream) {
+extern "C" int enh_minibatch_stddev_nhwc(const enh_h16* x, int B, int HW, int C, int Cp, int group, enh_h16* out, int dtype, void* stream) {
+  ENH_REQUIRE_DT(dtype, "enh_minibatch_stddev_nhwc");
   const int rc = stddev_check(x, out, B, HW, C, Cp, group, "enh_minibatch_stddev_nhwc");
   if (rc != ENH_OK) return rc;
-  stddev_fwd_kernel<<<dim3((unsigned)(B / group)), 256, 0, (hipStream_t)stream>>>(x, out, group, B / group, HW, C, Cp);
+  ENH_DT_DISPATCH(dtype, (stddev_fwd_kernel<OT><<<dim3((unsigned)(B / group)), 256, 0, (hipStream_t)stream>>>(x, out, group, B / group, HW, C, Cp)));
   return enh_check_launch("enh_minibatch_stddev_nhwc");
 }
-extern "C" int enh_minibatch_stddev_nhwc_backward(const enh_bf16* x, const enh_bf16* g, int B, int HW, int C, int Cp, int group, enh_bf16* dx, void* stream) {
+extern "C" int enh_minibatch_stddev_nhwc_backward(const enh_h16* x, const enh_h16* g, int B, int HW, int C, int Cp, int group, enh_h16* dx, int dtype, void* stream) {
+  ENH_REQUIRE_DT(dtype, "enh_minibatch_stddev_nhwc_backward");
   const int rc = stddev_check(x, dx, B, HW, C, Cp, group, "enh_minibatch_stddev_nhwc_backward");
   if (rc != ENH_OK) return rc;
   ENH_REQUIRE(g, ENH_E_BADARG, "enh_minibatch_stddev_nhwc_backward: g is NULL");
-  stddev_bwd_kernel<<<dim3((unsigned)(B / group)), 256, 0, (hipStream_t)stream>>>(x, g, dx, group, B / group, HW, C, Cp);
+  ENH_DT_DISPATCH(dtype, (stddev_bwd_kernel<OT><<<dim3((unsigned)(B / group)), 256, 0, (hipStream_t)stream>>>(x, g, dx, group, B / group, HW, C, Cp)));
   return enh_check_launch("enh_minibatch_stddev_nhwc_backward");
 }

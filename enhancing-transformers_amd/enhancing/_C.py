@@ -73,37 +73,37 @@ SIGNATURES = {
     "enh_upfirdn2d": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "enh_im2col": (_i32, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _i32, _vp]),
     "enh_col2im": (_i32, [_vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _i64, _i32, _vp]),
-    "enh_conv_nhwc_bf16": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _f32, _f32, _vp, _vp]),
-    "enh_conv_nhwc_bf16_ws": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _sz, _vp]),
+    "enh_conv_nhwc_h16": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _f32, _f32, _vp, _i32, _vp]),
+    "enh_conv_nhwc_h16_ws": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _sz, _i32, _vp]),
     "enh_conv_workspace_bytes": (_sz, [_vp]),
     "enh_conv_set_kernel": (_i32, [_i32]),
     "enh_conv_wgrad_workspace_bytes": (_sz, [_vp]),
-    "enh_conv_wgrad_nhwc_bf16": (_i32, [_vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "enh_conv_pack_weight": (_i32, [_vp, _i32, _i32, _i32, _f32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "enh_conv_wgrad_nhwc_h16": (_i32, [_vp, _vp, _vp, _vp, _vp, _sz, _i32, _vp]),
+    "enh_conv_pack_weight": (_i32, [_vp, _i32, _i32, _i32, _f32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
     "enh_conv_unpack_wgrad": (_i32, [_vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),
     "enh_blur_set_kernel": (_i32, [_i32]),
     "enh_debug_gemm_lab": (_i32, [_i32]),
     "enh_debug_gemm_order": (_i32, [_i32, _i32]),
     "enh_debug_gemm_splits": (_i32, [_i32]),
-    "enh_blur_nhwc_bf16": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
-    "enh_lrelu_gate_bf16": (_i32, [_vp, _vp, _i64, _f32, _f32, _vp, _vp]),
-    "enh_img_to_nhwc8": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
-    "enh_nhwc8_to_img": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
-    "enh_minibatch_stddev_nhwc": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
-    "enh_minibatch_stddev_nhwc_backward": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "enh_blur_nhwc_h16": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
+    "enh_lrelu_gate_h16": (_i32, [_vp, _vp, _i64, _f32, _f32, _vp, _i32, _vp]),
+    "enh_img_to_nhwc8": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
+    "enh_nhwc8_to_img": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
+    "enh_minibatch_stddev_nhwc": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
+    "enh_minibatch_stddev_nhwc_backward": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
     "enh_gemm_f32": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _i64, _i64, _i64, _vp, _i32, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _i64, _vp]),
     "enh_attention_forward_f32": (_i32, [_vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp]),
     "enh_attention_backward_f32": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp]),
     "enh_colsum_f32": (_i32, [_vp, _i64, _i64, _i64, _vp, _i32, _vp]),
     "enh_patch_perm_f32": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "enh_unpatchify_loss_f32": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp]),
-    "enh_conv3x3_nhwc_bf16": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),
-    "enh_vgg_conv1": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
-    "enh_vgg_conv1_backward": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
-    "enh_maxpool2_nhwc_bf16": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
-    "enh_maxpool2_nhwc_bf16_backward": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
-    "enh_lpips_head": (_i32, [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _i32, _vp]),
-    "enh_lpips_head_backward": (_i32, [_vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp]),
+    "enh_conv3x3_nhwc_h16": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _vp]),
+    "enh_vgg_conv1": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
+    "enh_vgg_conv1_backward": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
+    "enh_maxpool2_nhwc_h16": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
+    "enh_maxpool2_nhwc_h16_backward": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
+    "enh_lpips_head": (_i32, [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _i32, _i32, _vp]),
+    "enh_lpips_head_backward": (_i32, [_vp, _vp, _vp, _i32, _i64, _i32, _vp, _i32, _vp]),
     "enh_split3_bf16": (_i32, [_vp, _i64, _i64, _i64, _vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp]),
     "enh_split2_bf16": (_i32, [_vp, _i64, _vp, _vp, _vp]),
     "enh_gemm_bf16_split_fused": (_i32, [_i64, _i64, _i64]),
@@ -116,7 +116,7 @@ SIGNATURES = {
 }
 
 _LIB = None
-ABI_VERSION = 16  # ENH_ABI_VERSION of the include/enh_hip.h these signatures were written against
+ABI_VERSION = 17  # ENH_ABI_VERSION of the include/enh_hip.h these signatures were written against
 
 
 def lib():
@@ -654,16 +654,16 @@ def _geom(g) -> ConvGeom:
 
 
 def conv_nhwc(src, wt, geom, mode: int, bias=None, aux=None, add=None, p0: float = 0.0, p1: float = 1.0, out=None):
-    """src [B,Hs,Ws,C] bf16, wt [N, taps*C] bf16 -> out [B,HO,WO,N] bf16 (allocated unless given); see enh_conv_nhwc_bf16"""
+    """src [B,Hs,Ws,C], wt [N, taps*C] -> out [B,HO,WO,N] (allocated unless given), all in src's 16-bit format (bf16 | fp16); see enh_conv_nhwc_h16"""
     g = _geom(geom)
     if out is None:
-        out = torch.empty(g.B, g.HO, g.WO, g.N, dtype=BF16, device=src.device)
+        out = torch.empty(g.B, g.HO, g.WO, g.N, dtype=src.dtype, device=src.device)
     work = 2.0 * g.B * g.Hm * g.Wm * g.N * g.nty * g.ntx * g.C
     nb = lib().enh_conv_workspace_bytes(ctypes.byref(g))       # > 0: a small grid that the library splits over the contraction
     ws = _gemm_workspace(src.device, nb) if nb else None
     _timed("conv_igemm_kernel", work,
-           lambda: _check(lib().enh_conv_nhwc_bf16_ws(_p(src, BF16, "src"), _p(wt, BF16, "wt"), ctypes.byref(g), mode, _p(bias, F32, "bias"), _p(aux, BF16, "aux"),
-                                                      _p(add, BF16, "add"), p0, p1, _p(out, BF16, "out"), _p(ws), nb, _stream()), "enh_conv_nhwc_bf16_ws"))
+           lambda: _check(lib().enh_conv_nhwc_h16_ws(_p(src, H16, "src"), _p(wt, H16, "wt"), ctypes.byref(g), mode, _p(bias, F32, "bias"), _p(aux, H16, "aux"),
+                                                     _p(add, H16, "add"), p0, p1, _p(out, H16, "out"), _p(ws), nb, _dt(src, wt, aux, add, out), _stream()), "enh_conv_nhwc_h16_ws"))
     return out
 
 
@@ -675,18 +675,19 @@ def conv_wgrad_nhwc(src, dy, geom):
     ws = _gemm_workspace(src.device, nb) if nb else None
     work = 2.0 * g.B * g.Hm * g.Wm * g.N * g.nty * g.ntx * g.C
     _timed("conv_wgrad_igemm_kernel", work,
-           lambda: _check(lib().enh_conv_wgrad_nhwc_bf16(_p(src, BF16, "src"), _p(dy, BF16, "dy"), ctypes.byref(g), _p(dw), _p(ws), nb, _stream()),
-                          "enh_conv_wgrad_nhwc_bf16"))
+           lambda: _check(lib().enh_conv_wgrad_nhwc_h16(_p(src, H16, "src"), _p(dy, H16, "dy"), ctypes.byref(g), _p(dw), _p(ws), nb, _dt(src, dy), _stream()),
+                          "enh_conv_wgrad_nhwc_h16"))
     return dw
 
 
-def conv_pack_weight(w, scale: float, transposed: bool, kh0: int, kw0: int, kstep: int, nty: int, ntx: int, rows_padded: int, cols_padded: int):
-    """w [Cout,Cin,k,k] f32 -> bf16 [rows_padded, nty*ntx*cols_padded]"""
+def conv_pack_weight(w, scale: float, transposed: bool, kh0: int, kw0: int, kstep: int, nty: int, ntx: int, rows_padded: int, cols_padded: int,
+                     dtype: torch.dtype = BF16):
+    """w [Cout,Cin,k,k] f32 -> 16-bit operand image [rows_padded, nty*ntx*cols_padded] in `dtype` (bf16 | fp16)"""
     Cout, Cin, k, _ = w.shape
-    out = torch.empty(rows_padded, max(nty * ntx * cols_padded, 8), dtype=BF16, device=w.device)
+    out = torch.empty(rows_padded, max(nty * ntx * cols_padded, 8), dtype=dtype, device=w.device)
     if nty * ntx:
         _check(lib().enh_conv_pack_weight(_p(w, F32, "w"), Cout, Cin, k, scale, int(transposed), kh0, kw0, kstep, nty, ntx, rows_padded, cols_padded,
-                                          _p(out), _stream()), "enh_conv_pack_weight")
+                                          _p(out), _dt(out), _stream()), "enh_conv_pack_weight")
     return out
 
 
@@ -700,9 +701,9 @@ def blur_nhwc(x, kernel, pad0: int, pad1: int, flip: bool):
     """x [B,H,W,C] bf16, kernel [kh,kw] f32 -> [B, H+pad0+pad1-kh+1, W+pad0+pad1-kw+1, C] bf16"""
     B, H, W, C = x.shape
     kh, kw = kernel.shape
-    out = torch.empty(B, H + pad0 + pad1 - kh + 1, W + pad0 + pad1 - kw + 1, C, dtype=BF16, device=x.device)
-    _check(lib().enh_blur_nhwc_bf16(_p(x, BF16, "x"), _p(kernel, F32, "kernel"), B, H, W, C, kh, kw, pad0, pad1, pad0, pad1, int(flip), _p(out), _stream()),
-           "enh_blur_nhwc_bf16")
+    out = torch.empty(B, H + pad0 + pad1 - kh + 1, W + pad0 + pad1 - kw + 1, C, dtype=x.dtype, device=x.device)
+    _check(lib().enh_blur_nhwc_h16(_p(x, H16, "x"), _p(kernel, F32, "kernel"), B, H, W, C, kh, kw, pad0, pad1, pad0, pad1, int(flip), _p(out), _dt(x), _stream()),
+           "enh_blur_nhwc_h16")
     return out
 
 
@@ -713,36 +714,36 @@ def blur_set_kernel(variant: int) -> None:
 
 def lrelu_gate(g, ref, slope: float, scale: float):
     y = torch.empty_like(g)
-    _check(lib().enh_lrelu_gate_bf16(_p(g, BF16, "g"), _p(ref, BF16, "ref"), g.numel(), slope, scale, _p(y), _stream()), "enh_lrelu_gate_bf16")
+    _check(lib().enh_lrelu_gate_h16(_p(g, H16, "g"), _p(ref, H16, "ref"), g.numel(), slope, scale, _p(y), _dt(g, ref), _stream()), "enh_lrelu_gate_h16")
     return y
 
 
-def img_to_nhwc8(img):
+def img_to_nhwc8(img, dtype: torch.dtype = BF16):
     B, C, H, W = img.shape
-    out = torch.empty(B, H, W, 8, dtype=BF16, device=img.device)
-    _check(lib().enh_img_to_nhwc8(_p(img, F32, "img"), B, C, H, W, _p(out), _stream()), "enh_img_to_nhwc8")
+    out = torch.empty(B, H, W, 8, dtype=dtype, device=img.device)
+    _check(lib().enh_img_to_nhwc8(_p(img, F32, "img"), B, C, H, W, _p(out), _dt(out), _stream()), "enh_img_to_nhwc8")
     return out
 
 
 def nhwc8_to_img(src, C: int):
     B, H, W, _ = src.shape
     img = torch.empty(B, C, H, W, dtype=F32, device=src.device)
-    _check(lib().enh_nhwc8_to_img(_p(src, BF16, "src"), B, C, H, W, _p(img), _stream()), "enh_nhwc8_to_img")
+    _check(lib().enh_nhwc8_to_img(_p(src, H16, "src"), B, C, H, W, _p(img), _dt(src), _stream()), "enh_nhwc8_to_img")
     return img
 
 
 def minibatch_stddev_nhwc(x, group: int, Cp: int):
     """x [B,H,W,C] bf16 -> [B,H,W,Cp] bf16: x, the slot's mean standard deviation in channel C, zeros above (enh_minibatch_stddev_nhwc)"""
     B, H, W, C = x.shape
-    out = torch.empty(B, H, W, Cp, dtype=BF16, device=x.device)
-    _check(lib().enh_minibatch_stddev_nhwc(_p(x, BF16, "x"), B, H * W, C, Cp, group, _p(out), _stream()), "enh_minibatch_stddev_nhwc")
+    out = torch.empty(B, H, W, Cp, dtype=x.dtype, device=x.device)
+    _check(lib().enh_minibatch_stddev_nhwc(_p(x, H16, "x"), B, H * W, C, Cp, group, _p(out), _dt(x), _stream()), "enh_minibatch_stddev_nhwc")
     return out
 
 
 def minibatch_stddev_nhwc_backward(x, g, group: int):
     B, H, W, C = x.shape
     dx = torch.empty_like(x)
-    _check(lib().enh_minibatch_stddev_nhwc_backward(_p(x, BF16, "x"), _p(g, BF16, "g"), B, H * W, C, g.shape[3], group, _p(dx), _stream()),
+    _check(lib().enh_minibatch_stddev_nhwc_backward(_p(x, H16, "x"), _p(g, H16, "g"), B, H * W, C, g.shape[3], group, _p(dx), _dt(x, g), _stream()),
            "enh_minibatch_stddev_nhwc_backward")
     return dx
 
@@ -895,40 +896,40 @@ def unpatchify_loss_any(pix, target, B, C, H, W, p, w_l1, w_l2, xrec, sums, dpix
 # ------------------------------------------------------------------------------------------------
 def conv3x3_nhwc(x, wt, B: int, H: int, W: int, Cin: int, Cout: int, out, bias=None, mode: int = 0, aux=None, add=None):
     _timed("conv3x3_igemm_kernel", 2.0 * B * H * W * Cout * 9 * Cin,
-           lambda: _check(lib().enh_conv3x3_nhwc_bf16(_p(x, BF16, "x"), _p(wt, BF16, "wt"), B, H, W, Cin, Cout, _p(bias, F32, "bias"), mode, _p(aux, BF16, "aux"),
-                                                      _p(add, BF16, "add"), _p(out, BF16, "out"), _stream()), "enh_conv3x3_nhwc_bf16"))
+           lambda: _check(lib().enh_conv3x3_nhwc_h16(_p(x, H16, "x"), _p(wt, H16, "wt"), B, H, W, Cin, Cout, _p(bias, F32, "bias"), mode, _p(aux, H16, "aux"),
+                                                     _p(add, H16, "add"), _p(out, H16, "out"), _dt(x, wt, aux, add, out), _stream()), "enh_conv3x3_nhwc_h16"))
     return out
 
 
 def vgg_conv1(img, w, bias, shift, scale, normalize: bool, out):
     B, _, H, W = img.shape
     _check(lib().enh_vgg_conv1(_p(img, F32, "img"), _p(w, F32, "w"), _p(bias, F32, "bias"), _p(shift, F32, "shift"), _p(scale, F32, "scale"), int(normalize), B, H, W,
-                               _p(out, BF16, "out"), _stream()), "enh_vgg_conv1")
+                               _p(out, H16, "out"), _dt(out), _stream()), "enh_vgg_conv1")
     return out
 
 
 def vgg_conv1_backward(gpre, w, scale, normalize: bool, B: int, H: int, W: int, dimg):
-    _check(lib().enh_vgg_conv1_backward(_p(gpre, BF16, "gpre"), _p(w, F32, "w"), _p(scale, F32, "scale"), int(normalize), B, H, W, _p(dimg, F32, "dimg"), _stream()),
+    _check(lib().enh_vgg_conv1_backward(_p(gpre, H16, "gpre"), _p(w, F32, "w"), _p(scale, F32, "scale"), int(normalize), B, H, W, _p(dimg, F32, "dimg"), _dt(gpre), _stream()),
            "enh_vgg_conv1_backward")
     return dimg
 
 
 def maxpool2_nhwc(x, B: int, H: int, W: int, C: int, y):
-    _check(lib().enh_maxpool2_nhwc_bf16(_p(x, BF16, "x"), B, H, W, C, _p(y, BF16, "y"), _stream()), "enh_maxpool2_nhwc_bf16")
+    _check(lib().enh_maxpool2_nhwc_h16(_p(x, H16, "x"), B, H, W, C, _p(y, H16, "y"), _dt(x, y), _stream()), "enh_maxpool2_nhwc_h16")
     return y
 
 
 def maxpool2_nhwc_backward(x, gy, add, B: int, H: int, W: int, C: int, gx):
-    _check(lib().enh_maxpool2_nhwc_bf16_backward(_p(x, BF16, "x"), _p(gy, BF16, "gy"), _p(add, BF16, "add"), B, H, W, C, _p(gx, BF16, "gx"), _stream()),
-           "enh_maxpool2_nhwc_bf16_backward")
+    _check(lib().enh_maxpool2_nhwc_h16_backward(_p(x, H16, "x"), _p(gy, H16, "gy"), _p(add, H16, "add"), B, H, W, C, _p(gx, H16, "gx"), _dt(x, gy, add, gx), _stream()),
+           "enh_maxpool2_nhwc_h16_backward")
     return gx
 
 
 def lpips_head(feat, lin, B: int, HW: int, C: int, val_ws, out, accumulate: bool):
-    _check(lib().enh_lpips_head(_p(feat, BF16, "feat"), _p(lin, F32, "lin"), B, HW, C, _p(val_ws, F32, "val_ws"), _p(out, F32, "out"), int(accumulate), _stream()),
+    _check(lib().enh_lpips_head(_p(feat, H16, "feat"), _p(lin, F32, "lin"), B, HW, C, _p(val_ws, F32, "val_ws"), _p(out, F32, "out"), int(accumulate), _dt(feat), _stream()),
            "enh_lpips_head")
 
 
 def lpips_head_backward(feat, lin, gout, B: int, HW: int, C: int, dfeat1):
-    _check(lib().enh_lpips_head_backward(_p(feat, BF16, "feat"), _p(lin, F32, "lin"), _p(gout, F32, "gout"), B, HW, C, _p(dfeat1, BF16, "dfeat1"), _stream()),
+    _check(lib().enh_lpips_head_backward(_p(feat, H16, "feat"), _p(lin, F32, "lin"), _p(gout, F32, "gout"), B, HW, C, _p(dfeat1, H16, "dfeat1"), _dt(feat, dfeat1), _stream()),
            "enh_lpips_head_backward")

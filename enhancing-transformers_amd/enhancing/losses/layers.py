@@ -3,8 +3,8 @@
 StyleDiscriminator), running on this library's HIP kernels:
 
   convolutions   implicit GEMM on bf16 MFMA (gather in the load stage, no im2col tensor): forward, input gradient and weight gradient,
-                 bias + leaky-ReLU and the residual merge fused into the epilogue                    op/conv_nhwc.py  (enh_conv_nhwc_bf16, ...)
-  blur           4x4 FIR on channels-last bf16                                                        op/conv_nhwc.py  (enh_blur_nhwc_bf16)
+                 bias + leaky-ReLU and the residual merge fused into the epilogue                    op/conv_nhwc.py  (enh_conv_nhwc_h16, ...)
+  blur           4x4 FIR on channels-last bf16                                                        op/conv_nhwc.py  (enh_blur_nhwc_h16)
   linears        enh_gemm_h16                                                                        op/conv2d_gradfix.linear
 
 Inside ``StyleDiscriminator.forward`` the activations are channels-last bf16 ([B, H, W, C], C padded to a multiple of 8 with zero channels:

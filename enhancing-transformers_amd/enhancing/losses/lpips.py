@@ -20,7 +20,7 @@ too) from a PRIVATE generator (the global RNG is not consumed) — structurally 
 are not the published metric: "parity unpinned" (SURVEY.md §8c).  ``weights_loaded`` says which of the two is running.
 
 Execution: both images go through the trunk as one batch of 2B in channels-last bf16; the first convolution is fused with the scaling layer
-(``enh_vgg_conv1``), the other twelve are implicit GEMMs on MFMA (``enh_conv3x3_nhwc_bf16``: bias + ReLU fused; the input gradient is the same kernel on
+(``enh_vgg_conv1``), the other twelve are implicit GEMMs on MFMA (``enh_conv3x3_nhwc_h16``: bias + ReLU fused; the input gradient is the same kernel on
 flipped weights with the ReLU mask and the head's gradient fused into its epilogue), pooling / head are streaming kernels.  Gradients flow to ``in1``
 (the reconstruction) only — the weights are frozen and ``in0`` is the data — exactly what the reference needs from this term.
 """
@@ -198,10 +198,12 @@ class LPIPS(nn.Module):
     def _device_weights(self, device: torch.device) -> dict:
         """kernel operand forms of the frozen weights, built once per device and parameter version: tap-major bf16 [Cout][9*Cin] for the forward
         implicit GEMM and the flipped / transposed [Cin][9*Cout] for the input gradient"""
-        fp = self._weights_fingerprint()
+        from .op import conv_nhwc
+        op = conv_nhwc.OPERAND_DTYPE      # 16-bit operand format of the trunk (bf16 default | fp16: losses/op/conv_nhwc.py operand_dtype / ENH_LOSS_OPERANDS)
+        fp = (self._weights_fingerprint(), op)
         if self._dev.get("device") == device and self._dev.get("fingerprint") == fp:
             return self._dev
-        d: Dict[str, object] = {"device": device, "fingerprint": fp, "fwd": {}, "bwd": {}, "bias": {}, "lin": []}
+        d: Dict[str, object] = {"device": device, "fingerprint": fp, "fwd": {}, "bwd": {}, "bias": {}, "lin": [], "op": op}
         for convs in _SLICES:
             for idx, cin, cout in convs:
                 p = self._conv(idx)
@@ -210,8 +212,8 @@ class LPIPS(nn.Module):
                 if idx == 0:
                     d["w0"] = w.contiguous()                                         # the first layer runs in f32 on the vector ALUs
                     continue
-                d["fwd"][idx] = w.permute(0, 2, 3, 1).reshape(cout, 9 * cin).to(torch.bfloat16).contiguous()
-                d["bwd"][idx] = w.flip(2, 3).permute(1, 2, 3, 0).reshape(cin, 9 * cout).to(torch.bfloat16).contiguous()
+                d["fwd"][idx] = w.permute(0, 2, 3, 1).reshape(cout, 9 * cin).to(op).contiguous()
+                d["bwd"][idx] = w.flip(2, 3).permute(1, 2, 3, 0).reshape(cin, 9 * cout).to(op).contiguous()
         for k in range(self.L):
             d["lin"].append(getattr(self, f"lin{k}").model[1].weight.detach().to(device=device, dtype=torch.float32).reshape(-1).contiguous())
         d["shift"] = self.scaling_layer.shift.detach().to(device=device, dtype=torch.float32).reshape(-1).contiguous()
@@ -239,6 +241,7 @@ class LPIPS(nn.Module):
         if C != 3 or in0.shape != in1.shape or H % 16 or W % 16:
             raise RuntimeError(f"LPIPS: expected two [B,3,H,W] batches with H, W multiples of 16, got {tuple(in0.shape)} and {tuple(in1.shape)}")
         dw, dev = self._device_weights(in1.device), in1.device
+        op = dw["op"]
         x = torch.cat([in0, in1.detach()], 0)                      # one 2B batch through the trunk
         B2 = 2 * B
         feats: List[torch.Tensor] = []                              # post-ReLU output of every convolution, [2B, h, w, C] bf16
@@ -248,12 +251,12 @@ class LPIPS(nn.Module):
         out = torch.empty(B, dtype=torch.float32, device=dev)
         for k, convs in enumerate(_SLICES):
             if k > 0:                                               # the max-pool opening slices 2..5
-                pooled = torch.empty(B2, h // 2, w // 2, cur.shape[-1], dtype=torch.bfloat16, device=dev)
+                pooled = torch.empty(B2, h // 2, w // 2, cur.shape[-1], dtype=op, device=dev)
                 _C.maxpool2_nhwc(cur, B2, h, w, cur.shape[-1], pooled)
                 h, w, cur = h // 2, w // 2, pooled
                 acts[-k] = pooled
             for idx, cin, cout in convs:
-                y = torch.empty(B2, h, w, cout, dtype=torch.bfloat16, device=dev)
+                y = torch.empty(B2, h, w, cout, dtype=op, device=dev)
                 if idx == 0:
                     _C.vgg_conv1(x, dw["w0"], dw["bias"][0], dw["shift"], dw["scale"], normalize, y)
                 else:
@@ -268,13 +271,14 @@ class LPIPS(nn.Module):
     def _run_backward(self, saved, gout, normalize, shape):
         acts, feats, (B, H, W) = saved
         dw, dev = self._device_weights(gout.device), gout.device
+        op = feats[0].dtype      # the format the forward ran in
         rec = lambda t: t[B:]                                       # the reconstruction half of a [2B, ...] activation (contiguous slice)
         dims = [(H >> k, W >> k) for k in range(5)]
         # gradient of the head at every slice output, reconstruction half only
         head = []
         for k in range(5):
             h, w = dims[k]
-            g = torch.empty(B, h, w, _CHNS[k], dtype=torch.bfloat16, device=dev)
+            g = torch.empty(B, h, w, _CHNS[k], dtype=op, device=dev)
             _C.lpips_head_backward(feats[k], dw["lin"][k], gout, B, h * w, _CHNS[k], g)
             head.append(g)
         # walk the trunk backwards; gpre = gradient at a convolution's output BEFORE its ReLU
@@ -295,15 +299,15 @@ class LPIPS(nn.Module):
                     return d_in1
                 if ci > 0:                                          # previous layer of the same slice: conv-transpose + ReLU mask of ITS output
                     prev = rec(acts[convs[ci - 1][0]])
-                    nxt = torch.empty(B, h, w, cin, dtype=torch.bfloat16, device=dev)
+                    nxt = torch.empty(B, h, w, cin, dtype=op, device=dev)
                     _C.conv3x3_nhwc(gpre, dw["bwd"][idx], B, h, w, cout, cin, nxt, mode=1, aux=prev)
                     gpre = nxt
                 else:                                               # first layer of slice k > 0: its input is the pooled output of slice k-1
-                    gp = torch.empty(B, h, w, cin, dtype=torch.bfloat16, device=dev)
+                    gp = torch.empty(B, h, w, cin, dtype=op, device=dev)
                     _C.conv3x3_nhwc(gpre, dw["bwd"][idx], B, h, w, cout, cin, gp, mode=2)
                     hp, wp = dims[k - 1]
                     yprev = rec(acts[_SLICES[k - 1][-1][0]])
-                    nxt = torch.empty(B, hp, wp, cin, dtype=torch.bfloat16, device=dev)
+                    nxt = torch.empty(B, hp, wp, cin, dtype=op, device=dev)
                     _C.maxpool2_nhwc_backward(yprev, gp, head[k - 1], B, hp, wp, cin, nxt)   # routes, adds the head's gradient, applies the ReLU mask
                     gpre = nxt
         raise AssertionError("unreachable")

@@ -44,7 +44,7 @@ extern "C" {
  * mixed-precision dtype (main.py:25,52: --use_amp -> Lightning precision=16 = fp16 autocast + GradScaler): its operand rounding is 8x smaller than
  * bf16's, which is what brings the activations within 1e-3 of the fp32 reference in ONE MFMA pass; gradients need a loss scale (enh_nonfinite_flag,
  * enh_adamw_step skip_flag).  Every 16-bit tensor of one call has the call's dtype; entries whose names still say "bf16" and take no dtype (the x3
- * split-operand family, the convolution family) are bf16-only. */
+ * split-operand family) are bf16-only.  The channels-last convolution family (discriminator, LPIPS trunk) takes the dtype too (round 6). */
 #define ENH_DT_BF16 0
 #define ENH_DT_F16 1
 #define ENH_DT_F32 2   /* enh_im2col / enh_col2im only: f32 columns for the exact-f32 GEMM (the discriminator's parity instrument) */
@@ -52,7 +52,7 @@ typedef uint16_t enh_h16;  /* raw 16-bit float bits: bfloat16 or binary16, per t
 typedef enh_h16 enh_bf16;  /* raw bfloat16 bits (bf16-only entries) */
 
 const char* enh_last_error(void);
-#define ENH_ABI_VERSION 16  /* bumped whenever a signature below changes; the bindings check it at load */
+#define ENH_ABI_VERSION 17  /* bumped whenever a signature below changes; the bindings check it at load */
 int enh_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -372,15 +372,15 @@ typedef struct enh_conv_geom {
  *   mode 0: relu(acc + bias[n])                     mode 1: (acc + add[o,n]) * (aux[o,n] > 0)   (add optional)      mode 2: acc
  *   mode 3: lrelu(acc + bias[n], slope p0) * p1     (EqualConv2d + FusedLeakyReLU, layers.py:220-264 / fused_act.py:48-76; bias optional)
  *   mode 4: acc + p0 * add[o,n]                     (StyleBlock's (out + skip) / sqrt(2), layers.py:262, folded into the skip convolution) */
-int enh_conv_nhwc_bf16(const enh_bf16* src, const enh_bf16* wt, const enh_conv_geom* g, int mode, const float* bias, const enh_bf16* aux,
-                       const enh_bf16* add, float p0, float p1, enh_bf16* out, void* stream);
+int enh_conv_nhwc_h16(const enh_h16* src, const enh_h16* wt, const enh_conv_geom* g, int mode, const float* bias, const enh_h16* aux,
+                      const enh_h16* add, float p0, float p1, enh_h16* out, int dtype, void* stream);
 /* The same with a caller-provided workspace of enh_conv_workspace_bytes(g) bytes (0 = none needed): grids of less than half a round of workgroups
  * (the <= 16^2 layers at 16 images) are then split over the contraction — f32 partial slabs, added in ascending order by a second kernel that
  * applies the epilogue (deterministic).  ws == NULL or too small: not split. */
 size_t enh_conv_workspace_bytes(const enh_conv_geom* g);
-int enh_conv_nhwc_bf16_ws(const enh_bf16* src, const enh_bf16* wt, const enh_conv_geom* g, int mode, const float* bias, const enh_bf16* aux,
-                          const enh_bf16* add, float p0, float p1, enh_bf16* out, void* ws, size_t ws_bytes, void* stream);
-/* kernel choice of enh_conv_nhwc_bf16 / enh_conv_wgrad_nhwc_bf16 for A/B measurements (explicit library state, like enh_gemm_set_kernel):
+int enh_conv_nhwc_h16_ws(const enh_h16* src, const enh_h16* wt, const enh_conv_geom* g, int mode, const float* bias, const enh_h16* aux,
+                         const enh_h16* add, float p0, float p1, enh_h16* out, void* ws, size_t ws_bytes, int dtype, void* stream);
+/* kernel choice of enh_conv_nhwc_h16 / enh_conv_wgrad_nhwc_h16 for A/B measurements (explicit library state, like enh_gemm_set_kernel):
  * 0 = per shape (256-row tiles when C % 64 == 0, N % 128 == 0, at least four K stages and one tile per CU; else the 128 x 128 LDS-DMA kernel when
  * C % 64 == 0; else register-staged), 1 = register-staged everywhere, 2 = never the 256-row kernels (the round-2 choice), 3 = the 256-row kernels
  * wherever the shape allows them, however few tiles */
@@ -388,32 +388,32 @@ int enh_conv_set_kernel(int variant);
 /* dw[n][tap*C + c] = sum over pixels (b,y,x) of dy[b,y,x,n] * src[b, y*gs + oy0 + jy*sty, x*gs + ox0 + jx*stx, c]   (f32, overwritten).
  * The pixel axis is split over the grid; partial slabs go to `ws` (enh_conv_wgrad_workspace_bytes) and are added in a fixed order. */
 size_t enh_conv_wgrad_workspace_bytes(const enh_conv_geom* g);
-int enh_conv_wgrad_nhwc_bf16(const enh_bf16* src, const enh_bf16* dy, const enh_conv_geom* g, float* dw, void* ws, size_t ws_bytes, void* stream);
+int enh_conv_wgrad_nhwc_h16(const enh_h16* src, const enh_h16* dy, const enh_conv_geom* g, float* dw, void* ws, size_t ws_bytes, int dtype, void* stream);
 /* parameter layout [Cout][Cin][k][k] f32 (x scale) -> packed bf16 operand, taps (kh0 + jy*kstep, kw0 + jx*kstep):
  *   transposed = 0: out[co][(jy*ntx+jx)*cols_padded + ci]  (forward)      transposed = 1: out[ci][(jy*ntx+jx)*cols_padded + co]  (input gradient)
  * rows / columns beyond the real channel counts are zero.  enh_conv_unpack_wgrad: dw[co][ci][kh][kw] = scale * dwp[co][(kh*k+kw)*cin_padded + ci] */
 int enh_conv_pack_weight(const float* w, int Cout, int Cin, int k, float scale, int transposed, int kh0, int kw0, int kstep, int nty, int ntx,
-                         int rows_padded, int cols_padded, enh_bf16* out, void* stream);
+                         int rows_padded, int cols_padded, enh_h16* out, int dtype, void* stream);
 int enh_conv_unpack_wgrad(const float* dwp, int Cout, int Cin, int cin_padded, int k, float scale, float* dw, void* stream);
 /* Blur (layers.py:140-160 -> upfirdn2d with unit up / down): out[b,oy,ox,c] = sum_{i,j} w(i,j) x[b, oy+i-pad_y0, ox+j-pad_x0, c] with
  * w(i,j) = kernel[kh-1-i][kw-1-j] (flip = 0, upfirdn2d's convention) or kernel[i][j] (flip = 1, the adjoint); out is [B, H+pad_y0+pad_y1-kh+1, W+..., C];
  * pads may be negative (crop) */
-/* kernel choice of enh_blur_nhwc_bf16 (explicit library state): 0 = per shape (4 x 4 filters: the row-marching kernel, bit-identical results),
+/* kernel choice of enh_blur_nhwc_h16 (explicit library state): 0 = per shape (4 x 4 filters: the row-marching kernel, bit-identical results),
  * 1 = the one-row kernel everywhere */
 int enh_blur_set_kernel(int variant);
-int enh_blur_nhwc_bf16(const enh_bf16* x, const float* kernel, int B, int H, int W, int C, int kh, int kw, int pad_y0, int pad_y1, int pad_x0,
-                       int pad_x1, int flip, enh_bf16* out, void* stream);
+int enh_blur_nhwc_h16(const enh_h16* x, const float* kernel, int B, int H, int W, int C, int kh, int kw, int pad_y0, int pad_y1, int pad_x0,
+                      int pad_x1, int flip, enh_h16* out, int dtype, void* stream);
 /* y = g * (ref > 0 ? 1 : slope) * scale — the first / second derivative of FusedLeakyReLU through its saved output (fused_act.py:21-45);
  * ref == NULL: y = g * scale.  n % 8 == 0 */
-int enh_lrelu_gate_bf16(const enh_bf16* g, const enh_bf16* ref, int64_t n, float slope, float scale, enh_bf16* y, void* stream);
+int enh_lrelu_gate_h16(const enh_h16* g, const enh_h16* ref, int64_t n, float slope, float scale, enh_h16* y, int dtype, void* stream);
 /* Minibatch standard deviation (layers.py:358-367, stddev_feat = 1) fused with the concatenation and the channel padding of the final convolution's input:
  * x [B,HW,C] bf16 -> out [B,HW,Cp] bf16 with out[..,0..C-1] = x, out[..,C] = mean over (h,w,c) of sqrt(var over the group + 1e-8) of the sample's slot
  * (sample b is in slot b % (B/group); biased variance), out[..,C+1..] = 0.  Backward: dx [B,HW,C] from g [B,HW,Cp].  B % group == 0, C % 8 == 0, Cp % 8 == 0, Cp > C. */
-int enh_minibatch_stddev_nhwc(const enh_bf16* x, int B, int HW, int C, int Cp, int group, enh_bf16* out, void* stream);
-int enh_minibatch_stddev_nhwc_backward(const enh_bf16* x, const enh_bf16* g, int B, int HW, int C, int Cp, int group, enh_bf16* dx, void* stream);
+int enh_minibatch_stddev_nhwc(const enh_h16* x, int B, int HW, int C, int Cp, int group, enh_h16* out, int dtype, void* stream);
+int enh_minibatch_stddev_nhwc_backward(const enh_h16* x, const enh_h16* g, int B, int HW, int C, int Cp, int group, enh_h16* dx, int dtype, void* stream);
 /* img [B,C,H,W] f32, C <= 8  ->  [B,H,W,8] bf16 (channels C..7 zero), and the adjoint (padding channels dropped) */
-int enh_img_to_nhwc8(const float* img, int B, int C, int H, int W, enh_bf16* out, void* stream);
-int enh_nhwc8_to_img(const enh_bf16* src, int B, int C, int H, int W, float* img, void* stream);
+int enh_img_to_nhwc8(const float* img, int B, int C, int H, int W, enh_h16* out, int dtype, void* stream);
+int enh_nhwc8_to_img(const enh_h16* src, int B, int C, int H, int W, float* img, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * fp32 "exact mode": the same contractions with fp32 operands and fixed ascending-k fp32 accumulation (no bf16 anywhere), for end-to-end
@@ -441,21 +441,21 @@ int enh_unpatchify_loss_f32(const float* pix, const float* target, int B, int C,
  *   mode 1: out = (acc + add[m,co]) * (aux[m,co] > 0)             (input gradient: wt = flipped / transposed weights, aux = the saved post-ReLU
  *                                                                  activation this gradient is for, add = optional extra gradient at that activation)
  *   mode 2: out = acc                                             (input gradient in front of a max-pool) */
-int enh_conv3x3_nhwc_bf16(const enh_bf16* x, const enh_bf16* wt, int B, int H, int W, int Cin, int Cout, const float* bias, int mode,
-                          const enh_bf16* aux, const enh_bf16* add, enh_bf16* out, void* stream);
+int enh_conv3x3_nhwc_h16(const enh_h16* x, const enh_h16* wt, int B, int H, int W, int Cin, int Cout, const float* bias, int mode,
+                         const enh_h16* aux, const enh_h16* add, enh_h16* out, int dtype, void* stream);
 /* ScalingLayer + first convolution: img [B,3,H,W] f32 -> relu(conv3x3(((a img + b) - shift) / scale, w [64,3,3,3]) + bias) as [B,H,W,64] bf16, with
  * (a, b) = (2, -1) if normalize (images in [0,1]: lpips' normalize=True, = the inputs*2-1 of vqperceptual.py:43) else (1, 0); lpips ScalingLayer: shift
  * (-.030,-.088,-.188), scale (.458,.448,.450) ; and its gradient w.r.t. img given the gradient at the convolution output before the ReLU */
-int enh_vgg_conv1(const float* img, const float* w, const float* bias, const float* shift, const float* scale, int normalize, int B, int H, int W, enh_bf16* out, void* stream);
-int enh_vgg_conv1_backward(const enh_bf16* gpre, const float* w, const float* scale, int normalize, int B, int H, int W, float* dimg, void* stream);
+int enh_vgg_conv1(const float* img, const float* w, const float* bias, const float* shift, const float* scale, int normalize, int B, int H, int W, enh_h16* out, int dtype, void* stream);
+int enh_vgg_conv1_backward(const enh_h16* gpre, const float* w, const float* scale, int normalize, int B, int H, int W, float* dimg, int dtype, void* stream);
 /* 2x2 / stride-2 max-pool ; backward gx = (x > 0) * (gy routed to the first maximum of each window + add)  (add optional) */
-int enh_maxpool2_nhwc_bf16(const enh_bf16* x, int B, int H, int W, int C, enh_bf16* y, void* stream);
-int enh_maxpool2_nhwc_bf16_backward(const enh_bf16* x, const enh_bf16* gy, const enh_bf16* add, int B, int H, int W, int C, enh_bf16* gx, void* stream);
+int enh_maxpool2_nhwc_h16(const enh_h16* x, int B, int H, int W, int C, enh_h16* y, int dtype, void* stream);
+int enh_maxpool2_nhwc_h16_backward(const enh_h16* x, const enh_h16* gy, const enh_h16* add, int B, int H, int W, int C, enh_h16* gx, int dtype, void* stream);
 /* LPIPS head of one slice: feat [2B,h,w,C] (images 0..B-1 = references, B..2B-1 = reconstructions), lin [C] = the slice's 1x1 "lin" weights;
  * out[b] (+)= mean over pixels of sum_c lin[c] (f0/(|f0|+1e-10) - f1/(|f1|+1e-10))_c^2 ; val_ws [B*h*w] f32 scratch (deterministic two-stage sum).
  * Backward: gradient w.r.t. the reconstruction features only, dfeat1 [B,h,w,C] bf16, given gout[B] */
-int enh_lpips_head(const enh_bf16* feat, const float* lin, int B, int64_t HW, int C, float* val_ws, float* out, int accumulate, void* stream);
-int enh_lpips_head_backward(const enh_bf16* feat, const float* lin, const float* gout, int B, int64_t HW, int C, enh_bf16* dfeat1, void* stream);
+int enh_lpips_head(const enh_h16* feat, const float* lin, int B, int64_t HW, int C, float* val_ws, float* out, int accumulate, int dtype, void* stream);
+int enh_lpips_head_backward(const enh_h16* feat, const float* lin, const float* gout, int B, int64_t HW, int C, enh_h16* dfeat1, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -113,7 +113,7 @@ def install(monkeypatch, exact: bool = True):
         assert dy.shape == (g["B"], g["Hm"], g["Wm"], g["N"])
         return dy.float().reshape(-1, g["N"]).t() @ A
 
-    def conv_pack_weight(w, scale, transposed, kh0, kw0, kstep, nty, ntx, rows_padded, cols_padded):
+    def conv_pack_weight(w, scale, transposed, kh0, kw0, kstep, nty, ntx, rows_padded, cols_padded, dtype=None):
         Cout, Cin, k, _ = w.shape
         out = torch.zeros(rows_padded, max(nty * ntx * cols_padded, 8))
         if nty * ntx:
@@ -144,7 +144,7 @@ def install(monkeypatch, exact: bool = True):
             v = v * torch.where(ref > 0, torch.ones_like(v), torch.full_like(v, slope))
         return (v * scale).to(low)
 
-    def img_to_nhwc8(img):
+    def img_to_nhwc8(img, dtype=None):
         B, C, H, W = img.shape
         out = torch.zeros(B, H, W, 8)
         out[..., :C] = img.permute(0, 2, 3, 1)

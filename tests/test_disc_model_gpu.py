@@ -76,6 +76,7 @@ def test_conv2d_values_and_gradients(C, B, Cin, Cout, H, k, s, p):
 # does for the towers.  Bounds: 1.3 x the values measured on MI355X (profiles/r06_disc_parity.txt) for the two new modes.
 DISC_MODES = {
     "igemm_bf16":  ("igemm", "bf16", (2e-2, 0.15, 2e-2, 1e-2, 6e-2, 0.15, 0.2)),
+    "igemm_fp16":  ("igemm", "fp16", (2e-3, 3e-2, 8e-3, 4e-3, 8e-3, 2.5e-2, 6e-2)),       # the PRODUCT kernels (channels-last implicit GEMM, fused epilogues, 16-bit activations between layers) on fp16 operands (ABI v17): measured 1.2e-3, 2.1e-2, 5.6e-3, 2.3e-3, 5.0e-3, 1.5e-2, 4.0e-2 (final_conv bias; the others 1.1e-2) — 12x (logits) / 2.7x (gradients) under the bf16 row above
     "im2col_fp16": ("im2col", "fp16", (3e-3, 3e-2, 4e-3, 2e-3, 1.2e-2, 3e-2, 6e-2)),      # measured 2.1e-3, 2.0e-2, 2.4e-3, 9.8e-4, 7.4e-3, 2.0e-2, 4.5e-2 (final_conv bias; the others 1.0e-2)
     "im2col_fp32": ("im2col", "fp32", (1e-4, 1e-3, 1e-4, 1e-4, 1e-3, 1e-3, 1e-3)),        # measured 8.8e-6, 7.7e-4 (one leaky-ReLU gate of the random-init network sits within an fp32 ulp of zero), 2.0e-5, 8.0e-6, 5.8e-5, 2.8e-4, 1.1e-4: every quantity within north_star's 1e-3
 }
@@ -87,7 +88,8 @@ def test_discriminator_against_reference_golden(C, golden_dir, mode):
     from enhancing.losses.layers import vanilla_d_loss
     from enhancing.losses.op import conv2d_gradfix
     lowering, operand, (b_logits, b_dx, b_r1, b_loss, b_norm, b_gf, b_grad) = DISC_MODES[mode]
-    with conv2d_gradfix.operand_dtype(operand):
+    from enhancing.losses.op import conv_nhwc
+    with conv2d_gradfix.operand_dtype(operand), conv_nhwc.operand_dtype("fp16" if operand == "fp16" else "bf16"):      # (the igemm path's linears run on conv2d_gradfix's GEMM node)
         _disc_golden_case(C, golden_dir, lowering, mode, b_logits, b_dx, b_r1, b_loss, b_norm, b_gf, b_grad)
 
 

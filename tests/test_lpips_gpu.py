@@ -112,10 +112,21 @@ def test_lpips_head_forward_backward(C, Cc):
     assert rel(_nchw(df), f1.grad) <= 4e-3
 
 
-def test_lpips_distance_and_gradient_vs_oracle(lpips_random_init):
-    """the whole term: d(in0, in1) [B,1,1,1] and d/d in1, identical random weights on both sides (state-dict keys of lpips 0.1.4)"""
+@pytest.mark.parametrize("operand", ["bf16", "fp16"])
+def test_lpips_distance_and_gradient_vs_oracle(lpips_random_init, operand):
+    """the whole term: d(in0, in1) [B,1,1,1] and d/d in1, identical random weights on both sides (state-dict keys of lpips 0.1.4); with the trunk's 16-bit
+    operands in bf16 (default) and in fp16 (round 6: the convolution family takes the operand format per call — 8x narrower operand rounding is the cure the
+    comment below names; the upstream gradient d.mean() is scaled by 2^12 into fp16's range and scaled back, the torch.cuda.amp idiom)"""
+    from enhancing.losses.op import conv_nhwc
+    with conv_nhwc.operand_dtype(operand):
+        _lpips_case(operand)
+
+
+def _lpips_case(operand):
     import lpips_oracle as LO
     from enhancing.losses.lpips import LPIPS
+    S_ = 4096.0 if operand == "fp16" else 1.0
+    g_bound, v_bound = (0.15, 5e-3) if operand == "bf16" else (5e-2, 5e-4)      # measured: bf16 1.0e-1 / 6.2e-4, fp16 3.3e-2 / 7.3e-5
     m = LPIPS(net="vgg", verbose=False)
     assert not m.state_dict()          # a random trunk never reaches a checkpoint (ADVICE r3)
     sd = {k: v.clone() for k, v in m.full_state_dict().items()}
@@ -127,11 +138,12 @@ def test_lpips_distance_and_gradient_vs_oracle(lpips_random_init):
     x1 = in1.clone().cuda().requires_grad_(True)
     d = m(in0.cuda(), x1, normalize=True)
     assert d.shape == (B, 1, 1, 1)
-    d.mean().backward()
+    (d.mean() * S_).backward()
+    x1.grad.div_(S_)
     o1 = in1.clone().requires_grad_(True)
     do = LO.lpips_distance(in0, o1, sd, normalize=True)
     do.mean().backward()
-    print(f"LPIPS vs oracle: d {d.view(-1).tolist()} vs {do.view(-1).tolist()}, value rel {rel(d, do):.2e}, grad rel {rel(x1.grad, o1.grad):.2e}")
+    print(f"LPIPS [{operand} trunk] vs oracle: d {d.view(-1).tolist()} vs {do.view(-1).tolist()}, value rel {rel(d, do):.2e}, grad rel {rel(x1.grad, o1.grad):.2e}")
     a, b = x1.grad.cpu().double().flatten(), o1.grad.double().flatten()
     cos = float((a @ b) / (a.norm() * b.norm()))
     print(f"  gradient cosine {cos:.5f}, norm ratio {float(a.norm() / b.norm()):.4f}")
@@ -143,8 +155,8 @@ def test_lpips_distance_and_gradient_vs_oracle(lpips_random_init):
     # gradient 1.04e-1, unchanged.  The rounding that matters is not the last one: in1 = in0 + 10 % noise makes u ~ 10 % of a unit vector, and the
     # bf16 OPERANDS of every trunk convolution put ~0.5 % of (only partly common) error into f0 and f1 long before the slice output.  Removing it
     # needs an fp32 trunk for the reconstruction branch; the mirror was reverted (no effect, 2x the slice-output traffic).
-    assert rel(d, do) <= 5e-3
-    assert rel(x1.grad, o1.grad) <= 0.15 and cos >= 0.99
+    assert rel(d, do) <= v_bound
+    assert rel(x1.grad, o1.grad) <= g_bound and cos >= 0.99
     # [-1,1] inputs without normalize give the same distance
     d2 = m(2 * in0.cuda() - 1, 2 * in1.cuda() - 1)
     assert rel(d2, d) <= 1e-3
