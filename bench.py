@@ -462,7 +462,9 @@ def main():
                                 f"(LPIPS/GAN weights 0)") + f", K=8192 x 32 l2-normalised codes, fp32 master weights, {args.precision} MFMA operands / fp32 accumulate" +
                                (f", dynamic loss scale (now {int(eng.loss_scale)}; device-side inf/nan step skip + GradScaler update rule)" if args.precision == "fp16" else ""),
                    "per_gpu_batch": B, "global_batch": B * world, "image": f"{size}x{size}", "parallelism": f"dp{world}",
-                   "hip_graph_replay": bool(use_graphs)},
+                   "hip_graph_replay": bool(use_graphs),
+                   "loss_network_operands": (model.loss.loss_operands(model.decoder.get_last_layer()) if (adversarial or pw) and hasattr(model.loss, "loss_operands")
+                                             else None)},
         "final_loss": loss,
         "step_mfma_frac": round(img_per_s / world * STEP_TFLOP_PER_IMG_BASE / MFMA_BF16_PEAK_TFLOPS, 4) if is_base else None,
         "roofline": roofs[dom],

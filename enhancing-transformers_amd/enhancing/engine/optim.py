@@ -27,6 +27,35 @@ class FusedAdamW:
         self.param_groups = sd["param_groups"]
 
 
+class LossScaler:
+    """torch.cuda.amp.GradScaler's state machine with every quantity on the device (the same three launches the fp16 engine uses: enh_nonfinite_flag,
+    enh_adamw_step's skip / unscale operands, enh_loss_scale_update), for a ParamStore whose backward runs through plain autograd — the discriminator's.
+    `enabled` is decided by the forward that builds the graph (fp16 operands in the loss networks: gradients of ~1e-5 would sit in fp16's subnormal range);
+    disabled it is the identity everywhere.  Initial scale ENH_LOSS_NET_SCALE (default 2^12: a gradient of 1 per logit, times the scale, has to fit fp16
+    itself — GradScaler's 2^16 would spend its first steps backing off), growth x2 after `interval` clean steps, x0.5 on an inf / nan (that step is skipped)."""
+
+    def __init__(self, device, init_scale: float = None, growth_interval: int = None) -> None:
+        import os
+        import torch
+        init_scale = float(os.environ.get("ENH_LOSS_NET_SCALE", 4096.0)) if init_scale is None else float(init_scale)
+        self.growth_interval = int(os.environ.get("ENH_LOSS_SCALE_INTERVAL", 2000)) if growth_interval is None else int(growth_interval)
+        self.scale_t = torch.full((1,), init_scale, dtype=torch.float32, device=device)
+        self.tracker = torch.zeros(1, dtype=torch.int32, device=device)
+        self.found_inf = torch.zeros(1, dtype=torch.float32, device=device)
+        self.enabled = False
+        self.skipped_checks = 0
+
+    def scale(self, t):
+        return t * self.scale_t.view(()) if self.enabled else t
+
+    def unscale(self, t):
+        return t / self.scale_t.view(()) if self.enabled else t
+
+    @property
+    def value(self) -> float:
+        return float(self.scale_t.item()) if self.enabled else 1.0
+
+
 class FlatAdamW:
     """The same fused AdamW launch over any ``ParamStore`` (here: the discriminator's, the second optimizer of reference
     vitvqgan.py:163-164).  Under DDP the gradient buckets are all-reduced behind the discriminator's own backward (``attach_sync``: an
@@ -76,7 +105,15 @@ class FlatAdamW:
             dist.all_reduce(s.g)
             scale /= dist.get_world_size()
         s.step_count += 1
-        _C.adamw_step(s.p, s.g, s.m, s.v, None, s.step_count, g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], scale)
+        sc = getattr(s, "loss_scaler", None)
+        if sc is not None and sc.enabled:        # the backward ran on scale_t x the loss: inf / nan check, unscale inside the update, GradScaler.update — no host sync
+            sc.found_inf.zero_()
+            _C.nonfinite_flag(s.g, sc.found_inf)
+            _C.adamw_step(s.p, s.g, s.m, s.v, None, s.step_count, g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], scale,
+                          skip_flag=sc.found_inf, loss_scale=sc.scale_t)
+            _C.loss_scale_update(sc.scale_t, sc.found_inf, sc.tracker, 2.0, 0.5, sc.growth_interval)
+        else:
+            _C.adamw_step(s.p, s.g, s.m, s.v, None, s.step_count, g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], scale)
         from ..losses.op.conv_nhwc import invalidate_packed_weights
         invalidate_packed_weights()          # the kernel wrote the weights through raw pointers: cached operand images are stale
 

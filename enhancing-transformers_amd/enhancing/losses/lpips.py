@@ -195,14 +195,17 @@ class LPIPS(nn.Module):
         # (storage address, in-place version) of every parameter: any load / copy_ / optimizer-style write invalidates the packed operand cache
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
-    def _device_weights(self, device: torch.device) -> dict:
+    def _device_weights(self, device: torch.device, op=None) -> dict:
         """kernel operand forms of the frozen weights, built once per device and parameter version: tap-major bf16 [Cout][9*Cin] for the forward
         implicit GEMM and the flipped / transposed [Cin][9*Cout] for the input gradient"""
         from .op import conv_nhwc
-        op = conv_nhwc.OPERAND_DTYPE      # 16-bit operand format of the trunk (bf16 default | fp16: losses/op/conv_nhwc.py operand_dtype / ENH_LOSS_OPERANDS)
+        # 16-bit operand format of the trunk: what losses/op/conv_nhwc.py says when the forward runs (operand_dtype / ENH_LOSS_OPERANDS / the loss module
+        # following its engine); the backward passes the format its saved features are in — it may run outside the forward's context
+        op = conv_nhwc.OPERAND_DTYPE if op is None else op
         fp = (self._weights_fingerprint(), op)
-        if self._dev.get("device") == device and self._dev.get("fingerprint") == fp:
-            return self._dev
+        hit = self._dev.get(op)
+        if hit is not None and hit.get("device") == device and hit.get("fingerprint") == fp:
+            return hit
         d: Dict[str, object] = {"device": device, "fingerprint": fp, "fwd": {}, "bwd": {}, "bias": {}, "lin": [], "op": op}
         for convs in _SLICES:
             for idx, cin, cout in convs:
@@ -218,7 +221,7 @@ class LPIPS(nn.Module):
             d["lin"].append(getattr(self, f"lin{k}").model[1].weight.detach().to(device=device, dtype=torch.float32).reshape(-1).contiguous())
         d["shift"] = self.scaling_layer.shift.detach().to(device=device, dtype=torch.float32).reshape(-1).contiguous()
         d["scale"] = self.scaling_layer.scale.detach().to(device=device, dtype=torch.float32).reshape(-1).contiguous()
-        self._dev = d
+        self._dev[op] = d
         return d
 
     # ---- lpips API -------------------------------------------------------------------------------------------
@@ -270,8 +273,8 @@ class LPIPS(nn.Module):
 
     def _run_backward(self, saved, gout, normalize, shape):
         acts, feats, (B, H, W) = saved
-        dw, dev = self._device_weights(gout.device), gout.device
         op = feats[0].dtype      # the format the forward ran in
+        dw, dev = self._device_weights(gout.device, op), gout.device
         rec = lambda t: t[B:]                                       # the reconstruction half of a [2B, ...] activation (contiguous slice)
         dims = [(H >> k, W >> k) for k in range(5)]
         # gradient of the head at every slice output, reconstruction half only

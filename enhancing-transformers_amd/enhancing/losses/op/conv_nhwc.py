@@ -276,23 +276,24 @@ class _Blur(Function):
 
 class _ToNHWC8(Function):
     @staticmethod
-    def forward(ctx, img):
+    def forward(ctx, img, dtype=None):
         ctx.C = img.shape[1]
-        return _C.img_to_nhwc8(img.contiguous(), dtype=OPERAND_DTYPE)
+        return _C.img_to_nhwc8(img.contiguous(), dtype=OPERAND_DTYPE if dtype is None else dtype)
 
     @staticmethod
     def backward(ctx, g):
-        return _FromNHWC8.apply(g, ctx.C)
+        return _FromNHWC8.apply(g, ctx.C), None
 
 
 class _FromNHWC8(Function):
     @staticmethod
     def forward(ctx, x, C):
+        ctx.dtype = x.dtype      # (the double backward re-enters the 16-bit path in the format this graph runs in, whatever OPERAND_DTYPE says by then)
         return _C.nhwc8_to_img(x.contiguous(), C)
 
     @staticmethod
     def backward(ctx, g):
-        return _ToNHWC8.apply(g), None
+        return _ToNHWC8.apply(g, ctx.dtype), None
 
 
 def _stddev_torch(x32, group: int, Cp: int):

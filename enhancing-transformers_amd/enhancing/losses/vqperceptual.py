@@ -32,8 +32,42 @@ class VQLPIPS(nn.Module):
         self.loggaussian_weight = loggaussian_weight
         self.perceptual_weight = perceptual_weight
 
+    # 16-bit operand format of the loss networks (LPIPS trunk, discriminator): None -> ENH_LOSS_OPERANDS if set, else the format of the engine that produced
+    # the reconstruction (fp16 engine -> fp16: the reference's --use_amp autocasts the loss networks with everything else, main.py:52), else whatever
+    # conv_nhwc.OPERAND_DTYPE currently says; "bf16" / "fp16" pin it for this module.
+    operands: Optional[str] = None
+
+    def loss_operands(self, last_layer=None) -> str:
+        import os
+        from .op import conv_nhwc
+        name = self.operands or os.environ.get("ENH_LOSS_OPERANDS")
+        if name is None:
+            eng = getattr(last_layer, "_enh_engine", None)
+            if eng is not None:
+                name = "fp16" if getattr(eng, "scaled", False) else "bf16"
+            else:
+                name = "fp16" if conv_nhwc.OPERAND_DTYPE == torch.float16 else "bf16"
+        if name not in ("bf16", "fp16"):
+            raise ValueError(f"loss-network operands must be 'bf16' or 'fp16', got {name!r}")
+        return name
+
     def forward(self, codebook_loss: torch.Tensor, inputs: torch.Tensor, reconstructions: torch.Tensor, optimizer_idx: int,
                 global_step: int, batch_idx: int, last_layer: Optional[nn.Module] = None, split: Optional[str] = "train") -> Tuple:
+        from .op import conv2d_gradfix, conv_nhwc
+        name = self.loss_operands(last_layer)
+        eng = getattr(last_layer, "_enh_engine", None)
+        if name == "fp16" and optimizer_idx == 0 and reconstructions.requires_grad and eng is not None and not getattr(eng, "scaled", False) and \
+                (hasattr(self, "discriminator") or hasattr(self, "perceptual_loss")):
+            raise ValueError("fp16 loss-network operands need the fp16 engine's loss-scaled backward (generator-side gradients of ~1e-5 per pixel sit in "
+                             "fp16's subnormal range unscaled); run the engine in fp16 or set ENH_LOSS_OPERANDS=bf16")
+        import contextlib
+        # (a caller that pinned conv2d_gradfix to fp32 is running the exact-f32 parity instrument of the im2col lowering: left alone)
+        gemm_ctx = contextlib.nullcontext() if conv2d_gradfix._OPERAND == torch.float32 else conv2d_gradfix.operand_dtype(name)
+        with conv_nhwc.operand_dtype(name), gemm_ctx:
+            return self._forward(codebook_loss, inputs, reconstructions, optimizer_idx, global_step, batch_idx, last_layer, split)
+
+    def _forward(self, codebook_loss: torch.Tensor, inputs: torch.Tensor, reconstructions: torch.Tensor, optimizer_idx: int,
+                 global_step: int, batch_idx: int, last_layer: Optional[nn.Module] = None, split: Optional[str] = "train") -> Tuple:
         inputs = inputs.contiguous()
         reconstructions = reconstructions.contiguous()
         diff = reconstructions - inputs
@@ -90,8 +124,13 @@ class VQLPIPSWithDiscriminator(VQLPIPS):
         eng = getattr(last_layer, "_enh_engine", None)
         if eng is None:
             raise RuntimeError("use_adaptive_adv: last_layer must be ViTDecoder.get_last_layer() of a model bound to the HIP engine")
-        nll_g, = torch.autograd.grad(nll_loss, reconstructions, retain_graph=True)
-        g_g, = torch.autograd.grad(g_loss, reconstructions, retain_graph=True)
+        sc = self.loss_scaler(reconstructions.device) if hasattr(self, "discriminator") else None      # (fp16 loss networks: both probes run scaled)
+        if sc is not None and sc.enabled:
+            nll_g = sc.unscale(torch.autograd.grad(sc.scale(nll_loss), reconstructions, retain_graph=True)[0])
+            g_g = sc.unscale(torch.autograd.grad(sc.scale(g_loss), reconstructions, retain_graph=True)[0])
+        else:
+            nll_g, = torch.autograd.grad(nll_loss, reconstructions, retain_graph=True)
+            g_g, = torch.autograd.grad(g_loss, reconstructions, retain_graph=True)
         adapt = eng.last_layer_grad_norm(nll_g) / (eng.last_layer_grad_norm(g_g) + 1e-4)
         return adapt.clamp(0.0, 1e4).detach()
 
@@ -101,13 +140,27 @@ class VQLPIPSWithDiscriminator(VQLPIPS):
             from ..engine.stage1 import ParamStore
             self.discriminator.to(device)
             self._disc_store = ParamStore(self.discriminator, device, precision="fp32")
+            from ..engine.optim import LossScaler
+            self._disc_store.loss_scaler = LossScaler(device)
         return self._disc_store
 
-    def forward(self, codebook_loss: torch.Tensor, inputs: torch.Tensor, reconstructions: torch.Tensor, optimizer_idx: int,
-                global_step: int, batch_idx: int, last_layer: Optional[nn.Module] = None, split: Optional[str] = "train") -> Tuple:
+    def loss_scaler(self, device: torch.device):
+        """the loss networks' own scale (engine/optim.py LossScaler): enabled while their 16-bit operands are fp16 (ENH_LOSS_OPERANDS=fp16 /
+        conv_nhwc.operand_dtype / conv2d_gradfix.operand_dtype), the identity under bf16"""
+        from .op import conv2d_gradfix, conv_nhwc
+        sc = self.disc_store(device).loss_scaler
+        sc.enabled = bool(conv_nhwc.OPERAND_DTYPE == torch.float16 or conv2d_gradfix._OPERAND == torch.float16)
+        return sc
+
+    def scale_disc_loss(self, d_loss: torch.Tensor) -> torch.Tensor:
+        """what the caller runs .backward() on for optimizer 1 (torch.cuda.amp's `scaler.scale(loss).backward()`); FlatAdamW.step unscales"""
+        return self.disc_store(d_loss.device).loss_scaler.scale(d_loss)      # (`enabled` as the forward that built d_loss left it)
+
+    def _forward(self, codebook_loss: torch.Tensor, inputs: torch.Tensor, reconstructions: torch.Tensor, optimizer_idx: int,
+                 global_step: int, batch_idx: int, last_layer: Optional[nn.Module] = None, split: Optional[str] = "train") -> Tuple:
         if not hasattr(self, "discriminator"):
             if optimizer_idx == 0:
-                return super().forward(codebook_loss, inputs, reconstructions, optimizer_idx, global_step, batch_idx, last_layer, split)
+                return super()._forward(codebook_loss, inputs, reconstructions, optimizer_idx, global_step, batch_idx, last_layer, split)
             return None, {}
         from .op import conv2d_gradfix, conv_nhwc
         inputs = inputs.contiguous()
@@ -154,8 +207,10 @@ class VQLPIPSWithDiscriminator(VQLPIPS):
             logits_fake = self.discriminator(reconstructions.detach())
             d_loss = disc_factor * self.disc_loss(logits_fake, logits_real)
             if do_r1:
-                with conv2d_gradfix.no_weight_gradients():
-                    gradients, = torch.autograd.grad(outputs=logits_real.sum(), inputs=real, create_graph=True)
+                sc = self.loss_scaler(real.device)
+                with conv2d_gradfix.no_weight_gradients():       # (fp16 operands: the first-order pass of R1 runs on scale x sum(logits) and is divided back in f32)
+                    gradients, = torch.autograd.grad(outputs=sc.scale(logits_real.sum()), inputs=real, create_graph=True)
+                gradients = sc.unscale(gradients)
                 gradients_norm = gradients.square().sum([1, 2, 3]).mean()
                 d_loss = d_loss + self.r1_gamma * self.do_r1_every * gradients_norm / 2
             log = {"{}/disc_loss".format(split): d_loss.detach() if torch.is_tensor(d_loss) else torch.tensor(float(d_loss)),

@@ -280,7 +280,7 @@ class ViTVQ(nn.Module):
             discloss, log_dict_disc = self.loss(qloss, x.to(xrec.device), xrec, optimizer_idx, self.global_step, batch_idx,
                                                 last_layer=self.decoder.get_last_layer(), split="train")
             if torch.is_tensor(discloss) and discloss.requires_grad:
-                discloss.backward()
+                self.loss.scale_disc_loss(discloss).backward()      # (fp16 loss networks: scaled backward, unscaled inside the discriminator's AdamW launch)
             self.log("train/disc_loss", log_dict_disc["train/disc_loss"])
             self.log_dict({k: v for k, v in log_dict_disc.items() if k != "train/disc_loss"})
             return log_dict_disc["train/disc_loss"]

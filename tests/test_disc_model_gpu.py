@@ -90,10 +90,12 @@ def test_discriminator_against_reference_golden(C, golden_dir, mode):
     lowering, operand, (b_logits, b_dx, b_r1, b_loss, b_norm, b_gf, b_grad) = DISC_MODES[mode]
     from enhancing.losses.op import conv_nhwc
     with conv2d_gradfix.operand_dtype(operand), conv_nhwc.operand_dtype("fp16" if operand == "fp16" else "bf16"):      # (the igemm path's linears run on conv2d_gradfix's GEMM node)
-        _disc_golden_case(C, golden_dir, lowering, mode, b_logits, b_dx, b_r1, b_loss, b_norm, b_gf, b_grad)
+        _disc_golden_case(C, golden_dir, lowering, mode, b_logits, b_dx, b_r1, b_loss, b_norm, b_gf, b_grad, S=4096.0 if operand == "fp16" else 1.0)
 
 
-def _disc_golden_case(C, golden_dir, lowering, mode, b_logits, b_dx, b_r1, b_loss, b_norm, b_gf, b_grad):
+def _disc_golden_case(C, golden_dir, lowering, mode, b_logits, b_dx, b_r1, b_loss, b_norm, b_gf, b_grad, S=1.0):
+    """S: the loss networks' scale under fp16 operands (engine/optim.py LossScaler's initial value; what VQLPIPSWithDiscriminator.forward and
+    ViTVQ.training_step apply): the R1 first-order pass and the d-loss backward run on S x their scalar and are divided back in f32"""
     from enhancing.engine.stage1 import ParamStore
     from enhancing.losses.layers import vanilla_d_loss
     from enhancing.losses.op import conv2d_gradfix
@@ -108,11 +110,13 @@ def _disc_golden_case(C, golden_dir, lowering, mode, b_logits, b_dx, b_r1, b_los
     lr_, lf_ = D(x), D(fake)
     e_logits = max(rel(lr_, torch.from_numpy(G["logits_real"])), rel(lf_, torch.from_numpy(G["logits_fake"])))
     with conv2d_gradfix.no_weight_gradients():
-        gr, = torch.autograd.grad(lr_.sum(), x, create_graph=True)
+        gr, = torch.autograd.grad(lr_.sum() * S, x, create_graph=True)
+    gr = gr / S
     r1 = gr.square().sum([1, 2, 3]).mean()
     d_loss = vanilla_d_loss(lf_, lr_) + 10 * 16 * r1 / 2
     store.zero_grad()
-    d_loss.backward()
+    (d_loss * S).backward()
+    store.g.div_(S)
     e_dx = rel(gr, torch.from_numpy(G["dx_real"]))
     e_r1 = abs(r1.item() - float(G["r1"])) / float(G["r1"])
     e_loss = abs(d_loss.item() - float(G["d_loss"])) / abs(float(G["d_loss"]))
@@ -123,7 +127,8 @@ def _disc_golden_case(C, golden_dir, lowering, mode, b_logits, b_dx, b_r1, b_los
                                                                     ("final_linear.1.weight", "g_lin1_w"))}
     xf = fake.clone().requires_grad_(True)
     g_loss = vanilla_d_loss(D(xf))
-    gf, = torch.autograd.grad(g_loss, xf)
+    gf, = torch.autograd.grad(g_loss * S, xf)
+    gf = gf / S
     e_gf = rel(gf, torch.from_numpy(G["g_fake"]))
     line = (f"discriminator [{mode}] vs reference golden: logits {e_logits:.2e}, dx {e_dx:.2e}, r1 {e_r1:.2e}, d_loss {e_loss:.2e}, grad norms {e_norm:.2e}, "
             f"grads {({k: float(f'{v:.2e}') for k, v in e_t.items()})}, generator-side dx {e_gf:.2e}")
@@ -314,6 +319,75 @@ def test_adaptive_adversarial_weight_with_the_perceptual_term(C, lpips_random_in
     assert gn > 0 and gn == gn
     l1 = m.training_step({"image": x}, 0, 1)
     assert torch.isfinite(l1)
+
+
+def test_fp16_loss_networks_scaled_discriminator_step(C, lpips_random_init):
+    """the loss networks on fp16 operands (ENH_LOSS_OPERANDS=fp16 / conv_nhwc.operand_dtype): the discriminator's backward runs on LossScaler.scale_t x the
+    loss (R1's first-order pass included), FlatAdamW.step checks inf / nan, unscales inside the AdamW launch and updates the scale — GradScaler's protocol,
+    no host sync.  (1) two rounds of the two-optimizer protocol land within the operand-rounding distance of the bf16-operand run; (2) a scale that
+    overflows fp16 skips the discriminator step, leaves parameters and moments untouched and halves the scale; the next step goes through."""
+    import vitvq_oracle as O
+    from enhancing.losses.op import conv_nhwc
+    from enhancing.modules.stage1.vitvqgan import ViTVQ
+    from enhancing.utils.general import AttrDict
+    cfg = O.TINY_CFG
+    loss = {"target": "enhancing.losses.vqperceptual.VQLPIPSWithDiscriminator",
+            "params": dict(loglaplace_weight=0.0, loggaussian_weight=1.0, perceptual_weight=0.1, adversarial_weight=0.1, use_adaptive_adv=True, do_r1_every=2,
+                           disc_params={"size": cfg["image_size"]})}
+    batch = {"image": O.make_images(5, 2, cfg["image_size"])}
+
+    def build(operands):
+        torch.manual_seed(0)
+        m = ViTVQ("image", cfg["image_size"], cfg["patch_size"], AttrDict.wrap(cfg["encoder"]), AttrDict.wrap(cfg["decoder"]),
+                  AttrDict.wrap(cfg["quantizer"]), AttrDict.wrap(loss))
+        m.load_state_dict({**O.make_params(cfg, seed=11), **{"loss." + k: v for k, v in m.loss.state_dict().items()}}, strict=False)
+        m.train()
+        m.learning_rate = 1e-3
+        m.loss.operands = operands
+        return m, m.configure_optimizers()[0]
+
+    def rounds(m, opts, n):
+        out = []
+        for it in range(n):
+            l0 = m.training_step(batch, it, 0); opts[0].step()
+            l1 = m.training_step(batch, it, 1)
+            out.append((float(l0), float(l1), float(m.logged["train/r1_reg"]) if it % 2 == 0 else None, float(m.logged["train/d_weight"])))
+            opts[1].step()
+        return out
+
+    mb, ob = build("bf16")
+    ref = rounds(mb, ob, 2)
+    assert not mb.loss.disc_store(mb.engine.device).loss_scaler.enabled
+    if True:
+        mf, of = build(None)          # default: the loss networks follow the engine (fp16 since round 6)
+        assert mf.engine.precision == "fp16" and mf.loss.loss_operands(mf.decoder.get_last_layer()) == "fp16"
+        ds = mf.loss.disc_store(mf.engine.device)
+        p0 = ds.p.clone()
+        got = rounds(mf, of, 2)
+        sc = ds.loss_scaler
+        assert sc.enabled and sc.value == 4096.0 and float(sc.found_inf) == 0.0 and int(sc.tracker) == 2
+        assert not torch.equal(ds.p, p0)
+        for (a0, a1, ar, aw), (b0, b1, br, bw) in zip(got, ref):
+            assert abs(a0 - b0) <= 2e-2 * abs(b0) and abs(a1 - b1) <= 2e-2 * abs(b1) and abs(aw - bw) <= 0.1 * abs(bw), (got, ref)
+            assert (ar is None) == (br is None) and (ar is None or abs(ar - br) <= 5e-2 * br), (got, ref)
+        d_fp16, d_bf16 = ds.p - p0, mb.loss.disc_store(mb.engine.device).p - p0
+        cos = float((d_fp16 * d_bf16).sum() / (d_fp16.norm() * d_bf16.norm()))
+        print(f"discriminator update, fp16 vs bf16 loss networks after 2 rounds: cosine {cos:.4f}, losses {got} vs {ref}")
+        assert cos >= 0.9          # (AdamW's first steps are sign-like: elements whose tiny gradient changes sign between the two roundings flip)
+        # (2) overflow: the scale is forced above fp16's range
+        sc.scale_t.fill_(2.0 ** 24)
+        p1, m1, step1 = ds.p.clone(), ds.m.clone(), ds.step_count
+        mf.training_step(batch, 2, 1)
+        of[1].step()
+        assert float(sc.found_inf) == 1.0 and torch.equal(ds.p, p1) and torch.equal(ds.m, m1) and sc.value == 2.0 ** 23 and int(sc.tracker) == 0
+        sc.scale_t.fill_(4096.0)
+        mf.training_step(batch, 3, 1)
+        of[1].step()
+        assert float(sc.found_inf) == 0.0 and not torch.equal(ds.p, p1) and torch.isfinite(ds.p).all()
+    # pinned back to bf16 operands the scaler is the identity again
+    mf.loss.operands = "bf16"
+    l1 = mf.training_step(batch, 4, 1)
+    assert not ds.loss_scaler.enabled and torch.isfinite(l1)
 
 
 def test_graph_replay_of_the_two_optimizer_step_equals_the_eager_sequence(lpips_random_init):
