@@ -340,6 +340,7 @@ def test_fp16_loss_networks_scaled_discriminator_step(C, lpips_random_init):
         torch.manual_seed(0)
         m = ViTVQ("image", cfg["image_size"], cfg["patch_size"], AttrDict.wrap(cfg["encoder"]), AttrDict.wrap(cfg["decoder"]),
                   AttrDict.wrap(cfg["quantizer"]), AttrDict.wrap(loss))
+        m.precision = "fp16"           # (pinned before the engine binds: the suite also runs under ENH_PRECISION=bf16)
         m.load_state_dict({**O.make_params(cfg, seed=11), **{"loss." + k: v for k, v in m.loss.state_dict().items()}}, strict=False)
         m.train()
         m.learning_rate = 1e-3

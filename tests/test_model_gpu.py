@@ -88,7 +88,11 @@ def test_encode_codes_at_the_forward_precision_equals_the_forward_indices(tiny):
     cfg, P, x, m = tiny
     e = m.engine
     # round 6: the default engine is fp16 — one pass meets the tolerance, so encode_codes and the forward share it; x3 stays the instrument of encode_codes
-    assert e.precision == "fp16" and e.codes_precision == "fp16" and e.encoder_precision == "fp16"
+    import os
+    if os.environ.get("ENH_PRECISION", "fp16") == "fp16":      # (the suite is also run under ENH_PRECISION=bf16: there the x3 default of encode_codes is the round-5 behaviour)
+        assert e.precision == "fp16" and e.codes_precision == "fp16" and e.encoder_precision == "fp16"
+    else:
+        pytest.skip("default-precision assertions: ENH_PRECISION overrides the default")
     assert torch.equal(e.reconstruct(x)[2].view(-1), m.encode_codes(x).view(-1))
     assert m.encode_codes(x, precision="x3").shape == m.encode_codes(x).shape
     from enhancing.engine.stage1 import Stage1Engine
