@@ -180,7 +180,7 @@ __device__ __forceinline__ float4 epi_bias(const GemmArgs& args, int64_t n) {
 template <int MODE, typename OT = BF16>
 __device__ __forceinline__ void epi_value(const GemmArgs& args, float (&v)[4], const EpiIn& in, const float4& b4, int64_t n) {
   constexpr bool G = MODE == EPI_GENERIC;
-  if (MODE == EPI_BF16_BIAS_TANH || MODE == EPI_F32_BIAS_RES || MODE == EPI_BF16_TANH_SPLIT) { v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w; }
+  if (MODE == EPI_F32_BIAS_RES || MODE == EPI_BF16_TANH_SPLIT) { v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w; }
   if (MODE == EPI_BF16_TANH_SPLIT) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = tanh_x3(v[r]);      // common.h: the same function as the stand-alone split3 kernel (same bits in both forms)
@@ -192,11 +192,20 @@ __device__ __forceinline__ void epi_value(const GemmArgs& args, float (&v)[4], c
   if (MODE == EPI_BF16_BIAS_TANH) {
     // tanh(x) = 1 - 2 / (exp(2x) + 1) on the transcendental unit (v_exp_f32 + v_rcp_f32, ~6 instructions): absolute error ~1e-7, invisible after the
     // bf16 rounding of this mode's output.  libm's tanhf (~40 instructions) cost 0.55 ms of the 1.41 ms fc1 forward GEMM (402 M elements per launch).
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float t = __builtin_amdgcn_exp2f(v[r] * 2.8853900817779268f);
-      v[r] = 1.f - 2.f * __builtin_amdgcn_rcpf(t + 1.f);
-    }
+    // Round 6: the vector half of it in PACKED f32 (v_pk_fma_f32 / v_pk_add_f32, two columns per instruction; the bias folded into the exponent's fma:
+    // exp2(c*acc + c*bias), the c*bias pair is loop-invariant per column group) — per element 1.5 full-rate + 2 transcendental issues instead of 4.5 + 2.
+    // The one-wave-per-SIMD kernels cannot hide this under MFMAs (no second wave, no spare accumulator set): it is 256 elements per lane per 256 x 256 tile.
+    typedef __attribute__((ext_vector_type(2))) float f32x2_;
+    const float kC = 2.8853900817779268f;
+    const f32x2_ c2 = {kC, kC}, one2 = {1.f, 1.f}, mtwo2 = {-2.f, -2.f};
+    const f32x2_ bc01 = {b4.x * kC, b4.y * kC}, bc23 = {b4.z * kC, b4.w * kC};
+    f32x2_ a01 = {v[0], v[1]}, a23 = {v[2], v[3]};
+    a01 = a01 * c2 + bc01; a23 = a23 * c2 + bc23;
+    f32x2_ t01 = {__builtin_amdgcn_exp2f(a01[0]), __builtin_amdgcn_exp2f(a01[1])}, t23 = {__builtin_amdgcn_exp2f(a23[0]), __builtin_amdgcn_exp2f(a23[1])};
+    t01 = t01 + one2; t23 = t23 + one2;
+    f32x2_ r01 = {__builtin_amdgcn_rcpf(t01[0]), __builtin_amdgcn_rcpf(t01[1])}, r23 = {__builtin_amdgcn_rcpf(t23[0]), __builtin_amdgcn_rcpf(t23[1])};
+    r01 = r01 * mtwo2 + one2; r23 = r23 * mtwo2 + one2;
+    v[0] = r01[0]; v[1] = r01[1]; v[2] = r23[0]; v[3] = r23[1];
   } else if (G && args.act == ENH_ACT_TANH) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
