@@ -21,7 +21,8 @@ Extra objects (rank 0, N = 1 unless noted):
   "parity_mode"  north_star's parity clause priced per precision mode: images/s of encode_codes and of the AE train step for the headline engine (fp16 MFMA
                operands since round 6), the other single-pass 16-bit format (bf16), the split-bf16 "x3" instrument (three MFMA passes, ~1e-5) and the
                exact-fp32 engine mode; plus h error / end-to-end code match / free-running reconstruction error of each against the fp32 CPU oracle on a
-               2-image sample; 10 timed iterations per mode.
+               2-image sample, taken at the constructor's weights before the first training step ("vs_fp32_cpu_oracle_2_images": the state every parity
+               test pins) and again after the warm-up + timed steps ("..._after_training_steps"); 10 timed iterations per mode.
   "cpu_baseline"  the CPU oracle — a port of the reference's PyTorch path, oracle/vitvq_oracle.py — timed on the host cores on a bounded sample.
   "comm"       (N > 1) per rank: exposed communication of the timed steps (compute-stream wait and host wait), buckets, bytes reduced, un-announced elements;
                with the adversarial configs the discriminator's own bucketed all-reduce is reported separately ("discriminator").
@@ -148,33 +149,14 @@ def vq_match_rate(h_dev, idx_dev, codebook_dev, depth: int, use_residual: bool):
                         "HIP indices vs the reference formula (fp32, torch CPU) on the host"}
 
 
-def parity_mode_block(model, eng, cfg, batches, B, lr, dev, headline_precision):
-    """north_star's "indices bit-exact / activations within 1e-3 of the reference fp32 path" priced per precision mode, outside the timed region:
-    encode-only and training throughput, and the parity each mode reaches against the fp32 CPU oracle on a 2-image sample (h = the quantizer input,
-    xrec downstream of the oracle's own run, end-to-end code match).  Modes: "fp16" (one MFMA pass, fp16 operands: the headline since round 6 and the
-    reference's --use_amp dtype), "bf16" (one pass, bf16 operands: the round-1..5 headline), "x3" (three passes on split-bf16 operands, ~1e-5: the
-    instrument; needs the bf16 engine) and the exact-fp32 engine mode.  The headline engine is measured in place; the other 16-bit engine is a second
-    model with the same weights."""
+def parity_rows(model, eng, cfg, xs, headline_precision, keep_second_engine=False):
+    """h error / end-to-end code match / free-running reconstruction error of the headline engine, the other 16-bit format and the x3 instrument against the
+    fp32 CPU oracle (the reference's arithmetic) on the images xs, at the model's CURRENT weights.  Returns (rows, second model, second engine or None)."""
     import torch
-    from enhancing import _C
     from enhancing.utils.general import initialize_from_config
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import vitvq_oracle as O
-
-    def rate(fn, n_img, iters):
-        fn(); torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(iters):
-            fn()
-        torch.cuda.synchronize()
-        return round(iters * n_img / (time.perf_counter() - t0), 1)
-
-    N_IT = 10          # timed iterations per mode after one warm-up call
-    out = {"encode_only_images_per_s": {}, "train_images_per_s": {}, "timed_iterations": N_IT, "headline": headline_precision}
-    x = batches[0]
-    xs = x[:2].contiguous()
     weights = {k: v for k, v in model.state_dict().items() if not k.startswith("loss.")}
-    # the oracle on the host (the reference's arithmetic, fp32), same weights, 2 images
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
     P = {k: v.detach().float().cpu() for k, v in weights.items()}
     ocfg = dict(image_size=cfg.model.params.image_size, patch_size=cfg.model.params.patch_size, encoder=dict(cfg.model.params.encoder),
@@ -190,6 +172,62 @@ def parity_mode_block(model, eng, cfg, batches, B, lr, dev, headline_precision):
         codes = e_.encode_codes(xs, precision=prec).cpu().view(o_idx.shape)
         par[name] = {"h_rel_err": relerr(h, o_h), "code_match_end_to_end": float((codes == o_idx).float().mean())}
 
+    other = "bf16" if headline_precision == "fp16" else "fp16"
+
+    def xrec_of(name, m_, e_):     # free-running (the mode's own codes) and downstream of the ORACLE's codes (the decoder's arithmetic alone: north_star's clause)
+        with torch.no_grad():
+            par[name]["xrec_rel_err_free_running"] = relerr(e_.reconstruct(xs)[0].detach().float().cpu(), o_xrec)
+            par[name]["xrec_rel_err_same_codes"] = relerr(m_.decode_codes(o_idx.to(xs.device)).detach().float().cpu().view(o_xrec.shape), o_xrec)
+
+    parity_of(headline_precision, model, eng)
+    xrec_of(headline_precision, model, eng)
+    m2 = initialize_from_config(cfg.model)
+    m2.precision = other
+    m2.load_state_dict(weights, strict=False)
+    e2 = m2.engine
+    parity_of(other, m2, e2)
+    xrec_of(other, m2, e2)
+    mb, eb = (model, eng) if headline_precision == "bf16" else (m2, e2)      # the bf16 engine hosts the x3 instrument
+    parity_of("x3", mb, eb, prec="x3")
+    eb.encoder_precision = eb.decoder_precision = "x3"
+    try:
+        xrec_of("x3", mb, eb)
+    finally:
+        eb.encoder_precision = eb.decoder_precision = "bf16"
+    if keep_second_engine:
+        return par, m2, e2
+    del m2, e2
+    torch.cuda.empty_cache()
+    return par, None, None
+
+
+def parity_mode_block(model, eng, cfg, batches, B, lr, dev, headline_precision, par_at_init=None, steps_done=0):
+    """north_star's "indices bit-exact / activations within 1e-3 of the reference fp32 path" priced per precision mode, outside the timed region:
+    encode-only and training throughput, and the parity each mode reaches against the fp32 CPU oracle on a 2-image sample (h = the quantizer input,
+    xrec downstream of the oracle's own run, end-to-end code match).  Modes: "fp16" (one MFMA pass, fp16 operands: the headline since round 6 and the
+    reference's --use_amp dtype), "bf16" (one pass, bf16 operands: the round-1..5 headline), "x3" (three passes on split-bf16 operands, ~1e-5: the
+    instrument; needs the bf16 engine) and the exact-fp32 engine mode.  The headline engine is measured in place; the other 16-bit engine is a second
+    model with the same weights.  The parity rows are taken TWICE: at the constructor's weights before the first training step (par_at_init: the state of
+    every parity test in tests/ and of tests/rounding_ablation.py) and here, after the warm-up + timed steps have moved the weights."""
+    import torch
+    from enhancing import _C
+    from enhancing.utils.general import initialize_from_config
+
+    def rate(fn, n_img, iters):
+        fn(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize()
+        return round(iters * n_img / (time.perf_counter() - t0), 1)
+
+    N_IT = 10          # timed iterations per mode after one warm-up call
+    out = {"encode_only_images_per_s": {}, "train_images_per_s": {}, "timed_iterations": N_IT, "headline": headline_precision}
+    x = batches[0]
+    xs = x[:2].contiguous()
+    weights = {k: v for k, v in model.state_dict().items() if not k.startswith("loss.")}
+    other = "bf16" if headline_precision == "fp16" else "fp16"
+
     def tstep_of(e_):
         def f():
             e_.forward_backward(x, w_l1=0.0, w_l2=1.0, codebook_weight=1.0)
@@ -197,25 +235,18 @@ def parity_mode_block(model, eng, cfg, batches, B, lr, dev, headline_precision):
         return f
 
     # ---- parity first (the timed training steps below move the weights) ----
-    other = "bf16" if headline_precision == "fp16" else "fp16"
-    parity_of(headline_precision, model, eng)
-    par[headline_precision]["xrec_rel_err_free_running"] = relerr(eng.reconstruct(xs)[0].detach().float().cpu(), o_xrec)
-    m2 = initialize_from_config(cfg.model)
-    m2.precision = other
-    m2.load_state_dict(weights, strict=False)
-    e2 = m2.engine
-    parity_of(other, m2, e2)
-    par[other]["xrec_rel_err_free_running"] = relerr(e2.reconstruct(xs)[0].detach().float().cpu(), o_xrec)
-    mb, eb = (model, eng) if headline_precision == "bf16" else (m2, e2)      # the bf16 engine hosts the x3 instrument
-    parity_of("x3", mb, eb, prec="x3")
-    eb.encoder_precision = eb.decoder_precision = "x3"
-    try:
-        par["x3"]["xrec_rel_err_free_running"] = relerr(eb.reconstruct(xs)[0].detach().float().cpu(), o_xrec)
-    finally:
-        eb.encoder_precision = eb.decoder_precision = "bf16"
-    out["vs_fp32_cpu_oracle_2_images"] = par
+    par_now, m2, e2 = parity_rows(model, eng, cfg, xs, headline_precision, keep_second_engine=True)
+    mb, eb = (model, eng) if headline_precision == "bf16" else (m2, e2)
+    out["vs_fp32_cpu_oracle_2_images"] = par_at_init if par_at_init is not None else par_now
+    out["vs_fp32_cpu_oracle_2_images_state"] = ("the constructor's weights (reference init), before the first training step" if par_at_init is not None
+                                                else f"after {steps_done} training steps on the synthetic batches")
+    if par_at_init is not None:
+        out["vs_fp32_cpu_oracle_2_images_after_training_steps"] = dict(par_now, steps=steps_done, lr=lr)
     out["vs_fp32_cpu_oracle_note"] = ("h: relative Frobenius error of the quantizer input; xrec free-running: a flipped near-tie code moves a whole token of the "
-                                      "reconstruction (the same-codes figure is tests/test_fp16_gpu.py / test_parity_base_gpu.py)")
+                                      "reconstruction (the same-codes figure is tests/test_fp16_gpu.py / test_parity_base_gpu.py); xrec same codes: the decoder "
+                                      "alone, fed the oracle's codes (north_star's activation clause for the decoder side); the second block is the same sample after the "
+                                      "warm-up + timed AdamW steps on synthetic noise (code usage has collapsed to a handful of codes by then — a state no test pins; "
+                                      "tests/rounding_ablation.py --init model holds the per-class table of the first block)")
     # ---- throughput ----
     out["encode_only_images_per_s"][headline_precision] = rate(lambda: eng.encode_codes(x, precision=headline_precision), B, N_IT)
     out["encode_only_images_per_s"][other] = rate(lambda: e2.encode_codes(x, precision=other), B, N_IT)
@@ -381,6 +412,12 @@ def main():
 
     use_graphs = args.graphs and world == 1      # (the two-optimizer protocol replays one graph per optimizer and host-side variant: vitvqgan.py _graphed_training_step)
     eng.use_graphs = use_graphs
+    par_at_init = None
+    if world == 1 and rank == 0 and args.config == "imagenet_vitvq_base" and not args.no_parity_mode and not args.no_cpu_baseline and not adversarial:
+        try:       # parity of the three modes at the constructor's weights (the state every parity test pins), before any training step; outside the timed region
+            par_at_init = parity_rows(model, eng, cfg, batches[0][:2].contiguous(), args.precision)[0]
+        except Exception as ex:
+            print(f"[bench] parity at init skipped: {ex!r}", file=sys.stderr)
     for i in range(args.warmup):
         out = step(i)
     timer = _C.KernelTimer()
@@ -519,7 +556,7 @@ def main():
                 res["vq_match_rate_training_codebook"] = mr["value"]
                 res["vq_match_rate_spread_codebook"] = ms["value"]
             if is_base and not args.no_parity_mode:
-                res["parity_mode"] = parity_mode_block(model, eng, cfg, batches, B, lr, dev, args.precision)
+                res["parity_mode"] = parity_mode_block(model, eng, cfg, batches, B, lr, dev, args.precision, par_at_init, args.warmup + args.steps)
                 res["parity_mode"]["train_images_per_s"][f"{args.precision} (headline)"] = round(img_per_s, 1)
         res["cpu_baseline"] = cpu_baseline()
     print(json.dumps(res), flush=True)

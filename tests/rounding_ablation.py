@@ -99,11 +99,23 @@ def rel(a, b):
     return float((a.double() - b.double()).norm() / b.double().norm())
 
 
-def run(batch: int, spread: bool, cfg=None, seed: int = 0, out=sys.stdout):
+def model_init_params(seed: int):
+    """the weights bench.py's parity_mode block sees: configs/imagenet_vitvq_base.yaml through the package's own constructor (the reference's init, seed-for-seed:
+    tests/test_host_cpu.py), on the CPU — no engine is bound, no kernel runs"""
+    sys.path.insert(0, os.path.join(ROOT, "enhancing-transformers_amd"))
+    from enhancing.utils.general import get_config_from_file, initialize_from_config, set_seed
+    set_seed(seed)
+    cfg = get_config_from_file(os.path.join(ROOT, "configs", "imagenet_vitvq_base.yaml"))
+    m = initialize_from_config(cfg.model)
+    return {k: v.detach().float().clone() for k, v in m.state_dict().items() if not k.startswith("loss.")}
+
+
+def run(batch: int, spread: bool, cfg=None, seed: int = 0, out=sys.stdout, init: str = "oracle", decoder_classes: bool = False):
     cfg = cfg or dict(image_size=256, patch_size=8, encoder=dict(dim=768, depth=12, heads=12, mlp_dim=3072),
                       decoder=dict(dim=768, depth=12, heads=12, mlp_dim=3072), quantizer=dict(embed_dim=32, n_embed=8192))
     torch.manual_seed(seed)
-    P = O.make_params(cfg, seed)
+    P = model_init_params(seed) if init == "model" else O.make_params(cfg, seed)
+    print(f"# parameters: {'the package constructor on configs/imagenet_vitvq_base.yaml (the reference init; what bench.py measures)' if init == 'model' else 'oracle.make_params (the test-suite init)'}", file=out)
     img = O.make_images(seed, batch, cfg["image_size"])
     with torch.no_grad():
         tr0 = []
@@ -144,6 +156,14 @@ def run(batch: int, spread: bool, cfg=None, seed: int = 0, out=sys.stdout):
         x1 = decoder_xrec(zq, P, cfg, set(CLASSES))
         rows["xrec"] = dict(h=rel(x1, x0))
         print(f"# decoder (post_quant .. to_pixel) with every class rounded, same codes: xrec rel err {rows['xrec']['h']:.2e}", file=out)
+        if decoder_classes:       # which class carries the decoder's error ("the table that shows which class is the deliverable")
+            dq = 0.0
+            for c in [x for x in CLASSES if x != "patch"]:
+                e = rel(decoder_xrec(zq, P, cfg, {c}), x0)
+                dq += e * e
+                print(f"  decoder, only {c:<6} rounded: xrec rel err {e:.2e}", file=out)
+            print(f"# quadrature sum of the decoder's single-class errors: {dq ** 0.5:.2e}", file=out)
+            print(f"# norms: |xrec| per pixel rms {float(x0.double().pow(2).mean().sqrt()):.3f}, mean {float(x0.mean()):.3f}", file=out)
     return rows
 
 
@@ -152,8 +172,10 @@ if __name__ == "__main__":
     ap.add_argument("--batch", type=int, default=2)
     ap.add_argument("--spread", action="store_true")
     ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16", help="16-bit format of the rounding points")
+    ap.add_argument("--init", choices=["oracle", "model"], default="oracle", help="oracle.make_params (the test-suite init) or the package constructor (bench.py's weights)")
+    ap.add_argument("--decoder-classes", action="store_true", help="per-class table for the decoder side as well")
     a = ap.parse_args()
     RB_DTYPE = torch.float16 if a.dtype == "fp16" else torch.bfloat16
     print(f"# rounding points in {a.dtype}")
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
-    run(a.batch, a.spread)
+    run(a.batch, a.spread, init=a.init, decoder_classes=a.decoder_classes)
