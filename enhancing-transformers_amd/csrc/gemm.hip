@@ -83,7 +83,11 @@ extern "C" int enh_debug_gemm_splits(int splits) {
   return ENH_OK;
 }
 
-static GemmPlan gemm_plan(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, bool splittable) {
+// splittable: 0 = no K slices; 1 = the weight-gradient kind (accumulate-only epilogue: may take the 256 x 256 kernel with K slices; f32 atomics when the
+// caller gives no workspace); 2 = the forward kind (round 6: f32 output with optional bias / residual / accumulate, applied by the second pass) — the
+// 128 x 128 family only, only with a workspace: what fills the chip at 2 - 4 images per GPU (M = 2048: the large towers' N = 1280 GEMMs are 160 tiles
+// on 512 slots; K = 3840 / 5120).  At 8 images and above those calls have >= 256 tiles and are not split.
+static GemmPlan gemm_plan(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, int splittable) {
   const bool k64 = K % G_BK == 0 && (!trans_a || M >= 8) && (!trans_b || N >= 8);
   const int64_t ksteps = (K + G_BK - 1) / G_BK;
   GemmPlan pl = {0, 1, ksteps * G_BK};
@@ -109,7 +113,7 @@ static GemmPlan gemm_plan(int trans_a, int trans_b, int64_t M, int64_t N, int64_
     family = 3;
     if (w256_ok) {
       const int64_t tiles = (M / 256) * (N / 256);
-      const int sp = split_for(tiles, cu_budget_rows(), 64);
+      const int sp = splittable == 1 ? split_for(tiles, cu_budget_rows(), 64) : 1;
       const int64_t per = (ksteps + sp - 1) / sp;
       if (tiles * sp >= (3 * cu_budget()) / 4 && ksteps - (sp - 1) * per >= 2) family = 7;
     }
@@ -117,7 +121,7 @@ static GemmPlan gemm_plan(int trans_a, int trans_b, int64_t M, int64_t N, int64_
   pl.family = family;
   const int64_t bm = family == 7 ? 256 : 128;
   const int64_t tiles = ((M + bm - 1) / bm) * ((N + bm - 1) / bm);
-  pl.splits = split_for(tiles, family == 7 ? cu_budget_rows() : 2 * cu_budget_rows(), 64);
+  pl.splits = (family == 7 && splittable != 1) ? 1 : split_for(tiles, family == 7 ? cu_budget_rows() : 2 * cu_budget_rows(), 64);
   const int64_t per = (ksteps + pl.splits - 1) / pl.splits;
   pl.k_per_split = per * G_BK;
   pl.splits = (int)((ksteps + per - 1) / per);
@@ -125,8 +129,11 @@ static GemmPlan gemm_plan(int trans_a, int trans_b, int64_t M, int64_t N, int64_
   return pl;
 }
 
-static bool gemm_splittable(int accumulate, const float* c_f32, const enh_h16* c_bf16, const float* bias, int act, const float* res) {
-  return accumulate == 1 && c_f32 && !c_bf16 && !bias && act == ENH_ACT_NONE && !res;
+static int gemm_splittable(int accumulate, const float* c_f32, const enh_h16* c_bf16, const float* bias, int act, const float* res, const void* workspace) {
+  if (act != ENH_ACT_NONE || (c_f32 && c_bf16)) return 0;
+  if (c_bf16) return (workspace && !bias && !res && accumulate == 0) ? 2 : 0;      // plain 16-bit output (token gradients): the second pass packs
+  if (accumulate == 1 && !bias && !res) return 1;
+  return workspace ? 2 : 0;
 }
 
 extern "C" const char* enh_gemm_h16_variant(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K);
@@ -143,7 +150,7 @@ static bool gemm_regstaged(int64_t K, int mode) {
 }
 
 extern "C" const char* enh_gemm_h16_variant_mode(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, int epi_mode) {
-  const GemmPlan pl = gemm_plan(trans_a, trans_b, M, N, K, epi_mode == EPI_WS || epi_mode == EPI_ATOMIC);
+  const GemmPlan pl = gemm_plan(trans_a, trans_b, M, N, K, (epi_mode == EPI_WS || epi_mode == EPI_ATOMIC) ? 1 : 0);
   if (gemm_persistent(pl, trans_a, K, epi_mode)) return gemm_regstaged(K, epi_mode) ? "gemm_w256r_kernel" : "gemm_w256p_kernel";
   return enh_gemm_h16_variant(trans_a, trans_b, M, N, K);
 }
@@ -151,12 +158,13 @@ extern "C" const char* enh_gemm_h16_variant_mode(int trans_a, int trans_b, int64
 extern "C" const char* enh_gemm_h16_variant(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K) {
   static const char* names[8] = {"gemm_kernel", "", "", "gemm_pipe2_kernel", "", "", "", "gemm_w256_kernel"};
   // weight-gradient-shaped calls (both operands contraction-major) are the ones issued with accumulate -> report their split-K plan
-  return names[gemm_plan(trans_a, trans_b, M, N, K, trans_a && trans_b).family];
+  return names[gemm_plan(trans_a, trans_b, M, N, K, (trans_a && trans_b) ? 1 : 0).family];
 }
 
 extern "C" size_t enh_gemm_h16_workspace_bytes(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K) {
-  const GemmPlan pl = gemm_plan(trans_a, trans_b, M, N, K, true);
-  return pl.splits > 1 ? (size_t)pl.splits * (size_t)M * (size_t)N * sizeof(float) : 0;
+  const GemmPlan p1 = gemm_plan(trans_a, trans_b, M, N, K, 1), p2 = gemm_plan(trans_a, trans_b, M, N, K, 2);   // (either kind of split: the caller sizes once)
+  const int splits = p1.splits > p2.splits ? p1.splits : p2.splits;
+  return splits > 1 ? (size_t)splits * (size_t)M * (size_t)N * sizeof(float) : 0;
 }
 
 // colpart != null: the caller (enh_gemm_bf16_dtanh_colsum) has checked that the persistent tanh' kernel serves this call
@@ -178,7 +186,10 @@ static int gemm_h16_impl(const enh_h16* A, int64_t lda, int trans_a, const enh_h
   ENH_REQUIRE((!c_f32 || aligned16(c_f32)) && (!c_bf16 || (reinterpret_cast<uintptr_t>(c_bf16) & 7u) == 0), ENH_E_SHAPE, "enh_gemm_h16: output alignment");
   ENH_REQUIRE(!workspace || aligned16(workspace), ENH_E_SHAPE, "enh_gemm_h16: workspace must be 16-byte aligned");
 
-  const GemmPlan pl = gemm_plan(trans_a, trans_b, M, N, K, gemm_splittable(accumulate, c_f32, c_bf16, bias, act, res));
+  const int split_kind = gemm_splittable(accumulate, c_f32, c_bf16, bias, act, res, workspace);
+  GemmPlan pl = gemm_plan(trans_a, trans_b, M, N, K, split_kind);
+  if (split_kind == 2 && pl.splits > 1 && workspace_bytes < (size_t)pl.splits * (size_t)M * (size_t)N * sizeof(float))
+    pl = gemm_plan(trans_a, trans_b, M, N, K, 0);      // (the forward kind is an optimisation: a workspace sized for something else means "do not split")
   const int family = pl.family;
   const int bm = family == 7 ? G4_BM : G_BM;
   const int bn = family == 7 ? G4_BN : G_BN;
@@ -235,7 +246,12 @@ static int gemm_h16_impl(const enh_h16* A, int64_t lda, int trans_a, const enh_h
   if (dtype == ENH_DT_F16) gemm_launch<F16>(g, L, s); else gemm_launch<BF16>(g, L, s);
   if (two_pass) {
     const int64_t MN = M * N;
-    splitk_reduce_kernel<<<dim3((unsigned)((MN / 4 + 255) / 256)), 256, 0, s>>>(g.ws, pl.splits, MN, N, c_f32, ldc, accumulate);
+    const dim3 rg((unsigned)((MN / 4 + 255) / 256));
+    if (c_bf16) {
+      ENH_DT_DISPATCH(dtype, (splitk_reduce16_kernel<OT><<<rg, 256, 0, s>>>(g.ws, pl.splits, MN, N, c_bf16, ldc)));
+    } else {
+      splitk_reduce_kernel<<<rg, 256, 0, s>>>(g.ws, pl.splits, MN, N, c_f32, ldc, accumulate, bias, res, ldres, res_rows);
+    }
   }
   return enh_check_launch("enh_gemm_h16");
 }
@@ -253,7 +269,7 @@ extern "C" int enh_gemm_h16_ws(const enh_h16* A, int64_t lda, int trans_a, const
 // persistent tanh' kernel serves the call, its epilogue leaves one partial row per 128 rows in `ws` and a fixed-order second pass adds them (the
 // separate column-sum kernel would re-read all of C: 805 MB at the base config); otherwise: the plain GEMM, then enh_colsum_bf16_ws.
 static bool dtanh_colsum_fused(int trans_b, int64_t M, int64_t N, int64_t K) {
-  const GemmPlan pl = gemm_plan(0, trans_b, M, N, K, false);
+  const GemmPlan pl = gemm_plan(0, trans_b, M, N, K, 0);
   return gemm_persistent(pl, 0, K, EPI_BF16_DTANH) && M % 256 == 0 && N % 256 == 0;
 }
 extern "C" size_t enh_gemm_h16_dtanh_colsum_workspace_bytes(int trans_b, int64_t M, int64_t N, int64_t K) {
@@ -291,7 +307,7 @@ extern "C" int enh_gemm_h16(const enh_h16* A, int64_t lda, int trans_a, const en
 // Served where the persistent 256 x 256 kernel serves (enh_gemm_bf16_split_fused); the caller otherwise keeps the two-call form.
 static bool gemm_split_plan_ok(int64_t M, int64_t N, int64_t K) {
   if (g_kernel_override == 0 || g_kernel_override == 3 || g_kernel_override == 7) return false;
-  const GemmPlan pl = gemm_plan(0, 0, M, N, K, false);
+  const GemmPlan pl = gemm_plan(0, 0, M, N, K, 0);
   return pl.family == 7 && pl.splits == 1 && K / G_BK >= 3 && M % 256 == 0 && N % 256 == 0;
 }
 extern "C" int enh_gemm_bf16_split_fused(int64_t M, int64_t N, int64_t K) { return gemm_split_plan_ok(M, N, K) ? 1 : 0; }

@@ -503,8 +503,9 @@ __device__ __forceinline__ void gemm_epilogue32_loops(const GemmArgs& args, f32x
   }
 }
 
-// split-K second pass: C[m][n] (+)= sum over the splits of the partial slabs, in a fixed order (deterministic, no atomics)
-static __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, int64_t MN, int64_t N, float* __restrict__ c, int64_t ldc, int accumulate) {
+// the same for a 16-bit output (the token-gradient GEMMs write their result in the operand format): sum in f32, one RNE pack
+template <typename OT>
+static __global__ __launch_bounds__(256) void splitk_reduce16_kernel(const float* __restrict__ ws, int splits, int64_t MN, int64_t N, uint16_t* __restrict__ c, int64_t ldc) {
   const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i4 >= MN) return;
   f32x4 s = *reinterpret_cast<const f32x4*>(ws + i4);
@@ -513,6 +514,31 @@ static __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* 
     s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
   }
   const int64_t m = i4 / N, n = i4 - m * N;
+  const u32x2 o_ = {pack2<OT>(s[0], s[1]), pack2<OT>(s[2], s[3])};
+  *reinterpret_cast<u32x2*>(c + m * ldc + n) = o_;
+}
+
+// split-K second pass: C[m][n] (+)= sum over the splits of the partial slabs, in a fixed order (deterministic, no atomics).  The forward kind of split
+// (gemm.hip gemm_splittable == 2: few tiles, long K, f32 output) carries its epilogue here: + bias[n] + res[m mod res_rows][n] (either may be null).
+static __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, int64_t MN, int64_t N, float* __restrict__ c, int64_t ldc, int accumulate,
+                                                                   const float* __restrict__ bias = nullptr, const float* __restrict__ res = nullptr, int64_t ldres = 0,
+                                                                   int64_t res_rows = 0) {
+  const int64_t i4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 >= MN) return;
+  f32x4 s = *reinterpret_cast<const f32x4*>(ws + i4);
+  for (int k = 1; k < splits; ++k) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(ws + (int64_t)k * MN + i4);
+    s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+  }
+  const int64_t m = i4 / N, n = i4 - m * N;
+  if (bias) {       // the order of gemm_tiles.h epi_value: bias, residual, previous C
+    const f32x4 b = *reinterpret_cast<const f32x4*>(bias + n);
+    s[0] += b[0]; s[1] += b[1]; s[2] += b[2]; s[3] += b[3];
+  }
+  if (res) {
+    const f32x4 r = *reinterpret_cast<const f32x4*>(res + (res_rows == MN / N ? m : m % res_rows) * ldres + n);
+    s[0] += r[0]; s[1] += r[1]; s[2] += r[2]; s[3] += r[3];
+  }
   float* cp = c + m * ldc + n;
   if (accumulate) {
     const f32x4 o = *reinterpret_cast<const f32x4*>(cp);

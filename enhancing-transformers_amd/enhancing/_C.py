@@ -341,8 +341,11 @@ def gemm(a, b, M: int, N: int, K: int, trans_a: bool = False, trans_b: bool = Fa
     # small batch): partial slabs in a caller-owned workspace + a fixed-order second pass — deterministic, no f32 atomics.  (Until round 4 only the
     # weight-gradient layout got the workspace; the other layouts fell back to atomics and made the discriminator's forward differ by an ulp from call
     # to call — found by the graph-replay bit-identity test.)
+    # Round 6: any f32-output call without an activation may be split (bias / residual / accumulate move into the second pass): what fills the chip at
+    # 2 - 4 images per GPU, where the N = dim GEMMs are 96 - 192 tiles (csrc/gemm.hip gemm_splittable).
     ws, ws_bytes = None, 0
-    if accumulate and out_f32 is not None and out_bf16 is None and bias is None and res is None and act == ACT_NONE and ldc == N:
+    if act == ACT_NONE and ldc == N and ((out_f32 is not None and out_bf16 is None) or
+                                         (out_bf16 is not None and out_f32 is None and bias is None and res is None and not accumulate)):
         ws_bytes = lib().enh_gemm_h16_workspace_bytes(int(trans_a), int(trans_b), M, N, K)
         if ws_bytes:
             ws = _gemm_workspace(a.device, ws_bytes)

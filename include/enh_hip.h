@@ -146,7 +146,12 @@ int enh_gemm_h16(const enh_h16* A, int64_t lda, int trans_a, const enh_h16* B, i
 /* The same with a caller-owned split-K workspace.  Weight-gradient-shaped calls (accumulate = 1, f32 output only, no bias / act / res) whose
  * output tiles cannot fill the chip are split along K; with a workspace of enh_gemm_h16_workspace_bytes() the K slices write partial slabs
  * [splits][M][N] and a second pass adds them to C in a fixed order: bit-reproducible, no f32 atomics (needs ldc == N).  workspace = NULL
- * (what enh_gemm_h16 passes) falls back to f32 atomicAdd into C.  Replaces the autograd wgrad of every nn.Linear (layers.py:99-101,118,120). */
+ * (what enh_gemm_h16 passes) falls back to f32 atomicAdd into C.  Replaces the autograd wgrad of every nn.Linear (layers.py:99-101,118,120).
+ * Round 6 (the reference's shipped batch sizes, configs/imagenet_vitvq_large.yaml:31: 2 images per GPU): with a workspace, calls WITHOUT an activation whose
+ * 128 x 128 tiles cover less than half of the resident workgroup slots and whose K >= 2048 are split as well — f32 output with any of bias / residual /
+ * accumulate, or a plain 16-bit output; the second pass then carries the epilogue (bias, residual row m mod res_rows, previous C; or the one RNE pack).
+ * Same bits for the same call and workspace size; a workspace smaller than enh_gemm_h16_workspace_bytes() simply means "do not split" for these calls.
+ * Never chosen at training sizes (M >= 8192 token rows with N >= 768 has >= 256 tiles). */
 int enh_gemm_h16_ws(const enh_h16* A, int64_t lda, int trans_a, const enh_h16* B, int64_t ldb, int trans_b,
                     int64_t M, int64_t N, int64_t K, const float* bias, int act, const enh_h16* aux,
                     int64_t ldaux, const float* res, int64_t ldres, int64_t res_rows, int accumulate,
@@ -160,7 +165,7 @@ size_t enh_gemm_h16_dtanh_colsum_workspace_bytes(int trans_b, int64_t M, int64_t
 int enh_gemm_h16_dtanh_colsum(const enh_h16* A, int64_t lda, const enh_h16* B, int64_t ldb, int trans_b, int64_t M, int64_t N, int64_t K,
                               const enh_h16* aux, int64_t ldaux, enh_h16* c_h16, int64_t ldc, float* colsum, int accumulate_colsum,
                               void* ws, size_t ws_bytes, int dtype, void* stream);
-/* bytes of workspace the split-K plan of this shape needs (0 = the shape is not split) */
+/* bytes of workspace the split-K plan of this shape needs, whichever kind of call (weight-gradient or forward kind) would split it (0 = never split) */
 size_t enh_gemm_h16_workspace_bytes(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K);
 
 /* name of the kernel family enh_gemm_h16 launches for this shape (measurement aid: lets callers label timings with

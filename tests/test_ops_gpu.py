@@ -158,8 +158,8 @@ def test_layernorm_fwd_bwd(C, M, D):
 # ---------------------------------------------------------------------------------------------
 # GEMM
 # ---------------------------------------------------------------------------------------------
-def _mk(shape, g, scale=1.0):
-    return bf16r(torch.randn(*shape, generator=g) * scale)
+def _mk(shape, g, scale=1.0, dt=torch.bfloat16):
+    return (torch.randn(*shape, generator=g) * scale).to(dt).to(torch.float32)      # values exactly representable in the operand format
 
 
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
@@ -211,6 +211,42 @@ def test_gemm_epilogues(C, kernel_shape):
     o = res.clone().cuda()
     C.gemm(a, b, M, N, K, accumulate=True, out_f32=o)
     assert rel(o, base + res.double()) <= F32_TOL
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K,tb", [(2048, 1280, 5120, False), (2048, 1280, 3840, True), (4096, 768, 3072, False), (1024, 768, 2304, True)])
+def test_gemm_forward_split_k(C, M, N, K, tb, dt):
+    """Round 6 (shipped batch sizes): an f32-output GEMM with few tiles and a long K (the N = dim GEMMs at 2 - 4 images per GPU: 96 - 192 tiles of
+    128 x 128 on 512 slots) is split over K when the caller gives a workspace; bias / residual / position-table residual / accumulate are applied by the
+    fixed-order second pass.  Every epilogue against fp64, bit-reproducible, and the plan really is a split (the workspace query is non-zero; at training
+    sizes it is zero)."""
+    g = torch.Generator().manual_seed(77)
+    A, B = _mk((M, K), g, 0.5, dt), (_mk((K, N), g, 0.05, dt) if tb else _mk((N, K), g, 0.05, dt))
+    bias, res, pos = torch.randn(N, generator=g), torch.randn(M, N, generator=g), torch.randn(256, N, generator=g)
+    a, b = A.to(dt).cuda(), B.to(dt).cuda()
+    base = A.double() @ (B.double() if tb else B.double().t())
+    L = C.lib()
+    assert L.enh_gemm_h16_workspace_bytes(0, int(tb), M, N, K) > 0
+    assert L.enh_gemm_h16_workspace_bytes(0, int(tb), 131072, N, K) == 0
+    outs = []
+    for rep in range(2):
+        o = torch.empty(M, N, device="cuda")
+        C.gemm(a, b, M, N, K, trans_b=tb, out_f32=o)
+        assert rel(o, base) <= F32_TOL
+        x = res.clone().cuda()
+        C.gemm(a, b, M, N, K, trans_b=tb, bias=bias.cuda(), res=x, res_rows=M, out_f32=x)          # in place on the residual stream
+        assert rel(x, base + bias.double() + res.double()) <= F32_TOL
+        p_ = torch.empty(M, N, device="cuda")
+        C.gemm(a, b, M, N, K, trans_b=tb, bias=bias.cuda(), res=pos.cuda(), res_rows=256, out_f32=p_)
+        assert rel(p_, base + bias.double() + pos.double().repeat(M // 256, 1)) <= F32_TOL
+        acc = res.clone().cuda()
+        C.gemm(a, b, M, N, K, trans_b=tb, bias=bias.cuda(), accumulate=True, out_f32=acc)
+        assert rel(acc, base + bias.double() + res.double()) <= F32_TOL
+        o16 = torch.empty(M, N, dtype=dt, device="cuda")                                          # a plain 16-bit output (the token-gradient GEMMs): summed in f32, packed once
+        C.gemm(a, b, M, N, K, trans_b=tb, out_bf16=o16)
+        assert rel(o16.float(), base) <= (BF16_TOL if dt == torch.bfloat16 else 3e-4)
+        outs.append((o.clone(), x.clone(), p_.clone(), acc.clone(), o16.clone()))
+    assert all(torch.equal(u, v) for u, v in zip(*outs))
 
 
 @pytest.mark.parametrize("kind", ["fwd", "dgrad", "fwd_tanh", "dgrad_dtanh", "fwd_res", "fwd_f32"])

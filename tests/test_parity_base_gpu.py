@@ -129,7 +129,31 @@ def _run_case(label, cfg, B, seed, tols=None, spread=False, min_distinct=0):
         with open(os.path.join(out_dir, "parity_base.txt"), "a") as f:
             f.write("\n".join(lines) + "\n")
     assert set(errs) == set(ref["grads"])
-    assert match_ob == 1.0, "indices must be bit-exact for identical quantizer input"
+    # indices at the op boundary (identical quantizer input): bit-exact against the C oracle — the kernel's arithmetic twin, itself pinned to the REFERENCE's golden
+    # indices in tests/test_ops_gpu.py — and against the torch restatement up to audited fp32 near-ties (two fp32 evaluations of quantizers.py:78-80 may order
+    # two codes differently only if their exact distance gap is below (6n + 12) u = 1.22e-5: bench.py VQ_NEAR_TIE_BOUND; every mismatch is checked in fp64 at the
+    # first depth where the code tuples part)
+    import vq_oracle as VC
+    qp = O.qparams(cfg)
+    depth = int(qp["num_quantizers"]) if qp["use_residual"] else 1
+    h_np = io["h"].cpu().view(-1, io["h"].shape[-1]).numpy()
+    _, idx_c, _ = VC.forward(h_np, P["quantizer.embedding.weight"].numpy(), beta=qp["beta"], depth=depth, use_norm=qp["use_norm"])
+    assert torch.equal(codes.reshape(-1, depth), torch.from_numpy(idx_c).reshape(-1, depth)), "indices must be bit-exact against the C oracle for identical quantizer input"
+    if match_ob != 1.0:
+        assert qp["use_norm"], "the near-tie bound is derived for l2-normalised codes"
+        cg, co = codes.reshape(-1, depth), idx_ob.reshape(-1, depth)
+        bad = (cg != co).any(-1).nonzero().view(-1)
+        assert bad.numel() <= 1e-3 * cg.shape[0], f"{bad.numel()} tokens differ from the torch restatement"
+        E64 = torch.nn.functional.normalize(P["quantizer.embedding.weight"].double(), dim=-1)
+        for t in bad.tolist():
+            d0 = int((cg[t] != co[t]).nonzero()[0])
+            r = torch.from_numpy(h_np[t]).double()
+            for d_ in range(d0):
+                r = r - E64[cg[t, d_]]
+            zn = torch.nn.functional.normalize(r, dim=-1)
+            gap = abs(float(((zn - E64[cg[t, d0]]) ** 2).sum() - ((zn - E64[co[t, d0]]) ** 2).sum()))
+            assert gap <= (6 * 32 + 12) * 2.0 ** -24, f"token {t}, depth {d0}: exact gap {gap:.3e} is not a near-tie"
+        print(f"  op boundary vs the torch restatement: {bad.numel()} audited near-tie(s) of {cg.shape[0]} tokens")
     assert o_idx.unique().numel() >= min_distinct, f"only {o_idx.unique().numel()} distinct codes in play"
     assert max(e for _, e in rows) <= stream_tol, rows
     assert e_h <= h_tol and e_x <= xrec_tol
