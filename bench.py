@@ -21,7 +21,7 @@ Extra objects (rank 0, N = 1 unless noted):
   "parity_mode"  north_star's parity clause priced per precision mode: images/s of encode_codes and of the AE train step for the headline engine (fp16 MFMA
                operands since round 6), the other single-pass 16-bit format (bf16), the split-bf16 "x3" instrument (three MFMA passes, ~1e-5) and the
                exact-fp32 engine mode; plus h error / end-to-end code match / free-running reconstruction error of each against the fp32 CPU oracle on a
-               2-image sample, taken at the constructor's weights before the first training step ("vs_fp32_cpu_oracle_2_images": the state every parity
+               8-image sample (8192 tokens: the reference yaml's batch), taken at the constructor's weights before the first training step ("vs_fp32_cpu_oracle": the state every parity
                test pins) and again after the warm-up + timed steps ("..._after_training_steps"); 10 timed iterations per mode.
   "cpu_baseline"  the CPU oracle — a port of the reference's PyTorch path, oracle/vitvq_oracle.py — timed on the host cores on a bounded sample.
   "comm"       (N > 1) per rank: exposed communication of the timed steps (compute-stream wait and host wait), buckets, bytes reduced, un-announced elements;
@@ -50,6 +50,7 @@ HBM_PEAK_GBS = 8000.0                # spec; ~6300 achievable (same guide, "HBM"
 # codes can swap order in one implementation only if their exact gap is <= 2 (3n + 6) u, and two implementations can disagree only if one of them
 # swapped: gap <= (6n + 12) u = 204 u = 1.22e-5 = 51 ulp of the intermediate sum A + B ~ 2.  That is the worst case; the random-walk expectation for
 # the largest gap seen over ~1e9 comparisons is ~1e-6 (4-6 ulp), which is what the runs show.  Anything above the bound is a kernel bug -> FAIL.
+PARITY_IMAGES = 8        # images of the parity_mode sample (8192 tokens: the end-to-end code match-rate of a ~0.2 % flip rate needs more than 2048 tokens to be a number)
 VQ_N = 32
 VQ_NEAR_TIE_BOUND = (6 * VQ_N + 12) * 2.0 ** -24
 ULP_OF_2 = 2.0 ** -22
@@ -179,13 +180,13 @@ def parity_rows(model, eng, cfg, xs, headline_precision, keep_second_engine=Fals
             par[name]["xrec_rel_err_free_running"] = relerr(e_.reconstruct(xs)[0].detach().float().cpu(), o_xrec)
             par[name]["xrec_rel_err_same_codes"] = relerr(m_.decode_codes(o_idx.to(xs.device)).detach().float().cpu().view(o_xrec.shape), o_xrec)
 
-    parity_of(headline_precision, model, eng)
+    parity_of(headline_precision, model, eng, prec=headline_precision)      # (explicit: under the bf16 engine encode_codes DEFAULTS to the x3 encoder)
     xrec_of(headline_precision, model, eng)
     m2 = initialize_from_config(cfg.model)
     m2.precision = other
     m2.load_state_dict(weights, strict=False)
     e2 = m2.engine
-    parity_of(other, m2, e2)
+    parity_of(other, m2, e2, prec=other)
     xrec_of(other, m2, e2)
     mb, eb = (model, eng) if headline_precision == "bf16" else (m2, e2)      # the bf16 engine hosts the x3 instrument
     parity_of("x3", mb, eb, prec="x3")
@@ -203,7 +204,7 @@ def parity_rows(model, eng, cfg, xs, headline_precision, keep_second_engine=Fals
 
 def parity_mode_block(model, eng, cfg, batches, B, lr, dev, headline_precision, par_at_init=None, steps_done=0):
     """north_star's "indices bit-exact / activations within 1e-3 of the reference fp32 path" priced per precision mode, outside the timed region:
-    encode-only and training throughput, and the parity each mode reaches against the fp32 CPU oracle on a 2-image sample (h = the quantizer input,
+    encode-only and training throughput, and the parity each mode reaches against the fp32 CPU oracle on a PARITY_IMAGES-image sample (h = the quantizer input,
     xrec downstream of the oracle's own run, end-to-end code match).  Modes: "fp16" (one MFMA pass, fp16 operands: the headline since round 6 and the
     reference's --use_amp dtype), "bf16" (one pass, bf16 operands: the round-1..5 headline), "x3" (three passes on split-bf16 operands, ~1e-5: the
     instrument; needs the bf16 engine) and the exact-fp32 engine mode.  The headline engine is measured in place; the other 16-bit engine is a second
@@ -224,7 +225,7 @@ def parity_mode_block(model, eng, cfg, batches, B, lr, dev, headline_precision, 
     N_IT = 10          # timed iterations per mode after one warm-up call
     out = {"encode_only_images_per_s": {}, "train_images_per_s": {}, "timed_iterations": N_IT, "headline": headline_precision}
     x = batches[0]
-    xs = x[:2].contiguous()
+    xs = x[:PARITY_IMAGES].contiguous()
     weights = {k: v for k, v in model.state_dict().items() if not k.startswith("loss.")}
     other = "bf16" if headline_precision == "fp16" else "fp16"
 
@@ -237,11 +238,12 @@ def parity_mode_block(model, eng, cfg, batches, B, lr, dev, headline_precision, 
     # ---- parity first (the timed training steps below move the weights) ----
     par_now, m2, e2 = parity_rows(model, eng, cfg, xs, headline_precision, keep_second_engine=True)
     mb, eb = (model, eng) if headline_precision == "bf16" else (m2, e2)
-    out["vs_fp32_cpu_oracle_2_images"] = par_at_init if par_at_init is not None else par_now
-    out["vs_fp32_cpu_oracle_2_images_state"] = ("the constructor's weights (reference init), before the first training step" if par_at_init is not None
+    out["vs_fp32_cpu_oracle"] = par_at_init if par_at_init is not None else par_now
+    out["vs_fp32_cpu_oracle_sample_images"] = int(xs.shape[0])
+    out["vs_fp32_cpu_oracle_state"] = ("the constructor's weights (reference init), before the first training step" if par_at_init is not None
                                                 else f"after {steps_done} training steps on the synthetic batches")
     if par_at_init is not None:
-        out["vs_fp32_cpu_oracle_2_images_after_training_steps"] = dict(par_now, steps=steps_done, lr=lr)
+        out["vs_fp32_cpu_oracle_after_training_steps"] = dict(par_now, steps=steps_done, lr=lr)
     out["vs_fp32_cpu_oracle_note"] = ("h: relative Frobenius error of the quantizer input; xrec free-running: a flipped near-tie code moves a whole token of the "
                                       "reconstruction (the same-codes figure is tests/test_fp16_gpu.py / test_parity_base_gpu.py); xrec same codes: the decoder "
                                       "alone, fed the oracle's codes (north_star's activation clause for the decoder side); the second block is the same sample after the "
@@ -415,7 +417,7 @@ def main():
     par_at_init = None
     if world == 1 and rank == 0 and args.config == "imagenet_vitvq_base" and not args.no_parity_mode and not args.no_cpu_baseline and not adversarial:
         try:       # parity of the three modes at the constructor's weights (the state every parity test pins), before any training step; outside the timed region
-            par_at_init = parity_rows(model, eng, cfg, batches[0][:2].contiguous(), args.precision)[0]
+            par_at_init = parity_rows(model, eng, cfg, batches[0][:PARITY_IMAGES].contiguous(), args.precision)[0]
         except Exception as ex:
             print(f"[bench] parity at init skipped: {ex!r}", file=sys.stderr)
     for i in range(args.warmup):
