@@ -43,7 +43,6 @@ class LossScaler:
         self.tracker = torch.zeros(1, dtype=torch.int32, device=device)
         self.found_inf = torch.zeros(1, dtype=torch.float32, device=device)
         self.enabled = False
-        self.skipped_checks = 0
 
     def scale(self, t):
         return t * self.scale_t.view(()) if self.enabled else t

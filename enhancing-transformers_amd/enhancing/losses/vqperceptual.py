@@ -166,6 +166,7 @@ class VQLPIPSWithDiscriminator(VQLPIPS):
         inputs = inputs.contiguous()
         reconstructions = reconstructions.contiguous()
         self.disc_store(reconstructions.device)
+        sc = self.loss_scaler(reconstructions.device)      # (sets `enabled` for THIS forward's operand format: scale_disc_loss / FlatAdamW.step read it)
         if optimizer_idx == 0:
             # packed operand images of the discriminator's weights are reused for every pass of ONE training step (the weights only change in the
             # discriminator's optimizer step, which invalidates them itself); dropping them here as well covers writers that bypass both the
@@ -207,7 +208,6 @@ class VQLPIPSWithDiscriminator(VQLPIPS):
             logits_fake = self.discriminator(reconstructions.detach())
             d_loss = disc_factor * self.disc_loss(logits_fake, logits_real)
             if do_r1:
-                sc = self.loss_scaler(real.device)
                 with conv2d_gradfix.no_weight_gradients():       # (fp16 operands: the first-order pass of R1 runs on scale x sum(logits) and is divided back in f32)
                     gradients, = torch.autograd.grad(outputs=sc.scale(logits_real.sum()), inputs=real, create_graph=True)
                 gradients = sc.unscale(gradients)
