@@ -82,6 +82,37 @@ def test_loss_modules_construct_every_term():
     assert abs(loss.item() - (((r - x) ** 2).mean().item() + 0.5)) < 1e-6
 
 
+def test_loss_network_operand_format_resolution(monkeypatch):
+    """Round 6: the loss networks' 16-bit operand format — module attribute > ENH_LOSS_OPERANDS > the engine that produced the reconstruction (fp16 engine ->
+    fp16, as the reference's --use_amp autocast does, main.py:52; bf16 / fp32 engine -> bf16) > the conv_nhwc module default; a bf16 engine with fp16 loss
+    networks is refused for a differentiable generator-side call (their gradients would run unscaled in fp16)."""
+    import types
+    from enhancing.losses.op import conv_nhwc
+    from enhancing.losses.vqperceptual import VQLPIPS
+    monkeypatch.delenv("ENH_LOSS_OPERANDS", raising=False)
+    L = VQLPIPS(perceptual_weight=0.0)
+    fp16_layer = types.SimpleNamespace(_enh_engine=types.SimpleNamespace(scaled=True))
+    bf16_layer = types.SimpleNamespace(_enh_engine=types.SimpleNamespace(scaled=False))
+    assert L.loss_operands(fp16_layer) == "fp16" and L.loss_operands(bf16_layer) == "bf16"
+    assert L.loss_operands(None) == ("fp16" if conv_nhwc.OPERAND_DTYPE == torch.float16 else "bf16")
+    with conv_nhwc.operand_dtype("fp16"):
+        assert L.loss_operands(None) == "fp16" and L.loss_operands(bf16_layer) == "bf16"      # (an engine, when known, decides)
+    monkeypatch.setenv("ENH_LOSS_OPERANDS", "bf16")
+    assert L.loss_operands(fp16_layer) == "bf16"
+    L.operands = "fp16"
+    assert L.loss_operands(bf16_layer) == "fp16"
+    L.operands = "fp8"
+    with pytest.raises(ValueError, match="'bf16' or 'fp16'"):
+        L.loss_operands(None)
+    # the refusal: fp16 loss networks behind an unscaled engine, differentiable generator-side call with a loss network present
+    L2 = VQLPIPS(perceptual_weight=0.0)
+    L2.operands = "fp16"
+    L2.perceptual_loss = torch.nn.Identity()
+    x = torch.zeros(1, 3, 8, 8, requires_grad=True)
+    with pytest.raises(ValueError, match="loss-scaled backward"):
+        L2(torch.zeros(()), torch.zeros(1, 3, 8, 8), x, 0, 0, 0, last_layer=bf16_layer)
+
+
 def test_lpips_without_weights_raises_and_parent_load_supplies_them(monkeypatch):
     """(1) no silent random perceptual term — without weights the module constructs (so a checkpoint can be loaded into it) but its forward
     raises unless random init was an explicit opt-in; (2) a PARENT's load_state_dict (a reference checkpoint carrying loss.perceptual_loss.*) marks
