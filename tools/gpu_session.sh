@@ -36,7 +36,7 @@ lib-ab)
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['kernels']
 row=lambda n: next((f\"{v['total_ms']/v['launches']:.4f}\" for kk,v in k.items() if kk.startswith(n)), '-')
-print('$lib', d['value'], 'img/s', d['ms_per_step'], 'ms/step | qkv fwd', row('gemm_w256r_kernel<false, 1'), 'fc1+tanh', row('gemm_w256r_kernel<false, 2'), 'dgrad bf16', row('gemm_w256r_kernel<true, 1'), 'bias+res', row('gemm_w256p_kernel<false, false, 4'), 'dtanh', row('gemm_w256p_kernel<false, true, 3'), 'wgrad', row('gemm_w256_kernel<true, true, 6'), 'attn fwd', row('attn_fwd'), 'attn bwd', row('attn_bwd'), 'ln_bwd', row('ln_bwd'))" | tee -a gpurun_out/lib_ab.txt
+print('$lib', d['value'], 'img/s', d['ms_per_step'], 'ms/step | qkv fwd', row('gemm_w256r_kernel<F16, false, 1'), 'fc1+tanh', row('gemm_w256r_kernel<F16, false, 2'), 'dgrad 16-bit', row('gemm_w256r_kernel<F16, true, 1'), 'bias+res', row('gemm_w256p_kernel<F16, false, false, 4'), 'dtanh', row('gemm_w256p_kernel<F16, false, true, 3'), 'wgrad', row('gemm_w256_kernel<F16, true, true, 6'), 'attn fwd', row('attn_fwd'), 'attn bwd', row('attn_bwd'), 'ln_bwd', row('ln_bwd'))" | tee -a gpurun_out/lib_ab.txt
   done; done ;;
 landing-lab)
   timeout 600 python tools/gemm_ld_lab.py ${1:-128} 2>&1 | grep -v amdgpu.ids | tee gpurun_out/gemm_landing_lab.txt ;;
