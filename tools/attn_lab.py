@@ -1,15 +1,16 @@
 """Attention laboratory (GPU box): every kernel family of enh_attention_set_kernel at the bench shape (B = 128, H = 12, N = 1024) — correctness of a
 sampled (image, head) pair against fp64 and wall time per pass.  Usage: python tools/attn_lab.py [fwd,dq,dkv ...]   e.g.  5,3,2 1,1,1"""
 import os, sys, torch
+DT = torch.float16 if os.environ.get('ATTN_DTYPE', 'fp16') == 'fp16' else torch.bfloat16      # operand format of the lab (round 6: fp16 = the headline)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "enhancing-transformers_amd"))
 from enhancing import _C
 B, N, H = int(os.environ.get("MB_BATCH", "128")), 1024, 12
 dev = "cuda"
 g = torch.Generator(device=dev).manual_seed(0)
-qkv = (torch.randn(B, N, 3 * H * 64, device=dev, generator=g) * 1.2).to(torch.bfloat16)
-do = (torch.randn(B, N, H * 64, device=dev, generator=g)).to(torch.bfloat16)
-out = torch.empty(B, N, H * 64, dtype=torch.bfloat16, device=dev)
+qkv = (torch.randn(B, N, 3 * H * 64, device=dev, generator=g) * 1.2).to(DT)
+do = (torch.randn(B, N, H * 64, device=dev, generator=g)).to(DT)
+out = torch.empty(B, N, H * 64, dtype=DT, device=dev)
 lse = torch.empty(B, H, N, device=dev)
 dqkv = torch.empty_like(qkv); delta = torch.empty(B, H, N, device=dev)
 fl = 4 * B * H * N * N * 64
@@ -46,7 +47,7 @@ def check(b, h):
 PRE = os.environ.get("PRE", "0") == "1"          # q_prescaled convention: the q third holds bf16(q * scale * log2e)
 CP = 0.125 * 1.4426950408889634
 if PRE:
-    qkv.view(B, N, 3, H * 64)[:, :, 0] = (qkv.view(B, N, 3, H * 64)[:, :, 0].float() * CP).to(torch.bfloat16)
+    qkv.view(B, N, 3, H * 64)[:, :, 0] = (qkv.view(B, N, 3, H * 64)[:, :, 0].float() * CP).to(DT)
 fams = [tuple(int(x) for x in a.split(",")) for a in sys.argv[1:]] or [(5, 3, 2), (1, 1, 1)]
 ROUNDS = int(os.environ.get("ROUNDS", "4"))      # families are timed in interleaved rounds: the chip's clock drifts with temperature / power by +-10 %
 tfs, tbs, errs_of = {f: [] for f in fams}, {f: [] for f in fams}, {}
